@@ -1,0 +1,142 @@
+/*
+ * omcmc_hip.h -- C ABI of libomcmc_hip.so, the MI355X (gfx950) sampler core.
+ *
+ * The reference (sede-open/openMCMC v1.0.7) is pure Python and has no FFI: the boundary it
+ * offers is the duck-typed plugin API MCMCSampler.sample(state)->state called from
+ * MCMC.run_mcmc (mcmc.py:97-100).  This header is what a ctypes binding for that path needs:
+ * every entry point replaces the arithmetic behind one group of reference call sites, cited
+ * per function as file:line relative to /root/reference/src/openmcmc/.  INTEGRATION.md shows
+ * the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no torch / STL types; every `const double*` / `double*` is a DEVICE pointer
+ *     (hipMalloc, or torch.Tensor.data_ptr() of a float64 ROCm tensor) unless marked [host];
+ *   - "C" = number of chains held by the context; per-chain vectors are chain-major:
+ *     element i of chain c lives at base[c*ld + i] (ld >= n, leading stride in elements);
+ *     per-chain scalars are arrays of length C; vectors shared by all chains have length n;
+ *   - all arithmetic is IEEE fp64;
+ *   - calls on one context are issued to that context's HIP stream and return without
+ *     synchronising; numerical failures (non-positive pivot) are latched on the device and
+ *     read with omc_ctx_status(), which synchronises;
+ *   - every function returns an omc_status; nothing is retained after omc_ctx_destroy;
+ *   - every entry point that consumes randomness takes an optional pointer to injected draws
+ *     (the parity tests replay the reference's draws through it) and otherwise uses the
+ *     in-kernel Philox4x32-10 stream keyed by (seed, global chain id, draw_index), so results
+ *     do not depend on how chains are sharded over GPUs.
+ */
+#ifndef OMCMC_HIP_H
+#define OMCMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  OMC_OK = 0,
+  OMC_INVALID_ARG = 1,  /* -> ValueError  (gmrf.py:508-509, gmrf.py:149-150)                */
+  OMC_NOT_POSDEF = 2,   /* -> numpy.linalg.LinAlgError (gmrf.py:518 dense fallback raises)   */
+  OMC_HIP_ERROR = 3,    /* -> RuntimeError                                                   */
+  OMC_UNSUPPORTED = 4   /* -> NotImplementedError                                            */
+} omc_status;
+
+typedef struct omc_ctx omc_ctx;
+
+#define OMC_MAX_TERMS 4
+
+/* A conditional precision in "shared structure x per-chain scalar" form
+ *     Q_c = sum_k scale[k][c] * M_k,   M_k symmetric tridiagonal, shared by all chains,
+ *     rhs_c = sum_k scale[k][c] * rhs[k]  (+ optional per-chain vector),
+ * which is what NormalNormal.sample assembles from ScaledMatrix precisions (sampler.py:176-192,
+ * parameter.py:329): term 0 is usually the prior (lambda*P, rhs = P m), the others likelihoods
+ * (tau*W, rhs = A'W(y-d)).  center[k] is the vector the quadratic form of term k is taken
+ * around: quad[k][c] = (x_c - center_k)' M_k (x_c - center_k), the quantity NormalGamma.sample
+ * needs (sampler.py:276,284) and Normal.log_p reuses (gmrf.py:343-344).                    */
+typedef struct {
+  int32_t n_terms;                      /* 1..OMC_MAX_TERMS                                  */
+  const double* diag[OMC_MAX_TERMS];    /* [n]   shared; NULL = all ones                     */
+  const double* off[OMC_MAX_TERMS];     /* [n-1] shared; NULL = zeros (diagonal M_k)         */
+  const double* rhs[OMC_MAX_TERMS];     /* [n]   shared M_k m_k;  NULL = zeros               */
+  const double* center[OMC_MAX_TERMS];  /* [n]   shared m_k;      NULL = zeros               */
+  const double* scale[OMC_MAX_TERMS];   /* [C]   per-chain scalar; NULL = 1                  */
+} omc_tridiag_terms;
+
+/* ---- context ---------------------------------------------------------------------------- */
+
+/* device: HIP device ordinal.  stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)
+ * or NULL for the library to create its own.  chain_id_offset: global id of local chain 0
+ * (rank * chains_per_rank), used only to key the random stream.                              */
+omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64_t chain_id_offset,
+                          void* stream, omc_ctx** out);
+omc_status omc_ctx_destroy(omc_ctx* ctx);
+/* Synchronises the stream.  *first_bad_chain = -1 if no failure has been latched since the
+ * last call, else the smallest LOCAL chain index whose factorisation met a non-positive pivot
+ * (returns OMC_NOT_POSDEF; the latch is cleared).                                            */
+omc_status omc_ctx_status(omc_ctx* ctx, int64_t* first_bad_chain);
+omc_status omc_ctx_synchronize(omc_ctx* ctx);
+/* Tuning knobs, by name: "tridiag_algo" (0 auto, 1 serial lane-per-chain, 2 segmented),
+ * "tridiag_seg" (nodes per lane: 0 auto, 8, 16, 32).  Unknown name -> OMC_INVALID_ARG.       */
+omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value);
+const char* omc_last_error(void);          /* [host] text of the last HIP failure, thread-local */
+int32_t omc_abi_version(void);
+
+/* ---- Normal/GMRF conjugate-Gibbs draw, tridiagonal precision -------------------------------
+ * Replaces, for every chain at once, gmrf.sample_normal_canonical (gmrf.py:167-198):
+ *   L = sparse_cholesky(Q) (gmrf.py:489-520), mu = cho_solve((L,True), b) (gmrf.py:437-462),
+ *   x = mu + solve(L', z) (gmrf.py:29-61, 414-434),  z ~ N(0, I),
+ * with Q and b assembled as in NormalNormal.sample (sampler.py:176-192).
+ *   rhs_chain  [C][ld_rhs] optional per-chain addition to b (NULL = none)
+ *   z_inject   [C][ld_z]   injected N(0,1) draws (NULL = generate, keyed by draw_index)
+ *   x_out      [C][ld_x]   the draw
+ *   mean_out   [C][ld_mean] optional mu = Q^{-1} b (NULL = skip)
+ *   quad_out   [n_terms][C] optional quadratic forms around center[k] (NULL = skip)
+ *   logdet_out [C]         optional log det Q_c = 2 sum log L_ii (NULL = skip)               */
+omc_status omc_tridiag_sample_canonical(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
+                                        const double* rhs_chain, int64_t ld_rhs,
+                                        const double* z_inject, int64_t ld_z, uint64_t draw_index,
+                                        double* x_out, int64_t ld_x,
+                                        double* mean_out, int64_t ld_mean,
+                                        double* quad_out, double* logdet_out);
+
+/* quad_out[k][c] = (x_c - center_k)' M_k (x_c - center_k) for an existing x (sampler.py:276-284
+ * when the Gaussian block was not just drawn; gmrf.py:343-344).                              */
+omc_status omc_tridiag_quadform(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
+                                const double* x, int64_t ld_x, double* quad_out);
+
+/* Shared-vector helpers used once per model, not per sweep:
+ *   out = M v for a shared tridiagonal M (rhs[k] = M_k m_k, sampler.py:183)
+ *   *logdet [device, 1] = log det M via the same factorisation (gmrf.py:342), status latched */
+omc_status omc_tridiag_matvec(omc_ctx* ctx, int64_t n, const double* diag, const double* off,
+                              const double* v, double* out);
+omc_status omc_tridiag_logdet(omc_ctx* ctx, int64_t n, const double* diag, const double* off,
+                              double* logdet);
+
+/* ---- Normal-Gamma conjugate update ---------------------------------------------------------
+ * NormalGamma.sample (sampler.py:252-288) for a scalar precision per chain:
+ *   a = a0 + n_pos/2, b = b0 + quad[c]/2, out[c] = Gamma(a, scale = 1/b); b == 0 -> scale inf.
+ *   g_inject [C] injected standard-gamma draws Gamma(a,1) (NULL = generate, Marsaglia-Tsang). */
+omc_status omc_normal_gamma_update(omc_ctx* ctx, double a0, double b0, int64_t n_pos,
+                                   const double* quad, const double* g_inject,
+                                   uint64_t draw_index, double* out);
+
+/* ---- log-density pieces of Model.log_p (model.py:57-70) ------------------------------------
+ * Gaussian with precision scale[c]*M, M shared (location_scale.py:145-167 -> gmrf.py:321-348):
+ *   lp = 0.5*(n*log(scale[c]) + logdet_M - n*log(2 pi) - scale[c]*quad[c])
+ * Gamma prior (distribution.py:241-261): lp = a log b - lgamma(a) + (a-1) log x - b x.
+ * accumulate != 0 adds into out[c] instead of overwriting.                                    */
+omc_status omc_scaled_gauss_logpdf(omc_ctx* ctx, int64_t n, const double* scale,
+                                   const double* logdet_unscaled /* device, 1 */,
+                                   const double* quad, double* out, int32_t accumulate);
+omc_status omc_gamma_logpdf(omc_ctx* ctx, const double* x, double shape, double rate,
+                            double* out, int32_t accumulate);
+
+/* ---- raw random streams (tests, prior draws for missing state: mcmc.py:78-80) -------------- */
+omc_status omc_fill_normal(omc_ctx* ctx, int64_t n, uint64_t draw_index, double* out, int64_t ld);
+omc_status omc_fill_philox_u32(omc_ctx* ctx, int64_t n_words, uint64_t draw_index, uint32_t* out,
+                               int64_t ld); /* raw words: INT path, bit-exact vs the host model */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMCMC_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libomcmc_hip.so (include/omcmc_hip.h).
+
+The library is the product: there is no CPU fallback.  Importing this module without the
+built library raises ImportError; calling into it without a GPU raises RuntimeError from
+omc_ctx_create.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libomcmc_hip.so")
+
+OMC_MAX_TERMS = 4
+OK, INVALID_ARG, NOT_POSDEF, HIP_ERROR, UNSUPPORTED = range(5)
+
+c_dp = C.c_void_p  # device pointer
+i64, u64, i32 = C.c_int64, C.c_uint64, C.c_int32
+
+
+class TridiagTerms(C.Structure):
+    """omc_tridiag_terms."""
+
+    _fields_ = [
+        ("n_terms", i32),
+        ("diag", c_dp * OMC_MAX_TERMS),
+        ("off", c_dp * OMC_MAX_TERMS),
+        ("rhs", c_dp * OMC_MAX_TERMS),
+        ("center", c_dp * OMC_MAX_TERMS),
+        ("scale", c_dp * OMC_MAX_TERMS),
+    ]
+
+
+# name -> (restype, argtypes); the single source for the symbol-export test
+SIGNATURES = {
+    "omc_ctx_create": (i32, [i32, i64, u64, i64, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "omc_ctx_destroy": (i32, [C.c_void_p]),
+    "omc_ctx_status": (i32, [C.c_void_p, C.POINTER(i64)]),
+    "omc_ctx_synchronize": (i32, [C.c_void_p]),
+    "omc_ctx_set_option": (i32, [C.c_void_p, C.c_char_p, i64]),
+    "omc_last_error": (C.c_char_p, []),
+    "omc_abi_version": (i32, []),
+    "omc_tridiag_sample_canonical": (
+        i32,
+        [C.c_void_p, i64, C.POINTER(TridiagTerms), c_dp, i64, c_dp, i64, u64, c_dp, i64, c_dp, i64, c_dp, c_dp],
+    ),
+    "omc_tridiag_quadform": (i32, [C.c_void_p, i64, C.POINTER(TridiagTerms), c_dp, i64, c_dp]),
+    "omc_tridiag_matvec": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp]),
+    "omc_tridiag_logdet": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp]),
+    "omc_normal_gamma_update": (i32, [C.c_void_p, C.c_double, C.c_double, i64, c_dp, c_dp, u64, c_dp]),
+    "omc_scaled_gauss_logpdf": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, i32]),
+    "omc_gamma_logpdf": (i32, [C.c_void_p, c_dp, C.c_double, C.c_double, c_dp, i32]),
+    "omc_fill_normal": (i32, [C.c_void_p, i64, u64, c_dp, i64]),
+    "omc_fill_philox_u32": (i32, [C.c_void_p, i64, u64, c_dp, i64]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C openmcmc_amd/csrc`).  openmcmc_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(status, ctx=None):
+    """Map omc_status to the reference's exception conventions."""
+    if status == OK:
+        return
+    if status == INVALID_ARG:
+        raise ValueError("libomcmc_hip: invalid argument")
+    if status == NOT_POSDEF:
+        raise np.linalg.LinAlgError("Matrix is not positive definite")
+    if status == UNSUPPORTED:
+        raise NotImplementedError("libomcmc_hip: unsupported configuration")
+    raise RuntimeError("libomcmc_hip: " + (lib.omc_last_error() or b"HIP error").decode())

@@ -1,0 +1,95 @@
+// Shared internals of libomcmc_hip.so (gfx950 only).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "omcmc_hip.h"
+
+struct omc_ctx {
+  int device;
+  int64_t n_chains;
+  uint64_t seed;
+  int64_t chain_offset;
+  hipStream_t stream;
+  bool own_stream;
+  long long* d_bad_chain;  // device word: min local chain index with a non-positive pivot, or LLONG_MAX
+  double* workspace;       // scratch for the serial kernel (l vectors), grown on demand
+  size_t workspace_bytes;
+  int tridiag_algo;  // 0 auto, 1 serial, 2 segmented
+  int tridiag_seg;   // 0 auto, else nodes per lane
+};
+
+void omc_set_error(const char* what, hipError_t e);
+
+#define OMC_HIP_CHECK(expr)                  \
+  do {                                       \
+    hipError_t _e = (expr);                  \
+    if (_e != hipSuccess) {                  \
+      omc_set_error(#expr, _e);              \
+      return OMC_HIP_ERROR;                  \
+    }                                        \
+  } while (0)
+
+#define OMC_NO_BAD_CHAIN 0x7fffffffffffffffLL
+
+// ------------------------------------------------------------------------------------------
+// Random streams: Philox4x32-10 (Salmon et al., SC'11), the generator rocRAND's
+// rocrand_philox4x32_10 implements.  Counter layout (documented in DESIGN.md):
+//   key = (seed_lo, seed_hi)
+//   ctr = (block, draw_index_lo, global_chain_lo, purpose<<24 | global_chain_hi(8b)<<16 | draw_index_hi(16b))
+// so a draw is a pure function of (seed, global chain id, draw_index, position): independent of
+// launch geometry and of how chains are sharded over GPUs.
+enum : uint32_t { OMC_RNG_NORMAL = 0, OMC_RNG_GAMMA = 1, OMC_RNG_UNIFORM = 2, OMC_RNG_RAW = 3 };
+
+struct omc_rng_key {
+  uint32_t k0, k1;    // seed
+  uint32_t c1;        // draw_index lo
+  uint32_t c3_base;   // purpose and draw_index hi; chain hi bits are OR-ed in per chain
+};
+
+__host__ __device__ inline omc_rng_key omc_make_key(uint64_t seed, uint64_t draw_index, uint32_t purpose) {
+  omc_rng_key k;
+  k.k0 = (uint32_t)seed;
+  k.k1 = (uint32_t)(seed >> 32);
+  k.c1 = (uint32_t)draw_index;
+  k.c3_base = (purpose << 24) | (uint32_t)((draw_index >> 32) & 0xffffu);
+  return k;
+}
+
+__device__ __forceinline__ uint4 omc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                   uint32_t k0, uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += W0; k1 += W1;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+
+__device__ __forceinline__ uint4 omc_rng_block(const omc_rng_key& k, int64_t global_chain, uint32_t block) {
+  uint32_t c2 = (uint32_t)global_chain;
+  uint32_t c3 = k.c3_base | ((uint32_t)((uint64_t)global_chain >> 32) & 0xffu) << 16;
+  return omc_philox4x32_10(block, k.c1, c2, c3, k.k0, k.k1);
+}
+
+// 53-bit uniform in (0, 1] from two words (same mapping as rocRAND's box_muller_double).
+__device__ __forceinline__ double omc_u53(uint32_t lo, uint32_t hi) {
+  unsigned long long v = (unsigned long long)lo ^ ((unsigned long long)hi << 21);
+  return 0x1.0p-53 + (double)v * 0x1.0p-53;
+}
+
+// One Philox block -> two independent N(0,1) (Box-Muller, fp64).
+__device__ __forceinline__ void omc_normal_pair(uint4 w, double& n0, double& n1) {
+  double u = omc_u53(w.x, w.y);
+  unsigned long long v2 = (unsigned long long)w.z ^ ((unsigned long long)w.w << 21);
+  double ang = 0x1.0p-52 + (double)v2 * 0x1.0p-52;  // (0, 2]
+  double s = sqrt(-2.0 * log(u));
+  double sn, cs;
+  sincospi(ang, &sn, &cs);
+  n0 = sn * s;
+  n1 = cs * s;
+}

@@ -1,0 +1,101 @@
+// Context, status latch, options.
+#include <string.h>
+
+#include <string>
+
+#include "omc_common.h"
+
+static thread_local std::string g_last_error;
+
+void omc_set_error(const char* what, hipError_t e) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+}
+
+extern "C" {
+
+const char* omc_last_error(void) { return g_last_error.c_str(); }
+
+int32_t omc_abi_version(void) { return 1; }
+
+omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64_t chain_id_offset,
+                          void* stream, omc_ctx** out) {
+  if (!out || n_chains <= 0 || chain_id_offset < 0) return OMC_INVALID_ARG;
+  *out = nullptr;
+  int count = 0;
+  OMC_HIP_CHECK(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(device));
+  omc_ctx* c = new omc_ctx();
+  c->device = device;
+  c->n_chains = n_chains;
+  c->seed = seed;
+  c->chain_offset = chain_id_offset;
+  c->own_stream = (stream == nullptr);
+  c->workspace = nullptr;
+  c->workspace_bytes = 0;
+  c->tridiag_algo = 0;
+  c->tridiag_seg = 0;
+  if (c->own_stream) {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { omc_set_error("hipStreamCreate", e); delete c; return OMC_HIP_ERROR; }
+  } else {
+    c->stream = (hipStream_t)stream;
+  }
+  hipError_t e = hipMalloc(&c->d_bad_chain, sizeof(long long));
+  if (e != hipSuccess) { omc_set_error("hipMalloc", e); delete c; return OMC_HIP_ERROR; }
+  long long init = OMC_NO_BAD_CHAIN;
+  e = hipMemcpy(c->d_bad_chain, &init, sizeof(init), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { omc_set_error("hipMemcpy", e); hipFree(c->d_bad_chain); delete c; return OMC_HIP_ERROR; }
+  *out = c;
+  return OMC_OK;
+}
+
+omc_status omc_ctx_destroy(omc_ctx* ctx) {
+  if (!ctx) return OMC_INVALID_ARG;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->workspace) hipFree(ctx->workspace);
+  hipFree(ctx->d_bad_chain);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return OMC_OK;
+}
+
+omc_status omc_ctx_synchronize(omc_ctx* ctx) {
+  if (!ctx) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return OMC_OK;
+}
+
+omc_status omc_ctx_status(omc_ctx* ctx, int64_t* first_bad_chain) {
+  if (!ctx || !first_bad_chain) return OMC_INVALID_ARG;
+  long long v = OMC_NO_BAD_CHAIN;
+  OMC_HIP_CHECK(hipMemcpyAsync(&v, ctx->d_bad_chain, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+  OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (v == OMC_NO_BAD_CHAIN) {
+    *first_bad_chain = -1;
+    return OMC_OK;
+  }
+  *first_bad_chain = (int64_t)v;
+  long long init = OMC_NO_BAD_CHAIN;
+  OMC_HIP_CHECK(hipMemcpyAsync(ctx->d_bad_chain, &init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return OMC_NOT_POSDEF;
+}
+
+omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
+  if (!ctx || !name) return OMC_INVALID_ARG;
+  if (!strcmp(name, "tridiag_algo")) {
+    if (value < 0 || value > 2) return OMC_INVALID_ARG;
+    ctx->tridiag_algo = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "tridiag_seg")) {
+    if (value != 0 && value != 8 && value != 16 && value != 32) return OMC_INVALID_ARG;
+    ctx->tridiag_seg = (int)value;
+    return OMC_OK;
+  }
+  return OMC_INVALID_ARG;
+}
+
+}  // extern "C"

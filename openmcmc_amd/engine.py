@@ -1,0 +1,184 @@
+"""Thin object layer over the C ABI: one Engine = one omc_ctx = the chains held by one GPU.
+
+PyTorch is used only for device memory and the stream; every numerical call goes to
+libomcmc_hip.so.  Tensors are float64 ROCm tensors; per-chain vectors are (C, n) row-major
+(chain-major, include/omcmc_hip.h), per-chain scalars are (C,).
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from openmcmc_amd import _abi
+from openmcmc_amd._abi import check, lib
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class Engine:
+    """Owns an omc_ctx bound to torch's current stream on `device`."""
+
+    def __init__(self, n_chains, seed=0, device=0, chain_id_offset=0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("openmcmc_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.n_chains = int(n_chains)
+        self.seed = int(seed)
+        self.chain_id_offset = int(chain_id_offset)
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        torch.cuda.set_device(self.device)
+        self._stream = torch.cuda.current_stream(self.device)
+        ctx = C.c_void_p()
+        check(lib.omc_ctx_create(self.device_index, self.n_chains, self.seed, self.chain_id_offset,
+                                 C.c_void_p(self._stream.cuda_stream), C.byref(ctx)))
+        self._ctx = ctx
+        self._keep = []
+
+    # ------------------------------------------------------------------ memory helpers
+    def empty(self, *shape):
+        return _torch().empty(*shape, dtype=_torch().float64, device=self.device)
+
+    def zeros(self, *shape):
+        return _torch().zeros(*shape, dtype=_torch().float64, device=self.device)
+
+    def full(self, shape, value):
+        return _torch().full(shape, float(value), dtype=_torch().float64, device=self.device)
+
+    def to_device(self, array):
+        torch = _torch()
+        if isinstance(array, torch.Tensor):
+            return array.to(device=self.device, dtype=torch.float64).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(array, dtype=np.float64), device=self.device)
+
+    def _p(self, t, rows=None, min_cols=None):
+        """Device pointer of a float64 tensor (None passes through as NULL)."""
+        if t is None:
+            return None
+        torch = _torch()
+        if not isinstance(t, torch.Tensor) or t.dtype != torch.float64 or not t.is_cuda:
+            raise TypeError("expected a float64 ROCm tensor")
+        if t.dim() >= 1 and t.stride(-1) != 1 and t.shape[-1] != 1:
+            raise ValueError("last dimension must be contiguous")
+        if rows is not None and (t.dim() != 2 or t.shape[0] != rows or t.shape[1] < min_cols):
+            raise ValueError(f"expected shape ({rows}, >={min_cols}), got {tuple(t.shape)}")
+        return C.c_void_p(t.data_ptr())
+
+    def _vec(self, t, n):
+        if t is None:
+            return None
+        if t.numel() < n:
+            raise ValueError(f"shared vector shorter than {n}")
+        return self._p(t)
+
+    def _chain_scalar(self, t):
+        if t is None:
+            return None
+        if t.numel() != self.n_chains:
+            raise ValueError(f"per-chain scalar must have {self.n_chains} entries, got {t.numel()}")
+        return self._p(t)
+
+    # ------------------------------------------------------------------ context
+    def close(self):
+        if self._ctx is not None:
+            lib.omc_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(lib.omc_ctx_synchronize(self._ctx))
+
+    def check_status(self):
+        """Synchronise and raise numpy.linalg.LinAlgError if any chain's precision was not
+        positive definite (the reference raises from np.linalg.cholesky, gmrf.py:518)."""
+        bad = C.c_int64(-1)
+        st = lib.omc_ctx_status(self._ctx, C.byref(bad))
+        if st == _abi.NOT_POSDEF:
+            raise np.linalg.LinAlgError(f"Matrix is not positive definite (chain {bad.value})")
+        check(st)
+
+    def set_option(self, name, value):
+        check(lib.omc_ctx_set_option(self._ctx, name.encode(), int(value)))
+
+    # ------------------------------------------------------------------ tridiagonal GMRF
+    def tridiag_terms(self, terms, n):
+        """terms: list of dicts with optional keys diag, off, rhs, center (shared, length n / n-1)
+        and scale (per-chain, length C).  Returns the ctypes struct (keeps the tensors alive)."""
+        if not 1 <= len(terms) <= _abi.OMC_MAX_TERMS:
+            raise ValueError("1..4 terms supported")
+        T = _abi.TridiagTerms()
+        T.n_terms = len(terms)
+        keep = []
+        for k, t in enumerate(terms):
+            T.diag[k] = self._vec(t.get("diag"), n)
+            T.off[k] = self._vec(t.get("off"), n - 1) if n > 1 else None
+            T.rhs[k] = self._vec(t.get("rhs"), n)
+            T.center[k] = self._vec(t.get("center"), n)
+            T.scale[k] = self._chain_scalar(t.get("scale"))
+            keep.append(dict(t))
+        T._keep = keep
+        return T
+
+    def tridiag_sample_canonical(self, n, terms, x_out, z=None, rhs_chain=None, draw_index=0,
+                                 mean_out=None, quad_out=None, logdet_out=None):
+        T = terms if isinstance(terms, _abi.TridiagTerms) else self.tridiag_terms(terms, n)
+        Cn = self.n_chains
+        ld = lambda t: 0 if t is None else t.stride(0)  # noqa: E731
+        if quad_out is not None and quad_out.numel() < T.n_terms * Cn:
+            raise ValueError("quad_out too small")
+        check(lib.omc_tridiag_sample_canonical(
+            self._ctx, n, C.byref(T),
+            self._p(rhs_chain, Cn, n), ld(rhs_chain), self._p(z, Cn, n), ld(z), int(draw_index),
+            self._p(x_out, Cn, n), ld(x_out), self._p(mean_out, Cn, n), ld(mean_out),
+            self._p(quad_out), self._chain_scalar(logdet_out)))
+
+    def tridiag_quadform(self, n, terms, x, quad_out):
+        T = terms if isinstance(terms, _abi.TridiagTerms) else self.tridiag_terms(terms, n)
+        check(lib.omc_tridiag_quadform(self._ctx, n, C.byref(T), self._p(x, self.n_chains, n), x.stride(0),
+                                       self._p(quad_out)))
+
+    def tridiag_matvec(self, n, diag, off, v):
+        out = self.empty(n)
+        check(lib.omc_tridiag_matvec(self._ctx, n, self._vec(diag, n), self._vec(off, n - 1) if n > 1 else None,
+                                     self._vec(v, n), self._p(out)))
+        return out
+
+    def tridiag_logdet(self, n, diag, off):
+        out = self.empty(1)
+        check(lib.omc_tridiag_logdet(self._ctx, n, self._vec(diag, n), self._vec(off, n - 1) if n > 1 else None,
+                                     self._p(out)))
+        return out
+
+    # ------------------------------------------------------------------ scalars
+    def normal_gamma_update(self, a0, b0, n_pos, quad, out, g=None, draw_index=0):
+        check(lib.omc_normal_gamma_update(self._ctx, float(a0), float(b0), int(n_pos), self._chain_scalar(quad),
+                                          self._chain_scalar(g), int(draw_index), self._chain_scalar(out)))
+
+    def scaled_gauss_logpdf(self, n, scale, logdet_unscaled, quad, out, accumulate=False):
+        check(lib.omc_scaled_gauss_logpdf(self._ctx, n, self._chain_scalar(scale), self._p(logdet_unscaled),
+                                          self._chain_scalar(quad), self._chain_scalar(out), int(accumulate)))
+
+    def gamma_logpdf(self, x, shape, rate, out, accumulate=False):
+        check(lib.omc_gamma_logpdf(self._ctx, self._chain_scalar(x), float(shape), float(rate),
+                                   self._chain_scalar(out), int(accumulate)))
+
+    # ------------------------------------------------------------------ random fills
+    def fill_normal(self, n, draw_index=0):
+        out = self.empty(self.n_chains, n)
+        check(lib.omc_fill_normal(self._ctx, n, int(draw_index), self._p(out), n))
+        return out
+
+    def fill_philox_u32(self, n_words, draw_index=0):
+        torch = _torch()
+        out = torch.empty(self.n_chains, n_words, dtype=torch.int32, device=self.device)
+        check(lib.omc_fill_philox_u32(self._ctx, n_words, int(draw_index), C.c_void_p(out.data_ptr()), n_words))
+        return out

@@ -1,0 +1,309 @@
+"""Parity of the HIP tridiagonal GMRF path (through the C ABI) against the CPU oracle and the
+golden vectors of the reference.  Tolerance for Gaussian quantities: 1e-10 relative (north_star)."""
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+from oracle import gmrf_ref, sweep_ref
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch
+
+
+def make_engine(C, **kw):
+    from openmcmc_amd.engine import Engine
+
+    return Engine(C, **kw)
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def tridiag(diag, off):
+    n = diag.size
+    if n == 1:
+        return sparse.csc_matrix(np.array([[diag[0]]]))
+    return sparse.diags((off, diag, off), offsets=[-1, 0, 1], format="csc")
+
+
+def rw1(n, bump=1e-3):
+    d = np.full(n, 2.0)
+    d[0] = d[-1] = 1.0
+    if n == 1:
+        d[0] = 1.0
+    d[0] += bump
+    return d, -np.ones(max(n - 1, 0))
+
+
+def oracle_draw(n, pd, po, lam, tau, y, mu, z, rhs_extra=None):
+    """Oracle for one chain: Q = lam*P + tau*I, b = lam*P mu + tau*y (+ extra)."""
+    P = tridiag(pd, po)
+    Q = (lam * P + tau * sparse.identity(n, format="csc")).tocsc()
+    b = lam * (P @ mu.reshape(n, 1)) + tau * y.reshape(n, 1)
+    if rhs_extra is not None:
+        b = b + rhs_extra.reshape(n, 1)
+    x, m, L = gmrf_ref.draw_canonical(b, Q, z)
+    r1, r2 = x - mu.reshape(n, 1), x - y.reshape(n, 1)
+    quad = np.array([(r1.T @ P @ r1).item(), (r2.T @ r2).item()])
+    logdet = 2 * np.sum(np.log(L.diagonal()))
+    return np.asarray(x).ravel(), np.asarray(m).ravel(), quad, logdet
+
+
+def run_case(torch, n, C, algo, seg, rng, lam_tau=None, with_extra=False):
+    eng = make_engine(C)
+    eng.set_option("tridiag_algo", algo)
+    eng.set_option("tridiag_seg", seg)
+    pd, po = rw1(n)
+    pd = pd * (1 + 0.1 * rng.random(n))  # irregular diagonal, still PD after tau*I
+    y = rng.standard_normal(n) + 2
+    mu = 0.3 * rng.standard_normal(n)
+    if lam_tau is None:
+        lam = 50 + 100 * rng.random(C)
+        tau = 0.5 + rng.random(C)
+    else:
+        lam, tau = np.full(C, lam_tau[0]) * (1 + 0.01 * rng.random(C)), np.full(C, lam_tau[1])
+    z = rng.standard_normal((C, n))
+    extra = rng.standard_normal((C, n)) if with_extra else None
+    d_pd, d_po, d_y, d_mu = (eng.to_device(v) for v in (pd, po if n > 1 else np.zeros(1), y, mu))
+    Pmu = eng.tridiag_matvec(n, d_pd, d_po if n > 1 else None, d_mu)
+    terms = [
+        {"diag": d_pd, "off": d_po if n > 1 else None, "rhs": Pmu, "center": d_mu, "scale": eng.to_device(lam)},
+        {"rhs": d_y, "center": d_y, "scale": eng.to_device(tau)},
+    ]
+    x, mean = eng.empty(C, n), eng.empty(C, n)
+    quad, logdet = eng.empty(2, C), eng.empty(C)
+    eng.tridiag_sample_canonical(n, terms, x, z=eng.to_device(z), rhs_chain=None if extra is None else eng.to_device(extra),
+                                 mean_out=mean, quad_out=quad, logdet_out=logdet)
+    eng.check_status()
+    x, mean, quad, logdet = (t.cpu().numpy() for t in (x, mean, quad, logdet))
+    # separate quadform entry point on the drawn x
+    quad2 = eng.empty(2, C)
+    eng.tridiag_quadform(n, terms, eng.to_device(x), quad2)
+    quad2 = quad2.cpu().numpy()
+    worst = 0.0
+    chains = range(C) if C <= 8 else list(range(0, C, max(1, C // 6))) + [C - 1]
+    for c in chains:
+        xo, mo, qo, ldo = oracle_draw(n, pd, po, lam[c], tau[c], y, mu, z[c], None if extra is None else extra[c])
+        errs = [relerr(x[c], xo), relerr(mean[c], mo), relerr(quad[:, c], qo), relerr(logdet[c], ldo),
+                relerr(quad2[:, c], qo)]
+        worst = max(worst, *errs)
+    eng.close()
+    return worst
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 8, 64, 257])
+def test_golden_primitives(torch, golden, n):
+    """Reference vectors: x, mu and the factor diagonal (through log det) for the golden (lam, tau)."""
+    G = golden("tridiag_primitives")
+    k = f"n{n}_"
+    for algo, seg in ((1, 0), (2, 8), (2, 16), (2, 32)):
+        eng = make_engine(2)
+        eng.set_option("tridiag_algo", algo)
+        eng.set_option("tridiag_seg", seg)
+        lam, tau = float(G[k + "lam"]), float(G[k + "tau"])
+        d_pd = eng.to_device(G[k + "P_diag"])
+        d_po = eng.to_device(G[k + "P_off"]) if n > 1 else None
+        # b is a free vector here: feed it as the per-chain rhs, no shared rhs terms
+        terms = [{"diag": d_pd, "off": d_po, "scale": eng.full((2,), lam)}, {"scale": eng.full((2,), tau)}]
+        b = eng.to_device(np.tile(G[k + "b"], (2, 1)))
+        z = eng.to_device(np.tile(G[k + "z"], (2, 1)))
+        x, mean, logdet = eng.empty(2, n), eng.empty(2, n), eng.empty(2)
+        eng.tridiag_sample_canonical(n, terms, x, z=z, rhs_chain=b, mean_out=mean, logdet_out=logdet)
+        eng.check_status()
+        for c in range(2):
+            assert relerr(x[c].cpu().numpy(), G[k + "x"]) < TOL
+            assert relerr(mean[c].cpu().numpy(), G[k + "mu"]) < TOL
+            assert relerr(logdet[c].item(), 2 * np.sum(np.log(G[k + "L_diag"]))) < TOL
+        eng.close()
+
+
+@pytest.mark.parametrize("algo,seg", [(1, 0), (2, 8), (2, 16), (2, 32)])
+@pytest.mark.parametrize("n,C", [(1, 3), (2, 5), (7, 1), (15, 3), (16, 3), (17, 70), (33, 3), (100, 200),
+                                 (512, 3), (1000, 9), (1025, 2), (4097, 3)])
+def test_random_vs_oracle(torch, algo, seg, n, C):
+    rng = np.random.default_rng(1000 * n + C)
+    assert run_case(torch, n, C, algo, seg, rng) < TOL
+
+
+@pytest.mark.parametrize("algo,seg,n", [(1, 0, 10000), (2, 16, 10000), (2, 32, 10000), (2, 8, 8000), (2, 32, 16384),
+                                        (0, 0, 5000), (0, 0, 20000)])
+def test_long_chains(torch, algo, seg, n):
+    rng = np.random.default_rng(n + seg)
+    assert run_case(torch, n, 3, algo, seg, rng, with_extra=True) < TOL
+
+
+@pytest.mark.parametrize("lam_tau,tol", [((1e4, 1.0), 1e-10), ((1e6, 1.0), 1e-8), ((1.0, 1e3), 1e-10), ((1e-3, 1.0), 1e-10)])
+@pytest.mark.parametrize("seg", [8, 16, 32])
+def test_weak_and_strong_coupling(torch, seg, lam_tau, tol):
+    """lam/tau large = weakly contractive pivot recurrence: forces the Newton join-correction
+    branch of the segmented kernel.  Tolerance widens with cond(Q) ~ 4 lam/tau (the oracle itself
+    is only accurate to eps*cond)."""
+    rng = np.random.default_rng(5)
+    assert run_case(torch, 3000, 2, 2, seg, rng, lam_tau=lam_tau) < tol
+
+
+def test_not_positive_definite(torch):
+    eng = make_engine(4)
+    n = 300
+    pd, po = rw1(n)
+    lam = np.array([10.0, 10.0, -1.0, 10.0])  # chain 2: negative definite prior block
+    terms = [{"diag": eng.to_device(pd), "off": eng.to_device(po), "scale": eng.to_device(lam)},
+             {"scale": eng.full((4,), 0.5)}]
+    x = eng.empty(4, n)
+    for algo in (1, 2):
+        eng.set_option("tridiag_algo", algo)
+        eng.tridiag_sample_canonical(n, terms, x, z=eng.zeros(4, n))
+        with pytest.raises(np.linalg.LinAlgError, match="chain 2"):
+            eng.check_status()
+        eng.check_status()  # latch cleared
+    eng.close()
+
+
+def test_invalid_arguments(torch):
+    eng = make_engine(2)
+    terms = [{"scale": eng.full((2,), 1.0)}]
+    with pytest.raises(ValueError):
+        eng.tridiag_sample_canonical(4, terms, eng.empty(2, 3))  # x too narrow
+    with pytest.raises(ValueError):
+        eng.tridiag_sample_canonical(4, [{"scale": eng.full((3,), 1.0)}], eng.empty(2, 4))  # wrong chain count
+    with pytest.raises(ValueError):
+        eng.set_option("no_such_option", 1)
+    eng.close()
+
+
+@pytest.mark.parametrize("route", ["sparse", "sparsemu", "dense"])
+def test_gmrf_chain_golden(torch, golden, route):
+    """Replays MCMC.run_mcmc of the example-4 model (reference output in gmrf_chain.npz) through
+    the ABI: NormalNormal(b) -> NormalGamma(lambda) -> NormalGamma(tau) -> store + log_post,
+    with the reference's own draws injected; chain 1 of 2 carries a different start to prove
+    chains do not interact."""
+    G = golden("gmrf_chain")
+    k = route + "_"
+    n, n_burn, n_iter = int(G[k + "n"]), int(G[k + "n_burn"]), int(G[k + "n_iter"])
+    C = 2
+    eng = make_engine(C)
+    d_pd, d_po = eng.to_device(G[k + "P_diag"]), eng.to_device(G[k + "P_off"])
+    d_y, d_mu = eng.to_device(G[k + "y"]), eng.full((n,), float(G[k + "mu_val"]))
+    lam, tau = eng.to_device(np.array([100.0, 37.0])), eng.to_device(np.array([1.0, 2.5]))
+    Pmu = eng.tridiag_matvec(n, d_pd, d_po, d_mu)
+    terms = eng.tridiag_terms([{"diag": d_pd, "off": d_po, "rhs": Pmu, "center": d_mu, "scale": lam},
+                               {"rhs": d_y, "center": d_y, "scale": tau}], n)
+    logdetP, logdetI = eng.tridiag_logdet(n, d_pd, d_po), eng.zeros(1)
+    x, quad, lp = eng.empty(C, n), eng.empty(2, C), eng.empty(C)
+    store = {key: [] for key in ("b", "lambda", "tau", "log_post")}
+    for it in range(n_burn + n_iter):
+        z = eng.to_device(np.tile(G[k + "z"][it], (C, 1)))
+        g = G[k + "g"][it]
+        eng.tridiag_sample_canonical(n, terms, x, z=z, quad_out=quad)
+        eng.normal_gamma_update(10.0, 1.0, n, quad[0], lam, g=eng.full((C,), g[0]))
+        eng.normal_gamma_update(1.0, 1.0, n, quad[1], tau, g=eng.full((C,), g[1]))
+        if it < n_burn:
+            continue
+        eng.scaled_gauss_logpdf(n, tau, logdetI, quad[1], lp)
+        eng.scaled_gauss_logpdf(n, lam, logdetP, quad[0], lp, accumulate=True)
+        eng.gamma_logpdf(lam, 10.0, 1.0, lp, accumulate=True)
+        eng.gamma_logpdf(tau, 1.0, 1.0, lp, accumulate=True)
+        store["b"].append(x[0].cpu().numpy().copy())
+        store["lambda"].append(lam[0].item())
+        store["tau"].append(tau[0].item())
+        store["log_post"].append(lp[0].item())
+    eng.check_status()
+    assert relerr(np.array(store["b"]).T, G[k + "store_b"]) < TOL
+    assert relerr(store["lambda"], G[k + "store_lambda"].ravel()) < TOL
+    assert relerr(store["tau"], G[k + "store_tau"].ravel()) < TOL
+    assert relerr(store["log_post"], G[k + "store_log_post"].ravel()) < TOL
+    eng.close()
+
+
+@pytest.mark.parametrize("n", [5000, 10000])
+def test_gmrf_big_golden(torch, golden, n):
+    """BASELINE sizes: one full sweep against summaries of the reference's output."""
+    G = golden("gmrf_big")
+    k = f"n{n}_"
+    rng = np.random.default_rng(0)
+    t = np.arange(n) * 60.0 / n
+    y = np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + rng.standard_normal(n)
+    z = np.random.default_rng(int(G[k + "zseed"])).standard_normal(n)
+    pd, po = rw1(n)
+    C = 2
+    eng = make_engine(C)
+    d_pd, d_po, d_y = eng.to_device(pd), eng.to_device(po), eng.to_device(y)
+    lam, tau = eng.full((C,), 100.0), eng.full((C,), 1.0)
+    terms = [{"diag": d_pd, "off": d_po, "scale": lam}, {"rhs": d_y, "center": d_y, "scale": tau}]
+    x, quad, lp = eng.empty(C, n), eng.empty(2, C), eng.empty(C)
+    eng.tridiag_sample_canonical(n, terms, x, z=eng.to_device(np.tile(z, (C, 1))), quad_out=quad)
+    g = G[k + "gdraw"]
+    eng.normal_gamma_update(10.0, 1.0, n, quad[0], lam, g=eng.full((C,), g[0]))
+    eng.normal_gamma_update(1.0, 1.0, n, quad[1], tau, g=eng.full((C,), g[1]))
+    eng.scaled_gauss_logpdf(n, tau, eng.zeros(1), quad[1], lp)
+    eng.scaled_gauss_logpdf(n, lam, eng.tridiag_logdet(n, d_pd, d_po), quad[0], lp, accumulate=True)
+    eng.gamma_logpdf(lam, 10.0, 1.0, lp, accumulate=True)
+    eng.gamma_logpdf(tau, 1.0, 1.0, lp, accumulate=True)
+    eng.check_status()
+    xh = x[1].cpu().numpy()
+    assert relerr(xh[:8], G[k + "x_head"]) < TOL and relerr(xh[-8:], G[k + "x_tail"]) < TOL
+    assert relerr(xh[::97], G[k + "x_stride"]) < TOL
+    assert relerr(xh.sum(), G[k + "x_sum"]) < TOL and relerr((xh * xh).sum(), G[k + "x_sumsq"]) < TOL
+    assert relerr(lam[1].item(), G[k + "lambda"]) < TOL and relerr(tau[1].item(), G[k + "tau"]) < TOL
+    assert relerr(lp[1].item(), G[k + "log_post"]) < TOL
+    eng.close()
+
+
+def test_bench_size_properties(torch):
+    """cfg3 at full size (1024 chains x 10 000 nodes): size-independent checks.
+    (1) residual: Q x - b = L z  =>  (Qx-b)'Q^{-1}(Qx-b) = z'z, checked through the identity
+        x'Qx - 2 x'b + mu'b = z'z  with mu = Q^{-1}b from the same kernel;
+    (2) serial and segmented kernels agree to 1e-10 on every chain;
+    (3) linearity: doubling b and z doubles x."""
+    n, C = 10000, 1024
+    rng = np.random.default_rng(42)
+    eng = make_engine(C)
+    pd, po = rw1(n)
+    t = np.arange(n) * 60.0 / n
+    y = np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + rng.standard_normal(n)
+    d_pd, d_po, d_y = eng.to_device(pd), eng.to_device(po), eng.to_device(y)
+    lam = eng.to_device(50 + 100 * rng.random(C))
+    tau = eng.to_device(0.5 + rng.random(C))
+    terms = [{"diag": d_pd, "off": d_po, "scale": lam}, {"rhs": d_y, "center": d_y, "scale": tau}]
+    z = eng.fill_normal(n, draw_index=3)
+    xs, x1, x2 = eng.empty(C, n), eng.empty(C, n), eng.empty(C, n)
+    eng.set_option("tridiag_algo", 1)
+    eng.tridiag_sample_canonical(n, terms, xs, z=z)
+    eng.set_option("tridiag_algo", 2)
+    q1, mean = eng.empty(2, C), eng.empty(C, n)
+    eng.tridiag_sample_canonical(n, terms, x1, z=z, quad_out=q1, mean_out=mean)
+    eng.check_status()
+    scale = xs.abs().max().item()
+    assert (xs - x1).abs().max().item() / scale < TOL
+    # in-kernel generated draws must equal fill_normal's for the same draw_index
+    eng.tridiag_sample_canonical(n, terms, x2, z=None, draw_index=3)
+    assert (x2 - x1).abs().max().item() / scale < 1e-12
+    # (1) energy identity, in torch fp64 on device (plumbing ops only)
+    P_x = lambda v: d_pd * v + torch.nn.functional.pad(d_po * v[:, 1:], (0, 1)) + torch.nn.functional.pad(d_po * v[:, :-1], (1, 0))  # noqa: E731
+    Qx = lam[:, None] * P_x(x1) + tau[:, None] * x1
+    b = tau[:, None] * d_y[None, :]
+    lhs = (x1 * Qx).sum(1) - 2 * (x1 * b).sum(1) + (mean * b).sum(1)
+    zz = (z * z).sum(1)
+    assert ((lhs - zz).abs() / zz).max().item() < 1e-9
+    # quad outputs equal direct evaluation
+    r = x1 - d_y[None, :]
+    assert (((r * r).sum(1) - q1[1]).abs() / q1[1]).max().item() < TOL
+    assert (((x1 * P_x(x1)).sum(1) - q1[0]).abs() / q1[0]).max().item() < TOL
+    # (3) linearity
+    terms2 = [{"diag": d_pd, "off": d_po, "scale": lam}, {"rhs": 2 * d_y, "center": d_y, "scale": tau}]
+    eng.tridiag_sample_canonical(n, terms2, x2, z=2 * z)
+    assert (x2 - 2 * x1).abs().max().item() / scale < TOL
+    eng.check_status()
+    eng.close()
