@@ -1,0 +1,230 @@
+"""Headline benchmark: chain-updates/sec on the GMRF smoother (BASELINE.json configs[2]).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Workload: 10 000 latent nodes, RW1 prior precision lambda*P, Gaussian
+likelihood tau*I, samplers [NormalNormal(b), NormalGamma(lambda), NormalGamma(tau)], 1024 chains
+per GPU.  One step = one full sweep of all samplers for every chain plus the per-iteration
+bookkeeping of MCMC.run_mcmc (store of b/lambda/tau and log_post, mcmc.py:105-108); draws come
+from the in-kernel Philox stream; all inputs are resident in HBM before the timed region.
+
+Chains are independent, so ranks share nothing during sampling ("weak" scaling: every GPU runs
+1024 chains); the only collective is the gather of the small per-chain traces at the end,
+outside the timed region.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_NODES = 10000
+CHAINS_PER_GPU = 1024
+ALG_BYTES_PER_CHAIN_UPDATE = 40 * N_NODES  # d,t written+read (32n) + x written (8n)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+STORE_SLABS_MAX = 256  # stored iterations kept resident (ring); 82 MB each at 1024 x 10 000
+
+
+def gmrf_problem(n):
+    rng = np.random.default_rng(0)
+    t = np.arange(n) * 60.0 / n
+    y = np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + rng.standard_normal(n)
+    d = np.full(n, 2.0)
+    d[0] = d[-1] = 1.0
+    d[0] += 1e-3
+    return y, d, -np.ones(n - 1)
+
+
+class GmrfSweep:
+    """The cfg3 sweep driven through the C ABI (openmcmc_amd.engine)."""
+
+    A_LAM, B_LAM, A_TAU, B_TAU = 10.0, 1.0, 1.0, 1.0
+
+    def __init__(self, n, chains, seed, chain_offset, device, n_store):
+        from openmcmc_amd.engine import Engine
+
+        self.n, self.C = n, chains
+        self.eng = eng = Engine(chains, seed=seed, device=device, chain_id_offset=chain_offset)
+        y, d, off = gmrf_problem(n)
+        self.d_y, self.d_d, self.d_off = eng.to_device(y), eng.to_device(d), eng.to_device(off)
+        self.lam, self.tau = eng.full((chains,), 100.0), eng.full((chains,), 1.0)
+        self.terms = eng.tridiag_terms(
+            [{"diag": self.d_d, "off": self.d_off, "scale": self.lam},
+             {"rhs": self.d_y, "center": self.d_y, "scale": self.tau}], n)
+        self.logdetP = eng.tridiag_logdet(n, self.d_d, self.d_off)
+        self.logdetI = eng.zeros(1)
+        self.quad = eng.empty(2, chains)
+        self.n_store = n_store
+        self.store_b = eng.empty(n_store, chains, n)  # store["b"], iteration-major slabs
+        self.store_lam = eng.empty(n_store, chains)
+        self.store_tau = eng.empty(n_store, chains)
+        self.store_lp = eng.empty(n_store, chains)
+        self.it = 0
+
+    def step(self, kernel_events=None):
+        eng, n, it = self.eng, self.n, self.it
+        slot = it % self.n_store
+        x = self.store_b[slot]  # the draw is written straight into its store slab
+        if kernel_events is not None:
+            kernel_events[0].record()
+        eng.tridiag_sample_canonical(n, self.terms, x, z=None, draw_index=3 * it, quad_out=self.quad)
+        if kernel_events is not None:
+            kernel_events[1].record()
+        eng.normal_gamma_update(self.A_LAM, self.B_LAM, n, self.quad[0], self.lam, draw_index=3 * it + 1)
+        eng.normal_gamma_update(self.A_TAU, self.B_TAU, n, self.quad[1], self.tau, draw_index=3 * it + 2)
+        lp = self.store_lp[slot]
+        eng.scaled_gauss_logpdf(n, self.tau, self.logdetI, self.quad[1], lp)
+        eng.scaled_gauss_logpdf(n, self.lam, self.logdetP, self.quad[0], lp, accumulate=True)
+        eng.gamma_logpdf(self.lam, self.A_LAM, self.B_LAM, lp, accumulate=True)
+        eng.gamma_logpdf(self.tau, self.A_TAU, self.B_TAU, lp, accumulate=True)
+        self.store_lam[slot].copy_(self.lam)
+        self.store_tau[slot].copy_(self.tau)
+        self.it += 1
+
+
+def cpu_baseline(n, seconds_budget=12.0):
+    """Oracle (CPU restatement of the reference's sparse route: SuperLU factor + spsolve, same
+    call pattern as gmrf.py) timed on this host, 1 chain, bounded sample."""
+    from scipy import sparse
+
+    from oracle import c_ref, sweep_ref
+
+    y, d, off = gmrf_problem(n)
+    P = sparse.diags((off, d, off), offsets=[-1, 0, 1], format="csc")
+    rng = np.random.default_rng(1)
+    k = 4
+    t0 = time.perf_counter()
+    sweep_ref.gmrf_smoother_chain(y, P, 0, k, rng.standard_normal((k, n)), 1 + rng.random((k, 2)))
+    per = (time.perf_counter() - t0) / k
+    k = int(max(8, min(2000, seconds_budget / per)))
+    z, g = rng.standard_normal((k, n)), rng.standard_gamma(5000.0, size=(k, 2))
+    t0 = time.perf_counter()
+    sweep_ref.gmrf_smoother_chain(y, P, 0, k, z, g)
+    dt = time.perf_counter() - t0
+    # the plain-C Thomas restatement of the same sweep, for an un-flattering comparison
+    mu = np.zeros(n)
+    kc = 2000
+    zc = rng.standard_normal((8, n))
+    lam, tau = 100.0, 1.0
+    t1 = time.perf_counter()
+    for i in range(kc):
+        _, q, _ = c_ref.tridiag_draw(d, off, lam, tau, y, mu, zc[i % 8])
+    dtc = time.perf_counter() - t1
+    return {
+        "value": k / dt, "unit": "chain-updates/s", "cores": 1, "kind": "port",
+        "sample": f"{k} sweeps of 1 chain (n={n}) of the oracle's sparse-route restatement "
+                  f"(scipy SuperLU), draws pre-generated; host has {os.cpu_count()} cpus",
+        "c_thomas_value": kc / dtc,
+        "c_thomas_note": "oracle/c sequential O(n) restatement, draw only (no RNG, no log_post), 1 core",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--nodes", type=int, default=N_NODES)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    torch.cuda.set_stream(torch.cuda.Stream())  # a real stream: the legacy default stream serialises with everything
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    n, C = args.nodes, args.chains
+    n_store = max(1, min(args.steps, STORE_SLABS_MAX))
+    sweep = GmrfSweep(n, C, seed=2025, chain_offset=rank * C, device=local, n_store=n_store)
+
+    for _ in range(args.warmup):
+        sweep.step()
+    sweep.eng.check_status()
+
+    use_ev = not args.no_kernel_events
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if use_ev else None
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        sweep.step(events[i] if use_ev else None)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    sweep.eng.check_status()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+
+    # the one collective of the path: gather of the per-chain traces (outside the timed region)
+    trace = torch.stack([sweep.store_lam[: min(args.steps, n_store)], sweep.store_tau[: min(args.steps, n_store)]])
+    if dist is not None:
+        gathered = [torch.empty_like(trace) for _ in range(world)] if rank == 0 else None
+        dist.gather(trace, gathered, dst=0)
+        if rank == 0:
+            trace = torch.cat(gathered, dim=2)
+    lam_mean = trace[0].mean().item()
+
+    if rank == 0:
+        kern_ms = None
+        if use_ev:
+            kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        total_chains = C * world
+        value = total_chains * args.steps / dt
+        out = {
+            "metric": "chain-updates/sec (1024 chains, 10k-node GMRF) at 1/2/4/8 GPUs vs CPU ref",
+            "value": value, "unit": "chain-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"GMRF smoother (examples/4): {n} nodes, RW1 precision, {C} chains per GPU, "
+                                   "NormalNormal + 2x NormalGamma + store + log_post per step",
+                       "chains_total": total_chains, "nodes": n, "parallelism": f"chains sharded x{world}",
+                       "check": {"mean_lambda": lam_mean}},
+        }
+        if kern_ms is not None:
+            achieved = ALG_BYTES_PER_CHAIN_UPDATE * (n / N_NODES) * C / (kern_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                rec = json.load(open(tpath))
+                if rec.get("nodes") == n and rec.get("chains") == C:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "kernel": "k_tridiag_seg", "kernel_ms": kern_ms,
+                               "alg_bytes_per_launch": ALG_BYTES_PER_CHAIN_UPDATE * (n / N_NODES) * C}
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(n)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,11 +64,13 @@ typedef struct {
 
 /* ---- context ---------------------------------------------------------------------------- */
 
-/* device: HIP device ordinal.  stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)
- * or NULL for the library to create its own.  chain_id_offset: global id of local chain 0
- * (rank * chains_per_rank), used only to key the random stream.                              */
+/* device: HIP device ordinal.  stream: the hipStream_t every call of this context is issued to
+ * (e.g. torch.cuda.current_stream().cuda_stream; 0 is the legacy default stream); with
+ * create_stream != 0 `stream` is ignored and the library creates and owns a non-blocking stream.
+ * chain_id_offset: global id of local chain 0 (rank * chains_per_rank), used only to key the
+ * random stream.                                                                             */
 omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64_t chain_id_offset,
-                          void* stream, omc_ctx** out);
+                          void* stream, int32_t create_stream, omc_ctx** out);
 omc_status omc_ctx_destroy(omc_ctx* ctx);
 /* Synchronises the stream.  *first_bad_chain = -1 if no failure has been latched since the
  * last call, else the smallest LOCAL chain index whose factorisation met a non-positive pivot

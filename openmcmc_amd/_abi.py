@@ -35,7 +35,7 @@ class TridiagTerms(C.Structure):
 
 # name -> (restype, argtypes); the single source for the symbol-export test
 SIGNATURES = {
-    "omc_ctx_create": (i32, [i32, i64, u64, i64, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "omc_ctx_create": (i32, [i32, i64, u64, i64, C.c_void_p, i32, C.POINTER(C.c_void_p)]),
     "omc_ctx_destroy": (i32, [C.c_void_p]),
     "omc_ctx_status": (i32, [C.c_void_p, C.POINTER(i64)]),
     "omc_ctx_synchronize": (i32, [C.c_void_p]),
@@ -63,6 +63,10 @@ def _load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C openmcmc_amd/csrc`).  openmcmc_amd has no CPU fallback."
         )
+    # PyTorch-ROCm ships its own libamdhip64.so.7; load it first so that this library binds to
+    # the SAME HIP runtime (two runtimes in one process cannot share the device or a stream).
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

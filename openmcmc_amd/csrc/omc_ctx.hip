@@ -18,7 +18,7 @@ const char* omc_last_error(void) { return g_last_error.c_str(); }
 int32_t omc_abi_version(void) { return 1; }
 
 omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64_t chain_id_offset,
-                          void* stream, omc_ctx** out) {
+                          void* stream, int32_t create_stream, omc_ctx** out) {
   if (!out || n_chains <= 0 || chain_id_offset < 0) return OMC_INVALID_ARG;
   *out = nullptr;
   int count = 0;
@@ -30,7 +30,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->n_chains = n_chains;
   c->seed = seed;
   c->chain_offset = chain_id_offset;
-  c->own_stream = (stream == nullptr);
+  c->own_stream = (create_stream != 0);
   c->workspace = nullptr;
   c->workspace_bytes = 0;
   c->tridiag_algo = 0;

@@ -35,7 +35,7 @@ class Engine:
         self._stream = torch.cuda.current_stream(self.device)
         ctx = C.c_void_p()
         check(lib.omc_ctx_create(self.device_index, self.n_chains, self.seed, self.chain_id_offset,
-                                 C.c_void_p(self._stream.cuda_stream), C.byref(ctx)))
+                                 C.c_void_p(self._stream.cuda_stream), 0, C.byref(ctx)))
         self._ctx = ctx
         self._keep = []
 
