@@ -47,7 +47,7 @@ class GmrfSweep:
 
     A_LAM, B_LAM, A_TAU, B_TAU = 10.0, 1.0, 1.0, 1.0
 
-    def __init__(self, n, chains, seed, chain_offset, device, n_store):
+    def __init__(self, n, chains, seed, chain_offset, device, n_store, fused=True, seg=0):
         from openmcmc_amd.engine import Engine
 
         self.n, self.C = n, chains
@@ -67,8 +67,18 @@ class GmrfSweep:
         self.store_tau = eng.empty(n_store, chains)
         self.store_lp = eng.empty(n_store, chains)
         self.it = 0
+        self.fused = fused
+        if seg:
+            eng.set_option("tridiag_seg", seg)
+        # one prepared gamma-block array per store slot (the store pointers differ per slot)
+        self.blocks = [eng.gamma_blocks(
+            [{"a0": self.A_LAM, "b0": self.B_LAM, "n_pos": n, "store": self.store_lam[s], "logdet": self.logdetP},
+             {"a0": self.A_TAU, "b0": self.B_TAU, "n_pos": n, "store": self.store_tau[s], "logdet": self.logdetI}], 2)
+            for s in range(n_store)]
 
     def step(self, kernel_events=None):
+        if self.fused:
+            return self.step_fused(kernel_events)
         eng, n, it = self.eng, self.n, self.it
         slot = it % self.n_store
         x = self.store_b[slot]  # the draw is written straight into its store slab
@@ -86,6 +96,20 @@ class GmrfSweep:
         eng.gamma_logpdf(self.tau, self.A_TAU, self.B_TAU, lp, accumulate=True)
         self.store_lam[slot].copy_(self.lam)
         self.store_tau[slot].copy_(self.tau)
+        self.it += 1
+
+    def step_fused(self, kernel_events=None):
+        """The same sweep as ONE launch (omc_gmrf_sweep): draw, both Normal-Gamma updates, log_post,
+        and the store writes (x, lambda, tau, log_post go straight into their store slots)."""
+        eng, n, it = self.eng, self.n, self.it
+        slot = it % self.n_store
+        blocks = self.blocks[slot]
+        if kernel_events is not None:
+            kernel_events[0].record()
+        eng.gmrf_sweep(n, self.terms, blocks, self.store_b[slot], z=None, draw_index=3 * it,
+                       log_post_out=self.store_lp[slot])
+        if kernel_events is not None:
+            kernel_events[1].record()
         self.it += 1
 
 
@@ -135,6 +159,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=N_NODES)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="one launch per sampler instead of the fused sweep kernel")
+    ap.add_argument("--seg", type=int, default=0, help="nodes per lane of the segmented kernel (0 = auto)")
     args = ap.parse_args()
 
     import torch
@@ -154,7 +180,8 @@ def main():
 
     n, C = args.nodes, args.chains
     n_store = max(1, min(args.steps, STORE_SLABS_MAX))
-    sweep = GmrfSweep(n, C, seed=2025, chain_offset=rank * C, device=local, n_store=n_store)
+    sweep = GmrfSweep(n, C, seed=2025, chain_offset=rank * C, device=local, n_store=n_store,
+                      fused=not args.unfused, seg=args.seg)
 
     for _ in range(args.warmup):
         sweep.step()
@@ -203,7 +230,8 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"GMRF smoother (examples/4): {n} nodes, RW1 precision, {C} chains per GPU, "
-                                   "NormalNormal + 2x NormalGamma + store + log_post per step",
+                                   "NormalNormal + 2x NormalGamma + store + log_post per step"
+                                   + (" (one fused launch)" if not args.unfused else " (one launch per sampler)"),
                        "chains_total": total_chains, "nodes": n, "parallelism": f"chains sharded x{world}",
                        "check": {"mean_lambda": lam_mean}},
         }

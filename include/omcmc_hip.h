@@ -78,7 +78,7 @@ omc_status omc_ctx_destroy(omc_ctx* ctx);
 omc_status omc_ctx_status(omc_ctx* ctx, int64_t* first_bad_chain);
 omc_status omc_ctx_synchronize(omc_ctx* ctx);
 /* Tuning knobs, by name: "tridiag_algo" (0 auto, 1 serial lane-per-chain, 2 segmented),
- * "tridiag_seg" (nodes per lane: 0 auto, 8, 16, 32).  Unknown name -> OMC_INVALID_ARG.       */
+ * "tridiag_seg" (nodes per lane: 0 auto, 8, 10, 16, 20, 32).  Unknown name -> OMC_INVALID_ARG.       */
 omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value);
 const char* omc_last_error(void);          /* [host] text of the last HIP failure, thread-local */
 int32_t omc_abi_version(void);
@@ -100,6 +100,33 @@ omc_status omc_tridiag_sample_canonical(omc_ctx* ctx, int64_t n, const omc_tridi
                                         double* x_out, int64_t ld_x,
                                         double* mean_out, int64_t ld_mean,
                                         double* quad_out, double* logdet_out);
+
+/* ---- one whole Gibbs sweep of the "GMRF smoother" block structure in ONE launch ------------
+ * Equivalent to the sampler list [NormalNormal(x), NormalGamma(scale_0), NormalGamma(scale_1), ...]
+ * of MCMC.run_mcmc (mcmc.py:99-100) followed by the per-iteration bookkeeping (mcmc.py:105-108),
+ * for a Gaussian block whose conditional precision is given by `terms`:
+ *   1. x_c ~ N(Q_c^{-1} b_c, Q_c^{-1})                      (as omc_tridiag_sample_canonical)
+ *   2. for every term k with blocks[k].enabled: scale[k][c] ~ Gamma(a0 + n_pos/2,
+ *      rate = b0 + quad_k/2), written IN PLACE into terms->scale[k] (and to blocks[k].store)
+ *      (as omc_normal_gamma_update with draw_index + 1 + k);
+ *   3. log_post_out[c] = sum_k log N(. ; center_k, (scale_k M_k)^{-1}) + sum_{k enabled}
+ *      log Gamma(scale_k; a0, b0) with the NEW scales (model.py:57-70), if log_post_out != NULL;
+ *      needs blocks[k].logdet_unscaled = device scalar log det M_k for every term.
+ * The draw goes straight to x_out, which may be a slab of the device-resident store.         */
+typedef struct {
+  int32_t enabled;                /* 0: scale[k] is a fixed input, no prior term in log_post   */
+  double a0, b0;                  /* Gamma prior shape, rate (sampler.py:278-279)               */
+  int64_t n_pos;                  /* #{diag(M_k) > 0}  (sampler.py:283)                         */
+  const double* g_inject;         /* [C] injected Gamma(a,1) draws, or NULL                     */
+  double* store;                  /* [C] optional copy of the new scale (store[param]), or NULL */
+  const double* logdet_unscaled;  /* device scalar log det M_k; NULL allowed iff no log_post    */
+} omc_gamma_block;
+
+omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
+                          const omc_gamma_block* blocks /* [n_terms], host */,
+                          const double* rhs_chain, int64_t ld_rhs,
+                          const double* z_inject, int64_t ld_z, uint64_t draw_index,
+                          double* x_out, int64_t ld_x, double* log_post_out);
 
 /* quad_out[k][c] = (x_c - center_k)' M_k (x_c - center_k) for an existing x (sampler.py:276-284
  * when the Gaussian block was not just drawn; gmrf.py:343-344).                              */

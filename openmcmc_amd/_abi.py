@@ -33,6 +33,20 @@ class TridiagTerms(C.Structure):
     ]
 
 
+class GammaBlock(C.Structure):
+    """omc_gamma_block."""
+
+    _fields_ = [
+        ("enabled", i32),
+        ("a0", C.c_double),
+        ("b0", C.c_double),
+        ("n_pos", i64),
+        ("g_inject", c_dp),
+        ("store", c_dp),
+        ("logdet_unscaled", c_dp),
+    ]
+
+
 # name -> (restype, argtypes); the single source for the symbol-export test
 SIGNATURES = {
     "omc_ctx_create": (i32, [i32, i64, u64, i64, C.c_void_p, i32, C.POINTER(C.c_void_p)]),
@@ -45,6 +59,10 @@ SIGNATURES = {
     "omc_tridiag_sample_canonical": (
         i32,
         [C.c_void_p, i64, C.POINTER(TridiagTerms), c_dp, i64, c_dp, i64, u64, c_dp, i64, c_dp, i64, c_dp, c_dp],
+    ),
+    "omc_gmrf_sweep": (
+        i32,
+        [C.c_void_p, i64, C.POINTER(TridiagTerms), C.POINTER(GammaBlock), c_dp, i64, c_dp, i64, u64, c_dp, i64, c_dp],
     ),
     "omc_tridiag_quadform": (i32, [C.c_void_p, i64, C.POINTER(TridiagTerms), c_dp, i64, c_dp]),
     "omc_tridiag_matvec": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp]),

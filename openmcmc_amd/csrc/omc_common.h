@@ -61,8 +61,9 @@ __device__ __forceinline__ uint4 omc_philox4x32_10(uint32_t c0, uint32_t c1, uin
   constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += W0; k1 += W1;
@@ -93,3 +94,34 @@ __device__ __forceinline__ void omc_normal_pair(uint4 w, double& n0, double& n1)
   n0 = sn * s;
   n1 = cs * s;
 }
+
+// Marsaglia & Tsang (2000) Gamma(a,1), a > 0, from the chain's Philox stream.
+// Each attempt consumes one block: words (x,y) -> normal via Box-Muller radius/angle, (z,w) -> uniform.
+__device__ inline double omc_standard_gamma(const omc_rng_key& key, int64_t gc, double a, bool* failed) {
+  double boost = 1.0;
+  uint32_t blk = 0;
+  if (a < 1.0) {  // Gamma(a) = Gamma(a+1) * U^(1/a)
+    uint4 w = omc_rng_block(key, gc, blk++);
+    boost = exp(log(omc_u53(w.x, w.y)) / a);
+    a += 1.0;
+  }
+  const double d = a - 1.0 / 3.0, cst = 1.0 / sqrt(9.0 * d);
+  for (int attempt = 0; attempt < 256; ++attempt) {
+    double x0, x1;
+    omc_normal_pair(omc_rng_block(key, gc, blk++), x0, x1);
+    uint4 w = omc_rng_block(key, gc, blk++);
+    const double us[2] = {omc_u53(w.x, w.y), omc_u53(w.z, w.w)};
+    const double xs[2] = {x0, x1};
+    for (int t = 0; t < 2; ++t) {
+      const double x = xs[t], u = us[t];
+      double v = 1.0 + cst * x;
+      if (v <= 0.0) continue;
+      v = v * v * v;
+      const double x2 = x * x;
+      if (u < 1.0 - 0.0331 * x2 * x2 || log(u) < 0.5 * x2 + d * (1.0 - v + log(v))) return boost * d * v;
+    }
+  }
+  *failed = true;
+  return boost * d;
+}
+

@@ -91,7 +91,7 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
     return OMC_OK;
   }
   if (!strcmp(name, "tridiag_seg")) {
-    if (value != 0 && value != 8 && value != 16 && value != 32) return OMC_INVALID_ARG;
+    if (value != 0 && value != 8 && value != 10 && value != 16 && value != 20 && value != 32) return OMC_INVALID_ARG;
     ctx->tridiag_seg = (int)value;
     return OMC_OK;
   }

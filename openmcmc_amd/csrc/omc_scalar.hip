@@ -3,36 +3,6 @@
 
 #include "omc_common.h"
 
-// Marsaglia & Tsang (2000) Gamma(a,1), a > 0, from the chain's Philox stream.
-// Each attempt consumes one block: words (x,y) -> normal via Box-Muller radius/angle, (z,w) -> uniform.
-__device__ double omc_standard_gamma(const omc_rng_key& key, int64_t gc, double a, bool* failed) {
-  double boost = 1.0;
-  uint32_t blk = 0;
-  if (a < 1.0) {  // Gamma(a) = Gamma(a+1) * U^(1/a)
-    uint4 w = omc_rng_block(key, gc, blk++);
-    boost = pow(omc_u53(w.x, w.y), 1.0 / a);
-    a += 1.0;
-  }
-  const double d = a - 1.0 / 3.0, cst = 1.0 / sqrt(9.0 * d);
-  for (int attempt = 0; attempt < 256; ++attempt) {
-    double x0, x1;
-    omc_normal_pair(omc_rng_block(key, gc, blk++), x0, x1);
-    uint4 w = omc_rng_block(key, gc, blk++);
-    const double us[2] = {omc_u53(w.x, w.y), omc_u53(w.z, w.w)};
-    const double xs[2] = {x0, x1};
-    for (int t = 0; t < 2; ++t) {
-      const double x = xs[t], u = us[t];
-      double v = 1.0 + cst * x;
-      if (v <= 0.0) continue;
-      v = v * v * v;
-      const double x2 = x * x;
-      if (u < 1.0 - 0.0331 * x2 * x2 || log(u) < 0.5 * x2 + d * (1.0 - v + log(v))) return boost * d * v;
-    }
-  }
-  *failed = true;
-  return boost * d;
-}
-
 __global__ void k_normal_gamma(int64_t C, int64_t chain_offset, double a0, double b0, double half_npos,
                                const double* quad, const double* g_inject, omc_rng_key key, double* out,
                                long long* bad) {

@@ -22,8 +22,12 @@
 //                                   recurrence (one affine scan per sweep) then makes the
 //                                   segment joins consistent to a few ulp;
 //                        forward / backward substitution: affine maps, one scan each.
-//                      HBM traffic per chain-update is the x store (8n B) plus shared vectors
-//                      from L2; nothing is spilled between the sweeps.
+//                      Global memory is touched only through wave-private LDS tiles that turn
+//                      the lane-owns-M-consecutive-nodes layout into fully coalesced 512-B
+//                      wave accesses.  HBM traffic per chain-update is the x store (8n B) plus
+//                      shared vectors served from L2; nothing is spilled between the passes.
+//                      With gamma blocks attached the same launch also performs the
+//                      Normal-Gamma updates and log_post of the sweep (omc_gmrf_sweep).
 #include <math.h>
 
 #include "omc_common.h"
@@ -35,6 +39,17 @@ struct TermsDev {
   const double* rhs[OMC_MAX_TERMS];
   const double* center[OMC_MAX_TERMS];
   const double* scale[OMC_MAX_TERMS];
+};
+
+struct GammaDev {
+  int enabled;
+  double a0, b0, half_npos;
+  double lnorm;  // a0*log(b0) - lgamma(a0), host-computed
+  const double* g_inject;
+  double* store;
+  double* scale_out;  // writable alias of T.scale[k]
+  const double* logdet_unscaled;
+  omc_rng_key key;
 };
 
 struct TriArgs {
@@ -49,6 +64,10 @@ struct TriArgs {
   double* logdet;
   long long* bad;
   double* work;
+  // fused sweep (omc_gmrf_sweep)
+  int fused;
+  GammaDev gb[OMC_MAX_TERMS];
+  double* log_post;
 };
 
 __device__ __forceinline__ double fast_rcp(double d) {
@@ -58,6 +77,32 @@ __device__ __forceinline__ double fast_rcp(double d) {
   e = fma(-d, r, 1.0);
   r = fma(r, e, r);
   return r;
+}
+
+// Normal-Gamma updates + log_post of one chain, run by one lane (sampler.py:252-288, model.py:57-70)
+__device__ __forceinline__ void sweep_epilogue(const TriArgs& A, int64_t c, const double* quad) {
+  double lp = 0.0;
+  bool failed = false;
+  const double nd = (double)A.n;
+  for (int k = 0; k < A.T.n_terms; ++k) {
+    const GammaDev& g = A.gb[k];
+    double s = A.T.scale[k] ? A.T.scale[k][c] : 1.0;
+    if (g.enabled) {
+      const double a = g.a0 + g.half_npos;
+      const double b = g.b0 + 0.5 * quad[k];
+      const double sc = (b == 0.0) ? INFINITY : 1.0 / b;
+      const double gd = g.g_inject ? g.g_inject[c] : omc_standard_gamma(g.key, A.chain_offset + c, a, &failed);
+      s = gd * sc;
+      g.scale_out[c] = s;
+      if (g.store) g.store[c] = s;
+    }
+    if (A.log_post) {
+      lp += 0.5 * (nd * log(s) + g.logdet_unscaled[0] - nd * 1.8378770664093453 - s * quad[k]);
+      if (g.enabled) lp += g.lnorm + (g.a0 - 1.0) * log(s) - g.b0 * s;
+    }
+  }
+  if (A.log_post) A.log_post[c] = lp;
+  if (failed) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -102,12 +147,13 @@ __global__ void __launch_bounds__(64) k_tridiag_serial(TriArgs A) {
     lw[i] = lp;
     bprev = bv;
   }
+  const bool want_quad = A.quad || A.fused;
   double acc[OMC_MAX_TERMS] = {0, 0, 0, 0}, rnext[OMC_MAX_TERMS] = {0, 0, 0, 0};
   double x = 0.0;
   for (int64_t i = n - 1; i >= 0; --i) {
     x = fma(-lw[i], x, xo[i]);
     xo[i] = x;
-    if (A.quad) {
+    if (want_quad) {
       for (int k = 0; k < nt; ++k) {
         double r = x - (A.T.center[k] ? A.T.center[k][i] : 0.0);
         double dk = A.T.diag[k] ? A.T.diag[k][i] : 1.0;
@@ -121,6 +167,7 @@ __global__ void __launch_bounds__(64) k_tridiag_serial(TriArgs A) {
     for (int k = 0; k < nt; ++k) A.quad[k * A.C + c] = acc[k];
   if (A.logdet) A.logdet[c] = logdet;
   if (bad) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
+  if (A.fused) sweep_epilogue(A, c, acc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -207,11 +254,119 @@ __device__ __forceinline__ double group_sum(double v, int Wd, double* lds, int w
   return v;
 }
 
+// ------------------------------------------------------------------------------------------
+// Wave-private LDS tile: converts between "lane owns M consecutive nodes" (registers) and
+// "64 consecutive lanes touch 64 consecutive doubles" (global memory).  Tile element e
+// (0 <= e < 64*M; e = lane'*M + j) lives at tile[e + e/M]: row stride M+1 doubles, so the
+// per-lane reads at stride M+1 (odd) are bank-conflict free for ds_read_b64.
+template <int M, bool MULTI>
+struct Geom {
+  int lane, wave, G;   // G: lanes per chain (sub-wave groups) when !MULTI
+  int64_t chain0;      // MULTI: the chain; else first chain of this wave
+  __device__ __forceinline__ int64_t node(int e) const {
+    const int lp = e / M, j = e - lp * M;
+    const int seg = MULTI ? (wave * 64 + lp) : (lp & (G - 1));
+    return (int64_t)seg * M + j;
+  }
+  __device__ __forceinline__ int64_t chain(int e) const { return MULTI ? chain0 : chain0 + (e / M) / G; }
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // DS operations of one wave execute in order; this only stops the compiler from moving them.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// shared vector v[0..lim) -> tile (fill beyond lim); every sub-wave group then reads rows 0..G-1
+template <int M, bool MULTI>
+__device__ __forceinline__ void tile_fill_shared(double* tile, const Geom<M, MULTI>& g, const double* v, int64_t lim,
+                                                 double fill) {
+  wave_lds_fence();
+#pragma unroll 2
+  for (int t = 0; t < M; ++t) {
+    const int e = t * 64 + g.lane;
+    const int64_t nd = g.node(e);
+    tile[e + e / M] = (nd < lim) ? v[nd] : fill;
+  }
+  wave_lds_fence();
+}
+// per-chain vector v[chain*ld + node]; one tile row per lane
+template <int M, bool MULTI>
+__device__ __forceinline__ void tile_fill_chain(double* tile, const Geom<M, MULTI>& g, const double* v, int64_t ld,
+                                                int64_t lim, int64_t C, double fill) {
+  wave_lds_fence();
+#pragma unroll 2
+  for (int t = 0; t < M; ++t) {
+    const int e = t * 64 + g.lane;
+    const int64_t nd = g.node(e), ch = g.chain(e);
+    tile[e + e / M] = (nd < lim && ch < C) ? v[ch * ld + nd] : fill;
+  }
+  wave_lds_fence();
+}
+template <int M, bool MULTI>
+__device__ __forceinline__ void tile_store_chain(const double* tile, const Geom<M, MULTI>& g, double* v, int64_t ld,
+                                                 int64_t lim, int64_t C) {
+  wave_lds_fence();
+#pragma unroll 2
+  for (int t = 0; t < M; ++t) {
+    const int e = t * 64 + g.lane;
+    const int64_t nd = g.node(e), ch = g.chain(e);
+    if (nd < lim && ch < C) v[ch * ld + nd] = tile[e + e / M];
+  }
+  wave_lds_fence();
+}
+
+// Per-chain combination of the shared term vectors, formed while the tile is filled (coalesced):
+//   DIAG: a = sum_k s_k diag_k (1 beyond n), OFF: b = sum_k s_k off_k, RHS: r = sum_k s_k rhs_k + rhs_chain
+enum { COMB_DIAG = 0, COMB_OFF = 1, COMB_RHS = 2 };
+template <int M, bool MULTI, int WHICH>
+__device__ __forceinline__ void tile_fill_comb(double* tile, const Geom<M, MULTI>& g, const TriArgs& A,
+                                               const double (&sc)[OMC_MAX_TERMS]) {
+  const int nt = A.T.n_terms;
+  const int64_t n = A.n;
+  wave_lds_fence();
+#pragma unroll 2
+  for (int t = 0; t < M; ++t) {
+    const int e = t * 64 + g.lane;
+    const int64_t nd = g.node(e), ch = g.chain(e);
+    double v = (WHICH == COMB_DIAG) ? 1.0 : 0.0;
+    const int64_t lim = (WHICH == COMB_OFF) ? n - 1 : n;
+    if (nd < lim) {
+      v = 0.0;
+      for (int k = 0; k < nt; ++k) {
+        const double* src = (WHICH == COMB_DIAG) ? A.T.diag[k] : (WHICH == COMB_OFF ? A.T.off[k] : A.T.rhs[k]);
+        if (!src && WHICH != COMB_DIAG) continue;
+        const double sk = MULTI ? sc[k] : ((A.T.scale[k] && ch < A.C) ? A.T.scale[k][ch] : 1.0);
+        v = fma(sk, src ? src[nd] : 1.0, v);
+      }
+      if (WHICH == COMB_RHS && A.rhs_chain && ch < A.C) v += A.rhs_chain[ch * A.ld_rhs + nd];
+    }
+    tile[e + e / M] = v;
+  }
+  wave_lds_fence();
+}
+
+__device__ __forceinline__ double fast_sqrt(double r) {  // r > 0, normal range
+  const double g = __builtin_amdgcn_rsq(r);
+  double s = r * g;
+  const double h = 0.5 * g;
+  double e = fma(-s, s, r);
+  s = fma(e, h, s);
+  e = fma(-s, s, r);
+  s = fma(e, h, s);
+  return s;
+}
+
 #define OMC_NEWTON_TOL 4e-15
 #define OMC_NEWTON_MAX 4
 
+// Register plan per lane (M nodes): X = z -> z/sqrt(D) -> residuals ; Y = b -> l ; W = 1/D -> g -> x.
+// The combined diagonal a (then the right-hand side r) lives in the wave's LDS tile.
 template <int M, bool MULTI, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
+  constexpr int NWMAX = MAXT / 64;
+  __shared__ double lds_tile[NWMAX][64 * (M + 1)];
   __shared__ Mob lds_mob[16];
   __shared__ Aff lds_aff[16];
   __shared__ double lds_d[32];
@@ -219,14 +374,21 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   const int Wd = MULTI ? 64 : G;
   int64_t c;
   int s;
+  Geom<M, MULTI> geo;
+  geo.lane = lane; geo.wave = wave; geo.G = G;
   if (MULTI) {
     c = blockIdx.x;
     s = threadIdx.x;
+    geo.chain0 = c;
   } else {
     const int cpw = 64 / G;
-    c = ((int64_t)blockIdx.x * nw + wave) * cpw + lane / G;
+    geo.chain0 = ((int64_t)blockIdx.x * nw + wave) * cpw;
+    c = geo.chain0 + lane / G;
     s = lane % G;
   }
+  double* tile = lds_tile[wave];
+  const double* trow = tile + (MULTI ? lane : s) * (M + 1);  // shared vectors: every group reads rows 0..G-1
+  double* crow = tile + lane * (M + 1);                      // per-chain data: one row per lane
   const int pos = MULTI ? lane : s;
   const bool chain_ok = c < A.C;
   const int64_t cc = chain_ok ? c : 0;
@@ -238,38 +400,57 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 #pragma unroll
   for (int k = 0; k < OMC_MAX_TERMS; ++k) sc[k] = (k < nt && A.T.scale[k]) ? A.T.scale[k][cc] : 1.0;
 
-  // ---- phase 0: conditional precision of this segment ----
-  double va[M], vb[M], vr[M];  // a -> rhs ; b -> l ; rD -> g
-  double bm1 = 0.0;            // coupling b_{i0-1} into the segment
+  double X[M], Y[M], W[M];
+
+  // ---- draws first, while nothing else is live: X = z ----
+  if (A.z) {
+    tile_fill_chain<M, MULTI>(tile, geo, A.z, A.ld_z, n, A.C, 0.0);
 #pragma unroll
-  for (int j = 0; j < M; ++j) {
-    const int64_t i = i0 + j;
-    double av = 1.0, bv = 0.0;
-    if (i < n) {
-      av = 0.0;
-      for (int k = 0; k < nt; ++k) {
-        av = fma(sc[k], A.T.diag[k] ? A.T.diag[k][i] : 1.0, av);
-        if (A.T.off[k] && i < n - 1) bv = fma(sc[k], A.T.off[k][i], bv);
-      }
+    for (int j = 0; j < M; ++j) X[j] = crow[j];
+  } else if (A.zero_z) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) X[j] = 0.0;
+  } else {
+    // rolled loop through the lane's LDS row: the Philox + Box-Muller body is register-hungry and
+    // must not be software-pipelined across iterations by the unroller
+    const int64_t gc = A.chain_offset + cc;
+    const uint32_t blk0 = (uint32_t)(i0 >> 1);
+    wave_lds_fence();
+#pragma unroll 1
+    for (int jp = 0; jp < M / 2; ++jp) {
+      double z0, z1;
+      omc_normal_pair(omc_rng_block(A.key, gc, blk0 + (uint32_t)jp), z0, z1);
+      crow[2 * jp] = z0;
+      crow[2 * jp + 1] = z1;
     }
-    va[j] = av;
-    vb[j] = bv;
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < M; ++j) X[j] = crow[j];
   }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- conditional precision: b -> Y (registers), a -> LDS tile ----
+  tile_fill_comb<M, MULTI, COMB_OFF>(tile, geo, A, sc);
+#pragma unroll
+  for (int j = 0; j < M; ++j) Y[j] = crow[j];
+  double bm1 = 0.0;  // coupling b_{i0-1} into the segment
   if (i0 > 0 && i0 < n)
     for (int k = 0; k < nt; ++k)
       if (A.T.off[k]) bm1 = fma(sc[k], A.T.off[k][i0 - 1], bm1);
+  tile_fill_comb<M, MULTI, COMB_DIAG>(tile, geo, A, sc);
+  const double* arow = crow;
 
-  // ---- phase 1: Moebius product of the segment, scan -> incoming pivot ----
+  // ---- Moebius product of the segment, scan -> incoming pivot ----
   double Dst;
   {
     Mob m{1.0, 0.0, 0.0, 1.0};
     double bp = bm1;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      const double b2 = bp * bp;
-      const double na = fma(va[j], m.a, -b2 * m.c), nb = fma(va[j], m.b, -b2 * m.d);
+      const double b2 = bp * bp, aj = arow[j];
+      const double na = fma(aj, m.a, -b2 * m.c), nb = fma(aj, m.b, -b2 * m.d);
       m.c = m.a; m.d = m.b; m.a = na; m.b = nb;
-      bp = vb[j];
+      bp = Y[j];
       if ((j & 7) == 7) m = mob_norm(m);
     }
     m = mob_norm(m);
@@ -277,22 +458,23 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     Dst = (E.a + E.b) / (E.c + E.d);
   }
 
-  // ---- phase 3: true pivot recurrence, Newton multiple shooting on the segment joins ----
+  // ---- true pivot recurrence, Newton multiple shooting on the segment joins ----
   bool bad = false;
   double lin = 0.0;  // l_{i0-1}
   for (int it = 0;; ++it) {
+    wave_lds_fence();  // re-read a from LDS every pass instead of keeping a register copy
     const double rst = fast_rcp(Dst);
     lin = bm1 * rst;
     double lp = lin, bprev = bm1, J = 1.0, Dend = Dst;
     bool badp = false;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      const double D = fma(-lp, bprev, va[j]);
+      const double D = fma(-lp, bprev, arow[j]);
       badp |= !(D > 0.0);
       const double r = fast_rcp(D);
-      vr[j] = r;
+      W[j] = r;
       J *= lp * lp;
-      bprev = vb[j];
+      bprev = Y[j];
       lp = bprev * r;
       Dend = D;
     }
@@ -309,101 +491,94 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     const Aff ex = excl_scan<Aff, MULTI>(own, Aff{0.0, 1.0}, pos, Wd, false, lds_aff, wave, nw);
     Dst += fma(Jp, ex.p, e);  // delta_s = e_s + J_{s-1} delta_{s-1}
   }
-#pragma unroll
-  for (int j = 0; j < M; ++j) vb[j] *= vr[j];  // l_j = b_j / D_j
-
-  // ---- phase 4: right-hand side, forward substitution (local affine map + scan) ----
+  double logdet = 0.0;
 #pragma unroll
   for (int j = 0; j < M; ++j) {
-    const int64_t i = i0 + j;
-    double rv = 0.0;
-    if (i < n) {
-      for (int k = 0; k < nt; ++k)
-        if (A.T.rhs[k]) rv = fma(sc[k], A.T.rhs[k][i], rv);
-      if (A.rhs_chain) rv += A.rhs_chain[cc * A.ld_rhs + i];
-    }
-    va[j] = rv;
+    const double rD = bad ? 1.0 : W[j];
+    Y[j] *= W[j];               // l_j = b_j / D_j
+    X[j] *= fast_sqrt(rD);      // z_j / sqrt(D_j)
+    if (A.logdet && i0 + j < n) logdet -= log(rD);
   }
-  double ust;
+
+  // ---- right-hand side -> tile; forward substitution (local affine map, scan, true pass) ----
+  tile_fill_comb<M, MULTI, COMB_RHS>(tile, geo, A, sc);
   {
     Aff f{0.0, 1.0};
     double lp = lin;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      f.p = fma(-lp, f.p, va[j]);
+      f.p = fma(-lp, f.p, crow[j]);
       f.q = -lp * f.q;
-      lp = vb[j];
+      lp = Y[j];
     }
-    ust = excl_scan<Aff, MULTI>(f, Aff{0.0, 1.0}, pos, Wd, false, lds_aff, wave, nw).p;
+    double u = excl_scan<Aff, MULTI>(f, Aff{0.0, 1.0}, pos, Wd, false, lds_aff, wave, nw).p;
+    lp = lin;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      u = fma(-lp, u, crow[j]);
+      W[j] = fma(u, W[j], X[j]);  // g_j = u_j/D_j + z_j/sqrt(D_j)
+      lp = Y[j];
+    }
   }
 
-  // ---- phase 5: u, draws, g = u/D + z/sqrt(D);  local backward map + reverse scan ----
-  double logdet = 0.0;
-  {
-    double u = ust, lp = lin;
-    const int64_t gc = A.chain_offset + cc;
-#pragma unroll
-    for (int j = 0; j < M; j += 2) {
-      double z0, z1;
-      const int64_t i = i0 + j;
-      if (A.z) {
-        z0 = (i < n) ? A.z[cc * A.ld_z + i] : 0.0;
-        z1 = (i + 1 < n) ? A.z[cc * A.ld_z + i + 1] : 0.0;
-      } else if (A.zero_z) {
-        z0 = z1 = 0.0;
-      } else {
-        omc_normal_pair(omc_rng_block(A.key, gc, (uint32_t)(i >> 1)), z0, z1);
-      }
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const double rD = vr[j + jj];
-        u = fma(-lp, u, va[j + jj]);
-        vr[j + jj] = fma(u, rD, (jj ? z1 : z0) * sqrt(rD));
-        if (A.logdet && i + jj < n) logdet -= log(rD);
-        lp = vb[j + jj];
-      }
-    }
-  }
+  // ---- backward substitution: local affine map, reverse scan, true pass ----
   double xnext;
   {
     Aff f{0.0, 1.0};
 #pragma unroll
     for (int j = M - 1; j >= 0; --j) {
-      f.p = fma(-vb[j], f.p, vr[j]);
-      f.q = -vb[j] * f.q;
+      f.p = fma(-Y[j], f.p, W[j]);
+      f.q = -Y[j] * f.q;
     }
     xnext = excl_scan<Aff, MULTI>(f, Aff{0.0, 1.0}, pos, Wd, true, lds_aff, wave, nw).p;
-  }
-
-  // ---- phase 7: backward substitution, store, fused quadratic forms ----
-  double acc[OMC_MAX_TERMS] = {0, 0, 0, 0}, rnext[OMC_MAX_TERMS] = {0, 0, 0, 0};
-  if (A.quad && i0 + M < n)
-    for (int k = 0; k < nt; ++k) rnext[k] = xnext - (A.T.center[k] ? A.T.center[k][i0 + M] : 0.0);
-  {
     double x = xnext;
-    double* xo = A.x ? A.x + cc * A.ld_x : nullptr;
 #pragma unroll
     for (int j = M - 1; j >= 0; --j) {
-      const int64_t i = i0 + j;
-      x = fma(-vb[j], x, vr[j]);
-      if (i < n) {
-        if (xo && chain_ok) xo[i] = x;
-        if (A.quad) {
-          for (int k = 0; k < nt; ++k) {
-            const double r = x - (A.T.center[k] ? A.T.center[k][i] : 0.0);
-            const double dk = A.T.diag[k] ? A.T.diag[k][i] : 1.0;
-            const double ok = (A.T.off[k] && i < n - 1) ? A.T.off[k][i] : 0.0;
-            acc[k] = fma(dk * r, r, fma(2.0 * ok * r, rnext[k], acc[k]));
-            rnext[k] = r;
-          }
-        }
-      }
+      x = fma(-Y[j], x, W[j]);
+      W[j] = x;
     }
   }
-  if (A.quad) {
+  if (A.x) {
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < M; ++j) crow[j] = W[j];
+    tile_store_chain<M, MULTI>(tile, geo, A.x, A.ld_x, n, A.C);
+  }
+
+  // ---- fused quadratic forms (x - m_k)' M_k (x - m_k) ----
+  const bool want_quad = A.quad || A.fused;
+  double qsum[OMC_MAX_TERMS] = {0, 0, 0, 0};
+  if (want_quad) {
     for (int k = 0; k < nt; ++k) {
-      const double t = group_sum<MULTI>(acc[k], Wd, lds_d, wave, nw);
-      if (s == 0 && chain_ok) A.quad[k * A.C + c] = t;
+      // residual of this segment in X, residual of the next segment's first node in rn
+      double rn = 0.0;
+      if (A.T.center[k]) {
+        tile_fill_shared<M, MULTI>(tile, geo, A.T.center[k], n, 0.0);
+#pragma unroll
+        for (int j = 0; j < M; ++j) X[j] = W[j] - trow[j];
+        if (i0 + M < n) rn = xnext - A.T.center[k][i0 + M];
+      } else {
+#pragma unroll
+        for (int j = 0; j < M; ++j) X[j] = W[j];
+        if (i0 + M < n) rn = xnext;
+      }
+      double acc = 0.0;
+      if (A.T.diag[k]) {
+        tile_fill_shared<M, MULTI>(tile, geo, A.T.diag[k], n, 0.0);
+#pragma unroll
+        for (int j = 0; j < M; ++j) acc = fma(trow[j] * X[j], X[j], acc);
+      } else {
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+          if (i0 + j < n) acc = fma(X[j], X[j], acc);
+      }
+      if (A.T.off[k]) {
+        tile_fill_shared<M, MULTI>(tile, geo, A.T.off[k], n - 1, 0.0);
+#pragma unroll
+        for (int j = 0; j < M; ++j) acc = fma(2.0 * trow[j] * X[j], (j + 1 < M) ? X[(j + 1) % M] : rn, acc);
+      }
+      qsum[k] = group_sum<MULTI>(acc, Wd, lds_d, wave, nw);
+      if (A.quad && s == 0 && chain_ok) A.quad[k * A.C + c] = qsum[k];
     }
   }
   if (A.logdet) {
@@ -411,6 +586,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     if (s == 0 && chain_ok) A.logdet[c] = t;
   }
   if (bad && chain_ok) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
+  if (A.fused && s == 0 && chain_ok) sweep_epilogue(A, c, qsum);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -466,10 +642,45 @@ static bool terms_to_dev(const omc_tridiag_terms* t, TermsDev* d) {
   return true;
 }
 
+static void args_defaults(omc_ctx* ctx, TriArgs* A, int64_t n) {
+  A->n = n; A->C = ctx->n_chains; A->chain_offset = ctx->chain_offset;
+  A->rhs_chain = nullptr; A->ld_rhs = 0;
+  A->z = nullptr; A->ld_z = 0; A->zero_z = 0;
+  A->key = omc_make_key(ctx->seed, 0, OMC_RNG_NORMAL);
+  A->x = nullptr; A->ld_x = 0; A->quad = nullptr; A->logdet = nullptr;
+  A->bad = ctx->d_bad_chain;
+  A->work = nullptr;
+  A->fused = 0;
+  A->log_post = nullptr;
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+    A->gb[k].enabled = 0; A->gb[k].a0 = A->gb[k].b0 = A->gb[k].half_npos = A->gb[k].lnorm = 0.0;
+    A->gb[k].g_inject = nullptr; A->gb[k].store = nullptr; A->gb[k].scale_out = nullptr;
+    A->gb[k].logdet_unscaled = nullptr; A->gb[k].key = A->key;
+  }
+}
+
 static int pow2_ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;
   return p;
+}
+
+// nodes-per-lane variants: M -> (largest n, launch bound of the one-chain-per-workgroup form)
+template <int M> struct SegCfg;
+template <> struct SegCfg<8>  { static constexpr int MAXT = 1024; };
+template <> struct SegCfg<10> { static constexpr int MAXT = 1024; };
+template <> struct SegCfg<16> { static constexpr int MAXT = 640; };
+template <> struct SegCfg<20> { static constexpr int MAXT = 512; };
+template <> struct SegCfg<32> { static constexpr int MAXT = 512; };
+static int64_t seg_max_n(int seg) {
+  switch (seg) {
+    case 8: return 8 * 1024;
+    case 10: return 10 * 1024;
+    case 16: return 16 * 640;
+    case 20: return 20 * 512;
+    case 32: return 32 * 512;
+  }
+  return 0;
 }
 
 template <int M>
@@ -482,30 +693,43 @@ static void launch_seg(omc_ctx* ctx, const TriArgs& A) {
     hipLaunchKernelGGL((k_tridiag_seg<M, false, 256>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, G);
   } else {
     const int threads = 64 * ((S + 63) / 64);
-    constexpr int MAXT = (M == 8) ? 1024 : (M == 16 ? 640 : 512);
-    hipLaunchKernelGGL((k_tridiag_seg<M, true, MAXT>), dim3((unsigned)A.C), dim3(threads), 0, ctx->stream, A, threads);
+    hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT>), dim3((unsigned)A.C), dim3(threads), 0, ctx->stream,
+                       A, threads);
   }
 }
 
-// picks the kernel; returns false when no variant fits (caller reports OMC_UNSUPPORTED)
+static bool launch_seg_any(omc_ctx* ctx, const TriArgs& A, int seg) {
+  switch (seg) {
+    case 8: launch_seg<8>(ctx, A); return true;
+    case 10: launch_seg<10>(ctx, A); return true;
+    case 16: launch_seg<16>(ctx, A); return true;
+    case 20: launch_seg<20>(ctx, A); return true;
+    case 32: launch_seg<32>(ctx, A); return true;
+  }
+  return false;
+}
+
+static int auto_seg(int64_t n) {
+  if (n <= seg_max_n(16)) return 16;
+  return 32;
+}
+
 static omc_status launch_tridiag(omc_ctx* ctx, TriArgs& A) {
   int algo = ctx->tridiag_algo;
   int seg = ctx->tridiag_seg;
   const int64_t n = A.n;
-  if (algo == 0) algo = (n <= 16384) ? 2 : 1;
+  if (algo == 0) algo = (n <= seg_max_n(32)) ? 2 : 1;
   if (algo == 2) {
-    if (seg == 0) seg = (n <= 10240) ? 16 : 32;
-    const int64_t maxn = (seg == 8) ? 8192 : (seg == 16 ? 10240 : 16384);
-    if (n > maxn) {
+    if (seg == 0) seg = auto_seg(n);
+    if (n > seg_max_n(seg)) {
       if (ctx->tridiag_algo == 2) return OMC_UNSUPPORTED;
       algo = 1;
     }
   }
   if (algo == 2) {
-    if (seg == 8) launch_seg<8>(ctx, A);
-    else if (seg == 16) launch_seg<16>(ctx, A);
-    else launch_seg<32>(ctx, A);
+    if (!launch_seg_any(ctx, A, seg)) return OMC_INVALID_ARG;
   } else {
+    if (!A.x) return OMC_INVALID_ARG;
     const size_t need = (size_t)A.C * (size_t)n * sizeof(double);
     if (ctx->workspace_bytes < need) {
       OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -516,7 +740,6 @@ static omc_status launch_tridiag(omc_ctx* ctx, TriArgs& A) {
       ctx->workspace_bytes = need;
     }
     A.work = ctx->workspace;
-    if (!A.x) return OMC_INVALID_ARG;
     const int64_t grid = (A.C + 63) / 64;
     hipLaunchKernelGGL(k_tridiag_serial, dim3((unsigned)grid), dim3(64), 0, ctx->stream, A);
   }
@@ -533,21 +756,53 @@ omc_status omc_tridiag_sample_canonical(omc_ctx* ctx, int64_t n, const omc_tridi
   if (!ctx || n < 1 || !x_out || ld_x < n) return OMC_INVALID_ARG;
   if ((rhs_chain && ld_rhs < n) || (z_inject && ld_z < n) || (mean_out && ld_mean < n)) return OMC_INVALID_ARG;
   TriArgs A;
+  args_defaults(ctx, &A, n);
   if (!terms_to_dev(terms, &A.T)) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  A.n = n; A.C = ctx->n_chains; A.chain_offset = ctx->chain_offset;
   A.rhs_chain = rhs_chain; A.ld_rhs = ld_rhs;
   A.key = omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL);
-  A.bad = ctx->d_bad_chain;
-  A.work = nullptr;
   if (mean_out) {  // mu = Q^{-1} b is the same solve with z = 0 (gmrf.py:196)
-    A.z = nullptr; A.ld_z = 0; A.zero_z = 1;
-    A.x = mean_out; A.ld_x = ld_mean; A.quad = nullptr; A.logdet = nullptr;
+    A.zero_z = 1;
+    A.x = mean_out; A.ld_x = ld_mean;
     omc_status st = launch_tridiag(ctx, A);
     if (st != OMC_OK) return st;
   }
   A.z = z_inject; A.ld_z = ld_z; A.zero_z = 0;
   A.x = x_out; A.ld_x = ld_x; A.quad = quad_out; A.logdet = logdet_out;
+  return launch_tridiag(ctx, A);
+}
+
+omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms, const omc_gamma_block* blocks,
+                          const double* rhs_chain, int64_t ld_rhs, const double* z_inject, int64_t ld_z,
+                          uint64_t draw_index, double* x_out, int64_t ld_x, double* log_post_out) {
+  if (!ctx || n < 1 || !x_out || ld_x < n || !blocks) return OMC_INVALID_ARG;
+  if ((rhs_chain && ld_rhs < n) || (z_inject && ld_z < n)) return OMC_INVALID_ARG;
+  TriArgs A;
+  args_defaults(ctx, &A, n);
+  if (!terms_to_dev(terms, &A.T)) return OMC_INVALID_ARG;
+  for (int k = 0; k < A.T.n_terms; ++k) {
+    const omc_gamma_block& b = blocks[k];
+    GammaDev& g = A.gb[k];
+    g.enabled = b.enabled ? 1 : 0;
+    if (g.enabled) {
+      if (!terms->scale[k] || b.n_pos < 0 || !(b.a0 + 0.5 * (double)b.n_pos > 0.0)) return OMC_INVALID_ARG;
+      if (log_post_out && !(b.a0 > 0.0 && b.b0 > 0.0)) return OMC_INVALID_ARG;
+    }
+    if (log_post_out && !b.logdet_unscaled) return OMC_INVALID_ARG;
+    g.a0 = b.a0; g.b0 = b.b0; g.half_npos = 0.5 * (double)b.n_pos;
+    g.lnorm = (g.enabled && log_post_out) ? b.a0 * log(b.b0) - lgamma(b.a0) : 0.0;
+    g.g_inject = b.g_inject; g.store = b.store;
+    g.scale_out = const_cast<double*>(terms->scale[k]);
+    g.logdet_unscaled = b.logdet_unscaled;
+    g.key = omc_make_key(ctx->seed, draw_index + 1 + (uint64_t)k, OMC_RNG_GAMMA);
+  }
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  A.rhs_chain = rhs_chain; A.ld_rhs = ld_rhs;
+  A.z = z_inject; A.ld_z = ld_z;
+  A.key = omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL);
+  A.x = x_out; A.ld_x = ld_x;
+  A.fused = 1;
+  A.log_post = log_post_out;
   return launch_tridiag(ctx, A);
 }
 
@@ -576,23 +831,20 @@ omc_status omc_tridiag_matvec(omc_ctx* ctx, int64_t n, const double* diag, const
 
 omc_status omc_tridiag_logdet(omc_ctx* ctx, int64_t n, const double* diag, const double* off, double* logdet) {
   if (!ctx || n < 1 || !logdet) return OMC_INVALID_ARG;
+  if (n > seg_max_n(32)) return OMC_UNSUPPORTED;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   TriArgs A;
+  args_defaults(ctx, &A, n);
   for (int k = 0; k < OMC_MAX_TERMS; ++k)
     A.T.diag[k] = A.T.off[k] = A.T.rhs[k] = A.T.center[k] = A.T.scale[k] = nullptr;
   A.T.n_terms = 1;
   A.T.diag[0] = diag;
   A.T.off[0] = off;
-  A.n = n; A.C = 1; A.chain_offset = 0;
-  A.rhs_chain = nullptr; A.ld_rhs = 0;
-  A.z = nullptr; A.ld_z = 0; A.zero_z = 1;
-  A.key = omc_make_key(0, 0, OMC_RNG_NORMAL);
-  A.x = nullptr; A.ld_x = 0; A.quad = nullptr; A.logdet = logdet;
-  A.bad = ctx->d_bad_chain;
-  A.work = nullptr;
-  if (n > 16384) return OMC_UNSUPPORTED;
-  // the segmented kernel does not need x storage; force it regardless of the algo option
-  if (n <= 10240) launch_seg<16>(ctx, A); else launch_seg<32>(ctx, A);
+  A.C = 1; A.chain_offset = 0;
+  A.zero_z = 1;
+  A.logdet = logdet;
+  // the segmented kernel needs no x storage; use it regardless of the algo option
+  launch_seg_any(ctx, A, auto_seg(n));
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

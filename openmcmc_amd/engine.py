@@ -141,6 +141,34 @@ class Engine:
             self._p(x_out, Cn, n), ld(x_out), self._p(mean_out, Cn, n), ld(mean_out),
             self._p(quad_out), self._chain_scalar(logdet_out)))
 
+    def gamma_blocks(self, blocks, n_terms):
+        """blocks: list (one per term) of None or dict(a0, b0, n_pos, g=None, store=None, logdet=None)."""
+        arr = (_abi.GammaBlock * _abi.OMC_MAX_TERMS)()
+        keep = []
+        for k in range(n_terms):
+            b = blocks[k] if k < len(blocks) else None
+            if b is None:
+                continue
+            arr[k].enabled = int(b.get("enabled", True))
+            arr[k].a0, arr[k].b0, arr[k].n_pos = float(b.get("a0", 0.0)), float(b.get("b0", 0.0)), int(b.get("n_pos", 0))
+            arr[k].g_inject = self._chain_scalar(b.get("g"))
+            arr[k].store = self._chain_scalar(b.get("store"))
+            arr[k].logdet_unscaled = self._p(b.get("logdet"))
+            keep.append(dict(b))
+        arr._keep = keep
+        return arr
+
+    def gmrf_sweep(self, n, terms, blocks, x_out, z=None, rhs_chain=None, draw_index=0, log_post_out=None):
+        """One fused sweep [NormalNormal(x), NormalGamma(scale_k)..., log_post]; the precision scalars
+        of enabled blocks (terms[k]["scale"]) are updated in place."""
+        T = terms if isinstance(terms, _abi.TridiagTerms) else self.tridiag_terms(terms, n)
+        B = blocks if not isinstance(blocks, (list, tuple)) else self.gamma_blocks(blocks, T.n_terms)
+        Cn = self.n_chains
+        ld = lambda t: 0 if t is None else t.stride(0)  # noqa: E731
+        check(lib.omc_gmrf_sweep(self._ctx, n, C.byref(T), B, self._p(rhs_chain, Cn, n), ld(rhs_chain),
+                                 self._p(z, Cn, n), ld(z), int(draw_index), self._p(x_out, Cn, n), ld(x_out),
+                                 self._chain_scalar(log_post_out)))
+
     def tridiag_quadform(self, n, terms, x, quad_out):
         T = terms if isinstance(terms, _abi.TridiagTerms) else self.tridiag_terms(terms, n)
         check(lib.omc_tridiag_quadform(self._ctx, n, C.byref(T), self._p(x, self.n_chains, n), x.stride(0),

@@ -108,7 +108,7 @@ def test_golden_primitives(torch, golden, n):
     """Reference vectors: x, mu and the factor diagonal (through log det) for the golden (lam, tau)."""
     G = golden("tridiag_primitives")
     k = f"n{n}_"
-    for algo, seg in ((1, 0), (2, 8), (2, 16), (2, 32)):
+    for algo, seg in ((1, 0), (2, 8), (2, 10), (2, 16), (2, 20), (2, 32)):
         eng = make_engine(2)
         eng.set_option("tridiag_algo", algo)
         eng.set_option("tridiag_seg", seg)
@@ -129,7 +129,7 @@ def test_golden_primitives(torch, golden, n):
         eng.close()
 
 
-@pytest.mark.parametrize("algo,seg", [(1, 0), (2, 8), (2, 16), (2, 32)])
+@pytest.mark.parametrize("algo,seg", [(1, 0), (2, 8), (2, 10), (2, 16), (2, 20), (2, 32)])
 @pytest.mark.parametrize("n,C", [(1, 3), (2, 5), (7, 1), (15, 3), (16, 3), (17, 70), (33, 3), (100, 200),
                                  (512, 3), (1000, 9), (1025, 2), (4097, 3)])
 def test_random_vs_oracle(torch, algo, seg, n, C):
@@ -137,7 +137,7 @@ def test_random_vs_oracle(torch, algo, seg, n, C):
     assert run_case(torch, n, C, algo, seg, rng) < TOL
 
 
-@pytest.mark.parametrize("algo,seg,n", [(1, 0, 10000), (2, 16, 10000), (2, 32, 10000), (2, 8, 8000), (2, 32, 16384),
+@pytest.mark.parametrize("algo,seg,n", [(1, 0, 10000), (2, 16, 10000), (2, 10, 10000), (2, 20, 10000), (2, 32, 10000), (2, 8, 8000), (2, 32, 16384),
                                         (0, 0, 5000), (0, 0, 20000)])
 def test_long_chains(torch, algo, seg, n):
     rng = np.random.default_rng(n + seg)
@@ -145,7 +145,7 @@ def test_long_chains(torch, algo, seg, n):
 
 
 @pytest.mark.parametrize("lam_tau,tol", [((1e4, 1.0), 1e-10), ((1e6, 1.0), 1e-8), ((1.0, 1e3), 1e-10), ((1e-3, 1.0), 1e-10)])
-@pytest.mark.parametrize("seg", [8, 16, 32])
+@pytest.mark.parametrize("seg", [8, 10, 16, 20, 32])
 def test_weak_and_strong_coupling(torch, seg, lam_tau, tol):
     """lam/tau large = weakly contractive pivot recurrence: forces the Newton join-correction
     branch of the segmented kernel.  Tolerance widens with cond(Q) ~ 4 lam/tau (the oracle itself
@@ -307,3 +307,81 @@ def test_bench_size_properties(torch):
     assert (x2 - 2 * x1).abs().max().item() / scale < TOL
     eng.check_status()
     eng.close()
+
+
+@pytest.mark.parametrize("route", ["sparse", "sparsemu"])
+@pytest.mark.parametrize("algo", [1, 2])
+def test_fused_sweep_golden(torch, golden, route, algo):
+    """The same replay through omc_gmrf_sweep: one launch per sweep does the draw, both
+    Normal-Gamma updates, the store writes and log_post."""
+    G = golden("gmrf_chain")
+    k = route + "_"
+    n, n_burn, n_iter = int(G[k + "n"]), int(G[k + "n_burn"]), int(G[k + "n_iter"])
+    C = 3
+    eng = make_engine(C)
+    eng.set_option("tridiag_algo", algo)
+    d_pd, d_po = eng.to_device(G[k + "P_diag"]), eng.to_device(G[k + "P_off"])
+    d_y, d_mu = eng.to_device(G[k + "y"]), eng.full((n,), float(G[k + "mu_val"]))
+    lam, tau = eng.to_device(np.array([100.0, 37.0, 100.0])), eng.to_device(np.array([1.0, 2.5, 1.0]))
+    Pmu = eng.tridiag_matvec(n, d_pd, d_po, d_mu)
+    terms = eng.tridiag_terms([{"diag": d_pd, "off": d_po, "rhs": Pmu, "center": d_mu, "scale": lam},
+                               {"rhs": d_y, "center": d_y, "scale": tau}], n)
+    logdetP, logdetI = eng.tridiag_logdet(n, d_pd, d_po), eng.zeros(1)
+    store_b, store_lam = eng.empty(n_iter, C, n), eng.empty(n_iter, C)
+    store_tau, store_lp = eng.empty(n_iter, C), eng.empty(n_iter, C)
+    scratch = eng.empty(C, n)
+    for it in range(n_burn + n_iter):
+        j = it - n_burn
+        g = G[k + "g"][it]
+        blocks = [{"a0": 10.0, "b0": 1.0, "n_pos": n, "g": eng.full((C,), g[0]), "logdet": logdetP,
+                   "store": store_lam[j] if j >= 0 else None},
+                  {"a0": 1.0, "b0": 1.0, "n_pos": n, "g": eng.full((C,), g[1]), "logdet": logdetI,
+                   "store": store_tau[j] if j >= 0 else None}]
+        eng.gmrf_sweep(n, terms, blocks, store_b[j] if j >= 0 else scratch,
+                       z=eng.to_device(np.tile(G[k + "z"][it], (C, 1))),
+                       log_post_out=store_lp[j] if j >= 0 else None)
+    eng.check_status()
+    for c in (0, 2):
+        assert relerr(store_b[:, c, :].cpu().numpy().T, G[k + "store_b"]) < TOL
+        assert relerr(store_lam[:, c].cpu().numpy(), G[k + "store_lambda"].ravel()) < TOL
+        assert relerr(store_tau[:, c].cpu().numpy(), G[k + "store_tau"].ravel()) < TOL
+        assert relerr(store_lp[:, c].cpu().numpy(), G[k + "store_log_post"].ravel()) < TOL
+    eng.close()
+
+
+@pytest.mark.parametrize("n,C,seg", [(700, 5, 0), (10000, 64, 16), (10000, 64, 20), (10000, 64, 10), (37, 130, 0)])
+def test_fused_equals_unfused(torch, n, C, seg):
+    """omc_gmrf_sweep == omc_tridiag_sample_canonical + 2x omc_normal_gamma_update + the log-density
+    pieces, bit for bit, with the in-kernel random streams (same draw indices)."""
+    rng = np.random.default_rng(n)
+    pd, po = rw1(n)
+    y = rng.standard_normal(n) + 2
+    out = []
+    for fused in (False, True):
+        eng = make_engine(C, seed=9)
+        eng.set_option("tridiag_seg", seg)
+        d_pd, d_po, d_y = eng.to_device(pd), eng.to_device(po), eng.to_device(y)
+        lam, tau = eng.to_device(80 + np.arange(C) * 0.5), eng.full((C,), 1.25)
+        terms = eng.tridiag_terms([{"diag": d_pd, "off": d_po, "scale": lam},
+                                   {"rhs": d_y, "center": d_y, "scale": tau}], n)
+        logdetP, logdetI = eng.tridiag_logdet(n, d_pd, d_po), eng.zeros(1)
+        x, lp, quad = eng.empty(C, n), eng.empty(C), eng.empty(2, C)
+        for it in range(3):
+            if fused:
+                blocks = [{"a0": 10.0, "b0": 1.0, "n_pos": n, "logdet": logdetP},
+                          {"a0": 1.0, "b0": 1.0, "n_pos": n, "logdet": logdetI}]
+                eng.gmrf_sweep(n, terms, blocks, x, draw_index=3 * it, log_post_out=lp)
+            else:
+                eng.tridiag_sample_canonical(n, terms, x, draw_index=3 * it, quad_out=quad)
+                eng.normal_gamma_update(10.0, 1.0, n, quad[0], lam, draw_index=3 * it + 1)
+                eng.normal_gamma_update(1.0, 1.0, n, quad[1], tau, draw_index=3 * it + 2)
+                eng.scaled_gauss_logpdf(n, tau, logdetI, quad[1], lp)
+                eng.scaled_gauss_logpdf(n, lam, logdetP, quad[0], lp, accumulate=True)
+                eng.gamma_logpdf(lam, 10.0, 1.0, lp, accumulate=True)
+                eng.gamma_logpdf(tau, 1.0, 1.0, lp, accumulate=True)
+        eng.check_status()
+        out.append([t.cpu().numpy().copy() for t in (x, lam, tau, lp)])
+        eng.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert relerr(out[1][3], out[0][3]) < 1e-13  # log_post: summation order of the four terms differs
