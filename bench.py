@@ -107,7 +107,7 @@ class GmrfSweep:
         if kernel_events is not None:
             kernel_events[0].record()
         eng.gmrf_sweep(n, self.terms, blocks, self.store_b[slot], z=None, draw_index=3 * it,
-                       log_post_out=self.store_lp[slot])
+                       log_post_out=self.store_lp[slot], gamma_draw_base=3 * it + 1)
         if kernel_events is not None:
             kernel_events[1].record()
         self.it += 1

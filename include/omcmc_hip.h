@@ -108,7 +108,7 @@ omc_status omc_tridiag_sample_canonical(omc_ctx* ctx, int64_t n, const omc_tridi
  *   1. x_c ~ N(Q_c^{-1} b_c, Q_c^{-1})                      (as omc_tridiag_sample_canonical)
  *   2. for every term k with blocks[k].enabled: scale[k][c] ~ Gamma(a0 + n_pos/2,
  *      rate = b0 + quad_k/2), written IN PLACE into terms->scale[k] (and to blocks[k].store)
- *      (as omc_normal_gamma_update with draw_index + 1 + k);
+ *      (as omc_normal_gamma_update with blocks[k].draw_index);
  *   3. log_post_out[c] = sum_k log N(. ; center_k, (scale_k M_k)^{-1}) + sum_{k enabled}
  *      log Gamma(scale_k; a0, b0) with the NEW scales (model.py:57-70), if log_post_out != NULL;
  *      needs blocks[k].logdet_unscaled = device scalar log det M_k for every term.
@@ -118,6 +118,7 @@ typedef struct {
   double a0, b0;                  /* Gamma prior shape, rate (sampler.py:278-279)               */
   int64_t n_pos;                  /* #{diag(M_k) > 0}  (sampler.py:283)                         */
   const double* g_inject;         /* [C] injected Gamma(a,1) draws, or NULL                     */
+  uint64_t draw_index;            /* keys this block's gamma stream when g_inject == NULL       */
   double* store;                  /* [C] optional copy of the new scale (store[param]), or NULL */
   const double* logdet_unscaled;  /* device scalar log det M_k; NULL allowed iff no log_post    */
 } omc_gamma_block;

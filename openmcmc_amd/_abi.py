@@ -42,6 +42,7 @@ class GammaBlock(C.Structure):
         ("b0", C.c_double),
         ("n_pos", i64),
         ("g_inject", c_dp),
+        ("draw_index", u64),
         ("store", c_dp),
         ("logdet_unscaled", c_dp),
     ]

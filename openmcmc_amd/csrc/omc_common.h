@@ -83,14 +83,68 @@ __device__ __forceinline__ double omc_u53(uint32_t lo, uint32_t hi) {
   return 0x1.0p-53 + (double)v * 0x1.0p-53;
 }
 
-// One Philox block -> two independent N(0,1) (Box-Muller, fp64).
+// ---- lean fp64 elementary functions for the Box-Muller transform -------------------------------
+// The generic libm entry points carry range/special-case handling the transform never needs
+// (u in (0,1], angle in (0,2]); these restate the classic fdlibm kernels (e_log.c, k_sin.c,
+// k_cos.c: argument reduction + minimax polynomial, < 1 ulp) for exactly those domains.
+__device__ __forceinline__ double omc_rcp_nr(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  return fma(r, e, r);
+}
+__device__ __forceinline__ double omc_sqrt_nr(double r) {  // r > 0, normal range
+  const double g = __builtin_amdgcn_rsq(r);
+  double s = r * g;
+  const double h = 0.5 * g;
+  double e = fma(-s, s, r);
+  s = fma(e, h, s);
+  e = fma(-s, s, r);
+  return fma(e, h, s);
+}
+// log(u), 2^-53 <= u <= 1
+__device__ __forceinline__ double omc_log_unit(double u) {
+  int k = __builtin_amdgcn_frexp_exp(u);        // u = m * 2^k, m in [0.5, 1)
+  double m = __builtin_amdgcn_frexp_mant(u);
+  if (m < 0.70710678118654752440) { m *= 2.0; k -= 1; }
+  const double f = m - 1.0;
+  const double s = f * omc_rcp_nr(2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                   2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+// sin(pi a), cos(pi a) for 0 < a <= 2
+__device__ __forceinline__ void omc_sincospi02(double a, double& sn, double& cs) {
+  const double n = rint(2.0 * a);               // 0..4 quarter turns
+  const double t = fma(-0.5, n, a) * 3.14159265358979311600e+00;  // |t| <= pi/4, reduction exact
+  const double z = t * t;
+  const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                      2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                        8.33333333332248946124e-03);
+  const double s0 = fma(z * t, fma(z, ps, -1.66666666666666324348e-01), t);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                             -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                               -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int q = (int)n & 3;
+  const double sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;
+  sn = (q == 2 || q == 3) ? -sa : sa;
+  cs = (q == 1 || q == 2) ? -ca : ca;
+}
+
+// One Philox block -> two independent N(0,1) (Box-Muller, fp64; same word->uniform mapping as
+// rocRAND's box_muller_double).
 __device__ __forceinline__ void omc_normal_pair(uint4 w, double& n0, double& n1) {
-  double u = omc_u53(w.x, w.y);
-  unsigned long long v2 = (unsigned long long)w.z ^ ((unsigned long long)w.w << 21);
-  double ang = 0x1.0p-52 + (double)v2 * 0x1.0p-52;  // (0, 2]
-  double s = sqrt(-2.0 * log(u));
+  const double u = omc_u53(w.x, w.y);
+  const unsigned long long v2 = (unsigned long long)w.z ^ ((unsigned long long)w.w << 21);
+  const double ang = 0x1.0p-52 + (double)v2 * 0x1.0p-52;  // (0, 2]
+  const double s = omc_sqrt_nr(fmax(-2.0 * omc_log_unit(u), 1e-300));  // u == 1 -> radius 0, not NaN
   double sn, cs;
-  sincospi(ang, &sn, &cs);
+  omc_sincospi02(ang, sn, cs);
   n0 = sn * s;
   n1 = cs * s;
 }

@@ -70,14 +70,7 @@ struct TriArgs {
   double* log_post;
 };
 
-__device__ __forceinline__ double fast_rcp(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  double e = fma(-d, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-d, r, 1.0);
-  r = fma(r, e, r);
-  return r;
-}
+__device__ __forceinline__ double fast_rcp(double d) { return omc_rcp_nr(d); }
 
 // Normal-Gamma updates + log_post of one chain, run by one lane (sampler.py:252-288, model.py:57-70)
 __device__ __forceinline__ void sweep_epilogue(const TriArgs& A, int64_t c, const double* quad) {
@@ -255,6 +248,114 @@ __device__ __forceinline__ double group_sum(double v, int Wd, double* lds, int w
 }
 
 // ------------------------------------------------------------------------------------------
+// Full-wave (64 lanes = 64 consecutive segments of one chain) scans on DPP lane shifts: a shift is
+// one v_mov_dpp per 32-bit word instead of a ds_bpermute round trip.  Lanes without a source
+// receive the identity, so no lane needs a conditional.
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_SHL(n) (0x100 + (n))
+#define DPP_WAVE_SHL1 0x130
+#define DPP_WAVE_SHR1 0x138
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v, double fill) {
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), CTRL, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ Mob dpp_mov(const Mob& v, const Mob& f) {
+  return Mob{dpp_mov<CTRL>(v.a, f.a), dpp_mov<CTRL>(v.b, f.b), dpp_mov<CTRL>(v.c, f.c), dpp_mov<CTRL>(v.d, f.d)};
+}
+template <int CTRL> __device__ __forceinline__ Aff dpp_mov(const Aff& v, const Aff& f) {
+  return Aff{dpp_mov<CTRL>(v.p, f.p), dpp_mov<CTRL>(v.q, f.q)};
+}
+__device__ __forceinline__ double read_lane(double v, int l) {  // l must be wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ Mob read_lane(const Mob& v, int l) {
+  return Mob{read_lane(v.a, l), read_lane(v.b, l), read_lane(v.c, l), read_lane(v.d, l)};
+}
+__device__ __forceinline__ Aff read_lane(const Aff& v, int l) { return Aff{read_lane(v.p, l), read_lane(v.q, l)}; }
+
+// inclusive scan inside each row of 16 lanes, forward (REV = false) or from the high lane down
+template <class T, bool REV>
+__device__ __forceinline__ T row_scan(T v, const T& id) {
+  if (!REV) {
+    v = compose(v, dpp_mov<DPP_ROW_SHR(1)>(v, id));
+    v = compose(v, dpp_mov<DPP_ROW_SHR(2)>(v, id));
+    v = compose(v, dpp_mov<DPP_ROW_SHR(4)>(v, id));
+    v = compose(v, dpp_mov<DPP_ROW_SHR(8)>(v, id));
+  } else {
+    v = compose(v, dpp_mov<DPP_ROW_SHL(1)>(v, id));
+    v = compose(v, dpp_mov<DPP_ROW_SHL(2)>(v, id));
+    v = compose(v, dpp_mov<DPP_ROW_SHL(4)>(v, id));
+    v = compose(v, dpp_mov<DPP_ROW_SHL(8)>(v, id));
+  }
+  return v;
+}
+
+// Exclusive scan over all lanes of the workgroup (one chain), in segment order or reversed.
+// `lds` holds one entry per wave.  Every lane of the block must call it.
+template <class T, bool REV>
+__device__ __forceinline__ T excl_scan_wg(T v, const T id, T* lds, int lane, int wave, int nw) {
+  v = row_scan<T, REV>(v, id);
+  // row totals sit in the last (first) lane of each row; fold the preceding rows in
+  const int row = lane >> 4;
+  T pre = id;
+  if (!REV) {
+    const T t0 = read_lane(v, 15), t1 = read_lane(v, 31), t2 = read_lane(v, 47);
+    const T p2 = compose(t1, t0), p3 = compose(t2, p2);
+    pre = row == 1 ? t0 : (row == 2 ? p2 : (row == 3 ? p3 : id));
+  } else {
+    const T t3 = read_lane(v, 48), t2 = read_lane(v, 32), t1 = read_lane(v, 16);
+    const T p1 = compose(t2, t3), p0 = compose(t1, p1);
+    pre = row == 2 ? t3 : (row == 1 ? p1 : (row == 0 ? p0 : id));
+  }
+  v = compose(v, pre);
+  T e = REV ? dpp_mov<DPP_WAVE_SHL1>(v, id) : dpp_mov<DPP_WAVE_SHR1>(v, id);
+  if (nw > 1) {
+    if (lane == (REV ? 0 : 63)) lds[wave] = v;  // wave total
+    __syncthreads();
+    T t = (lane < nw) ? lds[lane] : id;        // nw <= 16: one row
+    t = row_scan<T, REV>(t, id);
+    const int w = __builtin_amdgcn_readfirstlane(wave);
+    const int src = REV ? w + 1 : w - 1;
+    if (src >= 0 && src < nw) e = compose(e, read_lane(t, src));
+    __syncthreads();
+  }
+  return e;
+}
+
+// previous segment's (v0, v1); (id0, id1) for the first segment of the chain
+__device__ __forceinline__ void prev_lane2_wg(double& v0, double& v1, double id0, double id1, double* lds, int lane,
+                                              int wave, int nw) {
+  double a = dpp_mov<DPP_WAVE_SHR1>(v0, id0), b = dpp_mov<DPP_WAVE_SHR1>(v1, id1);
+  if (nw > 1) {
+    if (lane == 63) { lds[2 * wave] = v0; lds[2 * wave + 1] = v1; }
+    __syncthreads();
+    if (lane == 0 && wave > 0) { a = lds[2 * (wave - 1)]; b = lds[2 * (wave - 1) + 1]; }
+    __syncthreads();
+  }
+  v0 = a; v1 = b;
+}
+
+__device__ __forceinline__ double sum_wg(double v, double* lds, int lane, int wave, int nw) {
+  v += dpp_mov<DPP_ROW_SHR(1)>(v, 0.0);
+  v += dpp_mov<DPP_ROW_SHR(2)>(v, 0.0);
+  v += dpp_mov<DPP_ROW_SHR(4)>(v, 0.0);
+  v += dpp_mov<DPP_ROW_SHR(8)>(v, 0.0);
+  double t = (read_lane(v, 15) + read_lane(v, 31)) + (read_lane(v, 47) + read_lane(v, 63));
+  if (nw > 1) {
+    if (lane == 0) lds[wave] = t;
+    __syncthreads();
+    double u = 0.0;
+    for (int w = 0; w < nw; ++w) u += lds[w];
+    __syncthreads();
+    t = u;
+  }
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------
 // Wave-private LDS tile: converts between "lane owns M consecutive nodes" (registers) and
 // "64 consecutive lanes touch 64 consecutive doubles" (global memory).  Tile element e
 // (0 <= e < 64*M; e = lane'*M + j) lives at tile[e + e/M]: row stride M+1 doubles, so the
@@ -347,16 +448,7 @@ __device__ __forceinline__ void tile_fill_comb(double* tile, const Geom<M, MULTI
   wave_lds_fence();
 }
 
-__device__ __forceinline__ double fast_sqrt(double r) {  // r > 0, normal range
-  const double g = __builtin_amdgcn_rsq(r);
-  double s = r * g;
-  const double h = 0.5 * g;
-  double e = fma(-s, s, r);
-  s = fma(e, h, s);
-  e = fma(-s, s, r);
-  s = fma(e, h, s);
-  return s;
-}
+__device__ __forceinline__ double fast_sqrt(double r) { return omc_sqrt_nr(r); }
 
 #define OMC_NEWTON_TOL 4e-15
 #define OMC_NEWTON_MAX 4
@@ -454,7 +546,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       if ((j & 7) == 7) m = mob_norm(m);
     }
     m = mob_norm(m);
-    const Mob E = excl_scan<Mob, MULTI>(m, Mob{1.0, 0.0, 0.0, 1.0}, pos, Wd, false, lds_mob, wave, nw);
+    const Mob idm{1.0, 0.0, 0.0, 1.0};
+    const Mob E = MULTI ? excl_scan_wg<Mob, false>(m, idm, lds_mob, lane, wave, nw)
+                        : excl_scan<Mob, false>(m, idm, pos, Wd, false, lds_mob, wave, nw);
     Dst = (E.a + E.b) / (E.c + E.d);
   }
 
@@ -480,7 +574,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     }
     bad = badp;
     double Dp = Dend, Jp = J;
-    prev_lane2<MULTI>(Dp, Jp, Dst, 0.0, pos, Wd, lds_d, wave);
+    if (MULTI) prev_lane2_wg(Dp, Jp, Dst, 0.0, lds_d, lane, wave, nw);
+    else prev_lane2<false>(Dp, Jp, Dst, 0.0, pos, Wd, lds_d, wave);
     const bool joined = (s > 0 && i0 < n);
     const double e = joined ? (Dp - Dst) : 0.0;
     if (!joined) Jp = 0.0;
@@ -488,7 +583,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     const int any = MULTI ? __syncthreads_or(need) : (__ballot(need) != 0ull);
     if (!any || it >= OMC_NEWTON_MAX) break;
     const Aff own{e, Jp};
-    const Aff ex = excl_scan<Aff, MULTI>(own, Aff{0.0, 1.0}, pos, Wd, false, lds_aff, wave, nw);
+    const Aff ex = MULTI ? excl_scan_wg<Aff, false>(own, Aff{0.0, 1.0}, lds_aff, lane, wave, nw)
+                          : excl_scan<Aff, false>(own, Aff{0.0, 1.0}, pos, Wd, false, lds_aff, wave, nw);
     Dst += fma(Jp, ex.p, e);  // delta_s = e_s + J_{s-1} delta_{s-1}
   }
   double logdet = 0.0;
@@ -511,7 +607,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       f.q = -lp * f.q;
       lp = Y[j];
     }
-    double u = excl_scan<Aff, MULTI>(f, Aff{0.0, 1.0}, pos, Wd, false, lds_aff, wave, nw).p;
+    double u = (MULTI ? excl_scan_wg<Aff, false>(f, Aff{0.0, 1.0}, lds_aff, lane, wave, nw)
+                      : excl_scan<Aff, false>(f, Aff{0.0, 1.0}, pos, Wd, false, lds_aff, wave, nw)).p;
     lp = lin;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
@@ -530,7 +627,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       f.p = fma(-Y[j], f.p, W[j]);
       f.q = -Y[j] * f.q;
     }
-    xnext = excl_scan<Aff, MULTI>(f, Aff{0.0, 1.0}, pos, Wd, true, lds_aff, wave, nw).p;
+    xnext = (MULTI ? excl_scan_wg<Aff, true>(f, Aff{0.0, 1.0}, lds_aff, lane, wave, nw)
+                   : excl_scan<Aff, false>(f, Aff{0.0, 1.0}, pos, Wd, true, lds_aff, wave, nw)).p;
     double x = xnext;
 #pragma unroll
     for (int j = M - 1; j >= 0; --j) {
@@ -538,6 +636,54 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       W[j] = x;
     }
   }
+  const bool want_quad = A.quad || A.fused;
+  double qsum[OMC_MAX_TERMS] = {0, 0, 0, 0};
+  if (MULTI) {
+    // ---- store + fused quadratic forms, both in the coalesced mapping: lane handles nodes
+    //      wbase + t*64 + lane; x comes back from the tile, the shared vectors straight from L2 ----
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < M; ++j) crow[j] = W[j];
+    if (want_quad) __syncthreads();  // the last element of a wave needs the next wave's first x
+    else wave_lds_fence();
+    const int64_t wbase = (int64_t)wave * 64 * M;
+    double* xo = (A.x && chain_ok) ? A.x + cc * A.ld_x : nullptr;
+    double acc[OMC_MAX_TERMS] = {0, 0, 0, 0};
+    int e = lane, q = lane / M, r = lane % M;  // tile element, e / M, e % M
+#pragma unroll 2
+    for (int t = 0; t < M; ++t) {
+      const int64_t i = wbase + e;
+      const double xi = tile[e + q];
+      if (i < n) {
+        if (xo) xo[i] = xi;
+        if (want_quad) {
+          double xn = 0.0;  // x_{i+1}
+          if (i + 1 < n) {
+            int e1 = e + 1, q1 = (r + 1 == M) ? q + 1 : q;
+            xn = (e1 < 64 * M) ? tile[e1 + q1] : lds_tile[wave + 1][0];
+          }
+          for (int k = 0; k < nt; ++k) {
+            const double* ck = A.T.center[k];
+            const double ri = xi - (ck ? ck[i] : 0.0);
+            double a2 = (A.T.diag[k] ? A.T.diag[k][i] : 1.0) * ri;
+            if (A.T.off[k] && i + 1 < n) {
+              const double rn = xn - (ck ? ck[i + 1] : 0.0);
+              a2 = fma(2.0 * A.T.off[k][i], rn, a2);
+            }
+            acc[k] = fma(a2, ri, acc[k]);
+          }
+        }
+      }
+      e += 64; q += 64 / M; r += 64 % M;
+      if (r >= M) { r -= M; ++q; }
+    }
+    if (want_quad) {
+      for (int k = 0; k < nt; ++k) {
+        qsum[k] = sum_wg(acc[k], lds_d, lane, wave, nw);
+        if (A.quad && s == 0 && chain_ok) A.quad[k * A.C + c] = qsum[k];
+      }
+    }
+  } else {
   if (A.x) {
     wave_lds_fence();
 #pragma unroll
@@ -545,9 +691,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     tile_store_chain<M, MULTI>(tile, geo, A.x, A.ld_x, n, A.C);
   }
 
-  // ---- fused quadratic forms (x - m_k)' M_k (x - m_k) ----
-  const bool want_quad = A.quad || A.fused;
-  double qsum[OMC_MAX_TERMS] = {0, 0, 0, 0};
+  // ---- fused quadratic forms (x - m_k)' M_k (x - m_k), segment-local form ----
   if (want_quad) {
     for (int k = 0; k < nt; ++k) {
       // residual of this segment in X, residual of the next segment's first node in rn
@@ -577,12 +721,13 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 #pragma unroll
         for (int j = 0; j < M; ++j) acc = fma(2.0 * trow[j] * X[j], (j + 1 < M) ? X[(j + 1) % M] : rn, acc);
       }
-      qsum[k] = group_sum<MULTI>(acc, Wd, lds_d, wave, nw);
+      qsum[k] = group_sum<false>(acc, Wd, lds_d, wave, nw);
       if (A.quad && s == 0 && chain_ok) A.quad[k * A.C + c] = qsum[k];
     }
   }
+  }
   if (A.logdet) {
-    const double t = group_sum<MULTI>(logdet, Wd, lds_d, wave, nw);
+    const double t = MULTI ? sum_wg(logdet, lds_d, lane, wave, nw) : group_sum<false>(logdet, Wd, lds_d, wave, nw);
     if (s == 0 && chain_ok) A.logdet[c] = t;
   }
   if (bad && chain_ok) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
@@ -794,7 +939,7 @@ omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* term
     g.g_inject = b.g_inject; g.store = b.store;
     g.scale_out = const_cast<double*>(terms->scale[k]);
     g.logdet_unscaled = b.logdet_unscaled;
-    g.key = omc_make_key(ctx->seed, draw_index + 1 + (uint64_t)k, OMC_RNG_GAMMA);
+    g.key = omc_make_key(ctx->seed, b.draw_index, OMC_RNG_GAMMA);
   }
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   A.rhs_chain = rhs_chain; A.ld_rhs = ld_rhs;

@@ -152,17 +152,22 @@ class Engine:
             arr[k].enabled = int(b.get("enabled", True))
             arr[k].a0, arr[k].b0, arr[k].n_pos = float(b.get("a0", 0.0)), float(b.get("b0", 0.0)), int(b.get("n_pos", 0))
             arr[k].g_inject = self._chain_scalar(b.get("g"))
+            arr[k].draw_index = int(b.get("draw_index", 0))
             arr[k].store = self._chain_scalar(b.get("store"))
             arr[k].logdet_unscaled = self._p(b.get("logdet"))
             keep.append(dict(b))
         arr._keep = keep
         return arr
 
-    def gmrf_sweep(self, n, terms, blocks, x_out, z=None, rhs_chain=None, draw_index=0, log_post_out=None):
+    def gmrf_sweep(self, n, terms, blocks, x_out, z=None, rhs_chain=None, draw_index=0, log_post_out=None,
+                   gamma_draw_base=None):
         """One fused sweep [NormalNormal(x), NormalGamma(scale_k)..., log_post]; the precision scalars
         of enabled blocks (terms[k]["scale"]) are updated in place."""
         T = terms if isinstance(terms, _abi.TridiagTerms) else self.tridiag_terms(terms, n)
         B = blocks if not isinstance(blocks, (list, tuple)) else self.gamma_blocks(blocks, T.n_terms)
+        if gamma_draw_base is not None:  # block k draws from stream gamma_draw_base + k
+            for k in range(T.n_terms):
+                B[k].draw_index = int(gamma_draw_base) + k
         Cn = self.n_chains
         ld = lambda t: 0 if t is None else t.stride(0)  # noqa: E731
         check(lib.omc_gmrf_sweep(self._ctx, n, C.byref(T), B, self._p(rhs_chain, Cn, n), ld(rhs_chain),

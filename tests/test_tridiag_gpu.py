@@ -370,7 +370,7 @@ def test_fused_equals_unfused(torch, n, C, seg):
             if fused:
                 blocks = [{"a0": 10.0, "b0": 1.0, "n_pos": n, "logdet": logdetP},
                           {"a0": 1.0, "b0": 1.0, "n_pos": n, "logdet": logdetI}]
-                eng.gmrf_sweep(n, terms, blocks, x, draw_index=3 * it, log_post_out=lp)
+                eng.gmrf_sweep(n, terms, blocks, x, draw_index=3 * it, log_post_out=lp, gamma_draw_base=3 * it + 1)
             else:
                 eng.tridiag_sample_canonical(n, terms, x, draw_index=3 * it, quad_out=quad)
                 eng.normal_gamma_update(10.0, 1.0, n, quad[0], lam, draw_index=3 * it + 1)
