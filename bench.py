@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="one launch per sampler instead of the fused sweep kernel")
+    ap.add_argument("--stamps", action="store_true", help="diagnostic: print in-kernel phase stamps (not a timing run)")
     ap.add_argument("--seg", type=int, default=0, help="nodes per lane of the segmented kernel (0 = auto)")
     args = ap.parse_args()
 
@@ -182,6 +183,10 @@ def main():
     n_store = max(1, min(args.steps, STORE_SLABS_MAX))
     sweep = GmrfSweep(n, C, seed=2025, chain_offset=rank * C, device=local, n_store=n_store,
                       fused=not args.unfused, seg=args.seg)
+    stamps = None
+    if args.stamps:
+        stamps = torch.zeros(C * 16 * 16, dtype=torch.int64, device="cuda")
+        sweep.eng.set_option("stamps_ptr", stamps.data_ptr())
 
     for _ in range(args.warmup):
         sweep.step()
@@ -218,6 +223,16 @@ def main():
             trace = torch.cat(gathered, dim=2)
     lam_mean = trace[0].mean().item()
 
+    if stamps is not None and rank == 0:
+        st = stamps.cpu().numpy().reshape(C, 16, 16).astype(np.float64)
+        nwv = int((st[0, :, 0] > 0).sum())
+        st = st[:, :nwv, :10]
+        d = np.diff(st, axis=2)
+        names = ["rng", "fill b,a", "moebius+scan", "newton", "l,sqrt", "rhs+fwd", "bwd", "store+quad", "epilogue"]
+        print("phase stamps (100 MHz ticks -> us), mean over chains/waves; wave0 and wave%d shown" % (nwv - 1), file=sys.stderr)
+        for i, nm in enumerate(names):
+            print(f"  {nm:14s} mean {d[:, :, i].mean() / 100:8.2f} us   wave0 {d[:, 0, i].mean() / 100:8.2f}   last {d[:, -1, i].mean() / 100:8.2f}", file=sys.stderr)
+        print(f"  total/wave     {(st[:, :, 9] - st[:, :, 0]).mean() / 100:8.2f} us; block span {((st[:, :, 9].max(1) - st[:, :, 0].min(1)).mean()) / 100:8.2f} us", file=sys.stderr)
     if rank == 0:
         kern_ms = None
         if use_ev:

@@ -17,6 +17,7 @@ struct omc_ctx {
   size_t workspace_bytes;
   int tridiag_algo;  // 0 auto, 1 serial, 2 segmented
   int tridiag_seg;   // 0 auto, else nodes per lane
+  unsigned long long* stamps;  // diagnostic phase stamps of the segmented kernel (NULL = off)
 };
 
 void omc_set_error(const char* what, hipError_t e);
@@ -150,32 +151,53 @@ __device__ __forceinline__ void omc_normal_pair(uint4 w, double& n0, double& n1)
 }
 
 // Marsaglia & Tsang (2000) Gamma(a,1), a > 0, from the chain's Philox stream.
-// Each attempt consumes one block: words (x,y) -> normal via Box-Muller radius/angle, (z,w) -> uniform.
-__device__ inline double omc_standard_gamma(const omc_rng_key& key, int64_t gc, double a, bool* failed) {
-  double boost = 1.0;
-  uint32_t blk = 0;
-  if (a < 1.0) {  // Gamma(a) = Gamma(a+1) * U^(1/a)
-    uint4 w = omc_rng_block(key, gc, blk++);
-    boost = exp(log(omc_u53(w.x, w.y)) / a);
+// Attempt j (j = 0, 1, ...) consumes blocks 1+2j (two N(0,1) candidates) and 2+2j (their two
+// uniforms); block 0 feeds the a < 1 boost Gamma(a) = Gamma(a+1) U^(1/a).  The draw is the first
+// accepted candidate in (attempt, candidate) order, so evaluating attempts on different lanes and
+// taking the lowest accepted one gives the same value as the serial loop.
+struct omc_gamma_prep { double d, cst, boost; };
+
+__device__ __forceinline__ omc_gamma_prep omc_gamma_prepare(const omc_rng_key& key, int64_t gc, double a) {
+  omc_gamma_prep p;
+  p.boost = 1.0;
+  if (a < 1.0) {
+    const uint4 w = omc_rng_block(key, gc, 0u);
+    p.boost = exp(omc_log_unit(omc_u53(w.x, w.y)) / a);
     a += 1.0;
   }
-  const double d = a - 1.0 / 3.0, cst = 1.0 / sqrt(9.0 * d);
-  for (int attempt = 0; attempt < 256; ++attempt) {
-    double x0, x1;
-    omc_normal_pair(omc_rng_block(key, gc, blk++), x0, x1);
-    uint4 w = omc_rng_block(key, gc, blk++);
-    const double us[2] = {omc_u53(w.x, w.y), omc_u53(w.z, w.w)};
-    const double xs[2] = {x0, x1};
-    for (int t = 0; t < 2; ++t) {
-      const double x = xs[t], u = us[t];
-      double v = 1.0 + cst * x;
-      if (v <= 0.0) continue;
-      v = v * v * v;
-      const double x2 = x * x;
-      if (u < 1.0 - 0.0331 * x2 * x2 || log(u) < 0.5 * x2 + d * (1.0 - v + log(v))) return boost * d * v;
-    }
-  }
-  *failed = true;
-  return boost * d;
+  p.d = a - 1.0 / 3.0;
+  p.cst = omc_rcp_nr(omc_sqrt_nr(9.0 * p.d));
+  return p;
 }
 
+// acceptance test of one candidate (x ~ N(0,1), u ~ U(0,1])
+__device__ __forceinline__ bool omc_gamma_candidate(const omc_gamma_prep& p, double x, double u, double& value) {
+  double v = fma(p.cst, x, 1.0);
+  if (!(v > 0.0)) return false;
+  v = v * v * v;
+  const double x2 = x * x;
+  if (u < 1.0 - 0.0331 * x2 * x2 || omc_log_unit(u) < fma(p.d, (1.0 - v) + log(v), 0.5 * x2)) {
+    value = p.boost * p.d * v;
+    return true;
+  }
+  return false;
+}
+
+// one attempt: returns true and the Gamma(a,1) value if one of its two candidates is accepted
+__device__ __forceinline__ bool omc_gamma_attempt(const omc_rng_key& key, int64_t gc, const omc_gamma_prep& p,
+                                                  uint32_t attempt, double& value) {
+  double x0, x1;
+  omc_normal_pair(omc_rng_block(key, gc, 1u + 2u * attempt), x0, x1);
+  const uint4 w = omc_rng_block(key, gc, 2u + 2u * attempt);
+  if (omc_gamma_candidate(p, x0, omc_u53(w.x, w.y), value)) return true;
+  return omc_gamma_candidate(p, x1, omc_u53(w.z, w.w), value);
+}
+
+__device__ inline double omc_standard_gamma(const omc_rng_key& key, int64_t gc, double a, bool* failed) {
+  const omc_gamma_prep p = omc_gamma_prepare(key, gc, a);
+  double v;
+  for (uint32_t attempt = 0; attempt < 256; ++attempt)
+    if (omc_gamma_attempt(key, gc, p, attempt, v)) return v;
+  *failed = true;
+  return p.boost * p.d;
+}

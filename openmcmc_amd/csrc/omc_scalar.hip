@@ -10,7 +10,7 @@ __global__ void k_normal_gamma(int64_t C, int64_t chain_offset, double a0, doubl
   if (c >= C) return;
   const double a = a0 + half_npos;
   const double b = b0 + 0.5 * quad[c];
-  const double scale = (b == 0.0) ? INFINITY : 1.0 / b;  // sampler.py:285-286
+  const double scale = (b == 0.0) ? INFINITY : omc_rcp_nr(b);  // sampler.py:285-286
   bool failed = false;
   const double g = g_inject ? g_inject[c] : omc_standard_gamma(key, chain_offset + c, a, &failed);
   out[c] = g * scale;

@@ -65,6 +65,7 @@ struct TriArgs {
   long long* bad;
   double* work;
   // fused sweep (omc_gmrf_sweep)
+  unsigned long long* stamps;  // diagnostic: [chain][wave][16] s_memtime at phase boundaries, or NULL
   int fused;
   GammaDev gb[OMC_MAX_TERMS];
   double* log_post;
@@ -77,24 +78,93 @@ __device__ __forceinline__ void sweep_epilogue(const TriArgs& A, int64_t c, cons
   double lp = 0.0;
   bool failed = false;
   const double nd = (double)A.n;
-  for (int k = 0; k < A.T.n_terms; ++k) {
+  _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < A.T.n_terms) {
     const GammaDev& g = A.gb[k];
     double s = A.T.scale[k] ? A.T.scale[k][c] : 1.0;
     if (g.enabled) {
       const double a = g.a0 + g.half_npos;
       const double b = g.b0 + 0.5 * quad[k];
-      const double sc = (b == 0.0) ? INFINITY : 1.0 / b;
+      const double sc = (b == 0.0) ? INFINITY : omc_rcp_nr(b);
       const double gd = g.g_inject ? g.g_inject[c] : omc_standard_gamma(g.key, A.chain_offset + c, a, &failed);
       s = gd * sc;
       g.scale_out[c] = s;
       if (g.store) g.store[c] = s;
     }
     if (A.log_post) {
-      lp += 0.5 * (nd * log(s) + g.logdet_unscaled[0] - nd * 1.8378770664093453 - s * quad[k]);
-      if (g.enabled) lp += g.lnorm + (g.a0 - 1.0) * log(s) - g.b0 * s;
+      double lpk = 0.5 * (nd * log(s) + g.logdet_unscaled[0] - nd * 1.8378770664093453 - s * quad[k]);
+      if (g.enabled) lpk += g.lnorm + (g.a0 - 1.0) * log(s) - g.b0 * s;
+      lp += lpk;
     }
   }
   if (A.log_post) A.log_post[c] = lp;
+  if (failed) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
+}
+
+__device__ __forceinline__ double read_lane_d(double v, int l) {  // l wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// The same epilogue spread over the 64 lanes of one wave (the workgroup-per-chain kernel runs it on
+// wave 0 while the other waves are already storing x): lanes 16k..16k+15 belong to term k and each
+// evaluates one Marsaglia-Tsang attempt; the lowest accepted attempt is the serial answer.
+__device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c, const double (&quad)[OMC_MAX_TERMS],
+                                                    int lane) {
+  const int k = lane >> 4, j = lane & 15;
+  const bool term_on = k < A.T.n_terms;
+  // per-lane copy of this lane's term, selected with compile-time indices (a dynamically indexed
+  // kernel-argument array would be spilled to scratch)
+  GammaDev g = A.gb[0];
+  const double* scale_p = A.T.scale[0];
+  double qk = quad[0];
+#pragma unroll
+  for (int t = 1; t < OMC_MAX_TERMS; ++t) {
+    if (k == t) { g = A.gb[t]; scale_p = A.T.scale[t]; qk = quad[t]; }
+  }
+  double s = (term_on && scale_p) ? scale_p[c] : 1.0;
+  const bool draw = term_on && g.enabled;
+  bool failed = false;
+  if (__ballot(draw) != 0ull) {
+    const double a = g.a0 + g.half_npos;
+    const double b = g.b0 + 0.5 * qk;
+    const double scl = (b == 0.0) ? INFINITY : omc_rcp_nr(b);
+    double gd = 0.0;
+    if (draw && g.g_inject) {
+      gd = g.g_inject[c];
+    } else if (draw) {
+      const omc_gamma_prep p = omc_gamma_prepare(g.key, A.chain_offset + c, a);
+      double v = 0.0;
+      bool ok = omc_gamma_attempt(g.key, A.chain_offset + c, p, (uint32_t)j, v);
+      // lowest accepted attempt inside the 16-lane group
+      unsigned long long m = (__ballot(ok) >> (16 * k)) & 0xffffull;
+      if (m == 0ull) {  // astronomically rare: continue serially on the group's first lane
+        if (j == 0) {
+          ok = false;
+          for (uint32_t at = 16; at < 256 && !ok; ++at) ok = omc_gamma_attempt(g.key, A.chain_offset + c, p, at, v);
+          failed = !ok;
+          gd = ok ? v : p.boost * p.d;
+        }
+      } else {
+        const int win = __ffsll((long long)m) - 1 + 16 * k;
+        gd = __shfl(v, win, 64);
+      }
+    }
+    if (draw) s = gd * scl;
+    if (draw && j == 0) {
+      g.scale_out[c] = s;
+      if (g.store) g.store[c] = s;
+    }
+  }
+  if (A.log_post) {
+    double lp = 0.0;
+    if (term_on && j == 0) {
+      const double nd = (double)A.n;
+      lp = 0.5 * (nd * log(s) + g.logdet_unscaled[0] - nd * 1.8378770664093453 - s * qk);
+      if (g.enabled) lp += g.lnorm + (g.a0 - 1.0) * log(s) - g.b0 * s;
+    }
+    // terms are summed in order 0,1,2,3 as the serial epilogue does
+    const double t0 = read_lane_d(lp, 0), t1 = read_lane_d(lp, 16), t2 = read_lane_d(lp, 32), t3 = read_lane_d(lp, 48);
+    if (lane == 0) A.log_post[c] = ((t0 + t1) + t2) + t3;
+  }
   if (failed) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
 }
 
@@ -106,7 +176,7 @@ __global__ void __launch_bounds__(64) k_tridiag_serial(TriArgs A) {
   const int nt = A.T.n_terms;
   const int64_t n = A.n;
   double sc[OMC_MAX_TERMS];
-  for (int k = 0; k < nt; ++k) sc[k] = A.T.scale[k] ? A.T.scale[k][c] : 1.0;
+  _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt) sc[k] = A.T.scale[k] ? A.T.scale[k][c] : 1.0;
   double* lw = A.work + c * n;
   double* xo = A.x + c * A.ld_x;
   const int64_t gc = A.chain_offset + c;
@@ -114,7 +184,7 @@ __global__ void __launch_bounds__(64) k_tridiag_serial(TriArgs A) {
   double lp = 0.0, bprev = 0.0, u = 0.0, logdet = 0.0, zodd = 0.0;
   for (int64_t i = 0; i < n; ++i) {
     double av = 0.0, bv = 0.0, rv = 0.0;
-    for (int k = 0; k < nt; ++k) {
+    _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt) {
       av = fma(sc[k], A.T.diag[k] ? A.T.diag[k][i] : 1.0, av);
       if (A.T.off[k] && i < n - 1) bv = fma(sc[k], A.T.off[k][i], bv);
       if (A.T.rhs[k]) rv = fma(sc[k], A.T.rhs[k][i], rv);
@@ -147,7 +217,7 @@ __global__ void __launch_bounds__(64) k_tridiag_serial(TriArgs A) {
     x = fma(-lw[i], x, xo[i]);
     xo[i] = x;
     if (want_quad) {
-      for (int k = 0; k < nt; ++k) {
+      _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt) {
         double r = x - (A.T.center[k] ? A.T.center[k][i] : 0.0);
         double dk = A.T.diag[k] ? A.T.diag[k][i] : 1.0;
         double ok = (A.T.off[k] && i < n - 1) ? A.T.off[k][i] : 0.0;
@@ -157,7 +227,7 @@ __global__ void __launch_bounds__(64) k_tridiag_serial(TriArgs A) {
     }
   }
   if (A.quad)
-    for (int k = 0; k < nt; ++k) A.quad[k * A.C + c] = acc[k];
+    _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt) A.quad[k * A.C + c] = acc[k];
   if (A.logdet) A.logdet[c] = logdet;
   if (bad) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
   if (A.fused) sweep_epilogue(A, c, acc);
@@ -320,7 +390,8 @@ __device__ __forceinline__ T excl_scan_wg(T v, const T id, T* lds, int lane, int
     const int w = __builtin_amdgcn_readfirstlane(wave);
     const int src = REV ? w + 1 : w - 1;
     if (src >= 0 && src < nw) e = compose(e, read_lane(t, src));
-    __syncthreads();
+    // no trailing barrier: consecutive calls must use different `lds` buffers (the barrier of
+    // the next call then orders this call's reads before the buffer is written again)
   }
   return e;
 }
@@ -333,7 +404,7 @@ __device__ __forceinline__ void prev_lane2_wg(double& v0, double& v1, double id0
     if (lane == 63) { lds[2 * wave] = v0; lds[2 * wave + 1] = v1; }
     __syncthreads();
     if (lane == 0 && wave > 0) { a = lds[2 * (wave - 1)]; b = lds[2 * (wave - 1) + 1]; }
-    __syncthreads();
+    // no trailing barrier: see excl_scan_wg
   }
   v0 = a; v1 = b;
 }
@@ -349,8 +420,7 @@ __device__ __forceinline__ double sum_wg(double v, double* lds, int lane, int wa
     __syncthreads();
     double u = 0.0;
     for (int w = 0; w < nw; ++w) u += lds[w];
-    __syncthreads();
-    t = u;
+    t = u;  // no trailing barrier: every call site owns its 16-entry slot of `lds`
   }
   return t;
 }
@@ -435,7 +505,7 @@ __device__ __forceinline__ void tile_fill_comb(double* tile, const Geom<M, MULTI
     const int64_t lim = (WHICH == COMB_OFF) ? n - 1 : n;
     if (nd < lim) {
       v = 0.0;
-      for (int k = 0; k < nt; ++k) {
+      _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt) {
         const double* src = (WHICH == COMB_DIAG) ? A.T.diag[k] : (WHICH == COMB_OFF ? A.T.off[k] : A.T.rhs[k]);
         if (!src && WHICH != COMB_DIAG) continue;
         const double sk = MULTI ? sc[k] : ((A.T.scale[k] && ch < A.C) ? A.T.scale[k][ch] : 1.0);
@@ -448,7 +518,78 @@ __device__ __forceinline__ void tile_fill_comb(double* tile, const Geom<M, MULTI
   wave_lds_fence();
 }
 
+// Workgroup-per-chain form of the combined fills: node index is linear in the tile element
+// (node = wave*64*M + e), so all loads of one fill are issued back to back (memory-level
+// parallelism; L2 latency is paid once per fill, not once per element) and only then combined.
+template <int M, int WHICH>
+__device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wave, const TriArgs& A,
+                                                  const double (&sc)[OMC_MAX_TERMS], bool chain_ok, int64_t cc) {
+  constexpr int CH = (M % 5 == 0) ? 5 : 4;  // loads in flight per lane and term
+  const int nt = A.T.n_terms;
+  // 32-bit node indices (n <= 32768 here): scalar base + 32-bit lane offset addressing, nothing
+  // 64-bit kept live per element
+  const int n = (int)A.n;
+  const int lim = (WHICH == COMB_OFF) ? n - 1 : n;
+  const int base = wave * 64 * M + lane;
+  const double* rc = (WHICH == COMB_RHS && A.rhs_chain && chain_ok) ? A.rhs_chain + cc * A.ld_rhs : nullptr;
+  wave_lds_fence();
+  int e = lane, q = lane / M, r = lane % M;
+#pragma unroll
+  for (int t0 = 0; t0 < M; t0 += CH) {
+    double v[CH];
+#pragma unroll
+    for (int t = 0; t < CH; ++t) v[t] = 0.0;
+#pragma unroll
+    for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+      if (k >= nt) continue;
+      const double* src = (WHICH == COMB_DIAG) ? A.T.diag[k] : (WHICH == COMB_OFF ? A.T.off[k] : A.T.rhs[k]);
+      if (!src) {
+        if (WHICH == COMB_DIAG) {
+#pragma unroll
+          for (int t = 0; t < CH; ++t) v[t] += sc[k];
+        }
+        continue;
+      }
+      double ld[CH];
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        const int nd = base + (t0 + t) * 64;
+        ld[t] = (nd < lim) ? src[(unsigned)nd] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < CH; ++t) v[t] = fma(sc[k], ld[t], v[t]);
+    }
+    if (rc) {
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        const int nd = base + (t0 + t) * 64;
+        if (nd < n) v[t] += rc[(unsigned)nd];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      const int nd = base + (t0 + t) * 64;
+      tile[e + q] = (WHICH == COMB_DIAG && nd >= n) ? 1.0 : v[t];
+      e += 64; q += 64 / M; r += 64 % M;
+      if (r >= M) { r -= M; ++q; }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the next chunk's loads from being hoisted over this one
+  }
+  wave_lds_fence();
+}
+
 __device__ __forceinline__ double fast_sqrt(double r) { return omc_sqrt_nr(r); }
+
+// diagnostic phase stamps (guide section 7, in-kernel stamps): lane 0 of every wave, only when enabled
+#define OMC_STAMP(k)                                                                                  \
+  do {                                                                                                \
+    if (A.stamps) {                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                              \
+      const unsigned long long _t = __builtin_amdgcn_s_memtime();                                     \
+      if (lane == 0 && chain_ok) A.stamps[((c * 16) + wave) * 16 + (k)] = _t;                          \
+      __builtin_amdgcn_sched_barrier(0);                                                              \
+    }                                                                                                 \
+  } while (0)
 
 #define OMC_NEWTON_TOL 4e-15
 #define OMC_NEWTON_MAX 4
@@ -460,8 +601,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   constexpr int NWMAX = MAXT / 64;
   __shared__ double lds_tile[NWMAX][64 * (M + 1)];
   __shared__ Mob lds_mob[16];
-  __shared__ Aff lds_aff[16];
-  __shared__ double lds_d[32];
+  __shared__ Aff lds_aff[4][16];   // scans alternate buffers instead of paying a trailing barrier
+  __shared__ double lds_x[2][32];  // neighbour exchange of the Newton passes (alternating)
+  __shared__ double lds_d[6][16];  // reductions: one slot per call site
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int Wd = MULTI ? 64 : G;
   int64_t c;
@@ -493,6 +635,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   for (int k = 0; k < OMC_MAX_TERMS; ++k) sc[k] = (k < nt && A.T.scale[k]) ? A.T.scale[k][cc] : 1.0;
 
   double X[M], Y[M], W[M];
+  OMC_STAMP(0);
 
   // ---- draws first, while nothing else is live: X = z ----
   if (A.z) {
@@ -520,18 +663,22 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     for (int j = 0; j < M; ++j) X[j] = crow[j];
   }
   __builtin_amdgcn_sched_barrier(0);
+  OMC_STAMP(1);
 
   // ---- conditional precision: b -> Y (registers), a -> LDS tile ----
-  tile_fill_comb<M, MULTI, COMB_OFF>(tile, geo, A, sc);
+  if (MULTI) tile_fill_comb_wg<M, COMB_OFF>(tile, lane, wave, A, sc, chain_ok, cc);
+  else tile_fill_comb<M, MULTI, COMB_OFF>(tile, geo, A, sc);
 #pragma unroll
   for (int j = 0; j < M; ++j) Y[j] = crow[j];
   double bm1 = 0.0;  // coupling b_{i0-1} into the segment
   if (i0 > 0 && i0 < n)
-    for (int k = 0; k < nt; ++k)
+    _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt)
       if (A.T.off[k]) bm1 = fma(sc[k], A.T.off[k][i0 - 1], bm1);
-  tile_fill_comb<M, MULTI, COMB_DIAG>(tile, geo, A, sc);
+  if (MULTI) tile_fill_comb_wg<M, COMB_DIAG>(tile, lane, wave, A, sc, chain_ok, cc);
+  else tile_fill_comb<M, MULTI, COMB_DIAG>(tile, geo, A, sc);
   const double* arow = crow;
 
+  OMC_STAMP(2);
   // ---- Moebius product of the segment, scan -> incoming pivot ----
   double Dst;
   {
@@ -552,6 +699,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     Dst = (E.a + E.b) / (E.c + E.d);
   }
 
+  OMC_STAMP(3);
   // ---- true pivot recurrence, Newton multiple shooting on the segment joins ----
   bool bad = false;
   double lin = 0.0;  // l_{i0-1}
@@ -574,8 +722,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     }
     bad = badp;
     double Dp = Dend, Jp = J;
-    if (MULTI) prev_lane2_wg(Dp, Jp, Dst, 0.0, lds_d, lane, wave, nw);
-    else prev_lane2<false>(Dp, Jp, Dst, 0.0, pos, Wd, lds_d, wave);
+    if (MULTI) prev_lane2_wg(Dp, Jp, Dst, 0.0, lds_x[it & 1], lane, wave, nw);
+    else prev_lane2<false>(Dp, Jp, Dst, 0.0, pos, Wd, lds_x[0], wave);
     const bool joined = (s > 0 && i0 < n);
     const double e = joined ? (Dp - Dst) : 0.0;
     if (!joined) Jp = 0.0;
@@ -583,10 +731,11 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     const int any = MULTI ? __syncthreads_or(need) : (__ballot(need) != 0ull);
     if (!any || it >= OMC_NEWTON_MAX) break;
     const Aff own{e, Jp};
-    const Aff ex = MULTI ? excl_scan_wg<Aff, false>(own, Aff{0.0, 1.0}, lds_aff, lane, wave, nw)
-                          : excl_scan<Aff, false>(own, Aff{0.0, 1.0}, pos, Wd, false, lds_aff, wave, nw);
+    const Aff ex = MULTI ? excl_scan_wg<Aff, false>(own, Aff{0.0, 1.0}, lds_aff[it & 1], lane, wave, nw)
+                          : excl_scan<Aff, false>(own, Aff{0.0, 1.0}, pos, Wd, false, lds_aff[0], wave, nw);
     Dst += fma(Jp, ex.p, e);  // delta_s = e_s + J_{s-1} delta_{s-1}
   }
+  OMC_STAMP(4);
   double logdet = 0.0;
 #pragma unroll
   for (int j = 0; j < M; ++j) {
@@ -596,8 +745,10 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     if (A.logdet && i0 + j < n) logdet -= log(rD);
   }
 
+  OMC_STAMP(5);
   // ---- right-hand side -> tile; forward substitution (local affine map, scan, true pass) ----
-  tile_fill_comb<M, MULTI, COMB_RHS>(tile, geo, A, sc);
+  if (MULTI) tile_fill_comb_wg<M, COMB_RHS>(tile, lane, wave, A, sc, chain_ok, cc);
+  else tile_fill_comb<M, MULTI, COMB_RHS>(tile, geo, A, sc);
   {
     Aff f{0.0, 1.0};
     double lp = lin;
@@ -607,8 +758,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       f.q = -lp * f.q;
       lp = Y[j];
     }
-    double u = (MULTI ? excl_scan_wg<Aff, false>(f, Aff{0.0, 1.0}, lds_aff, lane, wave, nw)
-                      : excl_scan<Aff, false>(f, Aff{0.0, 1.0}, pos, Wd, false, lds_aff, wave, nw)).p;
+    double u = (MULTI ? excl_scan_wg<Aff, false>(f, Aff{0.0, 1.0}, lds_aff[2], lane, wave, nw)
+                      : excl_scan<Aff, false>(f, Aff{0.0, 1.0}, pos, Wd, false, lds_aff[0], wave, nw)).p;
     lp = lin;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
@@ -618,6 +769,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     }
   }
 
+  OMC_STAMP(6);
   // ---- backward substitution: local affine map, reverse scan, true pass ----
   double xnext;
   {
@@ -627,8 +779,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       f.p = fma(-Y[j], f.p, W[j]);
       f.q = -Y[j] * f.q;
     }
-    xnext = (MULTI ? excl_scan_wg<Aff, true>(f, Aff{0.0, 1.0}, lds_aff, lane, wave, nw)
-                   : excl_scan<Aff, false>(f, Aff{0.0, 1.0}, pos, Wd, true, lds_aff, wave, nw)).p;
+    xnext = (MULTI ? excl_scan_wg<Aff, true>(f, Aff{0.0, 1.0}, lds_aff[3], lane, wave, nw)
+                   : excl_scan<Aff, false>(f, Aff{0.0, 1.0}, pos, Wd, true, lds_aff[0], wave, nw)).p;
     double x = xnext;
 #pragma unroll
     for (int j = M - 1; j >= 0; --j) {
@@ -636,6 +788,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       W[j] = x;
     }
   }
+  OMC_STAMP(7);
   const bool want_quad = A.quad || A.fused;
   double qsum[OMC_MAX_TERMS] = {0, 0, 0, 0};
   if (MULTI) {
@@ -646,40 +799,60 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     for (int j = 0; j < M; ++j) crow[j] = W[j];
     if (want_quad) __syncthreads();  // the last element of a wave needs the next wave's first x
     else wave_lds_fence();
-    const int64_t wbase = (int64_t)wave * 64 * M;
-    double* xo = (A.x && chain_ok) ? A.x + cc * A.ld_x : nullptr;
+    const int wbase = wave * 64 * M + lane, n32 = (int)n;
     double acc[OMC_MAX_TERMS] = {0, 0, 0, 0};
+    // processed in chunks of CH nodes per lane: enough loads in flight to cover L2 latency,
+    // few enough live values to stay inside the register budget
+    constexpr int CH = (M % 5 == 0) ? 5 : 4;
     int e = lane, q = lane / M, r = lane % M;  // tile element, e / M, e % M
-#pragma unroll 2
-    for (int t = 0; t < M; ++t) {
-      const int64_t i = wbase + e;
-      const double xi = tile[e + q];
-      if (i < n) {
-        if (xo) xo[i] = xi;
-        if (want_quad) {
-          double xn = 0.0;  // x_{i+1}
-          if (i + 1 < n) {
-            int e1 = e + 1, q1 = (r + 1 == M) ? q + 1 : q;
-            xn = (e1 < 64 * M) ? tile[e1 + q1] : lds_tile[wave + 1][0];
+    if (want_quad) {
+#pragma unroll
+    for (int t0 = 0; t0 < M; t0 += CH) {
+      double xv[CH], xn[CH];  // x_i and x_{i+1}
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        xv[t] = tile[e + q];
+        const int e1 = e + 1, q1 = (r + 1 == M) ? q + 1 : q;
+        xn[t] = (e1 < 64 * M) ? tile[e1 + q1] : ((wave + 1 < nw) ? lds_tile[(wave + 1) % NWMAX][0] : 0.0);
+        e += 64; q += 64 / M; r += 64 % M;
+        if (r >= M) { r -= M; ++q; }
+      }
+      const int ib = wbase + t0 * 64;
+      if (want_quad) {
+        _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt) {
+          const double *ck = A.T.center[k], *dk = A.T.diag[k], *ok = A.T.off[k];
+          double ri[CH], rn[CH], dv[CH];
+#pragma unroll
+          for (int t = 0; t < CH; ++t) {
+            const int i = ib + t * 64;
+            ri[t] = (ck && i < n32) ? ck[(unsigned)i] : 0.0;
+            rn[t] = (ck && ok && i + 1 < n32) ? ck[(unsigned)(i + 1)] : 0.0;
+            dv[t] = (i < n32) ? (dk ? dk[(unsigned)i] : 1.0) : 0.0;
           }
-          for (int k = 0; k < nt; ++k) {
-            const double* ck = A.T.center[k];
-            const double ri = xi - (ck ? ck[i] : 0.0);
-            double a2 = (A.T.diag[k] ? A.T.diag[k][i] : 1.0) * ri;
-            if (A.T.off[k] && i + 1 < n) {
-              const double rn = xn - (ck ? ck[i + 1] : 0.0);
-              a2 = fma(2.0 * A.T.off[k][i], rn, a2);
+          if (ok) {
+            double ov[CH];
+#pragma unroll
+            for (int t = 0; t < CH; ++t) ov[t] = (ib + t * 64 + 1 < n32) ? ok[(unsigned)(ib + t * 64)] : 0.0;
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+              const double a = xv[t] - ri[t], bnx = xn[t] - rn[t];
+              acc[k] = fma(fma(2.0 * ov[t], bnx, dv[t] * a), a, acc[k]);
             }
-            acc[k] = fma(a2, ri, acc[k]);
+          } else {
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+              const double a = xv[t] - ri[t];
+              acc[k] = fma(dv[t] * a, a, acc[k]);
+            }
           }
         }
       }
-      e += 64; q += 64 / M; r += 64 % M;
-      if (r >= M) { r -= M; ++q; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     }
     if (want_quad) {
-      for (int k = 0; k < nt; ++k) {
-        qsum[k] = sum_wg(acc[k], lds_d, lane, wave, nw);
+      _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt) {
+        qsum[k] = sum_wg(acc[k], lds_d[k], lane, wave, nw);
         if (A.quad && s == 0 && chain_ok) A.quad[k * A.C + c] = qsum[k];
       }
     }
@@ -693,7 +866,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 
   // ---- fused quadratic forms (x - m_k)' M_k (x - m_k), segment-local form ----
   if (want_quad) {
-    for (int k = 0; k < nt; ++k) {
+    _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt) {
       // residual of this segment in X, residual of the next segment's first node in rn
       double rn = 0.0;
       if (A.T.center[k]) {
@@ -721,17 +894,37 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 #pragma unroll
         for (int j = 0; j < M; ++j) acc = fma(2.0 * trow[j] * X[j], (j + 1 < M) ? X[(j + 1) % M] : rn, acc);
       }
-      qsum[k] = group_sum<false>(acc, Wd, lds_d, wave, nw);
+      qsum[k] = group_sum<false>(acc, Wd, lds_d[0], wave, nw);
       if (A.quad && s == 0 && chain_ok) A.quad[k * A.C + c] = qsum[k];
     }
   }
   }
+  OMC_STAMP(8);
   if (A.logdet) {
-    const double t = MULTI ? sum_wg(logdet, lds_d, lane, wave, nw) : group_sum<false>(logdet, Wd, lds_d, wave, nw);
+    const double t = MULTI ? sum_wg(logdet, lds_d[4], lane, wave, nw) : group_sum<false>(logdet, Wd, lds_d[0], wave, nw);
     if (s == 0 && chain_ok) A.logdet[c] = t;
   }
   if (bad && chain_ok) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
-  if (A.fused && s == 0 && chain_ok) sweep_epilogue(A, c, qsum);
+  if (MULTI) {
+    if (A.fused && wave == 0 && chain_ok) sweep_epilogue_wave(A, c, qsum, lane);
+    // x leaves last: a load issued behind a store would have to wait for the store to be
+    // acknowledged (vmcnt retires in order); this way nothing ever waits on the x stream.
+    if (A.x && chain_ok) {
+      double* xo = A.x + cc * A.ld_x;
+      const int wb = wave * 64 * M + lane, n32 = (int)n;
+      int e = lane, q = lane / M, r = lane % M;
+#pragma unroll
+      for (int t = 0; t < M; ++t) {
+        const int i = wb + t * 64;
+        if (i < n32) xo[(unsigned)i] = tile[e + q];
+        e += 64; q += 64 / M; r += 64 % M;
+        if (r >= M) { r -= M; ++q; }
+      }
+    }
+  } else if (A.fused && s == 0 && chain_ok) {
+    sweep_epilogue(A, c, qsum);
+  }
+  OMC_STAMP(9);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -796,6 +989,7 @@ static void args_defaults(omc_ctx* ctx, TriArgs* A, int64_t n) {
   A->bad = ctx->d_bad_chain;
   A->work = nullptr;
   A->fused = 0;
+  A->stamps = ctx->stamps;
   A->log_post = nullptr;
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
     A->gb[k].enabled = 0; A->gb[k].a0 = A->gb[k].b0 = A->gb[k].half_npos = A->gb[k].lnorm = 0.0;

@@ -1,0 +1,135 @@
+"""Normal distribution in mean/precision form (reference distribution/location_scale.py:126-272).
+
+On the GPU path a Normal is consumed structurally: precision = ScaledMatrix(shared matrix, per-chain
+scalar) or Identity(shared matrix); exactly one of {response, mean} is per chain.  `structure()`
+exposes that view to the samplers; log_p evaluates it with omc_tridiag_quadform +
+omc_scaled_gauss_logpdf.
+"""
+
+from dataclasses import dataclass
+from typing import Union
+
+import numpy as np
+from scipy import sparse
+
+from openmcmc_amd.chains import is_chain
+from openmcmc_amd.distribution.distribution import Distribution
+from openmcmc_amd.parameter import Identity, LinearCombination, ScaledMatrix, _is_identity
+
+
+def tridiagonal_bands(M, n):
+    """(diag, off) of a symmetric matrix with bandwidth <= 1, or None if it is wider.
+    diag is None for an exact identity (the kernels then skip the load)."""
+    if sparse.issparse(M):
+        M = M.tocsr()
+        coo = M.tocoo()
+        if coo.nnz and np.max(np.abs(coo.row - coo.col)) > 1:
+            return None
+        diag = np.asarray(M.diagonal(), dtype=np.float64)
+        off = np.asarray(M.diagonal(1), dtype=np.float64) if n > 1 else np.zeros(0)
+        low = np.asarray(M.diagonal(-1), dtype=np.float64) if n > 1 else np.zeros(0)
+    else:
+        M = np.asarray(M, dtype=np.float64)
+        if np.any(np.triu(M, 2)) or np.any(np.tril(M, -2)):
+            return None
+        diag, off, low = np.diag(M).copy(), np.diag(M, 1).copy(), np.diag(M, -1).copy()
+    if not np.array_equal(off, low):
+        raise ValueError("precision matrix is not symmetric")
+    if not off.any():
+        off = None
+    if off is None and np.all(diag == 1.0):
+        diag = None
+    return diag, off
+
+
+@dataclass
+class NormalStructure:
+    """What the samplers need to know about one Normal: precision = scale * M."""
+
+    n: int
+    matrix: object          # host matrix M (n x n)
+    scale_key: object       # state label of the scalar, or None (scale 1)
+    diag: object            # tridiagonal bands of M (None, None) if M is the identity
+    off: object
+    n_pos: int              # #{diag(M) > 0}  (sampler.py:283)
+
+
+@dataclass
+class Normal(Distribution):
+    """Multivariate normal in mean/precision form.  Truncation limits are accepted for API parity
+    but the truncated conditional sampler is not built yet."""
+
+    mean: Union[str, Identity, LinearCombination]
+    precision: Union[str, Identity, ScaledMatrix]
+    domain_response_lower: np.ndarray = None
+    domain_response_upper: np.ndarray = None
+
+    def __post_init__(self):
+        if isinstance(self.mean, str):
+            self.mean = Identity(self.mean)
+        if not isinstance(self.mean, (Identity, LinearCombination)):
+            raise TypeError("mean expected to be one of [Identity, LinearCombination, MixtureParameterVector]")
+        if isinstance(self.precision, str):
+            self.precision = Identity(self.precision)
+        if not isinstance(self.precision, (Identity, ScaledMatrix)):
+            raise TypeError("precision expected to be one of [Identity, ScaledMatrix, MixtureParameterMatrix]")
+
+    @property
+    def _dist_params(self) -> list:
+        return self.mean.get_param_list() + self.precision.get_param_list()
+
+    # ------------------------------------------------------------------ structure
+    def structure(self, state) -> NormalStructure:
+        if isinstance(self.precision, ScaledMatrix):
+            M, scale_key = state[self.precision.matrix], self.precision.scalar
+        else:
+            M, scale_key = state[self.precision.form], None
+        if is_chain(M):
+            raise NotImplementedError("per-chain precision matrices")
+        if M.shape[0] != M.shape[1]:
+            raise ValueError("Matrix is not square")
+        n = M.shape[0]
+        bands = tridiagonal_bands(M, n)
+        diag, off = bands if bands is not None else (False, False)  # False = not tridiagonal
+        d = M.diagonal() if sparse.issparse(M) else np.diag(np.asarray(M))
+        return NormalStructure(n=n, matrix=M, scale_key=scale_key, diag=diag, off=off, n_pos=int(np.sum(d > 0)))
+
+    def chain_and_center(self, state):
+        """(x, m): the per-chain vector and the shared vector such that the residual of the Gaussian
+        is +-(x - m).  Exactly one side of {response, mean} must be per chain."""
+        resp = state[self.response]
+        if isinstance(self.mean, Identity):
+            mean = state[self.mean.form]
+        else:
+            mean = self.mean.predictor(state)
+        if is_chain(resp) and not is_chain(mean):
+            return resp, np.asarray(mean, dtype=np.float64)
+        if is_chain(mean) and not is_chain(resp):
+            return mean, np.asarray(resp, dtype=np.float64)
+        raise NotImplementedError("Normal with response and mean both per-chain (or both shared) on the GPU path")
+
+    # ------------------------------------------------------------------ log density
+    def log_p(self, state: dict, by_observation: bool = False, engine=None, out=None, accumulate=False):
+        """location_scale.py:145-167 -> gmrf.py:321-348, one value per chain."""
+        if engine is None:
+            raise RuntimeError("Normal.log_p needs the engine (use Model.log_p)")
+        if by_observation:
+            raise NotImplementedError("by_observation")
+        st = self.structure(state)
+        if st.diag is False:
+            raise NotImplementedError("log_p for a non-tridiagonal precision (dense path: next round)")
+        x, m = self.chain_and_center(state)
+        if m.shape[1] != 1 or x.shape[1] != 1:
+            raise NotImplementedError("replicated responses")
+        cache = engine.model_cache(self, state, st, m)
+        scale = state[st.scale_key].scalar() if st.scale_key is not None else None
+        if scale is not None and not is_chain(state[st.scale_key]):
+            raise NotImplementedError("shared precision scalar")
+        quad = engine.empty(1, engine.n_chains)
+        engine.tridiag_quadform(st.n, cache["terms_unit"], x.vector(), quad)
+        out = engine.empty(engine.n_chains) if out is None else out
+        engine.scaled_gauss_logpdf(st.n, scale, cache["logdet"], quad[0], out, accumulate=accumulate)
+        return out
+
+    def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):
+        raise NotImplementedError("prior draws from a Normal: give the state an initial value")

@@ -191,6 +191,33 @@ class Engine:
                                      self._p(out)))
         return out
 
+    # ------------------------------------------------------------------ per-model constants
+    def model_cache(self, dist, state, st, center):
+        """Device copies of one Normal's shared pieces (bands of M, the vector m its residual is taken
+        around, M m, log det M), built once per (distribution, matrix, vector) and reused every sweep."""
+        if not hasattr(self, "_model_cache"):
+            self._model_cache = {}
+        key = (id(dist), id(st.matrix))
+        hit = self._model_cache.get(key)
+        c_host = np.ascontiguousarray(center, dtype=np.float64).reshape(-1)
+        if hit is not None and np.array_equal(hit["center_host"], c_host):
+            return hit
+        n = st.n
+        diag = None if st.diag is None else self.to_device(st.diag)
+        off = None if st.off is None else self.to_device(st.off)
+        cvec = self.to_device(c_host) if c_host.any() else None
+        if cvec is None:
+            rhs = None
+        elif diag is None and off is None:
+            rhs = cvec
+        else:
+            rhs = self.tridiag_matvec(n, diag, off, cvec)
+        logdet = self.zeros(1) if (diag is None and off is None) else self.tridiag_logdet(n, diag, off)
+        entry = {"diag": diag, "off": off, "center": cvec, "rhs": rhs, "logdet": logdet, "center_host": c_host,
+                 "terms_unit": self.tridiag_terms([{"diag": diag, "off": off, "center": cvec}], n)}
+        self._model_cache[key] = entry
+        return entry
+
     # ------------------------------------------------------------------ scalars
     def normal_gamma_update(self, a0, b0, n_pos, quad, out, g=None, draw_index=0):
         check(lib.omc_normal_gamma_update(self._ctx, float(a0), float(b0), int(n_pos), self._chain_scalar(quad),

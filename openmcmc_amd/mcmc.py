@@ -1,0 +1,186 @@
+"""MCMC driver on chain-batched state (reference mcmc.py:19-115).
+
+Same fields and loop as the reference plus `n_chains`, `seed`, `device`, `chain_id_offset`: C
+independent chains advance together, one HIP launch per sampler per sweep -- or ONE launch per
+sweep when the sampler list is the Gaussian-block pattern [NormalNormal(x), NormalGamma(s)...],
+which `fuse=True` (default) recognises and hands to omc_gmrf_sweep.  Both routes draw from the
+same random streams and give identical results.
+
+store[param] is a device tensor (n_iter, C, size); `collect()` returns host arrays shaped
+(C, size, n_iter), i.e. the reference's store per chain.
+"""
+
+from copy import copy
+from dataclasses import dataclass, field
+
+import numpy as np
+from scipy import sparse
+
+from openmcmc_amd.chains import ChainArray, host_2d, is_chain
+from openmcmc_amd.model import Model
+from openmcmc_amd.parameter import ScaledMatrix
+from openmcmc_amd.sampler.sampler import MCMCSampler, NormalGamma, NormalNormal
+
+
+@dataclass
+class MCMC:
+    state: dict
+    samplers: list
+    model: Model
+    n_burn: int = 5000
+    n_iter: int = 5000
+    n_thin: int = 1
+    n_chains: int = 1
+    seed: int = 0
+    device: int = 0
+    chain_id_offset: int = 0
+    fuse: bool = True
+    store: dict = field(default_factory=dict, init=False)
+
+    def __post_init__(self):
+        from openmcmc_amd.engine import Engine
+
+        self.state = copy(self.state)
+        for key, term in self.state.items():  # mcmc.py:65-76
+            if sparse.issparse(term) or is_chain(term):
+                continue
+            self.state[key] = host_2d(term)
+        self.engine = Engine(self.n_chains, seed=self.seed, device=self.device, chain_id_offset=self.chain_id_offset)
+        eng, C = self.engine, self.n_chains
+        ns = len(self.samplers)
+        for pos, sampler in enumerate(self.samplers):
+            sampler.bind(eng, pos, ns)
+            if sampler.param not in self.state:  # mcmc.py:79-80: draw the start from the prior
+                self.state[sampler.param] = sampler.model[sampler.param].rvs(
+                    self.state, engine=eng, draw_index=(1 << 40) + pos)
+            elif not is_chain(self.state[sampler.param]):
+                v = np.asarray(self.state[sampler.param], dtype=np.float64)
+                self.state[sampler.param] = ChainArray(eng.to_device(np.broadcast_to(v, (C,) + v.shape).copy()))
+            self.store = sampler.init_store(current_state=self.state, store=self.store, n_iterations=self.n_iter)
+        if self.model.response is not None:
+            for response in self.model.response.keys():
+                self.store[response] = eng.full((self.n_iter, C, self.state[response].size), float("nan"))
+        self.store["log_post"] = eng.full((self.n_iter, C), float("nan"))
+        self._fused = self._fusion_plan() if self.fuse else None
+        self._sweeps_done = 0
+
+    # ------------------------------------------------------------------ fusion
+    def _fusion_plan(self):
+        """[NormalNormal(x), NormalGamma(s_1), ...] with every s_j the ScaledMatrix scalar of one of
+        x's Gaussian terms, no fitted-value store, and the full model made of exactly those pieces."""
+        if len(self.samplers) < 2 or self.model.response is not None:
+            return None
+        nn = self.samplers[0]
+        if type(nn) is not NormalNormal or nn.inject is not None:
+            return None
+        gammas = self.samplers[1:]
+        if any(type(g) is not NormalGamma for g in gammas):
+            return None
+        try:
+            plan = nn.plan(self.state)
+        except NotImplementedError:
+            return None
+        term_of = {}
+        for k, key in enumerate(plan["keys"]):
+            prec = nn.model[key].precision
+            if isinstance(prec, ScaledMatrix):
+                term_of[prec.scalar] = k
+        blocks = [None] * len(plan["keys"])
+        for pos, g in enumerate(gammas, start=1):
+            k = term_of.get(g.param)
+            if k is None or g.normal_param != plan["keys"][k] or blocks[k] is not None:
+                return None
+            blocks[k] = (pos, g)
+        expected = set(plan["keys"]) | {g.param for g in gammas}
+        full_model = set(self.model.keys()) == expected
+        return {"nn": nn, "plan": plan, "blocks": blocks, "log_post": full_model}
+
+    def _fused_sweep(self, store_it):
+        eng, f = self.engine, self._fused
+        nn, plan = f["nn"], f["plan"]
+        ns, t = len(self.samplers), nn._sweep
+        n = plan["n"]
+        specs = []
+        for k, key in enumerate(plan["keys"]):
+            dist = nn.model[key]
+            st = dist.structure(self.state)
+            x_or_y, m = (None, None)
+            cache = eng._model_cache[(id(dist), id(st.matrix))]
+            spec = {"enabled": False, "logdet": cache["logdet"]}
+            if f["blocks"][k] is not None:
+                pos, g = f["blocks"][k]
+                a0, b0 = g.prior_shape_rate(self.state)
+                spec.update(enabled=True, a0=a0, b0=b0, n_pos=st.n_pos, draw_index=t * ns + pos,
+                            g=g.inject(g, g._sweep) if g.inject is not None else None,
+                            store=self.store[g.param][store_it, :, 0] if store_it is not None else None)
+            specs.append(spec)
+        x_out = self.store[nn.param][store_it] if store_it is not None else self._scratch(n)
+        lp = self.store["log_post"][store_it] if (store_it is not None and f["log_post"]) else None
+        eng.gmrf_sweep(n, plan["terms"], specs, x_out, z=None, draw_index=t * ns, log_post_out=lp)
+        self.state[nn.param] = ChainArray(x_out)
+        for s in self.samplers:
+            s._sweep += 1
+
+    def _scratch(self, n):
+        if getattr(self, "_scratch_x", None) is None or self._scratch_x.shape[1] != n:
+            self._scratch_x = self.engine.empty(self.n_chains, n)
+        return self._scratch_x
+
+    # ------------------------------------------------------------------ the loop (mcmc.py:87-115)
+    def run_mcmc(self):
+        eng = self.engine
+        for i_it in range(-self.n_burn, self.n_iter):
+            storing = i_it >= 0
+            for i_thin in range(self.n_thin):
+                last = i_thin == self.n_thin - 1
+                if self._fused is not None:
+                    self._fused_sweep(i_it if (storing and last) else None)
+                else:
+                    for sampler in self.samplers:
+                        self.state = sampler.sample(self.state)
+            if not storing:
+                continue
+            if self._fused is None:
+                for sampler in self.samplers:
+                    self.store = sampler.store(current_state=self.state, store=self.store, iteration=i_it)
+            if self._fused is None or not self._fused["log_post"]:
+                self.model.log_p(self.state, engine=eng, out=self.store["log_post"][i_it])
+            if self.model.response is not None:
+                for response, predictor in self.model.response.items():
+                    fitted = getattr(self.model[response], predictor).predictor(self.state)
+                    if is_chain(fitted):
+                        self.store[response][i_it].copy_(fitted.data.reshape(self.n_chains, -1))
+                    else:
+                        self.store[response][i_it].copy_(eng.to_device(np.asarray(fitted).reshape(1, -1)).expand(self.n_chains, -1))
+        eng.check_status()  # raises numpy.linalg.LinAlgError like gmrf.py:518 if a factorisation failed
+
+    # ------------------------------------------------------------------ results
+    def collect(self):
+        """Host copy of the store in the reference's per-chain layout: {key: (C, size, n_iter)},
+        log_post: (C, n_iter, 1)."""
+        out = {}
+        for key, t in self.store.items():
+            a = t.detach().cpu().numpy()
+            out[key] = np.transpose(a, (1, 0))[:, :, None] if key == "log_post" else np.transpose(a, (1, 2, 0))
+        return out
+
+    def gather(self, dst=0):
+        """The one collective of the path: gather every rank's store on rank `dst` over RCCL (xGMI).
+        Returns the host dict of `collect()` for all chains on dst, None elsewhere; without an
+        initialised process group it is `collect()`."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return self.collect()
+        world, rank = dist.get_world_size(), dist.get_rank()
+        result = {} if rank == dst else None
+        for key in sorted(self.store):
+            t = self.store[key].contiguous()
+            bucket = [t.new_empty(t.shape) for _ in range(world)] if rank == dst else None
+            dist.gather(t, bucket, dst=dst)
+            if rank == dst:
+                import torch
+
+                a = torch.cat(bucket, dim=1).cpu().numpy()
+                result[key] = np.transpose(a, (1, 0))[:, :, None] if key == "log_post" else np.transpose(a, (1, 2, 0))
+        return result

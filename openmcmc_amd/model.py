@@ -1,0 +1,40 @@
+"""Model: dict of distributions keyed by response (reference model.py:21-112)."""
+
+from openmcmc_amd.distribution.distribution import Distribution
+
+
+class Model(dict):
+    """Same constructor and sub-model selection as the reference (model.py:34-55)."""
+
+    def __init__(self, distributions: list, response: dict = None):
+        super().__init__({dist.response: dist for dist in distributions})
+        self.response = response
+
+    def conditional(self, param: str):
+        """Distributions that mention `param` (model.py:41-55)."""
+        return Model([dst for dst in self.values() if param in dst.param_list])
+
+    def log_p(self, state: dict, engine=None, out=None):
+        """Sum of the members' log densities, one value per chain (model.py:57-70)."""
+        if engine is None:
+            raise RuntimeError("Model.log_p needs the engine that holds the chains")
+        out = engine.empty(engine.n_chains) if out is None else out
+        first = True
+        host_sum = 0.0
+        for dst in self.values():
+            from openmcmc_amd.chains import is_chain
+
+            touches_chain = any(is_chain(state.get(k)) for k in dst.param_list)
+            if not touches_chain:
+                host_sum += dst.log_p(state)
+                continue
+            dst.log_p(state, engine=engine, out=out, accumulate=not first)
+            first = False
+        if first:
+            out.fill_(host_sum)
+        elif host_sum:
+            out += host_sum
+        return out
+
+
+__all__ = ["Model", "Distribution"]

@@ -1,0 +1,209 @@
+"""Conjugate Gibbs samplers on chain-batched state (reference sampler/sampler.py:37-288).
+
+Same constructor signature and plugin surface as the reference (`param`, `model`,
+`max_variable_size`, `sample`, `init_store`, `store`); `sample(state)` replaces state[param] for
+ALL chains with one launch of the HIP library.  A sampler is attached to the chains it serves with
+`bind(engine, position, n_samplers)` (MCMC does this), which also fixes its random stream:
+sweep t of sampler j uses draw index t * n_samplers + j, so results do not depend on fusion or on
+how chains are sharded over GPUs.
+"""
+
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from typing import Union
+
+import numpy as np
+
+from openmcmc_amd.chains import ChainArray, is_chain
+from openmcmc_amd.distribution.location_scale import Normal
+from openmcmc_amd.model import Model
+from openmcmc_amd.parameter import Identity, LinearCombination, ScaledMatrix, _is_identity
+
+
+@dataclass
+class MCMCSampler(ABC):
+    """Base class (sampler.py:37-118)."""
+
+    param: str
+    model: Model
+    max_variable_size: Union[int, tuple, None] = None
+
+    def __post_init__(self):
+        self.model = self.model.conditional(self.param)
+        self._init_runtime()
+
+    def _init_runtime(self):
+        self.engine = None
+        self._position, self._n_samplers, self._sweep = 0, 1, 0
+        self._plan = None
+        self.inject = None  # test hook: callable(sampler, sweep) -> injected draws (device tensor)
+
+    def bind(self, engine, position=0, n_samplers=1):
+        self.engine, self._position, self._n_samplers = engine, position, n_samplers
+        self._plan = None
+        return self
+
+    def _draw_index(self):
+        return self._sweep * self._n_samplers + self._position
+
+    def _need_engine(self):
+        if self.engine is None:
+            raise RuntimeError(f"{type(self).__name__}('{self.param}') is not bound to an Engine: "
+                               "construct it through MCMC or call sampler.bind(engine)")
+        return self.engine
+
+    @abstractmethod
+    def sample(self, current_state: dict) -> dict:
+        """Replace state[param] by a new draw for every chain."""
+
+    def init_store(self, current_state: dict, store: dict, n_iterations: int) -> dict:
+        """store[param]: (n_iterations, C, size) device tensor, NaN-filled (sampler.py:69-87; the
+        reference's (size, n_iterations) per chain, iteration-major so a draw can be written into its
+        slab directly)."""
+        eng = self._need_engine()
+        if self.max_variable_size is not None:
+            raise NotImplementedError("variable-size parameters (reversible jump): later round")
+        size = current_state[self.param].size
+        store[self.param] = eng.full((n_iterations, eng.n_chains, size), float("nan"))
+        return store
+
+    def store(self, current_state: dict, store: dict, iteration: int) -> dict:
+        """sampler.py:89-118."""
+        store[self.param][iteration].copy_(current_state[self.param].data.reshape(self.engine.n_chains, -1))
+        return store
+
+
+def _as_chain_scalar(engine, state, key):
+    """state[key] as a per-chain scalar; a shared host scalar is broadcast once and written back."""
+    v = state[key]
+    if not is_chain(v):
+        v = ChainArray(engine.full((engine.n_chains, 1, 1), float(np.asarray(v).item())))
+        state[key] = v
+    return v
+
+
+@dataclass
+class NormalNormal(MCMCSampler):
+    """Normal-Normal conjugate update (sampler.py:121-207): x ~ N(Q^{-1} b, Q^{-1}),
+    Q = P + sum_k A_k' W_k A_k, b = P m + sum_k A_k' W_k (y_k - d_k).
+
+    GPU path (this round): every term must reduce to (per-chain scalar) x (shared tridiagonal
+    matrix) -- ScaledMatrix/Identity precisions, Identity means or LinearCombination means whose
+    design matrix for `param` is an identity -- which covers the GMRF smoother of example 4 in both
+    its as-written and sparse-route forms."""
+
+    def __post_init__(self):
+        super().__post_init__()
+        self._is_response = {key: key == self.param for key in self.model.keys()}
+
+    # -- plan: the device-side description of Q and b, built once --
+    def _build_plan(self, state):
+        eng = self._need_engine()
+        prior = self.model[self.param]
+        if not isinstance(prior, Normal):
+            raise TypeError("NormalNormal needs a Normal prior on the parameter")
+        if prior.domain_response_lower is not None or prior.domain_response_upper is not None:
+            raise NotImplementedError("truncated Gaussian conditional (gmrf.gibbs_canonical_truncated_normal): next round")
+        n = state[self.param].shape[0]
+        terms, keys = [], []
+        for key, dist in self.model.items():
+            if not isinstance(dist, Normal):
+                raise TypeError("NormalNormal handles Normal distributions only")
+            st = dist.structure(state)
+            if st.diag is False:
+                raise NotImplementedError(f"precision of '{key}' is not tridiagonal: dense Normal-Normal path is a later round")
+            if self._is_response[key]:
+                mean = dist.mean.predictor(state)  # sampler.py:183: b += Q_rsp @ mean
+                if is_chain(mean):
+                    raise NotImplementedError("per-chain prior mean")
+                center = np.asarray(mean, dtype=np.float64)
+                n_rep = 1
+            else:
+                # likelihood: the parameter enters the mean linearly (sampler.py:185-192)
+                if isinstance(dist.mean, Identity):
+                    if dist.mean.form != self.param:
+                        raise TypeError("mean of the response does not depend on the parameter")
+                    rest = 0.0
+                else:
+                    A = state[dist.mean.form[self.param]]
+                    if not _is_identity(A, n):
+                        raise NotImplementedError("design matrix other than the identity: dense Normal-Normal path is a later round")
+                    rest = dist.mean.predictor_conditional(state, term_to_exclude=self.param)
+                    if is_chain(rest):
+                        raise NotImplementedError("per-chain offsets in the response mean (mixed models): later round")
+                y = state[key]
+                if is_chain(y):
+                    raise NotImplementedError("per-chain response")
+                y = np.asarray(y, dtype=np.float64)
+                n_rep = y.shape[1]
+                if n_rep != 1:
+                    raise NotImplementedError("replicated responses")
+                center = y - rest
+            if st.n != n:
+                raise ValueError("precision / parameter size mismatch")
+            cache = eng.model_cache(dist, state, st, center)
+            scale = _as_chain_scalar(eng, state, st.scale_key) if st.scale_key is not None else None
+            terms.append({"diag": cache["diag"], "off": cache["off"], "rhs": cache["rhs"], "center": cache["center"],
+                          "scale": None if scale is None else scale.scalar()})
+            keys.append(key)
+        return {"n": n, "terms_list": terms, "terms": eng.tridiag_terms(terms, n), "keys": keys,
+                "scale_ids": [None if t["scale"] is None else t["scale"].data_ptr() for t in terms]}
+
+    def plan(self, state):
+        p = self._plan
+        if p is not None:
+            # the per-chain scalars must still be the tensors the plan points at
+            for t, key in zip(p["terms_list"], p["keys"]):
+                st_key = self.model[key].precision.scalar if isinstance(self.model[key].precision, ScaledMatrix) else None
+                if st_key is not None and state[st_key].scalar().data_ptr() != t["scale"].data_ptr():
+                    p = None
+                    break
+        if p is None:
+            p = self._plan = self._build_plan(state)
+        return p
+
+    def sample(self, current_state: dict, out=None) -> dict:
+        """sampler.py:154-207.  `out`: optional (C, n) destination (e.g. a store slab)."""
+        eng = self._need_engine()
+        p = self.plan(current_state)
+        n = p["n"]
+        x = eng.empty(eng.n_chains, n) if out is None else out
+        z = self.inject(self, self._sweep) if self.inject is not None else None
+        eng.tridiag_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())
+        current_state[self.param] = ChainArray(x)
+        self._sweep += 1
+        return current_state
+
+
+@dataclass
+class NormalGamma(MCMCSampler):
+    """Normal-Gamma conjugate update of a scalar precision (sampler.py:210-288)."""
+
+    def __post_init__(self):
+        super().__post_init__()
+        others = [k for k in self.model.keys() if k != self.param]
+        self.normal_param = others[0]
+        precision = self.model[self.normal_param].precision
+        if not isinstance(precision, (Identity, ScaledMatrix)):
+            raise TypeError("precision must be either Identity, ScaledMatrix or MixtureParameterMatrix")
+
+    def prior_shape_rate(self, state):
+        return self.model[self.param].host_shape_rate(state)
+
+    def sample(self, current_state: dict) -> dict:
+        """a = a0 + #{diag(P)>0}/2, b = b0 + r'Pr/2, lambda ~ Gamma(a, scale 1/b)  (sampler.py:252-288)."""
+        eng = self._need_engine()
+        dist = self.model[self.normal_param]
+        st = dist.structure(current_state)
+        if st.diag is False:
+            raise NotImplementedError("non-tridiagonal precision: dense path is a later round")
+        x, m = dist.chain_and_center(current_state)
+        cache = eng.model_cache(dist, current_state, st, m)
+        quad = eng.empty(1, eng.n_chains)
+        eng.tridiag_quadform(st.n, cache["terms_unit"], x.vector(), quad)
+        a0, b0 = self.prior_shape_rate(current_state)
+        target = _as_chain_scalar(eng, current_state, self.param)
+        g = self.inject(self, self._sweep) if self.inject is not None else None
+        eng.normal_gamma_update(a0, b0, st.n_pos, quad[0], target.scalar(), g=g, draw_index=self._draw_index())
+        self._sweep += 1
+        return current_state
