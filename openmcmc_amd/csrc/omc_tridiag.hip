@@ -1049,7 +1049,9 @@ static bool launch_seg_any(omc_ctx* ctx, const TriArgs& A, int seg) {
 }
 
 static int auto_seg(int64_t n) {
-  if (n <= seg_max_n(16)) return 16;
+  // fewest nodes per lane that still fits one workgroup (measured on cfg3: 10 beats 16 and 20)
+  if (n <= seg_max_n(8)) return 8;
+  if (n <= seg_max_n(10)) return 10;
   return 32;
 }
 

@@ -158,29 +158,13 @@ class MCMC:
     def collect(self):
         """Host copy of the store in the reference's per-chain layout: {key: (C, size, n_iter)},
         log_post: (C, n_iter, 1)."""
-        out = {}
-        for key, t in self.store.items():
-            a = t.detach().cpu().numpy()
-            out[key] = np.transpose(a, (1, 0))[:, :, None] if key == "log_post" else np.transpose(a, (1, 2, 0))
-        return out
+        from openmcmc_amd.parallel import store_to_reference_layout
+
+        return {key: store_to_reference_layout(key, t.detach().cpu().numpy()) for key, t in self.store.items()}
 
     def gather(self, dst=0):
         """The one collective of the path: gather every rank's store on rank `dst` over RCCL (xGMI).
-        Returns the host dict of `collect()` for all chains on dst, None elsewhere; without an
-        initialised process group it is `collect()`."""
-        import torch.distributed as dist
+        Returns the host dict of `collect()` for all chains on dst, None elsewhere."""
+        from openmcmc_amd.parallel import gather_store
 
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return self.collect()
-        world, rank = dist.get_world_size(), dist.get_rank()
-        result = {} if rank == dst else None
-        for key in sorted(self.store):
-            t = self.store[key].contiguous()
-            bucket = [t.new_empty(t.shape) for _ in range(world)] if rank == dst else None
-            dist.gather(t, bucket, dst=dst)
-            if rank == dst:
-                import torch
-
-                a = torch.cat(bucket, dim=1).cpu().numpy()
-                result[key] = np.transpose(a, (1, 0))[:, :, None] if key == "log_post" else np.transpose(a, (1, 2, 0))
-        return result
+        return gather_store(self.store, dst=dst)

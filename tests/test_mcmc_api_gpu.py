@@ -1,0 +1,126 @@
+"""The reference-shaped API (Model / Normal / Gamma / ScaledMatrix / NormalNormal / NormalGamma /
+MCMC.run_mcmc) on chain-batched GPU state, replayed against the reference's own output
+(tests/golden/gmrf_chain.npz) and checked for fused == unfused."""
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def build(G, k, sparse_route, n_chains, fuse, n_burn=None, n_iter=None, seed=0):
+    from openmcmc_amd.distribution.distribution import Gamma
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import LinearCombination, ScaledMatrix
+    from openmcmc_amd.sampler.sampler import NormalGamma, NormalNormal
+
+    n = int(G[k + "n"])
+    pd, po = G[k + "P_diag"], G[k + "P_off"]
+    P = sparse.diags((po, pd, po), offsets=[-1, 0, 1], format="csc")
+    mean = LinearCombination(form={"b": "A"}) if sparse_route else "b"
+    mdl = Model([
+        Normal("y", mean=mean, precision=ScaledMatrix(matrix="P_tau", scalar="tau")),
+        Normal("b", mean="mu", precision=ScaledMatrix(matrix="P_lambda", scalar="lambda")),
+        Gamma("lambda", shape="a_lam", rate="b_lam"),
+        Gamma("tau", shape="a_tau", rate="b_tau"),
+    ])
+    state = {"y": G[k + "y"], "b": G[k + "y"], "mu": np.full(n, float(G[k + "mu_val"])), "lambda": 100,
+             "P_lambda": P, "a_lam": 10, "b_lam": 1, "tau": 1, "P_tau": sparse.csc_matrix(np.eye(n)),
+             "a_tau": 1, "b_tau": 1}
+    if sparse_route:
+        state["A"] = sparse.identity(n, format="csc")
+    samplers = [NormalNormal("b", mdl), NormalGamma("lambda", mdl), NormalGamma("tau", mdl)]
+    M = MCMC(state, samplers, model=mdl, n_burn=int(G[k + "n_burn"]) if n_burn is None else n_burn,
+             n_iter=int(G[k + "n_iter"]) if n_iter is None else n_iter, n_chains=n_chains, fuse=fuse, seed=seed)
+    return M, samplers
+
+
+@pytest.mark.parametrize("route", ["sparse", "dense", "sparsemu"])
+def test_run_mcmc_replays_reference(golden, route):
+    """Same model objects, same sampler list, the reference's recorded draws injected through the
+    samplers' `inject` hook: store matches the reference's store for every chain."""
+    G = golden("gmrf_chain")
+    k = route + "_"
+    C = 3
+    M, (nn, g_lam, g_tau) = build(G, k, route != "dense", C, fuse=False)
+    eng = M.engine
+    nn.inject = lambda smp, t: eng.to_device(np.tile(G[k + "z"][t], (C, 1)))
+    g_lam.inject = lambda smp, t: eng.full((C,), G[k + "g"][t, 0])
+    g_tau.inject = lambda smp, t: eng.full((C,), G[k + "g"][t, 1])
+    M.run_mcmc()
+    out = M.collect()
+    assert out["b"].shape == (C,) + G[k + "store_b"].shape
+    for c in range(C):
+        assert relerr(out["b"][c], G[k + "store_b"]) < TOL
+        assert relerr(out["lambda"][c], G[k + "store_lambda"]) < TOL
+        assert relerr(out["tau"][c], G[k + "store_tau"]) < TOL
+        assert relerr(out["log_post"][c], G[k + "store_log_post"]) < TOL
+
+
+def test_fused_and_unfused_loops_agree(golden):
+    """fuse=True hands the whole sampler list to omc_gmrf_sweep; results equal the sampler-by-sampler
+    loop to rounding (same random streams; the unfused NormalGamma sums its quadratic form in a
+    different order)."""
+    G = golden("gmrf_chain")
+    outs = []
+    for fuse in (False, True):
+        M, _ = build(G, "sparse_", True, 5, fuse=fuse, n_burn=4, n_iter=9, seed=123)
+        assert (M._fused is not None) == fuse
+        M.run_mcmc()
+        outs.append(M.collect())
+    for key in ("b", "lambda", "tau", "log_post"):
+        assert relerr(outs[1][key], outs[0][key]) < 1e-11, key
+    # chains are distinct draws from the same posterior
+    assert not np.array_equal(outs[0]["b"][0], outs[0]["b"][1])
+
+
+def test_store_shapes_and_state_untouched(golden):
+    """mcmc.py:78-85 / tests/test_sampler.py:181-198 of the reference: shapes, NaN-initialised store,
+    and no state entry other than the sampled one changes."""
+    G = golden("gmrf_chain")
+    M, (nn, g_lam, g_tau) = build(G, "sparse_", True, 2, fuse=False, n_burn=0, n_iter=3)
+    n = int(G["sparse_n"])
+    assert tuple(M.store["b"].shape) == (3, 2, n) and tuple(M.store["log_post"].shape) == (3, 2)
+    assert np.isnan(M.store["b"].cpu().numpy()).all()
+    before = {key: (v.numpy().copy() if hasattr(v, "numpy") and not isinstance(v, np.ndarray) else v)
+              for key, v in M.state.items()}
+    M.state = nn.sample(M.state)
+    assert M.state["b"].shape == (n, 1)
+    for key in ("lambda", "tau"):
+        assert np.array_equal(M.state[key].numpy(), before[key])
+    M.state = g_lam.sample(M.state)
+    assert not np.array_equal(M.state["lambda"].numpy(), before["lambda"])
+    assert np.array_equal(M.state["tau"].numpy(), before["tau"])
+
+
+def test_unsupported_structures_fail_loudly():
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.engine import Engine
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import ScaledMatrix
+    from openmcmc_amd.sampler.sampler import NormalNormal
+
+    n = 6
+    dense = np.eye(n) + 0.1 * np.ones((n, n))
+    mdl = Model([Normal("y", mean="b", precision=ScaledMatrix("P_tau", "tau")),
+                 Normal("b", mean="mu", precision=ScaledMatrix("P", "lam"))])
+    eng = Engine(2)
+    smp = NormalNormal("b", mdl).bind(eng)
+    from openmcmc_amd.chains import ChainArray
+
+    state = {"y": np.zeros((n, 1)), "b": ChainArray(eng.zeros(2, n)), "mu": np.zeros((n, 1)), "P": dense,
+             "lam": 1.0, "P_tau": sparse.identity(n, format="csc"), "tau": 1.0}
+    with pytest.raises(NotImplementedError):
+        smp.sample(state)
+    with pytest.raises(RuntimeError):
+        NormalNormal("b", mdl).sample(state)  # not bound to an engine
+    eng.close()
