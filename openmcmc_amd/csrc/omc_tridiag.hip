@@ -491,6 +491,8 @@ __device__ __forceinline__ void tile_store_chain(const double* tile, const Geom<
 // Per-chain combination of the shared term vectors, formed while the tile is filled (coalesced):
 //   DIAG: a = sum_k s_k diag_k (1 beyond n), OFF: b = sum_k s_k off_k, RHS: r = sum_k s_k rhs_k + rhs_chain
 enum { COMB_DIAG = 0, COMB_OFF = 1, COMB_RHS = 2 };
+// nodes per lane handled per batch of loads (memory-level parallelism vs registers)
+#define OMC_CH(M) ((M) % 5 == 0 ? 5 : 4)
 template <int M, bool MULTI, int WHICH>
 __device__ __forceinline__ void tile_fill_comb(double* tile, const Geom<M, MULTI>& g, const TriArgs& A,
                                                const double (&sc)[OMC_MAX_TERMS]) {
@@ -521,18 +523,17 @@ __device__ __forceinline__ void tile_fill_comb(double* tile, const Geom<M, MULTI
 // Workgroup-per-chain form of the combined fills: node index is linear in the tile element
 // (node = wave*64*M + e), so all loads of one fill are issued back to back (memory-level
 // parallelism; L2 latency is paid once per fill, not once per element) and only then combined.
-template <int M, int WHICH>
-__device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wave, const TriArgs& A,
-                                                  const double (&sc)[OMC_MAX_TERMS], bool chain_ok, int64_t cc) {
-  constexpr int CH = (M % 5 == 0) ? 5 : 4;  // loads in flight per lane and term
+template <int M, int WHICH, bool FULL>
+__device__ __forceinline__ void tile_fill_comb_body(double* tile, int lane, int wave_u, const TriArgs& A,
+                                                    const double (&sc)[OMC_MAX_TERMS], const double* rc) {
+  constexpr int CH = OMC_CH(M);  // loads in flight per lane and term
   const int nt = A.T.n_terms;
-  // 32-bit node indices (n <= 32768 here): scalar base + 32-bit lane offset addressing, nothing
-  // 64-bit kept live per element
+  // 32-bit node indices (n <= 32768 here) on a wave-uniform base pointer: scalar base + 32-bit
+  // lane offset addressing.  FULL = every node of this wave's tile is inside the vector: no
+  // per-element bounds test (true for all waves but the chain's last one).
   const int n = (int)A.n;
   const int lim = (WHICH == COMB_OFF) ? n - 1 : n;
-  const int base = wave * 64 * M + lane;
-  const double* rc = (WHICH == COMB_RHS && A.rhs_chain && chain_ok) ? A.rhs_chain + cc * A.ld_rhs : nullptr;
-  wave_lds_fence();
+  const int wbase = wave_u * 64 * M;
   int e = lane, q = lane / M, r = lane % M;
 #pragma unroll
   for (int t0 = 0; t0 < M; t0 += CH) {
@@ -550,31 +551,44 @@ __device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wa
         }
         continue;
       }
+      const double* ps = src + wbase;
       double ld[CH];
 #pragma unroll
       for (int t = 0; t < CH; ++t) {
-        const int nd = base + (t0 + t) * 64;
-        ld[t] = (nd < lim) ? src[(unsigned)nd] : 0.0;
+        const int off = lane + (t0 + t) * 64;
+        ld[t] = (FULL || wbase + off < lim) ? ps[(unsigned)off] : 0.0;
       }
 #pragma unroll
       for (int t = 0; t < CH; ++t) v[t] = fma(sc[k], ld[t], v[t]);
     }
-    if (rc) {
+    if (WHICH == COMB_RHS && rc) {
+      const double* pr = rc + wbase;
 #pragma unroll
       for (int t = 0; t < CH; ++t) {
-        const int nd = base + (t0 + t) * 64;
-        if (nd < n) v[t] += rc[(unsigned)nd];
+        const int off = lane + (t0 + t) * 64;
+        if (FULL || wbase + off < n) v[t] += pr[(unsigned)off];
       }
     }
 #pragma unroll
     for (int t = 0; t < CH; ++t) {
-      const int nd = base + (t0 + t) * 64;
-      tile[e + q] = (WHICH == COMB_DIAG && nd >= n) ? 1.0 : v[t];
+      const int off = lane + (t0 + t) * 64;
+      tile[e + q] = (!FULL && WHICH == COMB_DIAG && wbase + off >= n) ? 1.0 : v[t];
       e += 64; q += 64 / M; r += 64 % M;
       if (r >= M) { r -= M; ++q; }
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the next chunk's loads from being hoisted over this one
   }
+}
+
+template <int M, int WHICH>
+__device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wave, const TriArgs& A,
+                                                  const double (&sc)[OMC_MAX_TERMS], bool chain_ok, int64_t cc) {
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int lim = (WHICH == COMB_OFF) ? (int)A.n - 1 : (int)A.n;
+  const double* rc = (WHICH == COMB_RHS && A.rhs_chain && chain_ok) ? A.rhs_chain + cc * A.ld_rhs : nullptr;
+  wave_lds_fence();
+  if ((wave_u + 1) * 64 * M <= lim) tile_fill_comb_body<M, WHICH, true>(tile, lane, wave_u, A, sc, rc);
+  else tile_fill_comb_body<M, WHICH, false>(tile, lane, wave_u, A, sc, rc);
   wave_lds_fence();
 }
 
@@ -591,8 +605,68 @@ __device__ __forceinline__ double fast_sqrt(double r) { return omc_sqrt_nr(r); }
     }                                                                                                 \
   } while (0)
 
-#define OMC_NEWTON_TOL 4e-15
+// join residual (relative) below which the pivots are accepted: ~72 ulp; the Moebius start already
+// meets it for well-conditioned chains, weakly coupled ones take one or two Newton corrections
+#define OMC_NEWTON_TOL 1.6e-14
 #define OMC_NEWTON_MAX 4
+
+// Quadratic forms (x - m_k)' M_k (x - m_k) of one wave's 64*M nodes in the coalesced mapping: x comes
+// back from the tile (x_{i+1} = the next tile element; `xfirst_next` for the wave's last node), the
+// shared vectors straight from L2.  FULL: every node i of the wave has i + 1 < n (no bounds tests).
+template <int M, bool FULL>
+__device__ __forceinline__ void quad_chunks(const double* tile, int lane, int wave_u, const TriArgs& A,
+                                            double xfirst_next, double (&acc)[OMC_MAX_TERMS]) {
+  constexpr int CH = OMC_CH(M);
+  const int nt = A.T.n_terms, n32 = (int)A.n;
+  const int wbase = wave_u * 64 * M;
+  int e = lane, q = lane / M, r = lane % M;  // tile element, e / M, e % M
+#pragma unroll
+  for (int t0 = 0; t0 < M; t0 += CH) {
+    double xv[CH], xn[CH];  // x_i and x_{i+1}
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      xv[t] = tile[e + q];
+      const int e1 = e + 1, q1 = (r + 1 == M) ? q + 1 : q;
+      xn[t] = (e1 < 64 * M) ? tile[e1 + q1] : xfirst_next;
+      e += 64; q += 64 / M; r += 64 % M;
+      if (r >= M) { r -= M; ++q; }
+    }
+#pragma unroll
+    for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+      if (k >= nt) continue;
+      const double *ck = A.T.center[k], *dk = A.T.diag[k], *ok = A.T.off[k];
+      double ri[CH], rn[CH], dv[CH];
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        const int off = lane + (t0 + t) * 64, i = wbase + off;
+        const bool in = FULL || i < n32, in1 = FULL || i + 1 < n32;
+        ri[t] = (ck && in) ? (ck + wbase)[(unsigned)off] : 0.0;
+        rn[t] = (ck && ok && in1) ? (ck + wbase)[(unsigned)off + 1u] : 0.0;
+        dv[t] = in ? (dk ? (dk + wbase)[(unsigned)off] : 1.0) : 0.0;
+      }
+      if (ok) {
+        double ov[CH];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+          const int off = lane + (t0 + t) * 64;
+          ov[t] = (FULL || wbase + off + 1 < n32) ? (ok + wbase)[(unsigned)off] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+          const double a = xv[t] - ri[t], bnx = xn[t] - rn[t];
+          acc[k] = fma(fma(2.0 * ov[t], bnx, dv[t] * a), a, acc[k]);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+          const double a = xv[t] - ri[t];
+          acc[k] = fma(dv[t] * a, a, acc[k]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 
 // Register plan per lane (M nodes): X = z -> z/sqrt(D) -> residuals ; Y = b -> l ; W = 1/D -> g -> x.
 // The combined diagonal a (then the right-hand side r) lives in the wave's LDS tile.
@@ -799,56 +873,13 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     for (int j = 0; j < M; ++j) crow[j] = W[j];
     if (want_quad) __syncthreads();  // the last element of a wave needs the next wave's first x
     else wave_lds_fence();
-    const int wbase = wave * 64 * M + lane, n32 = (int)n;
+    const int n32 = (int)n;
     double acc[OMC_MAX_TERMS] = {0, 0, 0, 0};
-    // processed in chunks of CH nodes per lane: enough loads in flight to cover L2 latency,
-    // few enough live values to stay inside the register budget
-    constexpr int CH = (M % 5 == 0) ? 5 : 4;
-    int e = lane, q = lane / M, r = lane % M;  // tile element, e / M, e % M
     if (want_quad) {
-#pragma unroll
-    for (int t0 = 0; t0 < M; t0 += CH) {
-      double xv[CH], xn[CH];  // x_i and x_{i+1}
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        xv[t] = tile[e + q];
-        const int e1 = e + 1, q1 = (r + 1 == M) ? q + 1 : q;
-        xn[t] = (e1 < 64 * M) ? tile[e1 + q1] : ((wave + 1 < nw) ? lds_tile[(wave + 1) % NWMAX][0] : 0.0);
-        e += 64; q += 64 / M; r += 64 % M;
-        if (r >= M) { r -= M; ++q; }
-      }
-      const int ib = wbase + t0 * 64;
-      if (want_quad) {
-        _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt) {
-          const double *ck = A.T.center[k], *dk = A.T.diag[k], *ok = A.T.off[k];
-          double ri[CH], rn[CH], dv[CH];
-#pragma unroll
-          for (int t = 0; t < CH; ++t) {
-            const int i = ib + t * 64;
-            ri[t] = (ck && i < n32) ? ck[(unsigned)i] : 0.0;
-            rn[t] = (ck && ok && i + 1 < n32) ? ck[(unsigned)(i + 1)] : 0.0;
-            dv[t] = (i < n32) ? (dk ? dk[(unsigned)i] : 1.0) : 0.0;
-          }
-          if (ok) {
-            double ov[CH];
-#pragma unroll
-            for (int t = 0; t < CH; ++t) ov[t] = (ib + t * 64 + 1 < n32) ? ok[(unsigned)(ib + t * 64)] : 0.0;
-#pragma unroll
-            for (int t = 0; t < CH; ++t) {
-              const double a = xv[t] - ri[t], bnx = xn[t] - rn[t];
-              acc[k] = fma(fma(2.0 * ov[t], bnx, dv[t] * a), a, acc[k]);
-            }
-          } else {
-#pragma unroll
-            for (int t = 0; t < CH; ++t) {
-              const double a = xv[t] - ri[t];
-              acc[k] = fma(dv[t] * a, a, acc[k]);
-            }
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+      const double xfirst_next = (wave_u + 1 < nw) ? lds_tile[(wave_u + 1) % NWMAX][0] : 0.0;
+      if ((wave_u + 1) * 64 * M < n32) quad_chunks<M, true>(tile, lane, wave_u, A, xfirst_next, acc);
+      else quad_chunks<M, false>(tile, lane, wave_u, A, xfirst_next, acc);
     }
     if (want_quad) {
       _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt) {
