@@ -108,19 +108,19 @@ __device__ __forceinline__ double read_lane_d(double v, int l) {  // l wave-unif
 // wave 0 while the other waves are already storing x): lanes 16k..16k+15 belong to term k and each
 // evaluates one Marsaglia-Tsang attempt; the lowest accepted attempt is the serial answer.
 __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c, const double (&quad)[OMC_MAX_TERMS],
-                                                    int lane) {
+                                                    double s_old, double ldet, int lane) {
   const int k = lane >> 4, j = lane & 15;
   const bool term_on = k < A.T.n_terms;
   // per-lane copy of this lane's term, selected with compile-time indices (a dynamically indexed
   // kernel-argument array would be spilled to scratch)
   GammaDev g = A.gb[0];
-  const double* scale_p = A.T.scale[0];
-  double qk = quad[0];
+  double qk = quad[0], s = s_old;  // this lane's term; scalars were loaded before the quad phase
+  const double ld_k = ldet;
 #pragma unroll
   for (int t = 1; t < OMC_MAX_TERMS; ++t) {
-    if (k == t) { g = A.gb[t]; scale_p = A.T.scale[t]; qk = quad[t]; }
+    if (k == t) { g = A.gb[t]; qk = quad[t]; }
   }
-  double s = (term_on && scale_p) ? scale_p[c] : 1.0;
+  if (!term_on) s = 1.0;
   const bool draw = term_on && g.enabled;
   bool failed = false;
   if (__ballot(draw) != 0ull) {
@@ -158,7 +158,7 @@ __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c,
     double lp = 0.0;
     if (term_on && j == 0) {
       const double nd = (double)A.n;
-      lp = 0.5 * (nd * log(s) + g.logdet_unscaled[0] - nd * 1.8378770664093453 - s * qk);
+      lp = 0.5 * (nd * log(s) + ld_k - nd * 1.8378770664093453 - s * qk);
       if (g.enabled) lp += g.lnorm + (g.a0 - 1.0) * log(s) - g.b0 * s;
     }
     // terms are summed in order 0,1,2,3 as the serial epilogue does
@@ -865,6 +865,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   OMC_STAMP(7);
   const bool want_quad = A.quad || A.fused;
   double qsum[OMC_MAX_TERMS] = {0, 0, 0, 0};
+  double my_scale = 1.0, my_logdet = 0.0;  // epilogue scalars of this lane's term (wave 0)
   if (MULTI) {
     // ---- store + fused quadratic forms, both in the coalesced mapping: lane handles nodes
     //      wbase + t*64 + lane; x comes back from the tile, the shared vectors straight from L2 ----
@@ -875,6 +876,13 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     else wave_lds_fence();
     const int n32 = (int)n;
     double acc[OMC_MAX_TERMS] = {0, 0, 0, 0};
+    // scalars of the epilogue: issue their loads now so the latency hides behind the quad phase
+    if (A.fused && wave == 0) {  // lane group k = lane >> 4 serves term k
+      _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt && (lane >> 4) == k) {
+        if (A.T.scale[k]) my_scale = A.T.scale[k][cc];
+        if (A.log_post && A.gb[k].logdet_unscaled) my_logdet = A.gb[k].logdet_unscaled[0];
+      }
+    }
     if (want_quad) {
       const int wave_u = __builtin_amdgcn_readfirstlane(wave);
       const double xfirst_next = (wave_u + 1 < nw) ? lds_tile[(wave_u + 1) % NWMAX][0] : 0.0;
@@ -937,7 +945,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   }
   if (bad && chain_ok) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
   if (MULTI) {
-    if (A.fused && wave == 0 && chain_ok) sweep_epilogue_wave(A, c, qsum, lane);
+    if (A.fused && wave == 0 && chain_ok) sweep_epilogue_wave(A, c, qsum, my_scale, my_logdet, lane);
     // x leaves last: a load issued behind a store would have to wait for the store to be
     // acknowledged (vmcnt retires in order); this way nothing ever waits on the x stream.
     if (A.x && chain_ok) {
