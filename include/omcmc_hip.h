@@ -142,6 +142,42 @@ omc_status omc_tridiag_matvec(omc_ctx* ctx, int64_t n, const double* diag, const
 omc_status omc_tridiag_logdet(omc_ctx* ctx, int64_t n, const double* diag, const double* off,
                               double* logdet);
 
+/* ---- Normal/Normal conjugate-Gibbs draw, DENSE conditional precision ------------------------
+ * The same update as omc_tridiag_sample_canonical for Q_c = sum_k scale[k][c] * M_k with M_k shared
+ * dense symmetric p x p matrices (NULL = identity): the regression case of NormalNormal.sample where
+ * the likelihood Hessian is the Gram matrix G = A' W A (sampler.py:185-186 -> location_scale.py:
+ * 238-241) and b = P m + A' W (y - d) (sampler.py:183,190-192).  Per chain: dense Cholesky
+ * (gmrf.py:481 np.linalg.cholesky = LAPACK potrf; here rocSOLVER potrf_strided_batched),
+ * mu = cho_solve (gmrf.py:462), x = mu + L^{-T} z (gmrf.py:434; the reference calls a general LU
+ * solve there, the result is the same triangular solve).  Factors live in a workspace owned by
+ * the context (C * p * p doubles, allocated on first use).                                      */
+typedef struct {
+  int32_t n_terms;                      /* 1..OMC_MAX_TERMS                                  */
+  const double* mat[OMC_MAX_TERMS];     /* [p*p] shared symmetric; NULL = identity           */
+  const double* rhs[OMC_MAX_TERMS];     /* [p]   shared; NULL = zeros                        */
+  const double* scale[OMC_MAX_TERMS];   /* [C]   per-chain scalar; NULL = 1                  */
+} omc_dense_terms;
+
+omc_status omc_dense_sample_canonical(omc_ctx* ctx, int64_t p, const omc_dense_terms* terms,
+                                      const double* rhs_chain, int64_t ld_rhs,
+                                      const double* z_inject, int64_t ld_z, uint64_t draw_index,
+                                      double* x_out, int64_t ld_x,
+                                      double* mean_out, int64_t ld_mean, double* logdet_out);
+
+/* Design-matrix helpers; X is [n][p] row-major (a NumPy array as is), shared by all chains; w is an
+ * optional [n] diagonal weight (NULL = ones).
+ *   omc_gram:            G[p][p] = X' diag(w) X                 (location_scale.py:238-241; fp64 MFMA GEMM)
+ *   omc_design_rhs:      out[p]  = X' diag(w) y                 (sampler.py:192)
+ *   omc_design_predict:  fitted[c][:] = X beta_c                (parameter.py:196; one GEMM for all chains)
+ *   omc_weighted_resid_sq: out[c] = (y - f_c)' diag(w) (y - f_c) (sampler.py:276,284)              */
+omc_status omc_gram(omc_ctx* ctx, int64_t n, int64_t p, const double* X, const double* w, double* G_out);
+omc_status omc_design_rhs(omc_ctx* ctx, int64_t n, int64_t p, const double* X, const double* w,
+                          const double* y, double* out);
+omc_status omc_design_predict(omc_ctx* ctx, int64_t n, int64_t p, const double* X,
+                              const double* beta, int64_t ld_beta, double* fitted, int64_t ld_fitted);
+omc_status omc_weighted_resid_sq(omc_ctx* ctx, int64_t n, const double* y, const double* fitted,
+                                 int64_t ld_fitted, const double* w, double* out);
+
 /* ---- Normal-Gamma conjugate update ---------------------------------------------------------
  * NormalGamma.sample (sampler.py:252-288) for a scalar precision per chain:
  *   a = a0 + n_pos/2, b = b0 + quad[c]/2, out[c] = Gamma(a, scale = 1/b); b == 0 -> scale inf.

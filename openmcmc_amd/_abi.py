@@ -33,6 +33,17 @@ class TridiagTerms(C.Structure):
     ]
 
 
+class DenseTerms(C.Structure):
+    """omc_dense_terms."""
+
+    _fields_ = [
+        ("n_terms", i32),
+        ("mat", c_dp * OMC_MAX_TERMS),
+        ("rhs", c_dp * OMC_MAX_TERMS),
+        ("scale", c_dp * OMC_MAX_TERMS),
+    ]
+
+
 class GammaBlock(C.Structure):
     """omc_gamma_block."""
 
@@ -65,6 +76,14 @@ SIGNATURES = {
         i32,
         [C.c_void_p, i64, C.POINTER(TridiagTerms), C.POINTER(GammaBlock), c_dp, i64, c_dp, i64, u64, c_dp, i64, c_dp],
     ),
+    "omc_dense_sample_canonical": (
+        i32,
+        [C.c_void_p, i64, C.POINTER(DenseTerms), c_dp, i64, c_dp, i64, u64, c_dp, i64, c_dp, i64, c_dp],
+    ),
+    "omc_gram": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp]),
+    "omc_design_rhs": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp]),
+    "omc_design_predict": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, i64, c_dp, i64]),
+    "omc_weighted_resid_sq": (i32, [C.c_void_p, i64, c_dp, c_dp, i64, c_dp, c_dp]),
     "omc_tridiag_quadform": (i32, [C.c_void_p, i64, C.POINTER(TridiagTerms), c_dp, i64, c_dp]),
     "omc_tridiag_matvec": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp]),
     "omc_tridiag_logdet": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp]),
@@ -86,6 +105,13 @@ def _load():
     # the SAME HIP runtime (two runtimes in one process cannot share the device or a stream).
     import torch  # noqa: F401
 
+    # same for rocBLAS / rocSOLVER (dense path): bind to the copies PyTorch bundles, not to a
+    # second set from /opt/rocm
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    for name in ("librocblas.so", "librocsolver.so"):
+        path = os.path.join(tlib, name)
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -15,12 +15,18 @@ struct omc_ctx {
   long long* d_bad_chain;  // device word: min local chain index with a non-positive pivot, or LLONG_MAX
   double* workspace;       // scratch for the serial kernel (l vectors), grown on demand
   size_t workspace_bytes;
+  // dense path (omc_dense.hip): rocBLAS handle and workspaces, created on first use
+  void* blas;
+  double* dense_factor; size_t dense_factor_bytes;
+  int* dense_info; size_t dense_info_bytes;
+  double* dense_tmp; size_t dense_tmp_bytes;
   int tridiag_algo;  // 0 auto, 1 serial, 2 segmented
   int tridiag_seg;   // 0 auto, else nodes per lane
   unsigned long long* stamps;  // diagnostic phase stamps of the segmented kernel (NULL = off)
 };
 
 void omc_set_error(const char* what, hipError_t e);
+void omc_dense_release(omc_ctx* ctx);  // destroys the rocBLAS handle if one was created
 
 #define OMC_HIP_CHECK(expr)                  \
   do {                                       \

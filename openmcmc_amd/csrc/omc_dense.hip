@@ -1,0 +1,281 @@
+// Dense Normal-Normal path (regression-shaped conditionals): batched assembly + rocSOLVER batched
+// Cholesky + rocBLAS batched triangular solves, and the design-matrix GEMMs (fp64 MFMA through
+// rocBLAS).  Reference call sites: sampler.py:176-197, location_scale.py:234-242, gmrf.py:434,462,481.
+#include <math.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include "omc_common.h"
+
+struct DenseTermsDev {
+  int n_terms;
+  const double* mat[OMC_MAX_TERMS];
+  const double* rhs[OMC_MAX_TERMS];
+  const double* scale[OMC_MAX_TERMS];
+};
+
+#define OMC_BLAS_CHECK(expr)                                   \
+  do {                                                         \
+    rocblas_status _s = (expr);                                \
+    if (_s != rocblas_status_success) {                        \
+      omc_set_error(#expr, hipErrorUnknown);                   \
+      return OMC_HIP_ERROR;                                    \
+    }                                                          \
+  } while (0)
+
+static omc_status ensure_blas(omc_ctx* ctx) {
+  if (!ctx->blas) {
+    rocblas_handle h;
+    OMC_BLAS_CHECK(rocblas_create_handle(&h));
+    OMC_BLAS_CHECK(rocblas_set_stream(h, ctx->stream));
+    OMC_BLAS_CHECK(rocblas_set_pointer_mode(h, rocblas_pointer_mode_host));
+    ctx->blas = (void*)h;
+  }
+  return OMC_OK;
+}
+
+static omc_status ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need) {
+  if (*have >= need) return OMC_OK;
+  OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (*buf) OMC_HIP_CHECK(hipFree(*buf));
+  *buf = nullptr;
+  *have = 0;
+  OMC_HIP_CHECK(hipMalloc(buf, need));
+  *have = need;
+  return OMC_OK;
+}
+
+// Q[c] = sum_k s_k[c] M_k (full matrix; symmetric so the storage order does not matter)
+__global__ void __launch_bounds__(256) k_dense_assemble(DenseTermsDev T, int64_t p, int64_t C, double* Q) {
+  const int64_t c = blockIdx.y;
+  double sc[OMC_MAX_TERMS];
+#pragma unroll
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) sc[k] = (k < T.n_terms && T.scale[k]) ? T.scale[k][c] : 1.0;
+  double* q = Q + c * p * p;
+  const int64_t total = p * p;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / p, cl = i - r * p;
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+      if (k >= T.n_terms) continue;
+      v = fma(sc[k], T.mat[k] ? T.mat[k][i] : (r == cl ? 1.0 : 0.0), v);
+    }
+    q[i] = v;
+  }
+}
+
+// b[c] = sum_k s_k[c] rhs_k + rhs_chain[c]
+__global__ void k_dense_rhs(DenseTermsDev T, int64_t p, int64_t C, const double* rhs_chain, int64_t ld_rhs,
+                            double* b, int64_t ld_b) {
+  const int64_t c = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p; i += (int64_t)gridDim.x * blockDim.x) {
+    double v = rhs_chain ? rhs_chain[c * ld_rhs + i] : 0.0;
+#pragma unroll
+    for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+      if (k >= T.n_terms || !T.rhs[k]) continue;
+      v = fma(T.scale[k] ? T.scale[k][c] : 1.0, T.rhs[k][i], v);
+    }
+    b[c * ld_b + i] = v;
+  }
+}
+
+// after potrf: latch failures, log det = 2 sum log L_ii
+__global__ void __launch_bounds__(256) k_dense_post_factor(int64_t p, int64_t C, const double* L, const int* info,
+                                                          double* logdet, long long* bad) {
+  __shared__ double red[4];
+  const int64_t c = blockIdx.x;
+  if (threadIdx.x == 0 && info[c] != 0) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+  if (!logdet) return;
+  const double* l = L + c * p * p;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < p; i += blockDim.x) acc += log(l[i * p + i]);
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) logdet[c] = 2.0 * (red[0] + red[1] + red[2] + red[3]);
+}
+
+// t[c] = w[c] + z[c]   (z injected or from the chain's Philox stream)
+__global__ void k_add_draw(int64_t p, int64_t C, int64_t chain_offset, omc_rng_key key, const double* z,
+                           int64_t ld_z, double* t, int64_t ld_t) {
+  const int64_t c = blockIdx.y;
+  const int64_t npairs = (p + 1) / 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (int64_t)gridDim.x * blockDim.x) {
+    double z0, z1;
+    if (z) {
+      z0 = z[c * ld_z + 2 * q];
+      z1 = (2 * q + 1 < p) ? z[c * ld_z + 2 * q + 1] : 0.0;
+    } else {
+      omc_normal_pair(omc_rng_block(key, chain_offset + c, (uint32_t)q), z0, z1);
+    }
+    t[c * ld_t + 2 * q] += z0;
+    if (2 * q + 1 < p) t[c * ld_t + 2 * q + 1] += z1;
+  }
+}
+
+__global__ void k_copy_rows(int64_t p, const double* src, int64_t ld_s, double* dst, int64_t ld_d) {
+  const int64_t c = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p; i += (int64_t)gridDim.x * blockDim.x)
+    dst[c * ld_d + i] = src[c * ld_s + i];
+}
+
+// Xw[i][j] = w[i] * X[i][j]
+__global__ void k_scale_rows(int64_t n, int64_t p, const double* X, const double* w, double* out) {
+  const int64_t total = n * p;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = X[i] * w[i / p];
+}
+
+__global__ void __launch_bounds__(256) k_weighted_resid_sq(int64_t n, const double* y, const double* f, int64_t ld_f,
+                                                          const double* w, double* out) {
+  __shared__ double red[4];
+  const int64_t c = blockIdx.x;
+  const double* fc = f + c * ld_f;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const double r = y[i] - fc[i];
+    acc = fma((w ? w[i] : 1.0) * r, r, acc);
+  }
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[c] = red[0] + red[1] + red[2] + red[3];
+}
+
+static unsigned gx(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+void omc_dense_release(omc_ctx* ctx) {
+  if (ctx->blas) rocblas_destroy_handle((rocblas_handle)ctx->blas);
+  ctx->blas = nullptr;
+}
+
+extern "C" {
+
+omc_status omc_dense_sample_canonical(omc_ctx* ctx, int64_t p, const omc_dense_terms* terms, const double* rhs_chain,
+                                      int64_t ld_rhs, const double* z_inject, int64_t ld_z, uint64_t draw_index,
+                                      double* x_out, int64_t ld_x, double* mean_out, int64_t ld_mean,
+                                      double* logdet_out) {
+  if (!ctx || p < 1 || p > 32768 || !terms || terms->n_terms < 1 || terms->n_terms > OMC_MAX_TERMS) return OMC_INVALID_ARG;
+  if (!x_out || ld_x < p || (rhs_chain && ld_rhs < p) || (z_inject && ld_z < p) || (mean_out && ld_mean < p))
+    return OMC_INVALID_ARG;
+  const int64_t C = ctx->n_chains;
+  if (C > 65535) return OMC_UNSUPPORTED;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  omc_status st = ensure_blas(ctx);
+  if (st != OMC_OK) return st;
+  st = ensure_bytes(ctx, (void**)&ctx->dense_factor, &ctx->dense_factor_bytes, (size_t)C * p * p * sizeof(double));
+  if (st != OMC_OK) return st;
+  st = ensure_bytes(ctx, (void**)&ctx->dense_info, &ctx->dense_info_bytes, (size_t)C * sizeof(int));
+  if (st != OMC_OK) return st;
+  DenseTermsDev T;
+  T.n_terms = terms->n_terms;
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+    const bool on = k < terms->n_terms;
+    T.mat[k] = on ? terms->mat[k] : nullptr;
+    T.rhs[k] = on ? terms->rhs[k] : nullptr;
+    T.scale[k] = on ? terms->scale[k] : nullptr;
+  }
+  rocblas_handle h = (rocblas_handle)ctx->blas;
+  double* Q = ctx->dense_factor;
+  hipLaunchKernelGGL(k_dense_assemble, dim3(gx(p * p) > 64 ? 64 : gx(p * p), (unsigned)C), dim3(256), 0, ctx->stream, T, p, C, Q);
+  OMC_HIP_CHECK(hipGetLastError());
+  OMC_BLAS_CHECK(rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, (rocblas_int)p, Q, (rocblas_int)p,
+                                                  (rocblas_stride)(p * p), ctx->dense_info, (rocblas_int)C));
+  hipLaunchKernelGGL(k_dense_post_factor, dim3((unsigned)C), dim3(256), 0, ctx->stream, p, C, Q, ctx->dense_info,
+                     logdet_out, ctx->d_bad_chain);
+  OMC_HIP_CHECK(hipGetLastError());
+  // w = L^{-1} b in x_out
+  hipLaunchKernelGGL(k_dense_rhs, dim3(gx(p), (unsigned)C), dim3(256), 0, ctx->stream, T, p, C, rhs_chain, ld_rhs, x_out, ld_x);
+  OMC_HIP_CHECK(hipGetLastError());
+  OMC_BLAS_CHECK(rocblas_dtrsv_strided_batched(h, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+                                               (rocblas_int)p, Q, (rocblas_int)p, (rocblas_stride)(p * p), x_out, 1,
+                                               (rocblas_stride)ld_x, (rocblas_int)C));
+  if (mean_out) {  // mu = L^{-T} w  (gmrf.py:196)
+    hipLaunchKernelGGL(k_copy_rows, dim3(gx(p), (unsigned)C), dim3(256), 0, ctx->stream, p, x_out, ld_x, mean_out, ld_mean);
+    OMC_HIP_CHECK(hipGetLastError());
+    OMC_BLAS_CHECK(rocblas_dtrsv_strided_batched(h, rocblas_fill_lower, rocblas_operation_transpose,
+                                                 rocblas_diagonal_non_unit, (rocblas_int)p, Q, (rocblas_int)p,
+                                                 (rocblas_stride)(p * p), mean_out, 1, (rocblas_stride)ld_mean,
+                                                 (rocblas_int)C));
+  }
+  // x = L^{-T} (w + z)
+  hipLaunchKernelGGL(k_add_draw, dim3(gx((p + 1) / 2), (unsigned)C), dim3(256), 0, ctx->stream, p, C, ctx->chain_offset,
+                     omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), z_inject, ld_z, x_out, ld_x);
+  OMC_HIP_CHECK(hipGetLastError());
+  OMC_BLAS_CHECK(rocblas_dtrsv_strided_batched(h, rocblas_fill_lower, rocblas_operation_transpose,
+                                               rocblas_diagonal_non_unit, (rocblas_int)p, Q, (rocblas_int)p,
+                                               (rocblas_stride)(p * p), x_out, 1, (rocblas_stride)ld_x, (rocblas_int)C));
+  return OMC_OK;
+}
+
+// X is [n][p] row-major = column-major p x n (lda = p).
+omc_status omc_gram(omc_ctx* ctx, int64_t n, int64_t p, const double* X, const double* w, double* G_out) {
+  if (!ctx || n < 1 || p < 1 || !X || !G_out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  omc_status st = ensure_blas(ctx);
+  if (st != OMC_OK) return st;
+  const double* B = X;
+  if (w) {
+    st = ensure_bytes(ctx, (void**)&ctx->dense_tmp, &ctx->dense_tmp_bytes, (size_t)n * p * sizeof(double));
+    if (st != OMC_OK) return st;
+    hipLaunchKernelGGL(k_scale_rows, dim3(gx(n * p)), dim3(256), 0, ctx->stream, n, p, X, w, ctx->dense_tmp);
+    OMC_HIP_CHECK(hipGetLastError());
+    B = ctx->dense_tmp;
+  }
+  const double one = 1.0, zero = 0.0;
+  OMC_BLAS_CHECK(rocblas_dgemm((rocblas_handle)ctx->blas, rocblas_operation_none, rocblas_operation_transpose,
+                               (rocblas_int)p, (rocblas_int)p, (rocblas_int)n, &one, X, (rocblas_int)p, B,
+                               (rocblas_int)p, &zero, G_out, (rocblas_int)p));
+  return OMC_OK;
+}
+
+omc_status omc_design_rhs(omc_ctx* ctx, int64_t n, int64_t p, const double* X, const double* w, const double* y,
+                          double* out) {
+  if (!ctx || n < 1 || p < 1 || !X || !y || !out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  omc_status st = ensure_blas(ctx);
+  if (st != OMC_OK) return st;
+  const double* v = y;
+  if (w) {
+    st = ensure_bytes(ctx, (void**)&ctx->dense_tmp, &ctx->dense_tmp_bytes, (size_t)n * sizeof(double));
+    if (st != OMC_OK) return st;
+    hipLaunchKernelGGL(k_scale_rows, dim3(gx(n)), dim3(256), 0, ctx->stream, n, (int64_t)1, y, w, ctx->dense_tmp);
+    OMC_HIP_CHECK(hipGetLastError());
+    v = ctx->dense_tmp;
+  }
+  const double one = 1.0, zero = 0.0;
+  // out = A v with A = column-major p x n
+  OMC_BLAS_CHECK(rocblas_dgemv((rocblas_handle)ctx->blas, rocblas_operation_none, (rocblas_int)p, (rocblas_int)n, &one, X,
+                               (rocblas_int)p, v, 1, &zero, out, 1));
+  return OMC_OK;
+}
+
+omc_status omc_design_predict(omc_ctx* ctx, int64_t n, int64_t p, const double* X, const double* beta, int64_t ld_beta,
+                              double* fitted, int64_t ld_fitted) {
+  if (!ctx || n < 1 || p < 1 || !X || !beta || !fitted || ld_beta < p || ld_fitted < n) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  omc_status st = ensure_blas(ctx);
+  if (st != OMC_OK) return st;
+  const double one = 1.0, zero = 0.0;
+  // fitted (col-major n x C, ld = ld_fitted) = A' (n x p) * Beta (col-major p x C, ld = ld_beta)
+  OMC_BLAS_CHECK(rocblas_dgemm((rocblas_handle)ctx->blas, rocblas_operation_transpose, rocblas_operation_none,
+                               (rocblas_int)n, (rocblas_int)ctx->n_chains, (rocblas_int)p, &one, X, (rocblas_int)p, beta,
+                               (rocblas_int)ld_beta, &zero, fitted, (rocblas_int)ld_fitted));
+  return OMC_OK;
+}
+
+omc_status omc_weighted_resid_sq(omc_ctx* ctx, int64_t n, const double* y, const double* fitted, int64_t ld_fitted,
+                                 const double* w, double* out) {
+  if (!ctx || n < 1 || !y || !fitted || ld_fitted < n || !out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_weighted_resid_sq, dim3((unsigned)ctx->n_chains), dim3(256), 0, ctx->stream, n, y, fitted,
+                     ld_fitted, w, out);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+}  // extern "C"

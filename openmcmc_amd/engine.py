@@ -191,6 +191,63 @@ class Engine:
                                      self._p(out)))
         return out
 
+    # ------------------------------------------------------------------ dense Normal-Normal
+    def dense_terms(self, terms, p):
+        """terms: list of dicts with optional keys mat ((p,p) shared symmetric; None = identity),
+        rhs ((p,) shared), scale ((C,) per chain)."""
+        if not 1 <= len(terms) <= _abi.OMC_MAX_TERMS:
+            raise ValueError("1..4 terms supported")
+        T = _abi.DenseTerms()
+        T.n_terms = len(terms)
+        keep = []
+        for k, t in enumerate(terms):
+            m = t.get("mat")
+            if m is not None and (m.dim() != 2 or m.shape[0] != p or m.shape[1] != p or not m.is_contiguous()):
+                raise ValueError("mat must be a contiguous (p, p) tensor")
+            T.mat[k] = self._p(m)
+            T.rhs[k] = self._vec(t.get("rhs"), p)
+            T.scale[k] = self._chain_scalar(t.get("scale"))
+            keep.append(dict(t))
+        T._keep = keep
+        return T
+
+    def dense_sample_canonical(self, p, terms, x_out, z=None, rhs_chain=None, draw_index=0, mean_out=None,
+                               logdet_out=None):
+        T = terms if isinstance(terms, _abi.DenseTerms) else self.dense_terms(terms, p)
+        Cn = self.n_chains
+        ld = lambda t: 0 if t is None else t.stride(0)  # noqa: E731
+        check(lib.omc_dense_sample_canonical(
+            self._ctx, p, C.byref(T), self._p(rhs_chain, Cn, p), ld(rhs_chain), self._p(z, Cn, p), ld(z),
+            int(draw_index), self._p(x_out, Cn, p), ld(x_out), self._p(mean_out, Cn, p), ld(mean_out),
+            self._chain_scalar(logdet_out)))
+
+    def gram(self, X, w=None):
+        """G = X' diag(w) X for a shared (n, p) design matrix."""
+        n, p = X.shape
+        G = self.empty(p, p)
+        check(lib.omc_gram(self._ctx, n, p, self._p(X), self._vec(w, n), self._p(G)))
+        return G
+
+    def design_rhs(self, X, y, w=None):
+        """X' diag(w) y."""
+        n, p = X.shape
+        out = self.empty(p)
+        check(lib.omc_design_rhs(self._ctx, n, p, self._p(X), self._vec(w, n), self._vec(y, n), self._p(out)))
+        return out
+
+    def design_predict(self, X, beta, fitted=None):
+        """fitted[c] = X beta_c for all chains (one GEMM)."""
+        n, p = X.shape
+        fitted = self.empty(self.n_chains, n) if fitted is None else fitted
+        check(lib.omc_design_predict(self._ctx, n, p, self._p(X), self._p(beta, self.n_chains, p), beta.stride(0),
+                                     self._p(fitted, self.n_chains, n), fitted.stride(0)))
+        return fitted
+
+    def weighted_resid_sq(self, y, fitted, out, w=None):
+        n = y.numel()
+        check(lib.omc_weighted_resid_sq(self._ctx, n, self._vec(y, n), self._p(fitted, self.n_chains, n),
+                                        fitted.stride(0), self._vec(w, n), self._chain_scalar(out)))
+
     # ------------------------------------------------------------------ per-model constants
     def model_cache(self, dist, state, st, center):
         """Device copies of one Normal's shared pieces (bands of M, the vector m its residual is taken

@@ -1,0 +1,148 @@
+"""Dense Normal-Normal path (regression-shaped conditionals, BASELINE configs[0]/[1] shape) through
+the C ABI against the reference's golden vectors and the oracle."""
+
+import numpy as np
+import pytest
+
+from oracle import gmrf_ref, sweep_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def make_engine(C, **kw):
+    from openmcmc_amd.engine import Engine
+
+    return Engine(C, **kw)
+
+
+@pytest.mark.parametrize("p", [1, 7, 32])
+def test_dense_primitives_golden(golden, p):
+    """gmrf.cholesky / cho_solve / sample_normal_canonical on a dense Q (reference vectors)."""
+    G = golden("dense_primitives")
+    k = f"p{p}_"
+    C = 3
+    eng = make_engine(C)
+    Q = eng.to_device(G[k + "Q"])
+    terms = [{"mat": Q, "scale": eng.full((C,), 1.0)}]
+    b = eng.to_device(np.tile(G[k + "b"], (C, 1)))
+    z = eng.to_device(np.tile(G[k + "z"], (C, 1)))
+    x, mean, logdet = eng.empty(C, p), eng.empty(C, p), eng.empty(C)
+    eng.dense_sample_canonical(p, terms, x, z=z, rhs_chain=b, mean_out=mean, logdet_out=logdet)
+    eng.check_status()
+    for c in range(C):
+        assert relerr(x[c].cpu().numpy(), G[k + "x"]) < TOL
+        assert relerr(mean[c].cpu().numpy(), G[k + "mu"]) < TOL
+        assert relerr(logdet[c].item(), 2 * np.sum(np.log(np.diag(G[k + "L"])))) < TOL
+    eng.close()
+
+
+@pytest.mark.parametrize("tag", ["ex3", "p7"])
+def test_linreg_chain_golden(golden, tag):
+    """MCMC.run_mcmc of example 3 (BASELINE configs[0]) replayed through the ABI with the reference's
+    draws: beta, tau, lambda, log_post and the fitted values y = X beta."""
+    G = golden("linreg_chain")
+    k = tag + "_"
+    X, y = G[k + "X"], G[k + "y"]
+    N, p = X.shape
+    n_burn, n_iter = int(G[k + "n_burn"]), int(G[k + "n_iter"])
+    C = 2
+    eng = make_engine(C)
+    dX, dy = eng.to_device(X), eng.to_device(y)
+    Gram, Xty = eng.gram(dX), eng.design_rhs(dX, dy)
+    lam, tau = eng.full((C,), 0.01), eng.full((C,), 1.0)
+    terms = eng.dense_terms([{"mat": None, "scale": lam}, {"mat": Gram, "rhs": Xty, "scale": tau}], p)
+    ident = eng.tridiag_terms([{}], p)  # (beta - 0)' I (beta - 0)
+    beta, fitted = eng.empty(C, p), eng.empty(C, N)
+    q_tau, q_lam, lp = eng.empty(C), eng.empty(1, C), eng.empty(C)
+    zero = eng.zeros(1)
+    store = {key: [] for key in ("beta", "tau", "lambda", "log_post", "y")}
+    for it in range(n_burn + n_iter):
+        eng.dense_sample_canonical(p, terms, beta, z=eng.to_device(np.tile(G[k + "z"][it], (C, 1))))
+        eng.design_predict(dX, beta, fitted)
+        eng.weighted_resid_sq(dy, fitted, q_tau)
+        g = G[k + "g"][it]
+        eng.normal_gamma_update(1e-3, 1e-3, N, q_tau, tau, g=eng.full((C,), g[0]))
+        eng.tridiag_quadform(p, ident, beta, q_lam)
+        eng.normal_gamma_update(1e-3, 1e-3, p, q_lam[0], lam, g=eng.full((C,), g[1]))
+        if it < n_burn:
+            continue
+        eng.scaled_gauss_logpdf(N, tau, zero, q_tau, lp)
+        eng.scaled_gauss_logpdf(p, lam, zero, q_lam[0], lp, accumulate=True)
+        eng.gamma_logpdf(tau, 1e-3, 1e-3, lp, accumulate=True)
+        eng.gamma_logpdf(lam, 1e-3, 1e-3, lp, accumulate=True)
+        store["beta"].append(beta[1].cpu().numpy().copy())
+        store["tau"].append(tau[1].item())
+        store["lambda"].append(lam[1].item())
+        store["log_post"].append(lp[1].item())
+        store["y"].append(fitted[1].cpu().numpy().copy())
+    eng.check_status()
+    assert relerr(np.array(store["beta"]).T, G[k + "store_beta"]) < 1e-9
+    assert relerr(store["tau"], G[k + "store_tau"].ravel()) < 1e-9
+    assert relerr(store["lambda"], G[k + "store_lambda"].ravel()) < 1e-9
+    assert relerr(store["log_post"], G[k + "store_log_post"].ravel()) < 1e-9
+    assert relerr(np.array(store["y"]).T, G[k + "store_y"]) < 1e-9
+    eng.close()
+
+
+def test_dense_random_vs_oracle_and_helpers():
+    """Mid-size regression block (n=600, p=150, 5 chains): Gram, X'Wy, draw, mean, log det, fitted
+    values and weighted residuals against the oracle."""
+    rng = np.random.default_rng(3)
+    n, p, C = 600, 150, 5
+    X = rng.standard_normal((n, p))
+    w = 0.5 + rng.random(n)
+    y = X @ rng.standard_normal(p) + 0.1 * rng.standard_normal(n)
+    Pm = np.diag(0.5 + rng.random(p))
+    mu = rng.standard_normal(p)
+    lam, tau = 0.5 + rng.random(C), 1 + rng.random(C)
+    z = rng.standard_normal((C, p))
+    eng = make_engine(C)
+    dX, dy, dw = eng.to_device(X), eng.to_device(y), eng.to_device(w)
+    Gram, Xtwy = eng.gram(dX, dw), eng.design_rhs(dX, dy, dw)
+    assert relerr(Gram.cpu().numpy(), X.T @ (w[:, None] * X)) < 1e-12
+    assert relerr(Xtwy.cpu().numpy(), X.T @ (w * y)) < 1e-12
+    terms = [{"mat": eng.to_device(Pm), "rhs": eng.to_device(Pm @ mu), "scale": eng.to_device(lam)},
+             {"mat": Gram, "rhs": Xtwy, "scale": eng.to_device(tau)}]
+    x, mean, logdet = eng.empty(C, p), eng.empty(C, p), eng.empty(C)
+    eng.dense_sample_canonical(p, terms, x, z=eng.to_device(z), mean_out=mean, logdet_out=logdet)
+    fitted = eng.design_predict(dX, x)
+    rs = eng.empty(C)
+    eng.weighted_resid_sq(dy, fitted, rs, w=dw)
+    eng.check_status()
+    for c in range(C):
+        Q = lam[c] * Pm + tau[c] * (X.T @ (w[:, None] * X))
+        b = lam[c] * (Pm @ mu) + tau[c] * (X.T @ (w * y))
+        xo, mo, L = gmrf_ref.draw_canonical(b.reshape(p, 1), Q, z[c])
+        assert relerr(x[c].cpu().numpy(), xo.ravel()) < 1e-9
+        assert relerr(mean[c].cpu().numpy(), mo.ravel()) < 1e-9
+        assert relerr(logdet[c].item(), 2 * np.sum(np.log(np.diag(L)))) < TOL
+        f = X @ x[c].cpu().numpy()
+        assert relerr(fitted[c].cpu().numpy(), f) < 1e-12
+        assert relerr(rs[c].item(), np.sum(w * (y - f) ** 2)) < 1e-11
+    # in-kernel draws equal fill_normal's stream
+    x2 = eng.empty(C, p)
+    zz = eng.fill_normal(p, draw_index=9)
+    eng.dense_sample_canonical(p, terms, x, z=zz)
+    eng.dense_sample_canonical(p, terms, x2, z=None, draw_index=9)
+    assert relerr(x2.cpu().numpy(), x.cpu().numpy()) < 1e-12
+    eng.close()
+
+
+def test_dense_not_positive_definite():
+    eng = make_engine(3)
+    p = 20
+    A = np.eye(p)
+    A[3, 3] = -1.0
+    terms = [{"mat": eng.to_device(A), "scale": eng.to_device(np.array([1.0, 1.0, 1.0]))},
+             {"mat": None, "scale": eng.to_device(np.array([2.0, 0.5, 2.0]))}]  # chain 1: 0.5 - 1 < 0
+    x = eng.empty(3, p)
+    eng.dense_sample_canonical(p, terms, x, z=eng.zeros(3, p))
+    with pytest.raises(np.linalg.LinAlgError, match="chain 1"):
+        eng.check_status()
+    eng.close()
