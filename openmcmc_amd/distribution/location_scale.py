@@ -108,6 +108,34 @@ class Normal(Distribution):
             return mean, np.asarray(resp, dtype=np.float64)
         raise NotImplementedError("Normal with response and mean both per-chain (or both shared) on the GPU path")
 
+    def residual_quad(self, state, engine, st=None):
+        """(C,) tensor r' M r with r = response - mean, M the unscaled precision matrix: the sufficient
+        statistic of NormalGamma.sample (sampler.py:276,284) and of log_p (gmrf.py:343-344)."""
+        st = self.structure(state) if st is None else st
+        resp = state[self.response]
+        dense_design = (isinstance(self.mean, LinearCombination) and not is_chain(resp)
+                        and any(is_chain(state[k]) and not _is_identity(state[a], state[k].shape[0])
+                                for k, a in self.mean.form.items()))
+        if dense_design:
+            if st.diag is False or st.off is not None:
+                raise NotImplementedError("regression residual needs a diagonal response precision")
+            if resp.shape[1] != 1:
+                raise NotImplementedError("replicated responses")
+            fitted = self.mean.predictor_device(state, engine)
+            w = None if st.diag is None else engine.shared(st.diag)
+            quad = engine.empty(engine.n_chains)
+            engine.weighted_resid_sq(engine.shared(resp).reshape(-1), fitted, quad, w=w)
+            return quad
+        if st.diag is False:
+            raise NotImplementedError("quadratic form with a dense precision matrix: later round")
+        x, m = self.chain_and_center(state)
+        if m.shape[1] != 1 or x.shape[1] != 1:
+            raise NotImplementedError("replicated responses")
+        cache = engine.model_cache(self, state, st, m)
+        quad = engine.empty(1, engine.n_chains)
+        engine.tridiag_quadform(st.n, cache["terms_unit"], x.vector(), quad)
+        return quad[0]
+
     # ------------------------------------------------------------------ log density
     def log_p(self, state: dict, by_observation: bool = False, engine=None, out=None, accumulate=False):
         """location_scale.py:145-167 -> gmrf.py:321-348, one value per chain."""
@@ -116,19 +144,13 @@ class Normal(Distribution):
         if by_observation:
             raise NotImplementedError("by_observation")
         st = self.structure(state)
-        if st.diag is False:
-            raise NotImplementedError("log_p for a non-tridiagonal precision (dense path: next round)")
-        x, m = self.chain_and_center(state)
-        if m.shape[1] != 1 or x.shape[1] != 1:
-            raise NotImplementedError("replicated responses")
-        cache = engine.model_cache(self, state, st, m)
-        scale = state[st.scale_key].scalar() if st.scale_key is not None else None
-        if scale is not None and not is_chain(state[st.scale_key]):
+        quad = self.residual_quad(state, engine, st)
+        if st.scale_key is not None and not is_chain(state[st.scale_key]):
             raise NotImplementedError("shared precision scalar")
-        quad = engine.empty(1, engine.n_chains)
-        engine.tridiag_quadform(st.n, cache["terms_unit"], x.vector(), quad)
+        scale = state[st.scale_key].scalar() if st.scale_key is not None else None
+        logdet = engine.matrix_logdet(st)
         out = engine.empty(engine.n_chains) if out is None else out
-        engine.scaled_gauss_logpdf(st.n, scale, cache["logdet"], quad[0], out, accumulate=accumulate)
+        engine.scaled_gauss_logpdf(st.n, scale, logdet, quad, out, accumulate=accumulate)
         return out
 
     def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):

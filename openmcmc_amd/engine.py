@@ -249,6 +249,37 @@ class Engine:
                                         fitted.stride(0), self._vec(w, n), self._chain_scalar(out)))
 
     # ------------------------------------------------------------------ per-model constants
+    def matrix_logdet(self, st):
+        """Device scalar log det M of a Normal's unscaled precision (tridiagonal bands), cached."""
+        if not hasattr(self, "_logdet_cache"):
+            self._logdet_cache = {}
+        hit = self._logdet_cache.get(id(st.matrix))
+        if hit is not None and hit[0] is st.matrix:
+            return hit[1]
+        if st.diag is False:
+            raise NotImplementedError("log det of a dense precision matrix: later round")
+        if st.diag is None and st.off is None:
+            ld = self.zeros(1)
+        else:
+            diag = self.to_device(st.diag) if st.diag is not None else self.full((st.n,), 1.0)
+            ld = self.tridiag_logdet(st.n, diag, None if st.off is None else self.to_device(st.off))
+        self._logdet_cache[id(st.matrix)] = (st.matrix, ld)
+        return ld
+
+    def shared(self, array):
+        """Device copy of a shared host array (dense or scipy.sparse -> dense), cached by identity."""
+        from scipy import sparse
+
+        if not hasattr(self, "_shared_cache"):
+            self._shared_cache = {}
+        hit = self._shared_cache.get(id(array))
+        if hit is not None and hit[0] is array:
+            return hit[1]
+        dense = array.toarray() if sparse.issparse(array) else np.asarray(array, dtype=np.float64)
+        t = self.to_device(np.ascontiguousarray(dense, dtype=np.float64))
+        self._shared_cache[id(array)] = (array, t)
+        return t
+
     def model_cache(self, dist, state, st, center):
         """Device copies of one Normal's shared pieces (bands of M, the vector m its residual is taken
         around, M m, log det M), built once per (distribution, matrix, vector) and reused every sweep."""

@@ -80,6 +80,8 @@ class MCMC:
             plan = nn.plan(self.state)
         except NotImplementedError:
             return None
+        if plan["kind"] != "tridiag":
+            return None
         term_of = {}
         for k, key in enumerate(plan["keys"]):
             prec = nn.model[key].precision
@@ -147,7 +149,11 @@ class MCMC:
                 self.model.log_p(self.state, engine=eng, out=self.store["log_post"][i_it])
             if self.model.response is not None:
                 for response, predictor in self.model.response.items():
-                    fitted = getattr(self.model[response], predictor).predictor(self.state)
+                    par = getattr(self.model[response], predictor)
+                    if hasattr(par, "predictor_device") and any(is_chain(self.state[k]) for k in par.form):
+                        par.predictor_device(self.state, eng, out=self.store[response][i_it])
+                        continue
+                    fitted = par.predictor(self.state)
                     if is_chain(fitted):
                         self.store[response][i_it].copy_(fitted.data.reshape(self.n_chains, -1))
                     else:

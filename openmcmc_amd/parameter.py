@@ -80,6 +80,31 @@ class LinearCombination(Parameter):
 
         return ChainArray(chain_sum.data + torch.as_tensor(np.asarray(host_sum), device=chain_sum.data.device))
 
+    def predictor_device(self, state: dict, engine, out=None):
+        """(C, n) fitted values sum_i A_i x_i with per-chain terms evaluated on the GPU (one GEMM per
+        dense design matrix) and shared terms added once (parameter.py:174-197)."""
+        host_sum, fitted = 0, None
+        for prm, prefactor in self.form.items():
+            A, v = state[prefactor], state[prm]
+            if not is_chain(v):
+                host_sum = host_sum + A @ v
+                continue
+            if v.shape[1] != 1:
+                raise NotImplementedError("replicated parameters")
+            if _is_identity(A, v.shape[0]):
+                term = v.vector()
+            else:
+                term = engine.design_predict(engine.shared(A), v.vector(), out if fitted is None else None)
+            fitted = term if fitted is None else fitted + term
+        if fitted is None:
+            raise ValueError("no per-chain term: use predictor()")
+        if not isinstance(host_sum, int):
+            fitted = fitted + engine.to_device(np.asarray(host_sum, dtype=np.float64).reshape(1, -1))
+        if out is not None and fitted.data_ptr() != out.data_ptr():
+            out.copy_(fitted)
+            fitted = out
+        return fitted
+
     def get_param_list(self) -> list:
         return list(self.form.keys()) + list(self.form.values())
 
@@ -112,10 +137,22 @@ class ScaledMatrix(Parameter):
         return state[self.matrix]
 
 
+_IDENTITY_MEMO = {}
+
+
 def _is_identity(A, n):
+    """Is the (shared, immutable) matrix A the n x n identity?  Memoised per object: samplers ask
+    every sweep."""
     from scipy import sparse
 
+    if getattr(A, "shape", None) != (n, n):
+        return False
+    hit = _IDENTITY_MEMO.get(id(A))
+    if hit is not None and hit[0] is A:
+        return hit[1]
     if sparse.issparse(A):
-        return A.shape == (n, n) and (A - sparse.identity(n)).nnz == 0
-    A = np.asarray(A)
-    return A.shape == (n, n) and np.array_equal(A, np.eye(n))
+        ans = (A - sparse.identity(n)).nnz == 0
+    else:
+        ans = bool(np.array_equal(np.asarray(A), np.eye(n)))
+    _IDENTITY_MEMO[id(A)] = (A, ans)
+    return ans

@@ -105,19 +105,17 @@ class NormalNormal(MCMCSampler):
         if prior.domain_response_lower is not None or prior.domain_response_upper is not None:
             raise NotImplementedError("truncated Gaussian conditional (gmrf.gibbs_canonical_truncated_normal): next round")
         n = state[self.param].shape[0]
-        terms, keys = [], []
+        pieces = []  # one per distribution: what Q and b receive from it
         for key, dist in self.model.items():
             if not isinstance(dist, Normal):
                 raise TypeError("NormalNormal handles Normal distributions only")
             st = dist.structure(state)
-            if st.diag is False:
-                raise NotImplementedError(f"precision of '{key}' is not tridiagonal: dense Normal-Normal path is a later round")
+            piece = {"key": key, "dist": dist, "st": st, "design": None}
             if self._is_response[key]:
                 mean = dist.mean.predictor(state)  # sampler.py:183: b += Q_rsp @ mean
                 if is_chain(mean):
                     raise NotImplementedError("per-chain prior mean")
-                center = np.asarray(mean, dtype=np.float64)
-                n_rep = 1
+                piece["center"] = np.asarray(mean, dtype=np.float64)
             else:
                 # likelihood: the parameter enters the mean linearly (sampler.py:185-192)
                 if isinstance(dist.mean, Identity):
@@ -127,7 +125,7 @@ class NormalNormal(MCMCSampler):
                 else:
                     A = state[dist.mean.form[self.param]]
                     if not _is_identity(A, n):
-                        raise NotImplementedError("design matrix other than the identity: dense Normal-Normal path is a later round")
+                        piece["design"] = A
                     rest = dist.mean.predictor_conditional(state, term_to_exclude=self.param)
                     if is_chain(rest):
                         raise NotImplementedError("per-chain offsets in the response mean (mixed models): later round")
@@ -135,19 +133,48 @@ class NormalNormal(MCMCSampler):
                 if is_chain(y):
                     raise NotImplementedError("per-chain response")
                 y = np.asarray(y, dtype=np.float64)
-                n_rep = y.shape[1]
-                if n_rep != 1:
+                if y.shape[1] != 1:
                     raise NotImplementedError("replicated responses")
-                center = y - rest
-            if st.n != n:
-                raise ValueError("precision / parameter size mismatch")
-            cache = eng.model_cache(dist, state, st, center)
+                piece["center"] = y - rest
+            pieces.append(piece)
+        tridiagonal = all(pc["design"] is None and pc["st"].diag is not False and pc["st"].n == n for pc in pieces)
+        return self._tridiag_plan(state, n, pieces) if tridiagonal else self._dense_plan(state, n, pieces)
+
+    def _tridiag_plan(self, state, n, pieces):
+        eng = self.engine
+        terms, keys = [], []
+        for pc in pieces:
+            st = pc["st"]
+            cache = eng.model_cache(pc["dist"], state, st, pc["center"])
             scale = _as_chain_scalar(eng, state, st.scale_key) if st.scale_key is not None else None
             terms.append({"diag": cache["diag"], "off": cache["off"], "rhs": cache["rhs"], "center": cache["center"],
                           "scale": None if scale is None else scale.scalar()})
-            keys.append(key)
-        return {"n": n, "terms_list": terms, "terms": eng.tridiag_terms(terms, n), "keys": keys,
-                "scale_ids": [None if t["scale"] is None else t["scale"].data_ptr() for t in terms]}
+            keys.append(pc["key"])
+        return {"kind": "tridiag", "n": n, "terms_list": terms, "terms": eng.tridiag_terms(terms, n), "keys": keys}
+
+    def _dense_plan(self, state, n, pieces):
+        """Q_c = sum_k s_k[c] M_k with dense M_k: prior precision as is, a regression likelihood as the
+        Gram matrix A' W A (one fp64 GEMM at plan time) -- sampler.py:185-192, location_scale.py:238-241."""
+        eng = self.engine
+        terms, keys = [], []
+        for pc in pieces:
+            st, A = pc["st"], pc["design"]
+            center = eng.to_device(pc["center"].reshape(-1))
+            if A is None:
+                if st.n != n:
+                    raise ValueError("precision / parameter size mismatch")
+                mat = None if (st.diag is None and st.off is None) else eng.shared(st.matrix)
+                rhs = center if mat is None else eng.design_rhs(mat, center)  # M' m = M m, once per model
+            else:
+                if st.diag is False or st.off is not None:
+                    raise NotImplementedError("regression likelihood needs a diagonal response precision")
+                dA = eng.shared(A)
+                w = None if st.diag is None else eng.to_device(st.diag)
+                mat, rhs = eng.gram(dA, w), eng.design_rhs(dA, center, w)
+            scale = _as_chain_scalar(eng, state, st.scale_key) if st.scale_key is not None else None
+            terms.append({"mat": mat, "rhs": rhs, "scale": None if scale is None else scale.scalar()})
+            keys.append(pc["key"])
+        return {"kind": "dense", "n": n, "terms_list": terms, "terms": eng.dense_terms(terms, n), "keys": keys}
 
     def plan(self, state):
         p = self._plan
@@ -169,7 +196,10 @@ class NormalNormal(MCMCSampler):
         n = p["n"]
         x = eng.empty(eng.n_chains, n) if out is None else out
         z = self.inject(self, self._sweep) if self.inject is not None else None
-        eng.tridiag_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())
+        if p["kind"] == "tridiag":
+            eng.tridiag_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())
+        else:
+            eng.dense_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())
         current_state[self.param] = ChainArray(x)
         self._sweep += 1
         return current_state
@@ -195,15 +225,10 @@ class NormalGamma(MCMCSampler):
         eng = self._need_engine()
         dist = self.model[self.normal_param]
         st = dist.structure(current_state)
-        if st.diag is False:
-            raise NotImplementedError("non-tridiagonal precision: dense path is a later round")
-        x, m = dist.chain_and_center(current_state)
-        cache = eng.model_cache(dist, current_state, st, m)
-        quad = eng.empty(1, eng.n_chains)
-        eng.tridiag_quadform(st.n, cache["terms_unit"], x.vector(), quad)
+        quad = dist.residual_quad(current_state, eng, st)
         a0, b0 = self.prior_shape_rate(current_state)
         target = _as_chain_scalar(eng, current_state, self.param)
         g = self.inject(self, self._sweep) if self.inject is not None else None
-        eng.normal_gamma_update(a0, b0, st.n_pos, quad[0], target.scalar(), g=g, draw_index=self._draw_index())
+        eng.normal_gamma_update(a0, b0, st.n_pos, quad, target.scalar(), g=g, draw_index=self._draw_index())
         self._sweep += 1
         return current_state

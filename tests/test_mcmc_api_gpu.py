@@ -102,25 +102,74 @@ def test_store_shapes_and_state_untouched(golden):
     assert np.array_equal(M.state["tau"].numpy(), before["tau"])
 
 
-def test_unsupported_structures_fail_loudly():
+def test_dense_prior_and_unsupported_structures():
+    """A dense prior precision goes down the dense path (and matches the oracle); structures that are
+    not built yet fail loudly instead of falling back to anything."""
+    from openmcmc_amd.chains import ChainArray
     from openmcmc_amd.distribution.location_scale import Normal
     from openmcmc_amd.engine import Engine
     from openmcmc_amd.model import Model
     from openmcmc_amd.parameter import ScaledMatrix
     from openmcmc_amd.sampler.sampler import NormalNormal
+    from oracle import gmrf_ref
 
     n = 6
+    rng = np.random.default_rng(2)
     dense = np.eye(n) + 0.1 * np.ones((n, n))
+    yv = rng.standard_normal((n, 1))
     mdl = Model([Normal("y", mean="b", precision=ScaledMatrix("P_tau", "tau")),
                  Normal("b", mean="mu", precision=ScaledMatrix("P", "lam"))])
     eng = Engine(2)
     smp = NormalNormal("b", mdl).bind(eng)
-    from openmcmc_amd.chains import ChainArray
-
-    state = {"y": np.zeros((n, 1)), "b": ChainArray(eng.zeros(2, n)), "mu": np.zeros((n, 1)), "P": dense,
-             "lam": 1.0, "P_tau": sparse.identity(n, format="csc"), "tau": 1.0}
-    with pytest.raises(NotImplementedError):
-        smp.sample(state)
+    state = {"y": yv, "b": ChainArray(eng.zeros(2, n)), "mu": np.zeros((n, 1)), "P": dense,
+             "lam": 1.5, "P_tau": sparse.identity(n, format="csc"), "tau": 2.0}
+    z = rng.standard_normal(n)
+    smp.inject = lambda s_, t: eng.to_device(np.tile(z, (2, 1)))
+    state = smp.sample(state)
+    eng.check_status()
+    xo, _, _ = gmrf_ref.draw_canonical(2.0 * yv, 1.5 * dense + 2.0 * np.eye(n), z)
+    assert relerr(state["b"].chain(1).ravel(), xo.ravel()) < TOL
     with pytest.raises(RuntimeError):
         NormalNormal("b", mdl).sample(state)  # not bound to an engine
+    trunc = Model([Normal("y", mean="b", precision=ScaledMatrix("P_tau", "tau")),
+                   Normal("b", mean="mu", precision=ScaledMatrix("P", "lam"), domain_response_lower=np.zeros((n, 1)))])
+    with pytest.raises(NotImplementedError):
+        NormalNormal("b", trunc).bind(eng).sample(state)
     eng.close()
+
+
+@pytest.mark.parametrize("tag", ["ex3", "p7"])
+def test_linear_regression_example_replays_reference(golden, tag):
+    """BASELINE configs[0]: examples/3_linear_regression.ipynb verbatim (model, samplers, state,
+    response={'y': 'mean'}) on the chain-batched API; the reference's recorded draws injected."""
+    from openmcmc_amd.distribution.distribution import Gamma
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import LinearCombination, ScaledMatrix
+    from openmcmc_amd.sampler.sampler import NormalGamma, NormalNormal
+
+    G = golden("linreg_chain")
+    k = tag + "_"
+    X, y = G[k + "X"], G[k + "y"]
+    N, p = X.shape
+    mdl = Model([Normal("y", mean=LinearCombination(form={"beta": "X"}), precision=ScaledMatrix(matrix="P_tau", scalar="tau")),
+                 Normal("beta", mean="mu", precision=ScaledMatrix(matrix="P_lambda", scalar="lambda")),
+                 Gamma("tau", shape="a_tau", rate="b_tau"),
+                 Gamma("lambda", shape="a_lambda", rate="b_lambda")], response={"y": "mean"})
+    samplers = [NormalNormal("beta", mdl), NormalGamma("tau", mdl), NormalGamma("lambda", mdl)]
+    state = {"y": y, "X": X, "beta": [0.0] * p, "P_tau": sparse.csc_matrix(np.eye(N)), "tau": 1,
+             "P_lambda": sparse.csc_matrix(np.eye(p)), "mu": [0.0] * p, "lambda": 0.01,
+             "a_tau": 1e-3, "b_tau": 1e-3, "a_lambda": 1e-3, "b_lambda": 1e-3}
+    C = 2
+    M = MCMC(state, samplers, model=mdl, n_burn=int(G[k + "n_burn"]), n_iter=int(G[k + "n_iter"]), n_chains=C)
+    assert M._fused is None  # dense conditional: sampler-by-sampler loop
+    eng = M.engine
+    samplers[0].inject = lambda smp, t: eng.to_device(np.tile(G[k + "z"][t], (C, 1)))
+    samplers[1].inject = lambda smp, t: eng.full((C,), G[k + "g"][t, 0])
+    samplers[2].inject = lambda smp, t: eng.full((C,), G[k + "g"][t, 1])
+    M.run_mcmc()
+    out = M.collect()
+    for c in range(C):
+        for key in ("beta", "tau", "lambda", "log_post", "y"):
+            assert relerr(out[key][c], G[k + "store_" + key]) < 1e-9, key
