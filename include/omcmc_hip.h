@@ -178,6 +178,33 @@ omc_status omc_design_predict(omc_ctx* ctx, int64_t n, int64_t p, const double* 
 omc_status omc_weighted_resid_sq(omc_ctx* ctx, int64_t n, const double* y, const double* fitted,
                                  int64_t ld_fitted, const double* w, double* out);
 
+/* ---- Metropolis-Hastings on a Gaussian target with a shared constant Hessian -----------------
+ * Target Normal("x", mean=mu, precision=Q) with Q dense d x d and mu shared by all chains (cfg4).
+ *
+ * omc_dense_cholesky: L = chol(scale * A) (lower, LAPACK potrf as gmrf.py:481), *sumlogdiag =
+ *   sum_i log L_ii (device scalar); used once per model for L = chol(H / step^2)
+ *   (metropolis_hastings.py:345-346) and L_Q = chol(Q) (gmrf.py:339).
+ *
+ * omc_mala_step: one ManifoldMALA.sample for every chain (metropolis_hastings.py:102-125, 301-373):
+ *   g = -Q (x - mu), H = Q (location_scale.py:222-232); m = x + 1/2 (H/step^2)^{-1} g (347);
+ *   x' = m + L^{-T} z (317 -> gmrf.py:61); log q = sum log L_ii - 1/2 |L'(. - m)|^2 forward and
+ *   reverse (350-373); log alpha = lp' + q_rev - lp - q_fwd (155); accept iff log u < log alpha (173).
+ *   As batched level-3 BLAS on the d x C state matrix: 2 GEMM, 5 TRSM, 4 TRMM per step.
+ * omc_rw_step: one untruncated RandomWalk.sample (metropolis_hastings.py:212-269): x' = x + step z.
+ *   z_inject [C][ld_z] / u_inject [C]: injected N(0,1) / U(0,1) draws (NULL = generate);
+ *   accept_count / proposal_count [C] int64 (NULL = not kept): the AcceptRate counters
+ *   (metropolis_hastings.py:25-66), INT path: bit-exact.                                        */
+omc_status omc_dense_cholesky(omc_ctx* ctx, int64_t d, const double* A, double scale, double* L_out,
+                              double* sumlogdiag_out);
+omc_status omc_mala_step(omc_ctx* ctx, int64_t d, const double* Q, const double* mu, const double* L,
+                         const double* sumlogL, double step, const double* z_inject, int64_t ld_z,
+                         const double* u_inject, uint64_t draw_index, double* x, int64_t ld_x,
+                         int64_t* accept_count, int64_t* proposal_count);
+omc_status omc_rw_step(omc_ctx* ctx, int64_t d, const double* mu, const double* LQ, const double* sumlogLQ,
+                       double step, const double* z_inject, int64_t ld_z, const double* u_inject,
+                       uint64_t draw_index, double* x, int64_t ld_x, int64_t* accept_count,
+                       int64_t* proposal_count);
+
 /* ---- Normal-Gamma conjugate update ---------------------------------------------------------
  * NormalGamma.sample (sampler.py:252-288) for a scalar precision per chain:
  *   a = a0 + n_pos/2, b = b0 + quad[c]/2, out[c] = Gamma(a, scale = 1/b); b == 0 -> scale inf.

@@ -20,6 +20,7 @@ struct omc_ctx {
   double* dense_factor; size_t dense_factor_bytes;
   int* dense_info; size_t dense_info_bytes;
   double* dense_tmp; size_t dense_tmp_bytes;
+  double* mh_work; size_t mh_work_bytes;  // omc_mala.hip
   int tridiag_algo;  // 0 auto, 1 serial, 2 segmented
   int tridiag_seg;   // 0 auto, else nodes per lane
   unsigned long long* stamps;  // diagnostic phase stamps of the segmented kernel (NULL = off)

@@ -23,7 +23,7 @@ struct DenseTermsDev {
     }                                                          \
   } while (0)
 
-static omc_status ensure_blas(omc_ctx* ctx) {
+omc_status omc_ensure_blas(omc_ctx* ctx) {
   if (!ctx->blas) {
     rocblas_handle h;
     OMC_BLAS_CHECK(rocblas_create_handle(&h));
@@ -34,7 +34,7 @@ static omc_status ensure_blas(omc_ctx* ctx) {
   return OMC_OK;
 }
 
-static omc_status ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need) {
+omc_status omc_ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need) {
   if (*have >= need) return OMC_OK;
   OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (*buf) OMC_HIP_CHECK(hipFree(*buf));
@@ -165,11 +165,11 @@ omc_status omc_dense_sample_canonical(omc_ctx* ctx, int64_t p, const omc_dense_t
   const int64_t C = ctx->n_chains;
   if (C > 65535) return OMC_UNSUPPORTED;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  omc_status st = ensure_blas(ctx);
+  omc_status st = omc_ensure_blas(ctx);
   if (st != OMC_OK) return st;
-  st = ensure_bytes(ctx, (void**)&ctx->dense_factor, &ctx->dense_factor_bytes, (size_t)C * p * p * sizeof(double));
+  st = omc_ensure_bytes(ctx, (void**)&ctx->dense_factor, &ctx->dense_factor_bytes, (size_t)C * p * p * sizeof(double));
   if (st != OMC_OK) return st;
-  st = ensure_bytes(ctx, (void**)&ctx->dense_info, &ctx->dense_info_bytes, (size_t)C * sizeof(int));
+  st = omc_ensure_bytes(ctx, (void**)&ctx->dense_info, &ctx->dense_info_bytes, (size_t)C * sizeof(int));
   if (st != OMC_OK) return st;
   DenseTermsDev T;
   T.n_terms = terms->n_terms;
@@ -216,11 +216,11 @@ omc_status omc_dense_sample_canonical(omc_ctx* ctx, int64_t p, const omc_dense_t
 omc_status omc_gram(omc_ctx* ctx, int64_t n, int64_t p, const double* X, const double* w, double* G_out) {
   if (!ctx || n < 1 || p < 1 || !X || !G_out) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  omc_status st = ensure_blas(ctx);
+  omc_status st = omc_ensure_blas(ctx);
   if (st != OMC_OK) return st;
   const double* B = X;
   if (w) {
-    st = ensure_bytes(ctx, (void**)&ctx->dense_tmp, &ctx->dense_tmp_bytes, (size_t)n * p * sizeof(double));
+    st = omc_ensure_bytes(ctx, (void**)&ctx->dense_tmp, &ctx->dense_tmp_bytes, (size_t)n * p * sizeof(double));
     if (st != OMC_OK) return st;
     hipLaunchKernelGGL(k_scale_rows, dim3(gx(n * p)), dim3(256), 0, ctx->stream, n, p, X, w, ctx->dense_tmp);
     OMC_HIP_CHECK(hipGetLastError());
@@ -237,11 +237,11 @@ omc_status omc_design_rhs(omc_ctx* ctx, int64_t n, int64_t p, const double* X, c
                           double* out) {
   if (!ctx || n < 1 || p < 1 || !X || !y || !out) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  omc_status st = ensure_blas(ctx);
+  omc_status st = omc_ensure_blas(ctx);
   if (st != OMC_OK) return st;
   const double* v = y;
   if (w) {
-    st = ensure_bytes(ctx, (void**)&ctx->dense_tmp, &ctx->dense_tmp_bytes, (size_t)n * sizeof(double));
+    st = omc_ensure_bytes(ctx, (void**)&ctx->dense_tmp, &ctx->dense_tmp_bytes, (size_t)n * sizeof(double));
     if (st != OMC_OK) return st;
     hipLaunchKernelGGL(k_scale_rows, dim3(gx(n)), dim3(256), 0, ctx->stream, n, (int64_t)1, y, w, ctx->dense_tmp);
     OMC_HIP_CHECK(hipGetLastError());
@@ -258,7 +258,7 @@ omc_status omc_design_predict(omc_ctx* ctx, int64_t n, int64_t p, const double* 
                               double* fitted, int64_t ld_fitted) {
   if (!ctx || n < 1 || p < 1 || !X || !beta || !fitted || ld_beta < p || ld_fitted < n) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  omc_status st = ensure_blas(ctx);
+  omc_status st = omc_ensure_blas(ctx);
   if (st != OMC_OK) return st;
   const double one = 1.0, zero = 0.0;
   // fitted (col-major n x C, ld = ld_fitted) = A' (n x p) * Beta (col-major p x C, ld = ld_beta)

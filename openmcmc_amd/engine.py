@@ -248,6 +248,39 @@ class Engine:
         check(lib.omc_weighted_resid_sq(self._ctx, n, self._vec(y, n), self._p(fitted, self.n_chains, n),
                                         fitted.stride(0), self._vec(w, n), self._chain_scalar(out)))
 
+    # ------------------------------------------------------------------ Metropolis-Hastings steps
+    def _ip(self, t):
+        """Device pointer of an int64 (C,) counter tensor."""
+        if t is None:
+            return None
+        torch = _torch()
+        if t.dtype != torch.int64 or not t.is_cuda or t.numel() != self.n_chains:
+            raise TypeError("expected an int64 ROCm tensor with one entry per chain")
+        return C.c_void_p(t.data_ptr())
+
+    def dense_cholesky(self, A, scale=1.0):
+        """(L, sum log L_ii) with L = chol(scale * A) lower, shared by all chains."""
+        d = A.shape[0]
+        L, sl = self.empty(d, d), self.empty(1)
+        check(lib.omc_dense_cholesky(self._ctx, d, self._p(A), float(scale), self._p(L), self._p(sl)))
+        return L, sl
+
+    def mala_step(self, Q, mu, L, sumlogL, step, x, z=None, u=None, draw_index=0, accept_count=None,
+                  proposal_count=None):
+        d = Q.shape[0]
+        check(lib.omc_mala_step(self._ctx, d, self._p(Q), self._vec(mu, d), self._p(L), self._p(sumlogL), float(step),
+                                self._p(z, self.n_chains, d), 0 if z is None else z.stride(0), self._chain_scalar(u),
+                                int(draw_index), self._p(x, self.n_chains, d), x.stride(0), self._ip(accept_count),
+                                self._ip(proposal_count)))
+
+    def rw_step(self, mu, LQ, sumlogLQ, step, x, z=None, u=None, draw_index=0, accept_count=None,
+                proposal_count=None):
+        d = LQ.shape[0]
+        check(lib.omc_rw_step(self._ctx, d, self._vec(mu, d), self._p(LQ), self._p(sumlogLQ), float(step),
+                              self._p(z, self.n_chains, d), 0 if z is None else z.stride(0), self._chain_scalar(u),
+                              int(draw_index), self._p(x, self.n_chains, d), x.stride(0), self._ip(accept_count),
+                              self._ip(proposal_count)))
+
     # ------------------------------------------------------------------ per-model constants
     def matrix_logdet(self, st):
         """Device scalar log det M of a Normal's unscaled precision (tridiagonal bands), cached."""
