@@ -159,6 +159,11 @@ class MCMC:
                     else:
                         self.store[response][i_it].copy_(eng.to_device(np.asarray(fitted).reshape(1, -1)).expand(self.n_chains, -1))
         eng.check_status()  # raises numpy.linalg.LinAlgError like gmrf.py:518 if a factorisation failed
+        from openmcmc_amd.sampler.metropolis_hastings import MetropolisHastings
+
+        for sampler in self.samplers:  # mcmc.py:113-115
+            if isinstance(sampler, MetropolisHastings):
+                print(f"{sampler.param}: {sampler.accept_rate.get_acceptance_rate()}")
 
     # ------------------------------------------------------------------ results
     def collect(self):

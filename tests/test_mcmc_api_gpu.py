@@ -173,3 +173,33 @@ def test_linear_regression_example_replays_reference(golden, tag):
     for c in range(C):
         for key in ("beta", "tau", "lambda", "log_post", "y"):
             assert relerr(out[key][c], G[k + "store_" + key]) < 1e-9, key
+
+
+@pytest.mark.parametrize("kind", ["mala", "rw"])
+def test_mh_samplers_replay_reference(golden, kind):
+    """ManifoldMALA / RandomWalk objects with the reference's constructor signature on the cfg4 model
+    Normal("x", mean="mu", precision="Q"): 40-step traces of the reference, accept counts bit-exact."""
+    from openmcmc_amd.chains import ChainArray
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.engine import Engine
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.sampler.metropolis_hastings import ManifoldMALA, RandomWalk
+
+    G = golden("mala")
+    d, C = 32, 2
+    k = f"d{d}_"
+    mdl = Model([Normal("x", mean="mu", precision="Q")])
+    eng = Engine(C)
+    cls = ManifoldMALA if kind == "mala" else RandomWalk
+    smp = cls("x", mdl, step=np.array([[float(G[k + kind + "_step"])]])).bind(eng)
+    state = {"x": ChainArray(eng.to_device(np.tile(G[k + "x0"], (C, 1)))), "mu": np.zeros((d, 1)), "Q": G[k + "Q"]}
+    smp.inject = lambda s_, t: eng.to_device(np.tile(G[k + kind + "_z"][t], (C, 1)))
+    smp.inject_uniform = lambda s_, t: eng.full((C,), G[k + kind + "_u"][t])
+    assert smp.accept_rate.get_acceptance_rate() == "No proposals"
+    for i in range(G[k + kind + "_z"].shape[0]):
+        state = smp.sample(state)
+        assert relerr(state["x"].chain(1).ravel(), G[k + kind + "_x"][i]) < 1e-9
+    n_acc = int(G[k + kind + "_accept"].sum())
+    assert smp.accept_rate.count == {"accept": C * n_acc, "proposal": C * 40}
+    assert smp.accept_rate.get_acceptance_rate() == f"Acceptance rate {100 * n_acc / 40:.0f}%"
+    eng.close()
