@@ -668,7 +668,7 @@ __device__ __forceinline__ void quad_chunks(const double* tile, int lane, int wa
   }
 }
 
-// Register plan per lane (M nodes): X = z -> z/sqrt(D) -> residuals ; Y = b -> l ; W = 1/D -> g -> x.
+// Register plan per lane (M nodes): Y = b -> l ; W = 1/D -> g -> x (draws are consumed as they are made).
 // The combined diagonal a (then the right-hand side r) lives in the wave's LDS tile.
 template <int M, bool MULTI, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
@@ -708,35 +708,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 #pragma unroll
   for (int k = 0; k < OMC_MAX_TERMS; ++k) sc[k] = (k < nt && A.T.scale[k]) ? A.T.scale[k][cc] : 1.0;
 
-  double X[M], Y[M], W[M];
+  double Y[M], W[M];
   OMC_STAMP(0);
 
-  // ---- draws first, while nothing else is live: X = z ----
-  if (A.z) {
-    tile_fill_chain<M, MULTI>(tile, geo, A.z, A.ld_z, n, A.C, 0.0);
-#pragma unroll
-    for (int j = 0; j < M; ++j) X[j] = crow[j];
-  } else if (A.zero_z) {
-#pragma unroll
-    for (int j = 0; j < M; ++j) X[j] = 0.0;
-  } else {
-    // rolled loop through the lane's LDS row: the Philox + Box-Muller body is register-hungry and
-    // must not be software-pipelined across iterations by the unroller
-    const int64_t gc = A.chain_offset + cc;
-    const uint32_t blk0 = (uint32_t)(i0 >> 1);
-    wave_lds_fence();
-#pragma unroll 1
-    for (int jp = 0; jp < M / 2; ++jp) {
-      double z0, z1;
-      omc_normal_pair(omc_rng_block(A.key, gc, blk0 + (uint32_t)jp), z0, z1);
-      crow[2 * jp] = z0;
-      crow[2 * jp + 1] = z1;
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int j = 0; j < M; ++j) X[j] = crow[j];
-  }
-  __builtin_amdgcn_sched_barrier(0);
   OMC_STAMP(1);
 
   // ---- conditional precision: b -> Y (registers), a -> LDS tile ----
@@ -815,7 +789,6 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   for (int j = 0; j < M; ++j) {
     const double rD = bad ? 1.0 : W[j];
     Y[j] *= W[j];               // l_j = b_j / D_j
-    X[j] *= fast_sqrt(rD);      // z_j / sqrt(D_j)
     if (A.logdet && i0 + j < n) logdet -= log(rD);
   }
 
@@ -835,11 +808,29 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     double u = (MULTI ? excl_scan_wg<Aff, false>(f, Aff{0.0, 1.0}, lds_aff[2], lane, wave, nw)
                       : excl_scan<Aff, false>(f, Aff{0.0, 1.0}, pos, Wd, false, lds_aff[0], wave, nw)).p;
     lp = lin;
+    // g_j = u_j/D_j + z_j/sqrt(D_j); the draws are produced here, pair by pair, so that no array of
+    // z ever has to be kept in registers next to l and 1/D (Philox + Box-Muller interleave with the
+    // serial u recurrence; the scheduling barrier keeps the five bodies from being overlapped)
+    const int64_t gc = A.chain_offset + cc;
+    const uint32_t blk0 = (uint32_t)(i0 >> 1);
+    const double* zin = A.z ? A.z + cc * A.ld_z + i0 : nullptr;
 #pragma unroll
-    for (int j = 0; j < M; ++j) {
+    for (int j = 0; j < M; j += 2) {
+      double z0 = 0.0, z1 = 0.0;
+      if (zin) {
+        if (i0 + j < n) z0 = zin[j];
+        if (i0 + j + 1 < n) z1 = zin[j + 1];
+      } else if (!A.zero_z) {
+        omc_normal_pair(omc_rng_block(A.key, gc, blk0 + (uint32_t)(j >> 1)), z0, z1);
+      }
+      const double bad_guard0 = bad ? 1.0 : W[j], bad_guard1 = bad ? 1.0 : W[j + 1];
       u = fma(-lp, u, crow[j]);
-      W[j] = fma(u, W[j], X[j]);  // g_j = u_j/D_j + z_j/sqrt(D_j)
+      W[j] = fma(u, W[j], z0 * fast_sqrt(bad_guard0));
       lp = Y[j];
+      u = fma(-lp, u, crow[j + 1]);
+      W[j + 1] = fma(u, W[j + 1], z1 * fast_sqrt(bad_guard1));
+      lp = Y[j + 1];
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -905,6 +896,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 
   // ---- fused quadratic forms (x - m_k)' M_k (x - m_k), segment-local form ----
   if (want_quad) {
+    double X[M];  // residuals
     _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt) {
       // residual of this segment in X, residual of the next segment's first node in rn
       double rn = 0.0;
