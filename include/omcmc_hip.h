@@ -224,6 +224,20 @@ omc_status omc_scaled_gauss_logpdf(omc_ctx* ctx, int64_t n, const double* scale,
 omc_status omc_gamma_logpdf(omc_ctx* ctx, const double* x, double shape, double rate,
                             double* out, int32_t accumulate);
 
+/* ---- reversible-jump move bookkeeping (INT / index path: bit-exact) ---------------------------
+ * ReversibleJump.get_move_type, get_move_probabilities and the deletion index of death_proposal
+ * (reversible_jump.py:310-373, 173) for every chain:
+ *   n[c] == n_max -> death; n[c] == 1 -> birth; otherwise birth iff u <= birth_probability, where the
+ *   uniform is consumed ONLY in that last case (as in the reference);
+ *   p_birth/p_death with the edge cases at n_max, n_max-1, 1, 2;
+ *   del_index[c] = randint(0, n[c]) for a death, -1 for a birth.
+ *   u_inject [C] / idx_inject [C] (int64): injected draws (NULL = Philox: uniform from block 0,
+ *   unbiased bounded integer by Lemire's rejection from block 1).  Any n[c] < 1 or > n_max is
+ *   latched as a failure of that chain (the reference raises ValueError for n == 0).           */
+omc_status omc_rj_move(omc_ctx* ctx, int64_t n_max, double birth_probability, const int64_t* n,
+                       const double* u_inject, const int64_t* idx_inject, uint64_t draw_index,
+                       int32_t* birth_out, double* p_birth_out, double* p_death_out, int64_t* del_index_out);
+
 /* ---- raw random streams (tests, prior draws for missing state: mcmc.py:78-80) -------------- */
 omc_status omc_fill_normal(omc_ctx* ctx, int64_t n, uint64_t draw_index, double* out, int64_t ld);
 omc_status omc_fill_philox_u32(omc_ctx* ctx, int64_t n_words, uint64_t draw_index, uint32_t* out,

@@ -61,6 +61,65 @@ __global__ void k_fill_u32(int64_t C, int64_t chain_offset, int64_t n_words, omc
   }
 }
 
+// reversible_jump.py:310-373 and :173
+__global__ void k_rj_move(int64_t C, int64_t chain_offset, long long n_max, double q, const long long* n,
+                          const double* u_in, const long long* idx_in, omc_rng_key key, int* birth_out,
+                          double* p_birth_out, double* p_death_out, long long* del_out, long long* bad) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const long long nc = n[c];
+  if (nc < 1 || nc > n_max) {
+    atomicMin((unsigned long long*)bad, (unsigned long long)c);
+    birth_out[c] = 0; p_birth_out[c] = 0.0; p_death_out[c] = 0.0; del_out[c] = -1;
+    return;
+  }
+  bool birth;
+  if (nc == n_max) {
+    birth = false;
+  } else if (nc == 1) {
+    birth = true;
+  } else {
+    double u;
+    if (u_in) {
+      u = u_in[c];
+    } else {
+      const uint4 w = omc_rng_block(key, chain_offset + c, 0u);
+      u = omc_u53(w.x, w.y);
+    }
+    birth = u <= q;
+  }
+  double pb = q, pd = 1.0 - q;
+  if (nc == n_max) pd = 1.0;
+  if (nc == n_max - 1 && birth) pd = 1.0;
+  if (nc == 1) pb = 1.0;
+  if (nc == 2 && !birth) pb = 1.0;
+  long long idx = -1;
+  if (!birth) {
+    if (idx_in) {
+      idx = idx_in[c];
+    } else {  // unbiased integer in [0, nc): Lemire's multiply-shift with rejection on 32-bit words
+      const uint32_t range = (uint32_t)nc;
+      const uint32_t thresh = (uint32_t)(-range) % range;
+      uint32_t blk = 1u;
+      for (;;) {
+        const uint4 w = omc_rng_block(key, chain_offset + c, blk++);
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        bool done = false;
+        for (int t = 0; t < 4 && !done; ++t) {
+          const unsigned long long m = (unsigned long long)ws[t] * range;
+          if ((uint32_t)m >= thresh) { idx = (long long)(m >> 32); done = true; }
+        }
+        if (done || blk > 64u) break;
+      }
+      if (idx < 0) idx = 0;
+    }
+  }
+  birth_out[c] = birth ? 1 : 0;
+  p_birth_out[c] = pb;
+  p_death_out[c] = pd;
+  del_out[c] = idx;
+}
+
 static inline unsigned grid1(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
 extern "C" {
@@ -94,6 +153,21 @@ omc_status omc_gamma_logpdf(omc_ctx* ctx, const double* x, double shape, double 
   const double lnorm = shape * log(rate) - lgamma(shape);
   hipLaunchKernelGGL(k_gamma_logpdf, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, x,
                      shape, rate, lnorm, out, (int)accumulate);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_rj_move(omc_ctx* ctx, int64_t n_max, double birth_probability, const int64_t* n, const double* u_inject,
+                       const int64_t* idx_inject, uint64_t draw_index, int32_t* birth_out, double* p_birth_out,
+                       double* p_death_out, int64_t* del_index_out) {
+  if (!ctx || n_max < 1 || n_max > 0x7fffffffLL || !(birth_probability >= 0.0 && birth_probability <= 1.0) || !n ||
+      !birth_out || !p_birth_out || !p_death_out || !del_index_out)
+    return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_rj_move, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, ctx->chain_offset,
+                     (long long)n_max, birth_probability, (const long long*)n, u_inject, (const long long*)idx_inject,
+                     omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), birth_out, p_birth_out, p_death_out,
+                     (long long*)del_index_out, ctx->d_bad_chain);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

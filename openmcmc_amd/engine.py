@@ -352,6 +352,22 @@ class Engine:
         check(lib.omc_gamma_logpdf(self._ctx, self._chain_scalar(x), float(shape), float(rate),
                                    self._chain_scalar(out), int(accumulate)))
 
+    # ------------------------------------------------------------------ reversible-jump bookkeeping
+    def rj_move(self, n, n_max, birth_probability, u=None, idx=None, draw_index=0):
+        """(birth int32 (C,), p_birth, p_death, del_index int64) for every chain; n: int64 (C,) tensor."""
+        torch = _torch()
+        Cn = self.n_chains
+        if n.dtype != torch.int64 or n.numel() != Cn or not n.is_cuda:
+            raise TypeError("n must be an int64 ROCm tensor with one entry per chain")
+        birth = torch.empty(Cn, dtype=torch.int32, device=self.device)
+        dele = torch.empty(Cn, dtype=torch.int64, device=self.device)
+        pb, pd = self.empty(Cn), self.empty(Cn)
+        check(lib.omc_rj_move(self._ctx, int(n_max), float(birth_probability), C.c_void_p(n.data_ptr()),
+                              self._chain_scalar(u), None if idx is None else C.c_void_p(idx.data_ptr()),
+                              int(draw_index), C.c_void_p(birth.data_ptr()), self._p(pb), self._p(pd),
+                              C.c_void_p(dele.data_ptr())))
+        return birth, pb, pd, dele
+
     # ------------------------------------------------------------------ random fills
     def fill_normal(self, n, draw_index=0):
         out = self.empty(self.n_chains, n)

@@ -424,6 +424,54 @@ def gen_reference_timing():
     print(rec)
 
 
+# ----------------------------------------------------------------------------- G8
+def gen_rj_moves():
+    """ReversibleJump.get_move_type / get_move_probabilities / deletion index
+    (reversible_jump.py:173, 310-373): 10 000-step traces of the move bookkeeping, walking n through
+    every edge case (every proposal accepted so that n visits 1, 2, n_max-1, n_max)."""
+    from openmcmc.sampler.reversible_jump import ReversibleJump
+    import openmcmc.sampler.reversible_jump as rj
+
+    out = {}
+    cases = [(2, 0.5, 1), (2, 0.3, 2), (3, 0.5, 2), (3, 0.3, 3), (20, 0.5, 1), (20, 0.3, 20), (20, 0.7, 19), (5, 0.5, 2)]
+    out["cases"] = np.array(cases, dtype=float)
+    for ci, (n_max, q, n0) in enumerate(cases):
+        smp = ReversibleJump(param="n", model=Model([]), n_max=n_max, birth_probability=q)
+        rng = np.random.default_rng(500 + ci)
+        used_u, used_idx = [], []
+
+        def _uniform(loc=0, scale=1, size=None, **_):
+            u = rng.random()
+            used_u.append(u)
+            return u
+
+        def _randint(low, high, size=None, **_):
+            v = int(rng.integers(low, int(np.asarray(high).item())))
+            used_idx.append(v)
+            return v
+
+        saved = (rj.uniform.rvs, rj.randint.rvs)
+        rj.uniform.rvs, rj.randint.rvs = _uniform, _randint
+        try:
+            n = n0
+            rows = []
+            for _ in range(10000):
+                state = {"n": np.array([[float(n)]])}
+                nu = len(used_u)
+                birth = bool(smp.get_move_type(state))
+                pb, pd = smp.get_move_probabilities(state, birth)
+                u = used_u[-1] if len(used_u) > nu else -1.0
+                idx = -1
+                if not birth:
+                    idx = rj.randint.rvs(low=0, high=state["n"])  # reversible_jump.py:173
+                rows.append((n, u, int(birth), pb, pd, idx))
+                n = n + 1 if birth else n - 1
+        finally:
+            rj.uniform.rvs, rj.randint.rvs = saved
+        out[f"case{ci}"] = np.array(rows, dtype=float)
+    np.savez_compressed(os.path.join(OUT, "rj_moves.npz"), **out)
+
+
 if __name__ == "__main__":
     gen_tridiag_primitives()
     gen_dense_primitives()
@@ -432,6 +480,7 @@ if __name__ == "__main__":
     gen_linreg_chain()
     gen_mala()
     gen_precision_builders()
+    gen_rj_moves()
     gen_reference_timing()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
