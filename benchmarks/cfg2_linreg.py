@@ -1,7 +1,7 @@
 """Secondary measurement: BASELINE configs[1] (Bayesian linear regression p=1000, n=10000, 256 chains)
+through the dense path.  python benchmarks/cfg2_linreg.py [--p 1000 --n 10000 --chains 256 --steps 5]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-through the dense path.  python benchmarks/cfg2_linreg.py [--p 1000 --n 10000 --chains 256 --steps 5]"""
 import argparse, json, time
 import numpy as np
 import torch
