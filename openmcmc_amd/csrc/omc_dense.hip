@@ -143,6 +143,100 @@ __global__ void __launch_bounds__(256) k_weighted_resid_sq(int64_t n, const doub
   if (threadIdx.x == 0) out[c] = red[0] + red[1] + red[2] + red[3];
 }
 
+// ------------------------------------------------------------------------------------------
+// Batched triangular solve, one right-hand side per chain:  L w = b  (TRANS = false)  or  L' x = t
+// (TRANS = true), L lower, column-major, leading dimension p.  rocBLAS' trsv_strided_batched runs one
+// small workgroup per matrix and took 20 ms per call at p = 1000, C = 256 (72 % of the regression
+// sweep); here one 256-thread workgroup per chain keeps the right-hand side in LDS and walks L in
+// 64-column blocks: a 64 x 64 diagonal solve by one wave (block staged in LDS), then the update of
+// the remaining entries by all four waves, streaming L exactly once (p^2/2 doubles) with
+// line-complete accesses.  HBM-bound: 4 MB per chain per solve at p = 1000.
+#define OMC_TS_B 64
+template <bool TRANS>
+__global__ void __launch_bounds__(256) k_tri_solve_batched(int64_t p, const double* __restrict__ Lall, int64_t strideL,
+                                                           double* __restrict__ xall, int64_t ld_x) {
+  extern __shared__ double sm[];
+  double* xs = sm;                     // [p]   right-hand side / solution
+  double* blk = sm + ((p + 15) & ~15); // [64][65] diagonal block
+  const int64_t c = blockIdx.x;
+  const double* L = Lall + c * strideL;
+  double* x = xall + c * ld_x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int64_t i = tid; i < p; i += 256) xs[i] = x[i];
+  __syncthreads();
+  const int64_t nb = (p + OMC_TS_B - 1) / OMC_TS_B;
+  for (int64_t step = 0; step < nb; ++step) {
+    const int64_t kb = TRANS ? nb - 1 - step : step;
+    const int64_t k0 = kb * OMC_TS_B;
+    const int bs = (int)((p - k0) < OMC_TS_B ? (p - k0) : OMC_TS_B);
+    if (wave == 0) {
+      // stage the diagonal block: lane = row inside the block (rows are contiguous in memory)
+      for (int j = 0; j < bs; ++j)
+        blk[lane * (OMC_TS_B + 1) + j] = (lane < bs && j <= lane) ? L[(k0 + lane) + (k0 + j) * p] : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double xi = (lane < bs) ? xs[k0 + lane] : 0.0;
+      const double dinv = (lane < bs) ? 1.0 / blk[lane * (OMC_TS_B + 1) + lane] : 0.0;
+      if (!TRANS) {
+        for (int j = 0; j < bs; ++j) {
+          const double xj = __shfl(xi * dinv, j, 64);          // lane j is final at step j
+          if (lane == j) xi = xj;
+          if (lane > j && lane < bs) xi = fma(-blk[lane * (OMC_TS_B + 1) + j], xj, xi);
+        }
+      } else {
+        for (int i = bs - 1; i >= 0; --i) {
+          const double xv = __shfl(xi * dinv, i, 64);          // lane i is final at step i
+          if (lane == i) xi = xv;
+          if (lane < i) xi = fma(-blk[i * (OMC_TS_B + 1) + lane], xv, xi);   // L[i][lane] = (L')[lane][i]
+        }
+      }
+      if (lane < bs) xs[k0 + lane] = xi;
+    }
+    __syncthreads();
+    if (!TRANS) {
+      // x_i -= sum_j L[i, k0+j] x_{k0+j} for the rows below the block (thread per row, coalesced)
+      for (int64_t i = k0 + bs + tid; i < p; i += 256) {
+        const double* lp = L + i + k0 * p;
+        double acc = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < bs; ++j) acc = fma(lp[(int64_t)j * p], xs[k0 + j], acc);
+        xs[i] -= acc;
+      }
+    } else {
+      // t_j -= sum_i L[k0+i, j] x_{k0+i} for the columns left of the block (thread per column,
+      // each thread streams bs contiguous doubles)
+      for (int64_t j = tid; j < k0; j += 256) {
+        const double* lp = L + k0 + j * p;
+        double acc = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < bs; ++i) acc = fma(lp[i], xs[k0 + i], acc);
+        xs[j] -= acc;
+      }
+    }
+    __syncthreads();
+  }
+  for (int64_t i = tid; i < p; i += 256) x[i] = xs[i];
+}
+
+static omc_status tri_solve(omc_ctx* ctx, rocblas_handle h, bool trans, int64_t p, const double* Q, double* x, int64_t ld,
+                            int64_t C) {
+  if (p <= 8192) {
+    const size_t lds = (((size_t)p + 15) & ~(size_t)15) * sizeof(double) + OMC_TS_B * (OMC_TS_B + 1) * sizeof(double);
+    if (trans)
+      hipLaunchKernelGGL(k_tri_solve_batched<true>, dim3((unsigned)C), dim3(256), lds, ctx->stream, p, Q, p * p, x, ld);
+    else
+      hipLaunchKernelGGL(k_tri_solve_batched<false>, dim3((unsigned)C), dim3(256), lds, ctx->stream, p, Q, p * p, x, ld);
+    OMC_HIP_CHECK(hipGetLastError());
+    return OMC_OK;
+  }
+  OMC_BLAS_CHECK(rocblas_dtrsv_strided_batched(h, rocblas_fill_lower,
+                                               trans ? rocblas_operation_transpose : rocblas_operation_none,
+                                               rocblas_diagonal_non_unit, (rocblas_int)p, Q, (rocblas_int)p,
+                                               (rocblas_stride)(p * p), x, 1, (rocblas_stride)ld, (rocblas_int)C));
+  return OMC_OK;
+}
+
 static unsigned gx(int64_t n) {
   int64_t g = (n + 255) / 256;
   return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -191,24 +285,20 @@ omc_status omc_dense_sample_canonical(omc_ctx* ctx, int64_t p, const omc_dense_t
   // w = L^{-1} b in x_out
   hipLaunchKernelGGL(k_dense_rhs, dim3(gx(p), (unsigned)C), dim3(256), 0, ctx->stream, T, p, C, rhs_chain, ld_rhs, x_out, ld_x);
   OMC_HIP_CHECK(hipGetLastError());
-  OMC_BLAS_CHECK(rocblas_dtrsv_strided_batched(h, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
-                                               (rocblas_int)p, Q, (rocblas_int)p, (rocblas_stride)(p * p), x_out, 1,
-                                               (rocblas_stride)ld_x, (rocblas_int)C));
+  st = tri_solve(ctx, h, false, p, Q, x_out, ld_x, C);
+  if (st != OMC_OK) return st;
   if (mean_out) {  // mu = L^{-T} w  (gmrf.py:196)
     hipLaunchKernelGGL(k_copy_rows, dim3(gx(p), (unsigned)C), dim3(256), 0, ctx->stream, p, x_out, ld_x, mean_out, ld_mean);
     OMC_HIP_CHECK(hipGetLastError());
-    OMC_BLAS_CHECK(rocblas_dtrsv_strided_batched(h, rocblas_fill_lower, rocblas_operation_transpose,
-                                                 rocblas_diagonal_non_unit, (rocblas_int)p, Q, (rocblas_int)p,
-                                                 (rocblas_stride)(p * p), mean_out, 1, (rocblas_stride)ld_mean,
-                                                 (rocblas_int)C));
+    st = tri_solve(ctx, h, true, p, Q, mean_out, ld_mean, C);
+    if (st != OMC_OK) return st;
   }
   // x = L^{-T} (w + z)
   hipLaunchKernelGGL(k_add_draw, dim3(gx((p + 1) / 2), (unsigned)C), dim3(256), 0, ctx->stream, p, C, ctx->chain_offset,
                      omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), z_inject, ld_z, x_out, ld_x);
   OMC_HIP_CHECK(hipGetLastError());
-  OMC_BLAS_CHECK(rocblas_dtrsv_strided_batched(h, rocblas_fill_lower, rocblas_operation_transpose,
-                                               rocblas_diagonal_non_unit, (rocblas_int)p, Q, (rocblas_int)p,
-                                               (rocblas_stride)(p * p), x_out, 1, (rocblas_stride)ld_x, (rocblas_int)C));
+  st = tri_solve(ctx, h, true, p, Q, x_out, ld_x, C);
+  if (st != OMC_OK) return st;
   return OMC_OK;
 }
 
