@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="one launch per sampler instead of the fused sweep kernel")
+    ap.add_argument("--zero-z", action="store_true", help="diagnostic what-if: no draw generation (results are not samples)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic: print in-kernel phase stamps (not a timing run)")
     ap.add_argument("--seg", type=int, default=0, help="nodes per lane of the segmented kernel (0 = auto)")
     args = ap.parse_args()
@@ -183,6 +184,8 @@ def main():
     n_store = max(1, min(args.steps, STORE_SLABS_MAX))
     sweep = GmrfSweep(n, C, seed=2025, chain_offset=rank * C, device=local, n_store=n_store,
                       fused=not args.unfused, seg=args.seg)
+    if args.zero_z:
+        sweep.eng.set_option("debug_zero_z", 1)
     stamps = None
     if args.stamps:
         stamps = torch.zeros(C * 16 * 16, dtype=torch.int64, device="cuda")

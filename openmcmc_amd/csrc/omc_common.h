@@ -23,6 +23,7 @@ struct omc_ctx {
   double* mh_work; size_t mh_work_bytes;  // omc_mala.hip
   int tridiag_algo;  // 0 auto, 1 serial, 2 segmented
   int tridiag_seg;   // 0 auto, else nodes per lane
+  int debug_zero_z;  // diagnostic: skip the draw generation (timing what-if only)
   unsigned long long* stamps;  // diagnostic phase stamps of the segmented kernel (NULL = off)
 };
 

@@ -1173,6 +1173,7 @@ omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* term
   A.z = z_inject; A.ld_z = ld_z;
   A.key = omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL);
   A.x = x_out; A.ld_x = ld_x;
+  A.zero_z = ctx->debug_zero_z;
   A.fused = 1;
   A.log_post = log_post_out;
   return launch_tridiag(ctx, A);
