@@ -67,6 +67,7 @@ class GmrfSweep:
         self.store_tau = eng.empty(n_store, chains)
         self.store_lp = eng.empty(n_store, chains)
         self.it = 0
+        self.scratch = eng.empty(chains, n)
         self.fused = fused
         if seg:
             eng.set_option("tridiag_seg", seg)
@@ -97,6 +98,15 @@ class GmrfSweep:
         self.store_lam[slot].copy_(self.lam)
         self.store_tau[slot].copy_(self.tau)
         self.it += 1
+
+    def run_fused(self, k):
+        """k sweeps issued by ONE call into the library (omc_gmrf_run): no host work between launches."""
+        eng, n = self.eng, self.n
+        blocks = [{"a0": self.A_LAM, "b0": self.B_LAM, "n_pos": n, "store": self.store_lam, "logdet": self.logdetP, "draw_index": 1},
+                  {"a0": self.A_TAU, "b0": self.B_TAU, "n_pos": n, "store": self.store_tau, "logdet": self.logdetI, "draw_index": 2}]
+        eng.gmrf_run(n, self.terms, blocks, 0, k, 1, self.store_b, self.scratch, draw_index0=3 * self.it,
+                     draws_per_sweep=3, first_slot=self.it % self.n_store, log_post_store=self.store_lp)
+        self.it += k
 
     def step_fused(self, kernel_events=None):
         """The same sweep as ONE launch (omc_gmrf_sweep): draw, both Normal-Gamma updates, log_post,
@@ -159,6 +169,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=N_NODES)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--python-loop", action="store_true", help="issue every sweep from Python instead of omc_gmrf_run")
     ap.add_argument("--unfused", action="store_true", help="one launch per sampler instead of the fused sweep kernel")
     ap.add_argument("--zero-z", action="store_true", help="diagnostic what-if: no draw generation (results are not samples)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic: print in-kernel phase stamps (not a timing run)")
@@ -191,12 +202,17 @@ def main():
         stamps = torch.zeros(C * 16 * 16, dtype=torch.int64, device="cuda")
         sweep.eng.set_option("stamps_ptr", stamps.data_ptr())
 
-    for _ in range(args.warmup):
-        sweep.step()
+    c_loop = not (args.python_loop or args.unfused)
+    if c_loop:
+        sweep.run_fused(args.warmup)
+    else:
+        for _ in range(args.warmup):
+            sweep.step()
     sweep.eng.check_status()
 
     use_ev = not args.no_kernel_events
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if use_ev else None
+    n_ev = 1 if c_loop else args.steps
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)] if use_ev else None
 
     def barrier():
         if dist is not None:
@@ -205,8 +221,15 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        sweep.step(events[i] if use_ev else None)
+    if c_loop:  # one library call issues all K launches; the events bracket them on the launch stream
+        if use_ev:
+            events[0][0].record()
+        sweep.run_fused(args.steps)
+        if use_ev:
+            events[0][1].record()
+    else:
+        for i in range(args.steps):
+            sweep.step(events[i] if use_ev else None)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -239,7 +262,7 @@ def main():
     if rank == 0:
         kern_ms = None
         if use_ev:
-            kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+            kern_ms = float(np.sum([a.elapsed_time(b) for a, b in events])) / args.steps
         total_chains = C * world
         value = total_chains * args.steps / dt
         out = {

@@ -129,6 +129,19 @@ omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* term
                           const double* z_inject, int64_t ld_z, uint64_t draw_index,
                           double* x_out, int64_t ld_x, double* log_post_out);
 
+/* The whole MCMC.run_mcmc loop (mcmc.py:97-111) for that sampler list, issued from C: n_burn + n_iter *
+ * n_thin sweeps back to back with no host work in between.  Sweep t (0-based) uses draw index
+ * draw_index0 + t * draws_per_sweep for the Gaussian block and that base + blocks[k].draw_index for
+ * gamma block k.  Iteration i (the last sweep of every group of n_thin after the burn-in) is stored:
+ *   x      -> x_store + slot * x_slot_stride        ([C][ld_x] slab; written directly by the sweep)
+ *   scale  -> blocks[k].store + slot * C            (when blocks[k].store != NULL)
+ *   log_p  -> log_post_store + slot * C             (when != NULL)
+ * with slot = (first_slot + i) % n_slots.  Sweeps that are not stored draw into scratch_x [C][ld_x].  */
+omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms, const omc_gamma_block* blocks,
+                        int64_t n_burn, int64_t n_iter, int64_t n_thin, uint64_t draw_index0,
+                        uint64_t draws_per_sweep, double* x_store, int64_t ld_x, int64_t x_slot_stride,
+                        int64_t first_slot, int64_t n_slots, double* log_post_store, double* scratch_x);
+
 /* quad_out[k][c] = (x_c - center_k)' M_k (x_c - center_k) for an existing x (sampler.py:276-284
  * when the Gaussian block was not just drawn; gmrf.py:343-344).                              */
 omc_status omc_tridiag_quadform(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,

@@ -93,6 +93,11 @@ SIGNATURES = {
         i32,
         [C.c_void_p, i64, c_dp, c_dp, c_dp, C.c_double, c_dp, i64, c_dp, u64, c_dp, i64, c_dp, c_dp],
     ),
+    "omc_gmrf_run": (
+        i32,
+        [C.c_void_p, i64, C.POINTER(TridiagTerms), C.POINTER(GammaBlock), i64, i64, i64, u64, u64, c_dp, i64, i64,
+         i64, i64, c_dp, c_dp],
+    ),
     "omc_tridiag_quadform": (i32, [C.c_void_p, i64, C.POINTER(TridiagTerms), c_dp, i64, c_dp]),
     "omc_tridiag_matvec": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp]),
     "omc_tridiag_logdet": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp]),

@@ -1179,6 +1179,34 @@ omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* term
   return launch_tridiag(ctx, A);
 }
 
+omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms, const omc_gamma_block* blocks,
+                        int64_t n_burn, int64_t n_iter, int64_t n_thin, uint64_t draw_index0, uint64_t draws_per_sweep,
+                        double* x_store, int64_t ld_x, int64_t x_slot_stride, int64_t first_slot, int64_t n_slots,
+                        double* log_post_store, double* scratch_x) {
+  if (!ctx || !terms || !blocks || n_burn < 0 || n_iter < 0 || n_thin < 1 || n_slots < 1 || first_slot < 0 || !x_store ||
+      !scratch_x || x_slot_stride < ctx->n_chains * ld_x)
+    return OMC_INVALID_ARG;
+  const int64_t C = ctx->n_chains;
+  omc_gamma_block b[OMC_MAX_TERMS];
+  const int64_t total = n_burn + n_iter * n_thin;
+  for (int64_t t = 0; t < total; ++t) {
+    const bool stored = t >= n_burn && ((t - n_burn + 1) % n_thin == 0);
+    const int64_t i = stored ? (t - n_burn + 1) / n_thin - 1 : 0;
+    const int64_t slot = (first_slot + i) % n_slots;
+    const uint64_t base = draw_index0 + (uint64_t)t * draws_per_sweep;
+    for (int k = 0; k < terms->n_terms && k < OMC_MAX_TERMS; ++k) {
+      b[k] = blocks[k];
+      b[k].draw_index = base + blocks[k].draw_index;
+      b[k].store = (stored && blocks[k].store) ? blocks[k].store + slot * C : nullptr;
+    }
+    omc_status st = omc_gmrf_sweep(ctx, n, terms, b, nullptr, 0, nullptr, 0, base,
+                                   stored ? x_store + slot * x_slot_stride : scratch_x, ld_x,
+                                   (stored && log_post_store) ? log_post_store + slot * C : nullptr);
+    if (st != OMC_OK) return st;
+  }
+  return OMC_OK;
+}
+
 omc_status omc_tridiag_quadform(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms, const double* x,
                                 int64_t ld_x, double* quad_out) {
   if (!ctx || n < 1 || !x || ld_x < n || !quad_out) return OMC_INVALID_ARG;

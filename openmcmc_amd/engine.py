@@ -174,6 +174,37 @@ class Engine:
                                  self._p(z, Cn, n), ld(z), int(draw_index), self._p(x_out, Cn, n), ld(x_out),
                                  self._chain_scalar(log_post_out)))
 
+    def gmrf_run(self, n, terms, blocks, n_burn, n_iter, n_thin, x_store, scratch_x, draw_index0=0,
+                 draws_per_sweep=1, first_slot=0, log_post_store=None):
+        """The whole run_mcmc loop for [NormalNormal, NormalGamma...] issued from C (omc_gmrf_run).
+        x_store: (n_slots, C, n); blocks[k]["store"]: (n_slots, C) or None; blocks[k]["draw_index"] is the
+        block's offset inside a sweep's draw indices."""
+        T = terms if isinstance(terms, _abi.TridiagTerms) else self.tridiag_terms(terms, n)
+        B = blocks if not isinstance(blocks, (list, tuple)) else self._gamma_blocks_strided(blocks, T.n_terms)
+        n_slots = x_store.shape[0]
+        if x_store.dim() != 3 or x_store.shape[1] != self.n_chains or x_store.shape[2] < n or not x_store.is_contiguous():
+            raise ValueError("x_store must be a contiguous (n_slots, C, >=n) tensor")
+        check(lib.omc_gmrf_run(self._ctx, n, C.byref(T), B, int(n_burn), int(n_iter), int(n_thin), int(draw_index0),
+                               int(draws_per_sweep), self._p(x_store), x_store.stride(1), x_store.stride(0),
+                               int(first_slot), int(n_slots), self._p(log_post_store),
+                               self._p(scratch_x, self.n_chains, n)))
+
+    def _gamma_blocks_strided(self, blocks, n_terms):
+        arr = (_abi.GammaBlock * _abi.OMC_MAX_TERMS)()
+        keep = []
+        for k in range(n_terms):
+            b = blocks[k] if k < len(blocks) else None
+            if b is None:
+                continue
+            arr[k].enabled = int(b.get("enabled", True))
+            arr[k].a0, arr[k].b0, arr[k].n_pos = float(b.get("a0", 0.0)), float(b.get("b0", 0.0)), int(b.get("n_pos", 0))
+            arr[k].draw_index = int(b.get("draw_index", 0))
+            arr[k].store = self._p(b.get("store"))
+            arr[k].logdet_unscaled = self._p(b.get("logdet"))
+            keep.append(dict(b))
+        arr._keep = keep
+        return arr
+
     def tridiag_quadform(self, n, terms, x, quad_out):
         T = terms if isinstance(terms, _abi.TridiagTerms) else self.tridiag_terms(terms, n)
         check(lib.omc_tridiag_quadform(self._ctx, n, C.byref(T), self._p(x, self.n_chains, n), x.stride(0),

@@ -129,8 +129,38 @@ class MCMC:
         return self._scratch_x
 
     # ------------------------------------------------------------------ the loop (mcmc.py:87-115)
+    def _run_fused_in_c(self):
+        """The whole loop as one omc_gmrf_run call: possible when no draws are injected."""
+        eng, f = self.engine, self._fused
+        nn, plan = f["nn"], f["plan"]
+        ns, n = len(self.samplers), plan["n"]
+        specs = []
+        for k, key in enumerate(plan["keys"]):
+            dist = nn.model[key]
+            st = dist.structure(self.state)
+            spec = {"enabled": False, "logdet": eng._model_cache[(id(dist), id(st.matrix))]["logdet"]}
+            if f["blocks"][k] is not None:
+                pos, g = f["blocks"][k]
+                a0, b0 = g.prior_shape_rate(self.state)
+                spec.update(enabled=True, a0=a0, b0=b0, n_pos=st.n_pos, draw_index=pos,
+                            store=self.store[g.param][:, :, 0])
+            specs.append(spec)
+        eng.gmrf_run(n, plan["terms"], specs, self.n_burn, self.n_iter, self.n_thin, self.store[nn.param],
+                     self._scratch(n), draw_index0=nn._sweep * ns, draws_per_sweep=ns,
+                     log_post_store=self.store["log_post"] if f["log_post"] else None)
+        total = self.n_burn + self.n_iter * self.n_thin
+        for s in self.samplers:
+            s._sweep += total
+        last = self.store[nn.param][self.n_iter - 1] if self.n_iter > 0 else self._scratch(n)
+        self.state[nn.param] = ChainArray(last)
+
     def run_mcmc(self):
         eng = self.engine
+        if (self._fused is not None and self._fused["log_post"] and self.n_iter > 0
+                and all(getattr(s, "inject", None) is None for s in self.samplers)):
+            self._run_fused_in_c()
+            eng.check_status()
+            return
         for i_it in range(-self.n_burn, self.n_iter):
             storing = i_it >= 0
             for i_thin in range(self.n_thin):
