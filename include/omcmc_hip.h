@@ -129,7 +129,7 @@ omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* term
                           const double* z_inject, int64_t ld_z, uint64_t draw_index,
                           double* x_out, int64_t ld_x, double* log_post_out);
 
-/* The whole MCMC.run_mcmc loop (mcmc.py:97-111) for that sampler list, issued from C: n_burn + n_iter *
+/* The whole MCMC.run_mcmc loop (mcmc.py:97-111) for that sampler list, issued from C: (n_burn + n_iter) *
  * n_thin sweeps back to back with no host work in between.  Sweep t (0-based) uses draw index
  * draw_index0 + t * draws_per_sweep for the Gaussian block and that base + blocks[k].draw_index for
  * gamma block k.  Iteration i (the last sweep of every group of n_thin after the burn-in) is stored:

@@ -1188,10 +1188,11 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
     return OMC_INVALID_ARG;
   const int64_t C = ctx->n_chains;
   omc_gamma_block b[OMC_MAX_TERMS];
-  const int64_t total = n_burn + n_iter * n_thin;
+  // mcmc.py:97-98: every iteration, burn-in included, is n_thin sweeps
+  const int64_t burn = n_burn * n_thin, total = burn + n_iter * n_thin;
   for (int64_t t = 0; t < total; ++t) {
-    const bool stored = t >= n_burn && ((t - n_burn + 1) % n_thin == 0);
-    const int64_t i = stored ? (t - n_burn + 1) / n_thin - 1 : 0;
+    const bool stored = t >= burn && ((t - burn + 1) % n_thin == 0);
+    const int64_t i = stored ? (t - burn + 1) / n_thin - 1 : 0;
     const int64_t slot = (first_slot + i) % n_slots;
     const uint64_t base = draw_index0 + (uint64_t)t * draws_per_sweep;
     for (int k = 0; k < terms->n_terms && k < OMC_MAX_TERMS; ++k) {

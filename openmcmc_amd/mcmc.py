@@ -148,7 +148,7 @@ class MCMC:
         eng.gmrf_run(n, plan["terms"], specs, self.n_burn, self.n_iter, self.n_thin, self.store[nn.param],
                      self._scratch(n), draw_index0=nn._sweep * ns, draws_per_sweep=ns,
                      log_post_store=self.store["log_post"] if f["log_post"] else None)
-        total = self.n_burn + self.n_iter * self.n_thin
+        total = (self.n_burn + self.n_iter) * self.n_thin
         for s in self.samplers:
             s._sweep += total
         last = self.store[nn.param][self.n_iter - 1] if self.n_iter > 0 else self._scratch(n)

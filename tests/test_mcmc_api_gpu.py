@@ -74,6 +74,7 @@ def test_fused_and_unfused_loops_agree(golden):
     outs = []
     for fuse in (False, True):
         M, _ = build(G, "sparse_", True, 5, fuse=fuse, n_burn=4, n_iter=9, seed=123)
+        M.n_thin = 2  # burn-in and stored iterations are both n_thin sweeps long (mcmc.py:97-98)
         assert (M._fused is not None) == fuse
         M.run_mcmc()
         outs.append(M.collect())
