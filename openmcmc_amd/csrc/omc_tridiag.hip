@@ -107,49 +107,62 @@ __device__ __forceinline__ double read_lane_d(double v, int l) {  // l wave-unif
 // The same epilogue spread over the 64 lanes of one wave (the workgroup-per-chain kernel runs it on
 // wave 0 while the other waves are already storing x): lanes 16k..16k+15 belong to term k and each
 // evaluates one Marsaglia-Tsang attempt; the lowest accepted attempt is the serial answer.
+// The same epilogue spread over the 64 lanes of one wave (the workgroup-per-chain kernel runs it on
+// wave 0): lanes 16k..16k+15 belong to term k.
+//
+// Part 1, `sweep_gamma_draws_wave`: the standard-gamma draws Gamma(a,1).  They depend only on the
+// prior shape and the node count, not on the data, so the kernel makes them at its very start, in the
+// shadow of the first global loads; each lane evaluates one Marsaglia-Tsang attempt, the lowest
+// accepted attempt is the serial answer.  Part 2, `sweep_epilogue_wave`: scale by 1/b once the
+// quadratic forms are known, store, log_post.
+__device__ __forceinline__ double sweep_gamma_draws_wave(const TriArgs& A, int64_t c, int lane, bool* failed) {
+  const int k = lane >> 4, j = lane & 15;
+  const bool term_on = k < A.T.n_terms;
+  GammaDev g = A.gb[0];
+#pragma unroll
+  for (int t = 1; t < OMC_MAX_TERMS; ++t)
+    if (k == t) g = A.gb[t];
+  const bool draw = term_on && g.enabled;
+  double gd = 0.0;
+  if (__ballot(draw) == 0ull) return gd;
+  if (draw && g.g_inject) {
+    gd = g.g_inject[c];
+  } else if (draw) {
+    const omc_gamma_prep p = omc_gamma_prepare(g.key, A.chain_offset + c, g.a0 + g.half_npos);
+    double v = 0.0;
+    bool ok = omc_gamma_attempt(g.key, A.chain_offset + c, p, (uint32_t)j, v);
+    const unsigned long long m = (__ballot(ok) >> (16 * k)) & 0xffffull;  // accepted attempts of this group
+    if (m == 0ull) {  // astronomically rare: continue serially on the group's first lane
+      if (j == 0) {
+        ok = false;
+        for (uint32_t at = 16; at < 256 && !ok; ++at) ok = omc_gamma_attempt(g.key, A.chain_offset + c, p, at, v);
+        *failed = !ok;
+        gd = ok ? v : p.boost * p.d;
+      }
+    } else {
+      gd = __shfl(v, __ffsll((long long)m) - 1 + 16 * k, 64);
+    }
+  }
+  return gd;
+}
+
 __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c, const double (&quad)[OMC_MAX_TERMS],
-                                                    double s_old, double ldet, int lane) {
+                                                    double s_old, double ldet, double gd, bool failed, int lane) {
   const int k = lane >> 4, j = lane & 15;
   const bool term_on = k < A.T.n_terms;
   // per-lane copy of this lane's term, selected with compile-time indices (a dynamically indexed
   // kernel-argument array would be spilled to scratch)
   GammaDev g = A.gb[0];
   double qk = quad[0], s = s_old;  // this lane's term; scalars were loaded before the quad phase
-  const double ld_k = ldet;
 #pragma unroll
   for (int t = 1; t < OMC_MAX_TERMS; ++t) {
     if (k == t) { g = A.gb[t]; qk = quad[t]; }
   }
   if (!term_on) s = 1.0;
-  const bool draw = term_on && g.enabled;
-  bool failed = false;
-  if (__ballot(draw) != 0ull) {
-    const double a = g.a0 + g.half_npos;
+  if (term_on && g.enabled) {
     const double b = g.b0 + 0.5 * qk;
-    const double scl = (b == 0.0) ? INFINITY : omc_rcp_nr(b);
-    double gd = 0.0;
-    if (draw && g.g_inject) {
-      gd = g.g_inject[c];
-    } else if (draw) {
-      const omc_gamma_prep p = omc_gamma_prepare(g.key, A.chain_offset + c, a);
-      double v = 0.0;
-      bool ok = omc_gamma_attempt(g.key, A.chain_offset + c, p, (uint32_t)j, v);
-      // lowest accepted attempt inside the 16-lane group
-      unsigned long long m = (__ballot(ok) >> (16 * k)) & 0xffffull;
-      if (m == 0ull) {  // astronomically rare: continue serially on the group's first lane
-        if (j == 0) {
-          ok = false;
-          for (uint32_t at = 16; at < 256 && !ok; ++at) ok = omc_gamma_attempt(g.key, A.chain_offset + c, p, at, v);
-          failed = !ok;
-          gd = ok ? v : p.boost * p.d;
-        }
-      } else {
-        const int win = __ffsll((long long)m) - 1 + 16 * k;
-        gd = __shfl(v, win, 64);
-      }
-    }
-    if (draw) s = gd * scl;
-    if (draw && j == 0) {
+    s = gd * ((b == 0.0) ? INFINITY : omc_rcp_nr(b));  // sampler.py:285-287
+    if (j == 0) {
       g.scale_out[c] = s;
       if (g.store) g.store[c] = s;
     }
@@ -158,7 +171,7 @@ __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c,
     double lp = 0.0;
     if (term_on && j == 0) {
       const double nd = (double)A.n;
-      lp = 0.5 * (nd * log(s) + ld_k - nd * 1.8378770664093453 - s * qk);
+      lp = 0.5 * (nd * log(s) + ldet - nd * 1.8378770664093453 - s * qk);
       if (g.enabled) lp += g.lnorm + (g.a0 - 1.0) * log(s) - g.b0 * s;
     }
     // terms are summed in order 0,1,2,3 as the serial epilogue does
@@ -710,6 +723,10 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 
   double Y[M], W[M];
   OMC_STAMP(0);
+  // Normal-Gamma standard draws, made up front on wave 0 (see sweep_gamma_draws_wave)
+  double early_gamma = 0.0;
+  bool early_failed = false;
+  if (MULTI && A.fused && wave == 0 && chain_ok) early_gamma = sweep_gamma_draws_wave(A, c, lane, &early_failed);
 
   OMC_STAMP(1);
 
@@ -937,7 +954,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   }
   if (bad && chain_ok) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
   if (MULTI) {
-    if (A.fused && wave == 0 && chain_ok) sweep_epilogue_wave(A, c, qsum, my_scale, my_logdet, lane);
+    if (A.fused && wave == 0 && chain_ok) sweep_epilogue_wave(A, c, qsum, my_scale, my_logdet, early_gamma, early_failed, lane);
     // x leaves last: a load issued behind a store would have to wait for the store to be
     // acknowledged (vmcnt retires in order); this way nothing ever waits on the x stream.
     if (A.x && chain_ok) {
