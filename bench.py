@@ -183,13 +183,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if os.environ.get("OMC_BENCH_BACKEND", "nccl") != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     torch.cuda.set_stream(torch.cuda.Stream())  # a real stream: the legacy default stream serialises with everything
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL over xGMI in production; OMC_BENCH_BACKEND=gloo rehearses the same launch contract where
+        # ranks have to share one GPU (LOCAL_RANK is then folded onto the visible devices)
+        backend = os.environ.get("OMC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     n, C = args.nodes, args.chains
     n_store = max(1, min(args.steps, STORE_SLABS_MAX))
@@ -235,13 +243,16 @@ def main():
     dt = time.perf_counter() - t0
     sweep.eng.check_status()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    on_gpu = dist is None or dist.get_backend() == "nccl"
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
 
     # the one collective of the path: gather of the per-chain traces (outside the timed region)
     trace = torch.stack([sweep.store_lam[: min(args.steps, n_store)], sweep.store_tau[: min(args.steps, n_store)]])
+    if not on_gpu:
+        trace = trace.cpu()
     if dist is not None:
         gathered = [torch.empty_like(trace) for _ in range(world)] if rank == 0 else None
         dist.gather(trace, gathered, dst=0)
