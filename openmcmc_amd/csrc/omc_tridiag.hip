@@ -422,6 +422,36 @@ __device__ __forceinline__ void prev_lane2_wg(double& v0, double& v1, double id0
   v0 = a; v1 = b;
 }
 
+// four sums over the workgroup with a single barrier; lds: [4][16]
+__device__ __forceinline__ void sum4_wg(const double (&v)[OMC_MAX_TERMS], double (&out)[OMC_MAX_TERMS], double* lds, int lane,
+                                        int wave, int nw) {
+  double t[OMC_MAX_TERMS];
+#pragma unroll
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+    double x = v[k];
+    x += dpp_mov<DPP_ROW_SHR(1)>(x, 0.0);
+    x += dpp_mov<DPP_ROW_SHR(2)>(x, 0.0);
+    x += dpp_mov<DPP_ROW_SHR(4)>(x, 0.0);
+    x += dpp_mov<DPP_ROW_SHR(8)>(x, 0.0);
+    t[k] = (read_lane(x, 15) + read_lane(x, 31)) + (read_lane(x, 47) + read_lane(x, 63));
+  }
+  if (nw > 1) {
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < OMC_MAX_TERMS; ++k) lds[k * 16 + wave] = t[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+      double u = 0.0;
+      for (int w = 0; w < nw; ++w) u += lds[k * 16 + w];
+      t[k] = u;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) out[k] = t[k];
+}
+
 __device__ __forceinline__ double sum_wg(double v, double* lds, int lane, int wave, int nw) {
   v += dpp_mov<DPP_ROW_SHR(1)>(v, 0.0);
   v += dpp_mov<DPP_ROW_SHR(2)>(v, 0.0);
@@ -880,8 +910,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     wave_lds_fence();
 #pragma unroll
     for (int j = 0; j < M; ++j) crow[j] = W[j];
-    if (want_quad) __syncthreads();  // the last element of a wave needs the next wave's first x
-    else wave_lds_fence();
+    wave_lds_fence();  // wave-private tile: no workgroup barrier needed (see xfirst_next below)
     const int n32 = (int)n;
     double acc[OMC_MAX_TERMS] = {0, 0, 0, 0};
     // scalars of the epilogue: issue their loads now so the latency hides behind the quad phase
@@ -893,13 +922,15 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     }
     if (want_quad) {
       const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-      const double xfirst_next = (wave_u + 1 < nw) ? lds_tile[(wave_u + 1) % NWMAX][0] : 0.0;
+      // x at the first node of the NEXT wave's tile = what the reverse scan handed this wave's last
+      // segment as its successor value
+      const double xfirst_next = read_lane_d(xnext, 63);
       if ((wave_u + 1) * 64 * M < n32) quad_chunks<M, true>(tile, lane, wave_u, A, xfirst_next, acc);
       else quad_chunks<M, false>(tile, lane, wave_u, A, xfirst_next, acc);
     }
     if (want_quad) {
+      sum4_wg(acc, qsum, &lds_d[0][0], lane, wave, nw);  // all terms behind one barrier
       _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt) {
-        qsum[k] = sum_wg(acc[k], lds_d[k], lane, wave, nw);
         if (A.quad && s == 0 && chain_ok) A.quad[k * A.C + c] = qsum[k];
       }
     }
