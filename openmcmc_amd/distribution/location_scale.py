@@ -154,4 +154,51 @@ class Normal(Distribution):
         return out
 
     def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):
-        raise NotImplementedError("prior draws from a Normal: give the state an initial value")
+        """One draw per chain from N(mean, (scale * M)^-1) (location_scale.py:252-272 -> gmrf.py:29-61),
+        used by MCMC when the state has no initial value for a sampled parameter (mcmc.py:78-80)."""
+        if engine is None:
+            raise RuntimeError("Normal.rvs needs the engine")
+        if n != 1:
+            raise NotImplementedError("replicated prior draws")
+        if self.domain_response_lower is not None or self.domain_response_upper is not None:
+            raise NotImplementedError("truncated prior draws (gmrf.sample_truncated_normal): next round")
+        st = self.structure(state)
+        mean = self.mean.predictor(state)
+        if is_chain(mean):
+            raise NotImplementedError("per-chain mean in a prior draw")
+        mean = np.asarray(mean, dtype=np.float64).reshape(-1)
+        scale = None
+        if st.scale_key is not None:
+            sv = state[st.scale_key]
+            scale = sv.scalar() if is_chain(sv) else engine.full((engine.n_chains,), float(np.asarray(sv).item()))
+        from openmcmc_amd.chains import ChainArray
+
+        x = engine.empty(engine.n_chains, st.n)
+        if st.diag is False:  # dense precision: x = Q^-1 (Q mean) + L^-T z
+            M = engine.shared(st.matrix)
+            rhs = engine.design_rhs(M, engine.to_device(mean)) if mean.any() else None
+            engine.dense_sample_canonical(st.n, [{"mat": M, "rhs": rhs, "scale": scale}], x, draw_index=draw_index)
+        else:
+            cache = engine.model_cache(self, state, st, mean)
+            engine.tridiag_sample_canonical(st.n, [{"diag": cache["diag"], "off": cache["off"], "rhs": cache["rhs"],
+                                                    "scale": scale}], x, draw_index=draw_index)
+        return ChainArray(x)
+
+    def grad_log_p(self, state: dict, param: str, hessian_required: bool = True, engine=None):
+        """Gradient of +log p and Hessian of -log p for the case the reference's MH samplers use: `param` is
+        the response, the precision is a shared dense matrix (location_scale.py:222-232):
+        grad_c = -Q (x_c - mu) as one GEMM over all chains, hessian = Q (shared)."""
+        if engine is None:
+            raise RuntimeError("Normal.grad_log_p needs the engine")
+        if param != self.response or not isinstance(self.precision, Identity):
+            raise NotImplementedError("grad_log_p is built for the response of a Normal with a shared precision matrix")
+        Q, mu = state[self.precision.form], self.mean.predictor(state)
+        x = state[self.response]
+        if is_chain(Q) or is_chain(mu) or not is_chain(x):
+            raise NotImplementedError("grad_log_p needs a per-chain response and shared mean / precision")
+        from openmcmc_amd.chains import ChainArray
+
+        dQ = engine.shared(Q)
+        r = x.vector() - engine.to_device(np.asarray(mu, dtype=np.float64).reshape(1, -1))
+        grad = ChainArray(-engine.design_predict(dQ, r))  # Q symmetric: Q r for every chain
+        return (grad, Q) if hessian_required else grad

@@ -37,4 +37,21 @@ class Model(dict):
         return out
 
 
+    def _grad_log_p(self, state: dict, param: str, hessian_required: bool = True, engine=None):
+        grad, hess = None, None
+        for dst in self.values():
+            out = dst.grad_log_p(state, param, hessian_required=hessian_required, engine=engine)
+            g, h = out if hessian_required else (out, None)
+            if grad is None:
+                grad, hess = g, h
+            else:
+                from openmcmc_amd.chains import ChainArray
+
+                grad = ChainArray(grad.data + g.data)
+                hess = hess + h if hessian_required else None
+        return (grad, hess) if hessian_required else grad
+
+
+Model.grad_log_p = Model._grad_log_p  # summed over the member distributions (model.py:72-112)
+
 __all__ = ["Model", "Distribution"]

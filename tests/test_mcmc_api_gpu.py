@@ -204,3 +204,40 @@ def test_mh_samplers_replay_reference(golden, kind):
     assert smp.accept_rate.count == {"accept": C * n_acc, "proposal": C * 40}
     assert smp.accept_rate.get_acceptance_rate() == f"Acceptance rate {100 * n_acc / 40:.0f}%"
     eng.close()
+
+
+def test_grad_log_p_and_prior_draws(golden):
+    """Model.grad_log_p on the cfg4 model equals the reference's gradient/Hessian (mala.npz); Normal.rvs
+    starts chains from the prior when the state has no value (mcmc.py:78-80): Mahalanobis ~ chi^2_d."""
+    from openmcmc_amd.chains import ChainArray
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.engine import Engine
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import ScaledMatrix
+
+    G = golden("mala")
+    d, C = 32, 3
+    k = f"d{d}_"
+    eng = Engine(C, seed=8)
+    mdl = Model([Normal("x", mean="mu", precision="Q")])
+    state = {"x": ChainArray(eng.to_device(np.tile(G[k + "x0"], (C, 1)))), "mu": np.zeros((d, 1)), "Q": G[k + "Q"]}
+    grad, hess = mdl.grad_log_p(state, "x", engine=eng)
+    assert relerr(grad.chain(2).ravel(), G[k + "one_grad"]) < TOL and np.array_equal(hess, G[k + "one_hess"])
+    eng.close()
+    # prior draws: dense and tridiagonal
+    C = 4000
+    eng = Engine(C, seed=9)
+    Q = G[k + "Q"]
+    x = Normal("x", mean="mu", precision="Q").rvs({"mu": np.ones((d, 1)), "Q": Q}, engine=eng, draw_index=3)
+    r = x.numpy()[:, :, 0] - 1.0
+    maha = np.einsum("ci,ij,cj->c", r, Q, r)
+    assert abs(maha.mean() / d - 1) < 0.05 and abs(maha.var() / (2 * d) - 1) < 0.15
+    n = 50
+    P = sparse.diags((-np.ones(n - 1), 2.5 * np.ones(n), -np.ones(n - 1)), offsets=[-1, 0, 1], format="csc")
+    dist = Normal("b", mean="m", precision=ScaledMatrix("P", "lam"))
+    xb = dist.rvs({"m": np.full((n, 1), 0.3), "P": P, "lam": np.array([[4.0]])}, engine=eng, draw_index=4)
+    rb = xb.numpy()[:, :, 0] - 0.3
+    maha = 4.0 * np.einsum("ci,ij,cj->c", rb, P.toarray(), rb)
+    assert abs(maha.mean() / n - 1) < 0.05
+    eng.check_status()
+    eng.close()
