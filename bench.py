@@ -153,6 +153,9 @@ def cpu_baseline(n, seconds_budget=12.0):
     dtc = time.perf_counter() - t1
     return {
         "value": k / dt, "unit": "chain-updates/s", "cores": 1, "kind": "port",
+        "parallel_projection": k / dt * (os.cpu_count() or 1),
+        "parallel_projection_note": "value x os.cpu_count(): every host core running its own chain (the reference "
+                                    "itself has no multi-chain mode)",
         "sample": f"{k} sweeps of 1 chain (n={n}) of the oracle's sparse-route restatement "
                   f"(scipy SuperLU), draws pre-generated; host has {os.cpu_count()} cpus",
         "c_thomas_value": kc / dtc,
@@ -260,6 +263,29 @@ def main():
             trace = torch.cat(gathered, dim=2)
     lam_mean = trace[0].mean().item()
 
+    # ... and of the sample store itself: timed on a bounded part (the last <= 8 stored iterations of b,
+    # 82 MB each per rank) so the run stays short; reported next to the headline, never inside it
+    gather_info = None
+    if dist is not None:
+        try:
+            k_it = min(8, n_store)
+            part = sweep.store_b[:k_it].contiguous()
+            if not on_gpu:
+                part = part.cpu()
+            bucket = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
+            barrier()
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            dist.gather(part, bucket, dst=0)
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+            nbytes = part.numel() * 8 * (world - 1)
+            gather_info = {"iterations": k_it, "bytes_into_root": nbytes, "ms": 1e3 * tg,
+                           "GBps_into_root": nbytes / tg / 1e9}
+            del bucket
+        except Exception as exc:  # the headline must survive a collective problem
+            gather_info = {"error": repr(exc)}
+
     if stamps is not None and rank == 0:
         st = stamps.cpu().numpy().reshape(C, 16, 16).astype(np.float64)
         nwv = int((st[0, :, 0] > 0).sum())
@@ -285,7 +311,7 @@ def main():
                                    "NormalNormal + 2x NormalGamma + store + log_post per step"
                                    + (" (one fused launch)" if not args.unfused else " (one launch per sampler)"),
                        "chains_total": total_chains, "nodes": n, "parallelism": f"chains sharded x{world}",
-                       "check": {"mean_lambda": lam_mean}},
+                       "check": {"mean_lambda": lam_mean}, "store_gather": gather_info},
         }
         if kern_ms is not None:
             achieved = ALG_BYTES_PER_CHAIN_UPDATE * (n / N_NODES) * C / (kern_ms * 1e-3) / 1e9
