@@ -202,7 +202,9 @@ omc_status omc_weighted_resid_sq(omc_ctx* ctx, int64_t n, const double* y, const
  *   g = -Q (x - mu), H = Q (location_scale.py:222-232); m = x + 1/2 (H/step^2)^{-1} g (347);
  *   x' = m + L^{-T} z (317 -> gmrf.py:61); log q = sum log L_ii - 1/2 |L'(. - m)|^2 forward and
  *   reverse (350-373); log alpha = lp' + q_rev - lp - q_fwd (155); accept iff log u < log alpha (173).
- *   As batched level-3 BLAS on the d x C state matrix: 2 GEMM, 5 TRSM, 4 TRMM per step.
+ *   As level-3 BLAS on the d x C state matrix.  Because H is constant, the drift matrix
+ *   -(H/step^2)^{-1} Q and L^{-T} are formed once per (Q, L, step) (cached in the context, so Q and L
+ *   must stay unchanged while they are in use); a step is then 3 GEMM + 1 TRMM.
  * omc_rw_step: one untruncated RandomWalk.sample (metropolis_hastings.py:212-269): x' = x + step z.
  *   z_inject [C][ld_z] / u_inject [C]: injected N(0,1) / U(0,1) draws (NULL = generate);
  *   accept_count / proposal_count [C] int64 (NULL = not kept): the AcceptRate counters

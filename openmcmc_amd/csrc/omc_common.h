@@ -21,6 +21,8 @@ struct omc_ctx {
   int* dense_info; size_t dense_info_bytes;
   double* dense_tmp; size_t dense_tmp_bytes;
   double* mh_work; size_t mh_work_bytes;  // omc_mala.hip
+  double* mala_prep; size_t mala_prep_bytes;  // cached drift matrix and L^{-T} of the current (Q, L, step)
+  const double* mala_Q; const double* mala_L; double mala_step; int64_t mala_d;
   int tridiag_algo;  // 0 auto, 1 serial, 2 segmented
   int tridiag_seg;   // 0 auto, else nodes per lane
   int debug_zero_z;  // diagnostic: skip the draw generation (timing what-if only)

@@ -125,12 +125,13 @@ struct MhWork {
 static omc_status mh_workspace(omc_ctx* ctx, int64_t d, MhWork* w) {
   const int64_t C = ctx->n_chains;
   const size_t mat = (size_t)C * d;
-  const size_t need = (6 * mat + 4 * (size_t)C) * sizeof(double) + (size_t)C * sizeof(int) + 64;
+  const size_t need = (13 * mat + 4 * (size_t)C) * sizeof(double) + (size_t)C * sizeof(int) + 64;
   omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->mh_work, &ctx->mh_work_bytes, need);
   if (st != OMC_OK) return st;
   double* base = ctx->mh_work;
   w->R = base; w->G = base + mat; w->M = base + 2 * mat; w->V = base + 3 * mat; w->XP = base + 4 * mat;
-  w->T = base + 5 * mat; w->ss = base + 6 * mat;
+  w->T = base + 5 * mat;  // 8 * mat: T4 and its TRMM image
+  w->ss = base + 13 * mat;
   w->flag = (int*)(w->ss + 4 * C);
   return OMC_OK;
 }
@@ -155,6 +156,49 @@ omc_status omc_dense_cholesky(omc_ctx* ctx, int64_t d, const double* A, double s
   return OMC_OK;
 }
 
+// Shared constant Hessian: the drift matrix A1 = -(L L')^{-1} Q (one potrs) and the explicit L^{-T}
+// (one trsm on the identity) are formed once per (Q, L, step) and cached in the context; every step
+// is then 3 GEMMs + 1 TRMM instead of 2 GEMMs + 5 TRSMs + 4 TRMMs (TRSM with 512 right-hand sides is
+// ~10x slower than the GEMM of the same shape, and the old sequence was launch-bound).
+__global__ void k_set_identity(int64_t d, double* A) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d * d; i += (int64_t)gridDim.x * blockDim.x)
+    A[i] = (i / d == i % d) ? 1.0 : 0.0;
+}
+// T4 columns: [ R | XP - M | R' | X - M' ]  (each d x C), from X, mu, XP, M (current) and M' (proposed)
+__global__ void k_build_t4(int64_t d, int64_t C, const double* x, int64_t ld_x, const double* mu, const double* xp,
+                           const double* m_cur, const double* m_prop, double* t4) {
+  const int64_t c = blockIdx.y;
+  const int64_t blk = C * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d; i += (int64_t)gridDim.x * blockDim.x) {
+    const double xv = x[c * ld_x + i], pv = xp[c * d + i], mv = mu ? mu[i] : 0.0;
+    t4[c * d + i] = xv - mv;
+    t4[blk + c * d + i] = pv - m_cur[c * d + i];
+    t4[2 * blk + c * d + i] = pv - mv;
+    t4[3 * blk + c * d + i] = xv - m_prop[c * d + i];
+  }
+}
+
+static omc_status mala_prepare(omc_ctx* ctx, int64_t d, const double* Q, const double* L, double step) {
+  if (ctx->mala_Q == Q && ctx->mala_L == L && ctx->mala_step == step && ctx->mala_d == d && ctx->mala_prep) return OMC_OK;
+  omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->mala_prep, &ctx->mala_prep_bytes, (size_t)3 * d * d * sizeof(double));
+  if (st != OMC_OK) return st;
+  rocblas_handle h = (rocblas_handle)ctx->blas;
+  const rocblas_int di = (rocblas_int)d;
+  double* A1 = ctx->mala_prep;            // -(L L')^{-1} Q
+  double* LinvT = ctx->mala_prep + d * d; // L^{-T}
+  double* Lc = ctx->mala_prep + 2 * d * d; // scratch copy of L (potrs may not alias its factor argument)
+  hipLaunchKernelGGL(k_scale_copy, dim3(gx(d * d)), dim3(256), 0, ctx->stream, d * d, Q, -1.0, A1);
+  hipLaunchKernelGGL(k_scale_copy, dim3(gx(d * d)), dim3(256), 0, ctx->stream, d * d, L, 1.0, Lc);
+  OMC_BLAS_CHECK(rocsolver_dpotrs(h, rocblas_fill_lower, di, di, Lc, di, A1, di));
+  hipLaunchKernelGGL(k_set_identity, dim3(gx(d * d)), dim3(256), 0, ctx->stream, d, LinvT);
+  const double one = 1.0;
+  OMC_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                               rocblas_diagonal_non_unit, di, di, &one, L, di, LinvT, di));
+  OMC_HIP_CHECK(hipGetLastError());
+  ctx->mala_Q = Q; ctx->mala_L = L; ctx->mala_step = step; ctx->mala_d = d;
+  return OMC_OK;
+}
+
 omc_status omc_mala_step(omc_ctx* ctx, int64_t d, const double* Q, const double* mu, const double* L,
                          const double* sumlogL, double step, const double* z_inject, int64_t ld_z,
                          const double* u_inject, uint64_t draw_index, double* x, int64_t ld_x, int64_t* accept_count,
@@ -162,64 +206,52 @@ omc_status omc_mala_step(omc_ctx* ctx, int64_t d, const double* Q, const double*
   if (!ctx || d < 1 || !Q || !L || !sumlogL || !x || ld_x < d || (z_inject && ld_z < d) || !(step > 0.0))
     return OMC_INVALID_ARG;
   const int64_t C = ctx->n_chains;
-  if (C > 65535) return OMC_UNSUPPORTED;
+  if (C > 65535 || 4 * C > 0x7fffffffLL) return OMC_UNSUPPORTED;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   omc_status st = omc_ensure_blas(ctx);
   if (st != OMC_OK) return st;
   MhWork w;
   st = mh_workspace(ctx, d, &w);
   if (st != OMC_OK) return st;
+  st = mala_prepare(ctx, d, Q, L, step);
+  if (st != OMC_OK) return st;
+  const double* A1 = ctx->mala_prep;
+  const double* LinvT = ctx->mala_prep + d * d;
   rocblas_handle h = (rocblas_handle)ctx->blas;
   const rocblas_int di = (rocblas_int)d, Ci = (rocblas_int)C;
-  const double one = 1.0, zero = 0.0, mone = -1.0;
+  const double one = 1.0, zero = 0.0;
   const dim3 g2(gx(d) > 8 ? 8 : gx(d), (unsigned)C), b2(256);
   hipStream_t s = ctx->stream;
-  double *ss_fwd = w.ss, *ss_rev = w.ss + C, *ss_cur = w.ss + 2 * C, *ss_prop = w.ss + 3 * C;
+  // workspace roles: R (residual), G (drift), M (current mean), V (draws / M'), XP (proposal), T4 (4 d x C)
+  double* T4 = w.T;  // 4 * C * d doubles (mh_workspace sizes T for it)
+  double* N4 = w.T + 4 * C * d;
+  double *ss = w.ss;  // [4][C]: |L'R|^2, |L'(x'-M)|^2, |L'R'|^2, |L'(x-M')|^2
 
-  // current state: R = x - mu, |L'R|^2, G = -Q R, S = (L L')^{-1} G, M = x + S/2
+  // current state: M = x + 1/2 A1 (x - mu)
   hipLaunchKernelGGL(k_sub_shared, g2, b2, 0, s, d, x, ld_x, mu, w.R, d);
-  OMC_BLAS_CHECK(rocblas_dtrmm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                               rocblas_diagonal_non_unit, di, Ci, &one, L, di, w.R, di, w.T, di));
-  hipLaunchKernelGGL(k_colsumsq, dim3((unsigned)C), dim3(256), 0, s, d, w.T, d, ss_cur);
-  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &mone, Q, di, w.R, di, &zero,
+  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, A1, di, w.R, di, &zero,
                                w.G, di));
-  OMC_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
-                               di, Ci, &one, L, di, w.G, di));
-  OMC_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                               rocblas_diagonal_non_unit, di, Ci, &one, L, di, w.G, di));
   hipLaunchKernelGGL(k_axpby, g2, b2, 0, s, d, x, ld_x, 0.5, w.G, d, w.M, d);
   // proposal: x' = M + L^{-T} z
   hipLaunchKernelGGL(k_draw_normals, dim3(gx((d + 1) / 2) > 8 ? 8 : gx((d + 1) / 2), (unsigned)C), b2, 0, s, d,
-                     ctx->chain_offset, omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), z_inject, ld_z, w.V, d);
-  OMC_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                               rocblas_diagonal_non_unit, di, Ci, &one, L, di, w.V, di));
+                     ctx->chain_offset, omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), z_inject, ld_z, w.R, d);
+  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, LinvT, di, w.R, di,
+                               &zero, w.V, di));
   hipLaunchKernelGGL(k_axpby, g2, b2, 0, s, d, w.M, d, 1.0, w.V, d, w.XP, d);
-  // forward proposal density: |L'(x' - M)|^2
-  hipLaunchKernelGGL(k_axpby, g2, b2, 0, s, d, w.XP, d, -1.0, w.M, d, w.T, d);
-  OMC_BLAS_CHECK(rocblas_dtrmm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                               rocblas_diagonal_non_unit, di, Ci, &one, L, di, w.T, di, w.V, di));
-  hipLaunchKernelGGL(k_colsumsq, dim3((unsigned)C), dim3(256), 0, s, d, w.V, d, ss_fwd);
-  // proposed state: R' = x' - mu, |L'R'|^2, M' = x' + (L L')^{-1}(-Q R')/2
+  // proposed state: M' = x' + 1/2 A1 (x' - mu)
   hipLaunchKernelGGL(k_sub_shared, g2, b2, 0, s, d, w.XP, d, mu, w.R, d);
-  OMC_BLAS_CHECK(rocblas_dtrmm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                               rocblas_diagonal_non_unit, di, Ci, &one, L, di, w.R, di, w.T, di));
-  hipLaunchKernelGGL(k_colsumsq, dim3((unsigned)C), dim3(256), 0, s, d, w.T, d, ss_prop);
-  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &mone, Q, di, w.R, di, &zero,
+  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, A1, di, w.R, di, &zero,
                                w.G, di));
-  OMC_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
-                               di, Ci, &one, L, di, w.G, di));
-  OMC_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                               rocblas_diagonal_non_unit, di, Ci, &one, L, di, w.G, di));
-  hipLaunchKernelGGL(k_axpby, g2, b2, 0, s, d, w.XP, d, 0.5, w.G, d, w.M, d);
-  // reverse proposal density: |L'(x - M')|^2
-  hipLaunchKernelGGL(k_axpby, g2, b2, 0, s, d, x, ld_x, -1.0, w.M, d, w.T, d);
+  hipLaunchKernelGGL(k_axpby, g2, b2, 0, s, d, w.XP, d, 0.5, w.G, d, w.V, d);  // V = M'
+  // the four quadratic forms |L'(.)|^2 in one TRMM on [R | x'-M | R' | x-M']
+  hipLaunchKernelGGL(k_build_t4, g2, b2, 0, s, d, C, x, ld_x, mu, w.XP, w.M, w.V, T4);
   OMC_BLAS_CHECK(rocblas_dtrmm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                               rocblas_diagonal_non_unit, di, Ci, &one, L, di, w.T, di, w.V, di));
-  hipLaunchKernelGGL(k_colsumsq, dim3((unsigned)C), dim3(256), 0, s, d, w.V, d, ss_rev);
+                               rocblas_diagonal_non_unit, di, 4 * Ci, &one, L, di, T4, di, N4, di));
+  hipLaunchKernelGGL(k_colsumsq, dim3((unsigned)(4 * C)), dim3(256), 0, s, d, N4, d, ss);
   // accept / reject.  L = chol(Q / step^2) => chol(Q) = step * L
   hipLaunchKernelGGL(k_mh_decide, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, C, ctx->chain_offset,
                      omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), u_inject, (double)d, sumlogL,
-                     (double)d * log(step), 1, ss_fwd, ss_rev, ss_cur, ss_prop, step * step, w.flag,
+                     (double)d * log(step), 1, ss + C, ss + 3 * C, ss, ss + 2 * C, step * step, w.flag,
                      (long long*)accept_count, (long long*)proposal_count);
   hipLaunchKernelGGL(k_select_rows, g2, b2, 0, s, d, w.flag, w.XP, d, x, ld_x);
   OMC_HIP_CHECK(hipGetLastError());
