@@ -95,3 +95,35 @@ def test_gamma_zero_rate_guard():
     eng.normal_gamma_update(1.0, 0.0, 0, eng.zeros(2), out, g=eng.full((2,), 0.7))
     assert np.all(np.isinf(out.cpu().numpy()))
     eng.close()
+
+
+def test_canonical_draws_have_the_right_law():
+    """The reference's statistical check of sample_normal_canonical (tests/test_grmf.py:182-210): with
+    in-kernel draws, (x - mu)' Q (x - mu) over many chains is chi^2 with n degrees of freedom, and the
+    sample mean converges to Q^-1 b."""
+    from scipy import sparse
+
+    from oracle import gmrf_ref
+
+    n, C = 120, 6000
+    rng = np.random.default_rng(3)
+    d = np.full(n, 2.0) * (1 + 0.2 * rng.random(n))
+    d[0] = d[-1] = 1.2
+    off = -np.ones(n - 1)
+    y = rng.standard_normal(n) + 1
+    lam, tau = 30.0, 2.0
+    eng = make_engine(C, seed=31)
+    terms = [{"diag": eng.to_device(d), "off": eng.to_device(off), "scale": eng.full((C,), lam)},
+             {"rhs": eng.to_device(y), "center": eng.to_device(y), "scale": eng.full((C,), tau)}]
+    x = eng.empty(C, n)
+    eng.tridiag_sample_canonical(n, terms, x, draw_index=2)
+    eng.check_status()
+    xs = x.cpu().numpy()
+    P = sparse.diags((off, d, off), offsets=[-1, 0, 1], format="csc")
+    Q = (lam * P + tau * sparse.identity(n)).toarray()
+    mu = np.linalg.solve(Q, tau * y)
+    r = xs - mu
+    maha = np.einsum("ci,ij,cj->c", r, Q, r)
+    assert stats.kstest(maha, "chi2", args=(n,)).pvalue > 1e-3
+    assert np.max(np.abs(xs.mean(0) - mu)) < 5 * np.sqrt(np.max(np.diag(np.linalg.inv(Q))) / C)
+    eng.close()
