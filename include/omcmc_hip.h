@@ -253,6 +253,15 @@ omc_status omc_rj_move(omc_ctx* ctx, int64_t n_max, double birth_probability, co
                        const double* u_inject, const int64_t* idx_inject, uint64_t draw_index,
                        int32_t* birth_out, double* p_birth_out, double* p_death_out, int64_t* del_index_out);
 
+/* ---- on-device posterior summaries of the device-resident store ----
+ * store is [n_iter][C][size] (iteration-major, as MCMC writes it: mcmc.py:105-106 per chain).
+ *   pooled == 0: mean_out / var_out [C][size]: per chain over its n_iter stored iterations;
+ *   pooled != 0: mean_out / var_out [size]:    over all chains and iterations.
+ * var is the unbiased sample variance (0 when there is a single sample); either output may be NULL.
+ * Saves gathering the whole store (82 MB per iteration at cfg3) when only summaries are wanted.   */
+omc_status omc_store_moments(omc_ctx* ctx, int64_t n_iter, int64_t size, const double* store,
+                             int32_t pooled, double* mean_out, double* var_out);
+
 /* ---- raw random streams (tests, prior draws for missing state: mcmc.py:78-80) -------------- */
 omc_status omc_fill_normal(omc_ctx* ctx, int64_t n, uint64_t draw_index, double* out, int64_t ld);
 omc_status omc_fill_philox_u32(omc_ctx* ctx, int64_t n_words, uint64_t draw_index, uint32_t* out,

@@ -105,6 +105,7 @@ SIGNATURES = {
     "omc_scaled_gauss_logpdf": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, i32]),
     "omc_gamma_logpdf": (i32, [C.c_void_p, c_dp, C.c_double, C.c_double, c_dp, i32]),
     "omc_rj_move": (i32, [C.c_void_p, i64, C.c_double, c_dp, c_dp, c_dp, u64, c_dp, c_dp, c_dp, c_dp]),
+    "omc_store_moments": (i32, [C.c_void_p, i64, i64, c_dp, i32, c_dp, c_dp]),
     "omc_fill_normal": (i32, [C.c_void_p, i64, u64, c_dp, i64]),
     "omc_fill_philox_u32": (i32, [C.c_void_p, i64, u64, c_dp, i64]),
 }

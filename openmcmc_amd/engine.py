@@ -399,6 +399,17 @@ class Engine:
                               C.c_void_p(dele.data_ptr())))
         return birth, pb, pd, dele
 
+    # ------------------------------------------------------------------ posterior summaries
+    def store_moments(self, store, pooled=False):
+        """(mean, var) of a device store (n_iter, C, size): per chain (C, size) or pooled (size,)."""
+        if store.dim() != 3 or store.shape[1] != self.n_chains or not store.is_contiguous():
+            raise ValueError("store must be a contiguous (n_iter, C, size) tensor")
+        n_iter, _, size = store.shape
+        shape = (size,) if pooled else (self.n_chains, size)
+        mean, var = self.empty(*shape), self.empty(*shape)
+        check(lib.omc_store_moments(self._ctx, n_iter, size, self._p(store), int(pooled), self._p(mean), self._p(var)))
+        return mean, var
+
     # ------------------------------------------------------------------ random fills
     def fill_normal(self, n, draw_index=0):
         out = self.empty(self.n_chains, n)

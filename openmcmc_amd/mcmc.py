@@ -196,6 +196,15 @@ class MCMC:
                 print(f"{sampler.param}: {sampler.accept_rate.get_acceptance_rate()}")
 
     # ------------------------------------------------------------------ results
+    def summary(self, key, pooled=True):
+        """Posterior mean and variance of store[key] computed on the device (no gather of the store):
+        pooled over chains and iterations -> ((size,), (size,)), else per chain -> ((C, size), (C, size))."""
+        t = self.store[key]
+        if t.dim() == 2:
+            t = t.unsqueeze(-1)
+        mean, var = self.engine.store_moments(t.contiguous(), pooled=pooled)
+        return mean.cpu().numpy(), var.cpu().numpy()
+
     def collect(self):
         """Host copy of the store in the reference's per-chain layout: {key: (C, size, n_iter)},
         log_post: (C, n_iter, 1)."""

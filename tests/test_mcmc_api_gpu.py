@@ -241,3 +241,18 @@ def test_grad_log_p_and_prior_draws(golden):
     assert abs(maha.mean() / n - 1) < 0.05
     eng.check_status()
     eng.close()
+
+
+def test_on_device_posterior_summaries(golden):
+    """MCMC.summary: mean/variance of the device-resident store without gathering it."""
+    G = golden("gmrf_chain")
+    M, _ = build(G, "sparse_", True, 6, fuse=True, n_burn=3, n_iter=12, seed=5)
+    M.run_mcmc()
+    out = M.collect()
+    for key in ("b", "lambda", "log_post"):
+        arr = out[key] if key != "log_post" else np.transpose(out[key], (0, 2, 1))  # (C, size, n_iter)
+        mean, var = M.summary(key, pooled=False)
+        assert relerr(mean, arr.mean(axis=2)) < 1e-12 and relerr(var, arr.var(axis=2, ddof=1)) < 1e-10
+        mean, var = M.summary(key, pooled=True)
+        flat = np.transpose(arr, (1, 0, 2)).reshape(arr.shape[1], -1)
+        assert relerr(mean, flat.mean(axis=1)) < 1e-12 and relerr(var, flat.var(axis=1, ddof=1)) < 1e-10
