@@ -253,6 +253,102 @@ omc_status omc_rj_move(omc_ctx* ctx, int64_t n_max, double birth_probability, co
                        const double* u_inject, const int64_t* idx_inject, uint64_t draw_index,
                        int32_t* birth_out, double* p_birth_out, double* p_death_out, int64_t* del_index_out);
 
+/* ---- generic Metropolis-Hastings blocks, ragged state, reversible-jump transitions ----------------
+ * Ragged parameters (dimension changes under reversible jump: knots, their coefficients, the basis)
+ * are held padded to n_max with zeros; count[c] -- the float64 the reference keeps in
+ * state["n_basis"] -- is the number of live leading entries of chain c.  `count`/`index` pairs below
+ * gate a chain: it takes part iff count == NULL or index < count[c] (RandomWalkLoop over knots:
+ * metropolis_hastings.py:286-288 runs range(n_basis) steps, chains with fewer knots sit the step out).
+ * `sub` is the first Philox block the call may use within (seed, chain, draw_index): lets one sampler
+ * call make several independent draws.
+ *
+ * omc_rw_propose: RandomWalk.proposal (metropolis_hastings.py:212-269) for p elements per chain,
+ *   x[c*x_chain_stride + e*x_elem_stride] -> z[c*z_chain_stride + e*z_elem_stride]:
+ *   lower/upper == NULL: z = x + step*N(0,1), lq_fwd = lq_rev = 0 (symmetric, :250-251);
+ *   else truncated normal on [lower[e], upper[e]] (device, p each) by inverse CDF of a uniform
+ *   (gmrf.py:269-292 -> scipy truncnorm.rvs == ppf(U)), lq_fwd = sum_e log q(z|x), lq_rev = sum_e log q(x|z)
+ *   (:255-257 -> gmrf.py:295-318).  step[e*step_elem_stride] device (stride 0 = scalar step).
+ *   draw_inject [C][p]: the uniforms (truncated) or normals (untruncated) to use instead of Philox.   */
+omc_status omc_rw_propose(omc_ctx* ctx, int64_t p, const double* x, int64_t x_chain_stride,
+                          int64_t x_elem_stride, const double* step, int64_t step_elem_stride,
+                          const double* lower, const double* upper, const double* count, int64_t index,
+                          const double* draw_inject, uint64_t draw_index, uint32_t sub, double* z,
+                          int64_t z_chain_stride, int64_t z_elem_stride, double* lq_fwd, double* lq_rev);
+
+/* MetropolisHastings._accept_reject_proposal + accept_proposal (metropolis_hastings.py:127-173):
+ *   log_alpha = lp_prop + lq_rev - (lp_cur + lq_fwd); accept[c] = log(u) < log_alpha (NaN rejects);
+ *   counters (int64, per chain) incremented for participating chains; lq_* / log_alpha / counters may be NULL. */
+omc_status omc_mh_accept(omc_ctx* ctx, const double* lp_cur, const double* lp_prop, const double* lq_fwd,
+                         const double* lq_rev, const double* count, int64_t index, const double* u_inject,
+                         uint64_t draw_index, uint32_t sub, int32_t* accept, double* log_alpha,
+                         int64_t* accept_count, int64_t* proposal_count);
+
+/* current_state = prop_state for accepted chains (metropolis_hastings.py:157-159):
+ *   dst[c][0..width) = src[c][0..width) where accept[c] != 0.                                          */
+omc_status omc_chain_select(omc_ctx* ctx, const int32_t* accept, int64_t width, const double* src, double* dst);
+
+/* np.concatenate / np.delete along the ragged axis (reversible_jump.py:131, 175) for every chain:
+ *   birth[c] != 0: dst = src with new_vals[c][0..rows) appended at position count[c] (NULL = zeros);
+ *   birth[c] == 0: dst = src with entry del_index[c] removed, later entries shifted down.
+ *   element (c, r, j) lives at base[c*chain_stride + r*row_stride + j*col_stride], j < kmax the ragged axis;
+ *   dst is fully written (zeros beyond the new count); src and dst must not alias.                     */
+omc_status omc_ragged_resize(omc_ctx* ctx, int64_t rows, int64_t kmax, const double* count, const int32_t* birth,
+                             const int64_t* del_index, const double* new_vals, const double* src, double* dst,
+                             int64_t chain_stride, int64_t row_stride, int64_t col_stride);
+
+/* Per-chain design matrices B_c (n x kmax; column j of chain c contiguous at B[(c*kmax + j)*n]):
+ *   omc_design_predict_batched: out[c] = chain_scale[c] * (alpha * B_c coef_c + add_chain[c] + add_shared)
+ *     (LinearCombination.predictor / predictor_conditional, parameter.py:162-197, for a basis that depends on
+ *     per-chain knots; with alpha = -1, chain_scale = tau it is the per-chain part of b = A'W(y - d), sampler.py:192);
+ *     add_chain [C][n], add_shared [n], chain_scale [C] may be NULL;
+ *   omc_design_gram_batched:    gram[c] = B_c' diag(w) B_c (kmax x kmax, row-major),
+ *     rhs[c] = B_c' diag(w) (resid_shared - resid_chain[c])   (location_scale.py:238-241, sampler.py:192);
+ *     w [n] shared or NULL = ones; resid_* / rhs may be NULL.  kmax <= 36.                                  */
+omc_status omc_design_predict_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* coef,
+                                      const double* add_chain, const double* add_shared, double alpha,
+                                      const double* chain_scale, double* out);
+omc_status omc_design_gram_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* w,
+                                   const double* resid_shared, const double* resid_chain, double* gram, double* rhs);
+
+/* NormalNormal.sample (sampler.py:176-197 -> gmrf.py:167-198) for a small ragged parameter:
+ *   Q_c = diag(prior_prec[c]) + lik_scale[c]*gram[c],  b_c = prior_prec[c]*prior_mean[c] + lik_scale[c]*gram_rhs[c]
+ *   on the live count[c] x count[c] block; x = Q^{-1}b + L^{-T}z, natural-order Cholesky; entries beyond
+ *   count[c] are written as 0.  kmax <= 64.  z_inject [C][kmax]; prior_mean / lik_scale / count / mu may be NULL. */
+omc_status omc_small_sample_canonical(omc_ctx* ctx, int64_t kmax, const double* gram, const double* gram_rhs,
+                                      const double* lik_scale, const double* prior_prec, const double* prior_mean,
+                                      const double* count, const double* z_inject, uint64_t draw_index,
+                                      double* x, double* mu);
+
+/* ReversibleJump.matched_birth_transition / matched_death_transition (reversible_jump.py:195-308):
+ *   with X the larger of the two bases (the proposed one for a birth, the current one for a death),
+ *   G = (X'X + 1e-10 I)^{-1} X'X_small by LU with partial pivoting (np.linalg.solve);
+ *   birth: coef* = G coef, last entry ~ truncated N(coef*_last, scale) on [lim_lo, lim_hi] (has_limits) or
+ *          N(coef*_last, scale^2); lq_fwd += its log-density; lq_rev += log det [G | e_last];
+ *   death: F = G with e_idx inserted at column idx; coef_aug = F^{-1} coef; coef* = coef_aug without idx;
+ *          lq_fwd += log det F; lq_rev += log-density of coef_aug[idx] under (truncated) N(0, scale).
+ *   gram_cur / gram_prop [C][kmax][kmax]: Gram matrices of the current and proposed bases (the products
+ *   X'X_small are sub-blocks of the larger one).  draw_inject [C]: uniform (limits) or normal draw.      */
+omc_status omc_rj_matched_transition(omc_ctx* ctx, int64_t kmax, const double* gram_cur, const double* gram_prop,
+                                     const double* count, const int32_t* birth, const int64_t* del_index,
+                                     const double* coef_cur, double scale, int32_t has_limits, double lim_lo,
+                                     double lim_hi, const double* draw_inject, uint64_t draw_index, uint32_t sub,
+                                     double* coef_prop, double* lq_fwd, double* lq_rev);
+
+/* Log-density pieces for ragged parameters (accumulate != 0 adds into out[c]):
+ *   omc_diag_gauss_logpdf: Normal with diagonal precision (MixtureParameterMatrix, parameter.py:474-538):
+ *     0.5*(sum_j log prec_j - k log 2pi - sum_j prec_j (x_j - mean_j)^2) over the k = count[c] live entries;
+ *   omc_poisson_logpmf:    Poisson.log_p (distribution.py:490-508): k log(rate) - rate - lgamma(k+1), k = x[c];
+ *   omc_count_logpdf:      out = per_element * count[c]  (Uniform.log_p, distribution.py:422-442: every live
+ *     replicate contributes -sum log(upper - lower));
+ *   omc_mixture_gather:    MixtureParameterVector.predictor (parameter.py:447): out[c][j] = param[alloc[c][j]]
+ *     for live j, `fill` beyond (param [m] shared, alloc holds integer values as float64).               */
+omc_status omc_diag_gauss_logpdf(omc_ctx* ctx, int64_t kmax, const double* x, const double* mean, const double* prec,
+                                 const double* count, double* out, int32_t accumulate);
+omc_status omc_poisson_logpmf(omc_ctx* ctx, const double* x, double rate, double* out, int32_t accumulate);
+omc_status omc_count_logpdf(omc_ctx* ctx, const double* count, double per_element, double* out, int32_t accumulate);
+omc_status omc_mixture_gather(omc_ctx* ctx, int64_t kmax, int64_t m, const double* param, const double* alloc,
+                              const double* count, double fill, double* out);
+
 /* ---- on-device posterior summaries of the device-resident store ----
  * store is [n_iter][C][size] (iteration-major, as MCMC writes it: mcmc.py:105-106 per chain).
  *   pooled == 0: mean_out / var_out [C][size]: per chain over its n_iter stored iterations;

@@ -17,7 +17,7 @@ OMC_MAX_TERMS = 4
 OK, INVALID_ARG, NOT_POSDEF, HIP_ERROR, UNSUPPORTED = range(5)
 
 c_dp = C.c_void_p  # device pointer
-i64, u64, i32 = C.c_int64, C.c_uint64, C.c_int32
+i64, u64, i32, u32 = C.c_int64, C.c_uint64, C.c_int32, C.c_uint32
 
 
 class TridiagTerms(C.Structure):
@@ -106,6 +106,25 @@ SIGNATURES = {
     "omc_gamma_logpdf": (i32, [C.c_void_p, c_dp, C.c_double, C.c_double, c_dp, i32]),
     "omc_rj_move": (i32, [C.c_void_p, i64, C.c_double, c_dp, c_dp, c_dp, u64, c_dp, c_dp, c_dp, c_dp]),
     "omc_store_moments": (i32, [C.c_void_p, i64, i64, c_dp, i32, c_dp, c_dp]),
+    "omc_rw_propose": (
+        i32,
+        [C.c_void_p, i64, c_dp, i64, i64, c_dp, i64, c_dp, c_dp, c_dp, i64, c_dp, u64, u32, c_dp, i64, i64, c_dp, c_dp],
+    ),
+    "omc_mh_accept": (i32, [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, i64, c_dp, u64, u32, c_dp, c_dp, c_dp, c_dp]),
+    "omc_chain_select": (i32, [C.c_void_p, c_dp, i64, c_dp, c_dp]),
+    "omc_ragged_resize": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, i64]),
+    "omc_design_predict_batched": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, C.c_double, c_dp, c_dp]),
+    "omc_design_gram_batched": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "omc_small_sample_canonical": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, u64, c_dp, c_dp]),
+    "omc_rj_matched_transition": (
+        i32,
+        [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_double, i32, C.c_double, C.c_double, c_dp, u64, u32,
+         c_dp, c_dp, c_dp],
+    ),
+    "omc_diag_gauss_logpdf": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i32]),
+    "omc_poisson_logpmf": (i32, [C.c_void_p, c_dp, C.c_double, c_dp, i32]),
+    "omc_count_logpdf": (i32, [C.c_void_p, c_dp, C.c_double, c_dp, i32]),
+    "omc_mixture_gather": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, C.c_double, c_dp]),
     "omc_fill_normal": (i32, [C.c_void_p, i64, u64, c_dp, i64]),
     "omc_fill_philox_u32": (i32, [C.c_void_p, i64, u64, c_dp, i64]),
 }

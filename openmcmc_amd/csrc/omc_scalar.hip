@@ -229,3 +229,92 @@ omc_status omc_fill_philox_u32(omc_ctx* ctx, int64_t n_words, uint64_t draw_inde
 }
 
 }  // extern "C"
+
+// ---- log-density pieces for ragged parameters ---------------------
+__global__ void k_diag_gauss_logpdf(int64_t C, int64_t kmax, const double* x, const double* mean, const double* prec,
+                                    const double* count, double* out, int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int64_t k = count ? (int64_t)count[c] : kmax;
+  double ld = 0.0, q = 0.0;
+  for (int64_t j = 0; j < k; ++j) {
+    const double d = prec[c * kmax + j];
+    const double r = x[c * kmax + j] - (mean ? mean[c * kmax + j] : 0.0);
+    ld += log(d);
+    q = fma(d * r, r, q);
+  }
+  const double lp = 0.5 * (ld - (double)k * 1.8378770664093453 - q);
+  out[c] = accumulate ? out[c] + lp : lp;
+}
+
+__global__ void k_poisson_logpmf(int64_t C, const double* x, double rate, double* out, int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double k = x[c];
+  double lp = -INFINITY;
+  if (k >= 0.0 && k == floor(k)) lp = (k == 0.0 ? 0.0 : k * log(rate)) - lgamma(k + 1.0) - rate;
+  out[c] = accumulate ? out[c] + lp : lp;
+}
+
+__global__ void k_count_logpdf(int64_t C, const double* count, double per_element, double* out, int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double lp = per_element * count[c];
+  out[c] = accumulate ? out[c] + lp : lp;
+}
+
+__global__ void k_mixture_gather(int64_t C, int64_t kmax, int64_t m, const double* param, const double* alloc,
+                                 const double* count, double fill, double* out, long long* bad) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= C * kmax) return;
+  const int64_t c = t / kmax, j = t % kmax;
+  double v = fill;
+  if (!count || (double)j < count[c]) {
+    const int64_t a = (int64_t)alloc[t];
+    if (a < 0 || a >= m) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+    else v = param[a];
+  }
+  out[t] = v;
+}
+
+extern "C" {
+
+omc_status omc_diag_gauss_logpdf(omc_ctx* ctx, int64_t kmax, const double* x, const double* mean, const double* prec,
+                                 const double* count, double* out, int32_t accumulate) {
+  if (!ctx || kmax < 1 || !x || !prec || !out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_diag_gauss_logpdf, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, kmax,
+                     x, mean, prec, count, out, (int)accumulate);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_poisson_logpmf(omc_ctx* ctx, const double* x, double rate, double* out, int32_t accumulate) {
+  if (!ctx || !x || !out || !(rate > 0.0)) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_poisson_logpmf, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, x, rate,
+                     out, (int)accumulate);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_count_logpdf(omc_ctx* ctx, const double* count, double per_element, double* out, int32_t accumulate) {
+  if (!ctx || !count || !out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_count_logpdf, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, count,
+                     per_element, out, (int)accumulate);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_mixture_gather(omc_ctx* ctx, int64_t kmax, int64_t m, const double* param, const double* alloc,
+                              const double* count, double fill, double* out) {
+  if (!ctx || kmax < 1 || m < 1 || !param || !alloc || !out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_mixture_gather, dim3(grid1(ctx->n_chains * kmax, 256)), dim3(256), 0, ctx->stream, ctx->n_chains,
+                     kmax, m, param, alloc, count, fill, out, ctx->d_bad_chain);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+}  // extern "C"

@@ -399,6 +399,146 @@ class Engine:
                               C.c_void_p(dele.data_ptr())))
         return birth, pb, pd, dele
 
+    # ------------------------------------------------------------------ generic MH / ragged state / RJ transitions
+    def _i32(self, t):
+        torch = _torch()
+        if t.dtype != torch.int32 or not t.is_cuda or t.numel() != self.n_chains:
+            raise TypeError("expected an int32 ROCm tensor with one entry per chain")
+        return C.c_void_p(t.data_ptr())
+
+    def _i64(self, t):
+        torch = _torch()
+        if t.dtype != torch.int64 or not t.is_cuda or t.numel() != self.n_chains:
+            raise TypeError("expected an int64 ROCm tensor with one entry per chain")
+        return C.c_void_p(t.data_ptr())
+
+    def rw_propose(self, x, z_out, step, lower=None, upper=None, column=None, count=None, inject=None, draw_index=0,
+                   sub=0):
+        """RandomWalk.proposal for column `column` (None: n_rep must be 1) of the (C, p, n_rep) tensor x,
+        written into the same column of z_out.  step/lower/upper: device tensors (step of 1 or p entries).
+        Returns (lq_fwd, lq_rev), each (C,)."""
+        Cn, p, n_rep = x.shape
+        if z_out.shape != x.shape or not x.is_contiguous() or not z_out.is_contiguous():
+            raise ValueError("x and z_out must be contiguous tensors of the same (C, p, n_rep) shape")
+        col = 0 if column is None else int(column)
+        if column is None and n_rep != 1:
+            raise ValueError("column is required when the parameter has replicates")
+        lq_f, lq_r = self.empty(Cn), self.empty(Cn)
+        esz = x.element_size()
+        check(lib.omc_rw_propose(self._ctx, p, C.c_void_p(x.data_ptr() + col * esz), p * n_rep, n_rep, self._p(step),
+                                 0 if step.numel() == 1 else 1, self._p(lower), self._p(upper),
+                                 self._chain_scalar(count), col, self._p(inject), int(draw_index), int(sub),
+                                 C.c_void_p(z_out.data_ptr() + col * esz), p * n_rep, n_rep, self._p(lq_f), self._p(lq_r)))
+        return lq_f, lq_r
+
+    def mh_accept(self, lp_cur, lp_prop, lq_fwd=None, lq_rev=None, count=None, index=0, u=None, draw_index=0, sub=0,
+                  accept_count=None, proposal_count=None, log_alpha=None):
+        """accept (C,) int32 of the Metropolis-Hastings test; counters are updated in place."""
+        torch = _torch()
+        acc = torch.empty(self.n_chains, dtype=torch.int32, device=self.device)
+        check(lib.omc_mh_accept(self._ctx, self._chain_scalar(lp_cur), self._chain_scalar(lp_prop),
+                                self._chain_scalar(lq_fwd), self._chain_scalar(lq_rev), self._chain_scalar(count),
+                                int(index), self._chain_scalar(u), int(draw_index), int(sub), self._i32(acc),
+                                self._chain_scalar(log_alpha),
+                                None if accept_count is None else self._i64(accept_count),
+                                None if proposal_count is None else self._i64(proposal_count)))
+        return acc
+
+    def chain_select(self, accept, src, dst):
+        """dst[c] = src[c] for accepted chains (tensors of identical shape, chain-major, contiguous)."""
+        if src.shape != dst.shape or not src.is_contiguous() or not dst.is_contiguous():
+            raise ValueError("src and dst must be contiguous and of the same shape")
+        width = src.numel() // self.n_chains
+        check(lib.omc_chain_select(self._ctx, self._i32(accept), width, self._p(src.view(self.n_chains, -1)),
+                                   self._p(dst.view(self.n_chains, -1))))
+        return dst
+
+    def ragged_resize(self, src, count, birth, del_index, axis, new_vals=None, physical_transposed=False):
+        """np.concatenate / np.delete along the ragged axis of a (C, p, n_rep) tensor for every chain.
+        axis = 0: rows are ragged (beta (k, 1)); axis = 1: columns (theta (1, k), basis (n, k))."""
+        torch = _torch()
+        Cn, p, n_rep = src.shape
+        dst = torch.empty_like(src)
+        if axis == 1:
+            rows, kmax = p, n_rep
+        else:
+            rows, kmax = n_rep, p
+        st = src.stride()
+        rs, js = (st[1], st[2]) if axis == 1 else (st[2], st[1])
+        if dst.stride() != st:
+            raise ValueError("unsupported memory layout")
+        check(lib.omc_ragged_resize(self._ctx, rows, kmax, self._chain_scalar(count), self._i32(birth),
+                                    self._i64(del_index), self._p(new_vals), C.c_void_p(src.data_ptr()),
+                                    C.c_void_p(dst.data_ptr()), st[0], rs, js))
+        return dst
+
+    def design_predict_batched(self, B, coef, add_chain=None, add_shared=None, alpha=1.0, chain_scale=None, out=None):
+        """out[c] = chain_scale[c] * (alpha * B_c coef_c + add_chain[c] + add_shared);
+        B: (C, kmax, n) contiguous (column j of chain c contiguous)."""
+        Cn, kmax, n = B.shape
+        if not B.is_contiguous():
+            raise ValueError("B must be a contiguous (C, kmax, n) tensor")
+        out = self.empty(Cn, n) if out is None else out
+        check(lib.omc_design_predict_batched(self._ctx, n, kmax, self._p(B.view(Cn, -1)), self._p(coef, Cn, kmax),
+                                             self._p(add_chain), self._vec(add_shared, n), float(alpha),
+                                             self._chain_scalar(chain_scale), self._p(out)))
+        return out
+
+    def design_gram_batched(self, B, w=None, resid_shared=None, resid_chain=None):
+        """(gram (C, kmax, kmax), rhs (C, kmax) or None) = (B_c' W B_c, B_c' W (resid_shared - resid_chain[c]))."""
+        Cn, kmax, n = B.shape
+        if not B.is_contiguous():
+            raise ValueError("B must be a contiguous (C, kmax, n) tensor")
+        gram = self.empty(Cn, kmax, kmax)
+        want_rhs = resid_shared is not None or resid_chain is not None
+        rhs = self.empty(Cn, kmax) if want_rhs else None
+        check(lib.omc_design_gram_batched(self._ctx, n, kmax, self._p(B.view(Cn, -1)), self._vec(w, n),
+                                          self._vec(resid_shared, n), self._p(resid_chain), self._p(gram.view(Cn, -1)),
+                                          self._p(rhs)))
+        return gram, rhs
+
+    def small_sample_canonical(self, gram, gram_rhs, prior_prec, lik_scale=None, prior_mean=None, count=None, z=None,
+                               draw_index=0, mean_out=None):
+        Cn, kmax, _ = gram.shape
+        x = self.empty(Cn, kmax)
+        check(lib.omc_small_sample_canonical(self._ctx, kmax, self._p(gram.view(Cn, -1)), self._p(gram_rhs),
+                                             self._chain_scalar(lik_scale), self._p(prior_prec), self._p(prior_mean),
+                                             self._chain_scalar(count), self._p(z), int(draw_index), self._p(x),
+                                             self._p(mean_out)))
+        return x
+
+    def rj_matched_transition(self, gram_cur, gram_prop, count, birth, del_index, coef_cur, scale, limits, lq_fwd,
+                              lq_rev, inject=None, draw_index=0, sub=0):
+        """coef_prop (C, kmax); lq_fwd / lq_rev (C,) are added to in place."""
+        Cn, kmax, _ = gram_cur.shape
+        out = self.empty(Cn, kmax)
+        lo, hi = (0.0, 0.0) if limits is None else (float(limits[0]), float(limits[1]))
+        check(lib.omc_rj_matched_transition(self._ctx, kmax, self._p(gram_cur.view(Cn, -1)), self._p(gram_prop.view(Cn, -1)),
+                                            self._chain_scalar(count), self._i32(birth), self._i64(del_index),
+                                            self._p(coef_cur, Cn, kmax), float(scale), int(limits is not None), lo, hi,
+                                            self._chain_scalar(inject), int(draw_index), int(sub), self._p(out),
+                                            self._chain_scalar(lq_fwd), self._chain_scalar(lq_rev)))
+        return out
+
+    def diag_gauss_logpdf(self, x, prec, out, mean=None, count=None, accumulate=False):
+        Cn, kmax = x.shape
+        check(lib.omc_diag_gauss_logpdf(self._ctx, kmax, self._p(x), self._p(mean), self._p(prec),
+                                        self._chain_scalar(count), self._chain_scalar(out), int(accumulate)))
+
+    def poisson_logpmf(self, x, rate, out, accumulate=False):
+        check(lib.omc_poisson_logpmf(self._ctx, self._chain_scalar(x), float(rate), self._chain_scalar(out), int(accumulate)))
+
+    def count_logpdf(self, count, per_element, out, accumulate=False):
+        check(lib.omc_count_logpdf(self._ctx, self._chain_scalar(count), float(per_element), self._chain_scalar(out),
+                                   int(accumulate)))
+
+    def mixture_gather(self, param, alloc, count=None, fill=0.0):
+        Cn, kmax = alloc.shape
+        out = self.empty(Cn, kmax)
+        check(lib.omc_mixture_gather(self._ctx, kmax, param.numel(), self._p(param), self._p(alloc),
+                                     self._chain_scalar(count), float(fill), self._p(out)))
+        return out
+
     # ------------------------------------------------------------------ posterior summaries
     def store_moments(self, store, pooled=False):
         """(mean, var) of a device store (n_iter, C, size): per chain (C, size) or pooled (size,)."""

@@ -1,0 +1,315 @@
+"""Golden vectors for the reversible-jump rows of SURVEY.md section 8 (a12-a14, a16, cfg5), made by
+RUNNING the reference (openMCMC v1.0.7) in the build container:
+
+    PYTHONPATH=/root/reference/src python3 tests/golden/make_golden_rj.py
+
+Writes truncnorm.npz and rj_gmrf_chain.npz.  Fixtures hold data only: inputs, the draws the
+reference consumed, and what it produced.  Recorded-draw convention for the new kinds (SURVEY.md
+section 8c, re-checked at the top of gen_truncnorm):
+
+    truncnorm.rvs(a, b, loc, scale, size) -> u ~ U(0,1); value returned truncnorm.ppf(u, a, b)*scale + loc
+    randint.rvs(low, high)                -> the integer itself
+"""
+
+import os
+import sys
+
+import numpy as np
+from scipy import sparse, stats
+
+REF_SRC = "/root/reference/src"
+if REF_SRC not in sys.path:
+    sys.path.insert(0, REF_SRC)
+
+from openmcmc import gmrf, parameter  # noqa: E402
+from openmcmc.distribution.distribution import Gamma, Poisson, Uniform  # noqa: E402
+from openmcmc.distribution.location_scale import Normal  # noqa: E402
+from openmcmc.mcmc import MCMC  # noqa: E402
+from openmcmc.model import Model  # noqa: E402
+from openmcmc.sampler.metropolis_hastings import MetropolisHastings, RandomWalkLoop  # noqa: E402
+from openmcmc.sampler.reversible_jump import ReversibleJump  # noqa: E402
+from openmcmc.sampler.sampler import NormalGamma, NormalNormal  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ----------------------------------------------------------------------------- truncated normal
+def gen_truncnorm():
+    """gmrf.truncated_normal_rv / truncated_normal_log_pdf (gmrf.py:269-318) on a grid that covers
+    central, one-sided and deep-tail windows (the windows cfg5 meets: limits +-10, scales 0.2 and 1)."""
+    # the draw convention: truncnorm.rvs == ppf(uniform) * scale + loc on the legacy global RandomState
+    np.random.seed(5)
+    got = gmrf.truncated_normal_rv(np.array([0.3, 9.9]), np.array([0.2, 0.2]), np.array([-10.0]), np.array([10.0]), size=2)
+    u = np.random.RandomState(5).uniform(size=2)
+    a, b = (-10 - np.array([0.3, 9.9])) / 0.2, (10 - np.array([0.3, 9.9])) / 0.2
+    assert np.array_equal(got, stats.truncnorm.ppf(u, a, b) * 0.2 + np.array([0.3, 9.9]))
+
+    rng = np.random.default_rng(31)
+    rows = []
+    for mean in (-9.99, -9.5, -3.0, 0.0, 0.4, 7.7, 9.9, 9.999, 12.0, -14.0, 25.0):
+        for scale in (0.05, 0.2, 1.0, 3.0):
+            for lower, upper in ((-10.0, 10.0), (0.5, 2.0), (-np.inf, 1.0), (-2.0, np.inf)):
+                for u in (1e-12, 1e-3, 0.25, 0.5, 0.9, 1 - 1e-9, float(rng.random())):
+                    rows.append((mean, scale, lower, upper, u))
+    arr = np.array(rows)
+    mean, scale, lower, upper, u = arr.T
+    a, b = (lower - mean) / scale, (upper - mean) / scale
+    x = stats.truncnorm.ppf(u, a, b) * scale + mean
+    lp_fwd = gmrf.truncated_normal_log_pdf(x, mean, scale, lower, upper)
+    lp_rev = gmrf.truncated_normal_log_pdf(mean, x, scale, lower, upper)  # reverse move (metropolis_hastings.py:257)
+    np.savez_compressed(os.path.join(OUT, "truncnorm.npz"), mean=mean, scale=scale, lower=lower, upper=upper, u=u,
+                        x=x, logpdf_fwd=lp_fwd, logpdf_rev=lp_rev)
+
+
+# ----------------------------------------------------------------------------- cfg5-shaped model
+def make_basis(X, knots):
+    """Gaussian-kernel basis of the reference's own RJ test (tests/test_reversible_jump.py:24-40), unit scales."""
+    B = np.full((X.shape[0], knots.shape[1]), np.nan)
+    for k in range(knots.shape[1]):
+        B[:, [k]] = stats.norm.pdf(X, loc=knots[:, k], scale=1.0)
+    return B
+
+
+def move_function(state, col):
+    state["B"] = make_basis(state["X"], state["theta"])
+    return state, 0.0, 0.0
+
+
+def birth_function(cur, prop):
+    prop["B"] = make_basis(prop["X"], prop["theta"])
+    prop["alloc_beta"] = np.concatenate((prop["alloc_beta"], np.array([0], ndmin=2)), axis=0)
+    return prop, 0.0, 0.0
+
+
+def death_function(cur, prop, idx):
+    prop["B"] = np.delete(prop["B"], obj=idx, axis=1)
+    prop["alloc_beta"] = np.delete(prop["alloc_beta"], obj=idx, axis=0)
+    return prop, 0.0, 0.0
+
+
+def rj_gmrf_problem(n, n_max, seed=0):
+    """Data + model + sampler list of SURVEY.md section 8d cfg5 (any n, n_max)."""
+    rng = np.random.default_rng(seed)
+    X = np.linspace(-10, 10, n).reshape(n, 1)
+    theta_true = np.array([[-6.0, -1.0, 4.5]])
+    beta_true = np.array([[3.0], [-2.0], [4.0]])
+    b_true = 0.05 * np.cumsum(rng.standard_normal(n))
+    y = make_basis(X, theta_true) @ beta_true + b_true.reshape(n, 1) + 0.1 * rng.standard_normal((n, 1))
+    P = sparse.csc_matrix(gmrf.precision_irregular(np.arange(float(n)))).tolil()
+    P[0, 0] += 1e-3
+    mdl = Model(
+        [
+            Normal("y", mean=parameter.LinearCombination({"beta": "B", "b": "A"}), precision=parameter.ScaledMatrix("P_tau", "tau")),
+            Normal("b", mean="mu_b", precision=parameter.ScaledMatrix("P_lambda", "lambda")),
+            Normal("beta", mean=parameter.MixtureParameterVector("mu_beta", "alloc_beta"),
+                   precision=parameter.MixtureParameterMatrix("tau_beta", "alloc_beta")),
+            Poisson("n_basis", rate="rho"),
+            Uniform("theta", domain_response_lower=np.array([[-10.0]]), domain_response_upper=np.array([[10.0]])),
+            Gamma("lambda", shape="a_lam", rate="b_lam"),
+            Gamma("tau", shape="a_tau", rate="b_tau"),
+        ]
+    )
+    mdl.response = {"y": "mean"}
+    shared = {
+        "y": y, "X": X, "A": sparse.eye(n, format="csc"), "P_tau": sparse.eye(n, format="csc"), "P_lambda": P.tocsc(),
+        "mu_b": np.zeros((n, 1)), "mu_beta": np.zeros((1, 1)), "tau_beta": 0.25 * np.ones((1, 1)), "rho": 5.0,
+        "a_lam": 10.0, "b_lam": 1.0, "a_tau": 1.0, "b_tau": 1.0,
+    }  # fmt: skip
+
+    def samplers():
+        return [
+            NormalNormal("b", mdl),
+            NormalNormal("beta", mdl, max_variable_size=n_max),
+            NormalGamma("lambda", mdl),
+            NormalGamma("tau", mdl),
+            RandomWalkLoop("theta", mdl, step=np.array(0.2), max_variable_size=n_max, domain_limits=np.array([[-10.0, 10.0]]),
+                           state_update_function=move_function),
+            ReversibleJump("n_basis", mdl, associated_params=["theta"], n_max=n_max, state_birth_function=birth_function,
+                           state_death_function=death_function,
+                           matching_params={"variable": "beta", "matrix": "B", "scale": 1.0, "limits": [-10.0, 10.0]}),
+        ]  # fmt: skip
+
+    return mdl, shared, samplers
+
+
+def chain_init(shared, k0, rng):
+    theta = rng.uniform(-10, 10, size=(1, k0))
+    st = dict(shared)
+    st.update({"theta": theta, "B": make_basis(shared["X"], theta), "beta": rng.standard_normal((k0, 1)),
+               "b": np.zeros_like(shared["y"]), "n_basis": k0, "alloc_beta": np.zeros((k0, 1), dtype=int),
+               "lambda": 100.0, "tau": 10.0})  # fmt: skip
+    return st
+
+
+class Tape:
+    """Per-sweep record of every draw and of the MH internals, keyed by the consuming call site."""
+
+    def __init__(self, seed, n, n_max):
+        self.rng = np.random.default_rng(seed)
+        self.n, self.n_max = n, n_max
+        self.rows, self.cur, self.where = [], None, None
+
+    def new_sweep(self):
+        k = self.n_max
+        self.cur = {
+            "z_b": np.full(self.n, np.nan), "z_beta": np.full(k, np.nan), "g": np.full(2, np.nan),
+            "rw_u": np.full(k, np.nan), "rw_acc_u": np.full(k, np.nan), "rw_z": np.full(k, np.nan),
+            "rw_lq_fwd": np.full(k, np.nan), "rw_lq_rev": np.full(k, np.nan), "rw_log_accept": np.full(k, np.nan),
+            "rj_move_u": np.nan, "rj_theta_u": np.nan, "rj_beta_u": np.nan, "rj_idx": -1.0, "rj_acc_u": np.nan,
+            "rj_birth": np.nan, "rj_lq_fwd": np.nan, "rj_lq_rev": np.nan, "rj_log_accept": np.nan,
+            "rj_prop_beta": np.full(k, np.nan), "rj_prop_theta": np.full(k, np.nan), "rj_n_before": np.nan,
+        }  # fmt: skip
+        self.rows.append(self.cur)
+        self._gi = 0
+
+    # --- replacement draw functions
+    def norm(self, loc=0, scale=1, size=None, **_):
+        z = self.rng.standard_normal(size)
+        flat = np.asarray(z).reshape(-1)
+        if self.where == "b":
+            self.cur["z_b"][:] = flat
+        elif self.where == "beta":
+            self.cur["z_beta"][: flat.size] = flat
+        else:
+            raise RuntimeError(f"unexpected normal draw in {self.where}")
+        return loc + z * scale
+
+    def gamma(self, a, loc=0, scale=1, size=None, **_):
+        g = self.rng.standard_gamma(np.asarray(a, dtype=np.float64), size=size)
+        self.cur["g"][0 if self.where == "lambda" else 1] = float(np.asarray(g).reshape(-1)[0])
+        return loc + g * scale
+
+    def uniform(self, loc=0, scale=1, size=None, **_):
+        u = self.rng.random(size)
+        if self.where == "theta":  # accept/reject of knot self.knot (metropolis_hastings.py:173)
+            self.cur["rw_acc_u"][self.knot] = float(u)
+        elif self.where == "n_basis":
+            if size is not None:  # Uniform.rvs of the new knot (distribution.py:456)
+                self.cur["rj_theta_u"] = float(np.asarray(u).reshape(-1)[0])
+            elif self.stage == "move":  # get_move_type (reversible_jump.py:333)
+                self.cur["rj_move_u"] = float(u)
+            else:
+                self.cur["rj_acc_u"] = float(u)
+        else:
+            raise RuntimeError(f"unexpected uniform draw in {self.where}")
+        return loc + u * scale
+
+    def truncnorm(self, a, b, loc=0, scale=1, size=None, **_):
+        u = self.rng.random(size)
+        if self.where == "theta":
+            self.cur["rw_u"][self.knot] = float(np.asarray(u).reshape(-1)[0])
+        else:
+            self.cur["rj_beta_u"] = float(np.asarray(u).reshape(-1)[0])
+        return stats.truncnorm.ppf(u, a, b) * scale + loc
+
+    def randint(self, low, high, size=None, **_):
+        v = int(self.rng.integers(low, int(np.asarray(high).item())))
+        self.cur["rj_idx"] = float(v)
+        return v
+
+
+def run_reference_chain(mdl, state, samplers, tape, n_iter):
+    """MCMC.run_mcmc (mcmc.py:87-115) with every sampler call wrapped so the tape knows who is drawing."""
+    names = ["b", "beta", "lambda", "tau", "theta", "n_basis"]
+
+    def wrap_sample(smp, name):
+        inner = smp.sample
+
+        def sample(st):
+            if name == "b":
+                tape.new_sweep()
+            tape.where, tape.stage = name, "move"
+            return inner(st)
+
+        smp.sample = sample
+
+    for smp, name in zip(samplers, names):
+        wrap_sample(smp, name)
+
+    rw, rj = samplers[4], samplers[5]
+    rw_prop = rw.proposal
+
+    def rw_proposal(st, param_index=None):
+        tape.knot = param_index
+        prop, f, r = rw_prop(st, param_index)
+        tape.cur["rw_z"][param_index] = prop["theta"][0, param_index]
+        tape.cur["rw_lq_fwd"][param_index], tape.cur["rw_lq_rev"][param_index] = float(f), float(r)
+        return prop, f, r
+
+    rw.proposal = rw_proposal
+    rj_prop = rj.proposal
+
+    def rj_proposal(st, param_index=None):
+        tape.cur["rj_n_before"] = float(np.asarray(st["n_basis"]).item())
+        prop, f, r = rj_prop(st)
+        tape.stage = "accept"
+        k = prop["beta"].shape[0]
+        tape.cur["rj_birth"] = float(k > st["beta"].shape[0])
+        tape.cur["rj_prop_beta"][:k] = prop["beta"].ravel()
+        tape.cur["rj_prop_theta"][:k] = prop["theta"].ravel()
+        tape.cur["rj_lq_fwd"], tape.cur["rj_lq_rev"] = float(np.squeeze(f)), float(np.squeeze(r))
+        return prop, f, r
+
+    rj.proposal = rj_proposal
+
+    saved_accept = MetropolisHastings.accept_proposal
+
+    def accept_proposal(log_accept):
+        la = float(np.squeeze(log_accept))
+        if tape.where == "theta":
+            tape.cur["rw_log_accept"][tape.knot] = la
+        else:
+            tape.cur["rj_log_accept"] = la
+        return saved_accept(log_accept)
+
+    MetropolisHastings.accept_proposal = staticmethod(accept_proposal)
+    saved = (stats.norm.rvs, stats.gamma.rvs, stats.uniform.rvs, stats.truncnorm.rvs, stats.randint.rvs)
+    stats.norm.rvs, stats.gamma.rvs, stats.uniform.rvs = tape.norm, tape.gamma, tape.uniform
+    stats.truncnorm.rvs, stats.randint.rvs = tape.truncnorm, tape.randint
+    try:
+        M = MCMC(state, samplers, model=mdl, n_burn=0, n_iter=n_iter)
+        M.run_mcmc()
+    finally:
+        stats.norm.rvs, stats.gamma.rvs, stats.uniform.rvs, stats.truncnorm.rvs, stats.randint.rvs = saved
+        MetropolisHastings.accept_proposal = staticmethod(saved_accept)
+    return M
+
+
+def gen_rj_gmrf_chain():
+    """Full MCMC.run_mcmc of the cfg5-shaped model for several independent chains that share the data
+    (what the chain-batched build runs in one go): the draw tape, the MH internals per sweep, the store."""
+    n, n_max, n_iter = 48, 6, 150
+    mdl, shared, make_samplers = rj_gmrf_problem(n, n_max, seed=2)
+    out = {"n": n, "n_max": n_max, "n_iter": n_iter, "y": shared["y"].ravel(), "X": shared["X"].ravel()}
+    P = shared["P_lambda"].toarray()
+    out["P_diag"], out["P_off"] = np.diag(P).copy(), np.diag(P, -1).copy()
+    inits = (1, 3, 5, 6, 2)
+    per_chain = []
+    for c, k0 in enumerate(inits):
+        rng = np.random.default_rng(900 + c)
+        st = chain_init(shared, k0, rng)
+        init = {"theta": np.full(n_max, np.nan), "beta": np.full(n_max, np.nan)}
+        init["theta"][:k0], init["beta"][:k0] = st["theta"].ravel(), st["beta"].ravel()
+        tape = Tape(4000 + c, n, n_max)
+        samplers = make_samplers()
+        M = run_reference_chain(mdl, st, samplers, tape, n_iter)
+        rec = {"init_theta": init["theta"], "init_beta": init["beta"], "init_k": float(k0)}
+        for key in tape.rows[0]:
+            rec["tape_" + key] = np.array([row[key] for row in tape.rows])
+        for key in ("b", "beta", "lambda", "tau", "theta", "n_basis", "log_post", "y"):
+            rec["store_" + key] = np.asarray(M.store[key])
+        rec["accept_rw"] = np.array([samplers[4].accept_rate.count["accept"], samplers[4].accept_rate.count["proposal"]], dtype=float)
+        rec["accept_rj"] = np.array([samplers[5].accept_rate.count["accept"], samplers[5].accept_rate.count["proposal"]], dtype=float)
+        per_chain.append(rec)
+        print("chain", c, "k0", k0, "n_basis visits", np.unique(M.store["n_basis"]), samplers[4].accept_rate.get_acceptance_rate(),
+              samplers[5].accept_rate.get_acceptance_rate())
+    for key in per_chain[0]:
+        out[key] = np.stack([rec[key] for rec in per_chain])
+    np.savez_compressed(os.path.join(OUT, "rj_gmrf_chain.npz"), **out)
+
+
+if __name__ == "__main__":
+    gen_truncnorm()
+    gen_rj_gmrf_chain()
+    for f in ("truncnorm.npz", "rj_gmrf_chain.npz"):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
