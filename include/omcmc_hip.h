@@ -342,6 +342,10 @@ omc_status omc_rj_matched_transition(omc_ctx* ctx, int64_t kmax, const double* g
  *     replicate contributes -sum log(upper - lower));
  *   omc_mixture_gather:    MixtureParameterVector.predictor (parameter.py:447): out[c][j] = param[alloc[c][j]]
  *     for live j, `fill` beyond (param [m] shared, alloc holds integer values as float64).               */
+/* Uniform.rvs (distribution.py:444-458): out[c][e] = lower[e] + range[e] * U(0,1], e < p (lower/range device [p]);
+ * u_inject [C][p]; in-kernel uniforms come from Philox blocks sub, sub+1, ... (two per block).               */
+omc_status omc_uniform_draw(omc_ctx* ctx, int64_t p, const double* lower, const double* range, const double* u_inject,
+                            uint64_t draw_index, uint32_t sub, double* out);
 omc_status omc_diag_gauss_logpdf(omc_ctx* ctx, int64_t kmax, const double* x, const double* mean, const double* prec,
                                  const double* count, double* out, int32_t accumulate);
 omc_status omc_poisson_logpmf(omc_ctx* ctx, const double* x, double rate, double* out, int32_t accumulate);

@@ -277,7 +277,38 @@ __global__ void k_mixture_gather(int64_t C, int64_t kmax, int64_t m, const doubl
   out[t] = v;
 }
 
+// Uniform.rvs (distribution.py:444-458): lower + range * U, product rounded before the sum as numpy does
+__global__ void k_uniform_draw(int64_t C, int64_t chain_offset, int64_t p, const double* lower, const double* range,
+                               const double* u_in, omc_rng_key key, uint32_t sub, double* out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= C * p) return;
+  const int64_t c = t / p, e = t % p;
+  double u;
+  if (u_in) {
+    u = u_in[t];
+  } else {
+    const uint4 w = omc_rng_block(key, chain_offset + c, sub + (uint32_t)(e >> 1));
+    u = (e & 1) ? omc_u53(w.z, w.w) : omc_u53(w.x, w.y);
+  }
+  {
+#pragma clang fp contract(off)
+    const double prod = range[e] * u;
+    out[t] = lower[e] + prod;
+  }
+}
+
 extern "C" {
+
+omc_status omc_uniform_draw(omc_ctx* ctx, int64_t p, const double* lower, const double* range, const double* u_inject,
+                            uint64_t draw_index, uint32_t sub, double* out) {
+  if (!ctx || p < 1 || !lower || !range || !out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_uniform_draw, dim3(grid1(ctx->n_chains * p, 256)), dim3(256), 0, ctx->stream, ctx->n_chains,
+                     ctx->chain_offset, p, lower, range, u_inject, omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), sub,
+                     out);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
 
 omc_status omc_diag_gauss_logpdf(omc_ctx* ctx, int64_t kmax, const double* x, const double* mean, const double* prec,
                                  const double* count, double* out, int32_t accumulate) {

@@ -10,7 +10,7 @@ from typing import Union
 import numpy as np
 
 from openmcmc_amd.chains import ChainArray, is_chain
-from openmcmc_amd.parameter import Identity, LinearCombination
+from openmcmc_amd.parameter import Identity, LinearCombination, MixtureParameterVector
 
 
 @dataclass
@@ -91,3 +91,104 @@ class Gamma(Distribution):
         # Gamma(a, rate b) = the conjugate update with no data: n_pos = 0, quad = 0
         engine.normal_gamma_update(a, b, 0, engine.zeros(engine.n_chains), out, draw_index=draw_index)
         return ChainArray(out.reshape(-1, 1, 1))
+
+
+@dataclass
+class Uniform(Distribution):
+    """Uniform on a p-dimensional box (distribution.py:377-458); limits are shared (p, 1) arrays."""
+
+    domain_response_lower: Union[float, np.ndarray] = 0.0
+    domain_response_upper: Union[float, np.ndarray] = 1.0
+
+    def __post_init__(self):
+        self.domain_response_lower = np.array(self.domain_response_lower, ndmin=2, dtype=np.float64)
+        if self.domain_response_lower.shape[0] == 1:
+            self.domain_response_lower = self.domain_response_lower.T
+        self.domain_response_upper = np.array(self.domain_response_upper, ndmin=2, dtype=np.float64)
+        if self.domain_response_upper.shape[0] == 1:
+            self.domain_response_upper = self.domain_response_upper.T
+
+    @property
+    def _dist_params(self) -> list:
+        return []
+
+    def domain_range(self, state) -> np.ndarray:
+        d = state[self.response].shape[0]
+        rng = self.domain_response_upper - self.domain_response_lower
+        return np.ones((d, 1)) * rng if rng.size == 1 else rng
+
+    def log_p_per_replicate(self, state) -> float:
+        """-sum_p log(range): what every replicate contributes (distribution.py:437)."""
+        return float(-np.sum(np.log(self.domain_range(state))))
+
+    def log_p(self, state: dict, by_observation: bool = False, engine=None, out=None, accumulate=False):
+        """distribution.py:422-442: n_rep * (-sum log range); per chain n_rep is the live length of a ragged response."""
+        x = state[self.response]
+        per = self.log_p_per_replicate(state)
+        if by_observation:
+            if is_chain(x):
+                raise NotImplementedError("by_observation on a per-chain response (use log_p_per_replicate)")
+            return np.ones(x.shape[1]) * per
+        if not is_chain(x):
+            return x.shape[1] * per
+        if engine is None:
+            raise RuntimeError("Uniform.log_p on a per-chain response needs the engine (use Model.log_p)")
+        out = engine.empty(engine.n_chains) if out is None else out
+        if x.ragged is not None and x.ragged[1] == 1:
+            engine.count_logpdf(x.count(state), per, out, accumulate=accumulate)
+        elif accumulate:
+            out += x.shape[1] * per
+        else:
+            out.fill_(x.shape[1] * per)
+        return out
+
+    def rvs(self, state, n: int = 1, engine=None, draw_index=0, sub=0, inject=None):
+        """lower + range * U(0,1)^(p x n) for every chain (distribution.py:444-458); `inject` (C, p*n) uniforms."""
+        if engine is None:
+            raise RuntimeError("Uniform.rvs needs the engine")
+        p = state[self.response].shape[0]
+        lo = np.broadcast_to(self.domain_response_lower, (p, 1)).reshape(-1)
+        rng = self.domain_range(state).reshape(-1)
+        u = None if inject is None else inject.reshape(engine.n_chains, p * n).contiguous()
+        draw = engine.uniform_draw(engine.to_device(np.repeat(lo, n)), engine.to_device(np.repeat(rng, n)), inject=u,
+                                   draw_index=draw_index, sub=sub)
+        return ChainArray(draw.reshape(engine.n_chains, p, n))
+
+
+@dataclass
+class Poisson(Distribution):
+    """Poisson count (distribution.py:461-523); the rate is a shared scalar on the GPU path."""
+
+    rate: Union[str, Identity, LinearCombination, MixtureParameterVector]
+
+    def __post_init__(self):
+        if isinstance(self.rate, str):
+            self.rate = Identity(self.rate)
+        if not isinstance(self.rate, (Identity, LinearCombination, MixtureParameterVector)):
+            raise TypeError("rate expected to be one of [Identity, LinearCombination, MixtureParameterVector]")
+
+    @property
+    def _dist_params(self) -> list:
+        return self.rate.get_param_list()
+
+    def log_p(self, state: dict, by_observation: bool = False, engine=None, out=None, accumulate=False):
+        """distribution.py:490-508: k log(rate) - rate - lgamma(k + 1)."""
+        x = state[self.response]
+        rate = self.rate.predictor(state)
+        if is_chain(rate) or np.size(rate) != 1:
+            raise NotImplementedError("Poisson rate must be a shared scalar on the GPU path")
+        rate = float(np.asarray(rate).item())
+        if not is_chain(x):
+            from scipy import stats
+
+            return float(np.sum(stats.poisson.logpmf(x, rate)))
+        if x.size != 1:
+            raise NotImplementedError("vector-valued Poisson response")
+        if engine is None:
+            raise RuntimeError("Poisson.log_p on a per-chain response needs the engine (use Model.log_p)")
+        out = engine.empty(engine.n_chains) if out is None else out
+        engine.poisson_logpmf(x.scalar(), rate, out, accumulate=accumulate)
+        return out
+
+    def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):
+        raise NotImplementedError("Poisson prior draws on the device: give the jump parameter an initial value")

@@ -14,7 +14,8 @@ from scipy import sparse
 
 from openmcmc_amd.chains import is_chain
 from openmcmc_amd.distribution.distribution import Distribution
-from openmcmc_amd.parameter import Identity, LinearCombination, ScaledMatrix, _is_identity
+from openmcmc_amd.parameter import (Identity, LinearCombination, MixtureParameterMatrix, MixtureParameterVector,
+                                     ScaledMatrix, _is_identity)
 
 
 def tridiagonal_bands(M, n):
@@ -59,27 +60,46 @@ class Normal(Distribution):
     """Multivariate normal in mean/precision form.  Truncation limits are accepted for API parity
     but the truncated conditional sampler is not built yet."""
 
-    mean: Union[str, Identity, LinearCombination]
-    precision: Union[str, Identity, ScaledMatrix]
+    mean: Union[str, Identity, LinearCombination, MixtureParameterVector]
+    precision: Union[str, Identity, ScaledMatrix, MixtureParameterMatrix]
     domain_response_lower: np.ndarray = None
     domain_response_upper: np.ndarray = None
 
     def __post_init__(self):
         if isinstance(self.mean, str):
             self.mean = Identity(self.mean)
-        if not isinstance(self.mean, (Identity, LinearCombination)):
+        if not isinstance(self.mean, (Identity, LinearCombination, MixtureParameterVector)):
             raise TypeError("mean expected to be one of [Identity, LinearCombination, MixtureParameterVector]")
         if isinstance(self.precision, str):
             self.precision = Identity(self.precision)
-        if not isinstance(self.precision, (Identity, ScaledMatrix)):
+        if not isinstance(self.precision, (Identity, ScaledMatrix, MixtureParameterMatrix)):
             raise TypeError("precision expected to be one of [Identity, ScaledMatrix, MixtureParameterMatrix]")
 
     @property
     def _dist_params(self) -> list:
         return self.mean.get_param_list() + self.precision.get_param_list()
 
+    # ------------------------------------------------------------------ mixture (diagonal, per-chain, ragged) form
+    @property
+    def is_mixture(self) -> bool:
+        return isinstance(self.precision, MixtureParameterMatrix)
+
+    def mixture_pieces(self, state, engine):
+        """(x, mean, prec, count): (C, kmax) tensors of a Normal whose mean / precision are picked per element by an
+        allocation (parameter.py:420-538) -- the prior of basis coefficients whose number changes under reversible
+        jump.  prec is 1 and mean 0 beyond each chain's live length `count`."""
+        x = state[self.response]
+        if not is_chain(x) or x.shape[1] != 1:
+            raise NotImplementedError("mixture Normal needs a per-chain (k, 1) response")
+        if not isinstance(self.mean, MixtureParameterVector):
+            raise NotImplementedError("mixture precision with a non-mixture mean")
+        return (x.vector(), self.mean.gather_device(state, engine, 0.0), self.precision.gather_device(state, engine, 1.0),
+                x.count(state))
+
     # ------------------------------------------------------------------ structure
     def structure(self, state) -> NormalStructure:
+        if self.is_mixture:
+            raise NotImplementedError("mixture precision has no shared-matrix structure (use mixture_pieces)")
         if isinstance(self.precision, ScaledMatrix):
             M, scale_key = state[self.precision.matrix], self.precision.scalar
         else:
@@ -143,6 +163,11 @@ class Normal(Distribution):
             raise RuntimeError("Normal.log_p needs the engine (use Model.log_p)")
         if by_observation:
             raise NotImplementedError("by_observation")
+        if self.is_mixture:
+            x, mean, prec, count = self.mixture_pieces(state, engine)
+            out = engine.empty(engine.n_chains) if out is None else out
+            engine.diag_gauss_logpdf(x, prec, out, mean=mean, count=count, accumulate=accumulate)
+            return out
         st = self.structure(state)
         quad = self.residual_quad(state, engine, st)
         if st.scale_key is not None and not is_chain(state[st.scale_key]):

@@ -520,6 +520,14 @@ class Engine:
                                             self._chain_scalar(lq_fwd), self._chain_scalar(lq_rev)))
         return out
 
+    def uniform_draw(self, lower, rng, inject=None, draw_index=0, sub=0):
+        """(C, p) tensor lower + range * U(0, 1]."""
+        p = lower.numel()
+        out = self.empty(self.n_chains, p)
+        check(lib.omc_uniform_draw(self._ctx, p, self._p(lower), self._p(rng), self._p(inject), int(draw_index), int(sub),
+                                   self._p(out)))
+        return out
+
     def diag_gauss_logpdf(self, x, prec, out, mean=None, count=None, accumulate=False):
         Cn, kmax = x.shape
         check(lib.omc_diag_gauss_logpdf(self._ctx, kmax, self._p(x), self._p(mean), self._p(prec),

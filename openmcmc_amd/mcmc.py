@@ -80,7 +80,7 @@ class MCMC:
             plan = nn.plan(self.state)
         except NotImplementedError:
             return None
-        if plan["kind"] != "tridiag":
+        if plan["kind"] != "tridiag" or plan.get("offsets"):
             return None
         term_of = {}
         for k, key in enumerate(plan["keys"]):

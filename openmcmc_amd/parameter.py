@@ -80,30 +80,59 @@ class LinearCombination(Parameter):
 
         return ChainArray(chain_sum.data + torch.as_tensor(np.asarray(host_sum), device=chain_sum.data.device))
 
-    def predictor_device(self, state: dict, engine, out=None):
-        """(C, n) fitted values sum_i A_i x_i with per-chain terms evaluated on the GPU (one GEMM per
-        dense design matrix) and shared terms added once (parameter.py:174-197)."""
-        host_sum, fitted = 0, None
+    def predictor_device(self, state: dict, engine, out=None, exclude=None, alpha=1.0, chain_scale=None):
+        """(C, n) tensor chain_scale[c] * alpha * sum_i A_i x_i over the terms not excluded, with per-chain terms
+        evaluated on the GPU and shared terms added once (parameter.py:162-197).  A design matrix may be shared
+        (one GEMM over all chains), an identity, or itself per chain -- a ChainArray (n, k) basis that depends on
+        per-chain knots, possibly ragged -- which goes to omc_design_predict_batched."""
+        skip = [] if exclude is None else ([exclude] if isinstance(exclude, str) else list(exclude))
+        host_sum, ident, batched, dense = 0, [], [], []
         for prm, prefactor in self.form.items():
-            A, v = state[prefactor], state[prm]
-            if not is_chain(v):
-                host_sum = host_sum + A @ v
+            if prm in skip:
                 continue
-            if v.shape[1] != 1:
+            A, v = state[prefactor], state[prm]
+            if is_chain(A):
+                if not is_chain(v) or v.shape[1] != 1:
+                    raise NotImplementedError("a per-chain design matrix needs a per-chain (k, 1) coefficient vector")
+                batched.append((A, v))
+            elif not is_chain(v):
+                host_sum = host_sum + A @ v
+            elif v.shape[1] != 1:
                 raise NotImplementedError("replicated parameters")
-            if _is_identity(A, v.shape[0]):
-                term = v.vector()
+            elif _is_identity(A, v.shape[0]):
+                ident.append(v.vector())
             else:
-                term = engine.design_predict(engine.shared(A), v.vector(), out if fitted is None else None)
-            fitted = term if fitted is None else fitted + term
-        if fitted is None:
+                dense.append((A, v))
+        if not (ident or batched or dense):
             raise ValueError("no per-chain term: use predictor()")
-        if not isinstance(host_sum, int):
-            fitted = fitted + engine.to_device(np.asarray(host_sum, dtype=np.float64).reshape(1, -1))
+        shared = None if isinstance(host_sum, int) else engine.to_device(np.asarray(host_sum, dtype=np.float64).reshape(-1))
+        if len(batched) == 1 and len(ident) <= 1 and not dense:
+            # the whole expression in one launch
+            B, v = batched[0]
+            cs = None if (alpha == 1.0 and chain_scale is None) else _scaled(engine, chain_scale, alpha)
+            return engine.design_predict_batched(B.columns(), v.vector(), add_chain=ident[0] if ident else None,
+                                                 add_shared=shared, chain_scale=cs, out=out)
+        fitted = None
+        for t in ident:
+            fitted = t if fitted is None else fitted + t
+        for A, v in dense:
+            term = engine.design_predict(engine.shared(A), v.vector(), out if fitted is None else None)
+            fitted = term if fitted is None else fitted + term
+        for B, v in batched:
+            fitted = engine.design_predict_batched(B.columns(), v.vector(), add_chain=fitted)
+        if shared is not None:
+            fitted = fitted + shared.reshape(1, -1)
+        if alpha != 1.0 or chain_scale is not None:
+            fitted = fitted * _scaled(engine, chain_scale, alpha).reshape(-1, 1)
         if out is not None and fitted.data_ptr() != out.data_ptr():
             out.copy_(fitted)
             fitted = out
         return fitted
+
+    def has_chain_terms(self, state: dict, exclude=None) -> bool:
+        """Is any term other than `exclude` per chain (a per-chain offset in the response mean)?"""
+        skip = [] if exclude is None else ([exclude] if isinstance(exclude, str) else list(exclude))
+        return any(prm not in skip and (is_chain(state[prm]) or is_chain(state[pre])) for prm, pre in self.form.items())
 
     def get_param_list(self) -> list:
         return list(self.form.keys()) + list(self.form.values())
@@ -145,7 +174,7 @@ def _is_identity(A, n):
     every sweep."""
     from scipy import sparse
 
-    if getattr(A, "shape", None) != (n, n):
+    if is_chain(A) or getattr(A, "shape", None) != (n, n):
         return False
     hit = _IDENTITY_MEMO.get(id(A))
     if hit is not None and hit[0] is A:
@@ -156,3 +185,62 @@ def _is_identity(A, n):
         ans = bool(np.array_equal(np.asarray(A), np.eye(n)))
     _IDENTITY_MEMO[id(A)] = (A, ans)
     return ans
+
+
+def _scaled(engine, chain_scale, alpha):
+    """(C,) tensor alpha * chain_scale (chain_scale None = ones)."""
+    if chain_scale is None:
+        return engine.full((engine.n_chains,), alpha)
+    return chain_scale if alpha == 1.0 else chain_scale * alpha
+
+
+@dataclass
+class MixtureParameter(Parameter, ABC):
+    """Parameter whose elements are picked from a short vector by an allocation (parameter.py:376-417).
+    On the GPU path `param` is a shared host vector (m, 1) and `allocation` a per-chain, usually ragged,
+    ChainArray of integer values (k, 1): the reference grows/shrinks it with the jump parameter
+    (tests/test_reversible_jump.py:86-87, 113-114)."""
+
+    param: str
+    allocation: str
+
+    def get_param_list(self) -> list:
+        return [self.param, self.allocation]
+
+    def gather_device(self, state: dict, engine, fill: float):
+        """(C, kmax) tensor param[allocation] with `fill` beyond each chain's live length."""
+        alloc, par = state[self.allocation], state[self.param]
+        if not is_chain(alloc) or is_chain(par):
+            raise NotImplementedError("mixture parameters need a per-chain allocation and a shared parameter vector")
+        return engine.mixture_gather(engine.shared(np.asarray(par, dtype=np.float64).reshape(-1)), alloc.vector(),
+                                     count=alloc.count(state), fill=fill)
+
+
+@dataclass
+class MixtureParameterVector(MixtureParameter):
+    """predictor = param[allocation]  (parameter.py:420-471)."""
+
+    def predictor(self, state: dict):
+        alloc = state[self.allocation]
+        if is_chain(alloc):
+            raise NotImplementedError("per-chain allocation: use gather_device (consumed structurally by the samplers)")
+        return state[self.param][np.asarray(alloc).astype(int).flatten()]
+
+    def get_grad_param_list(self) -> list:
+        return [self.param]
+
+
+@dataclass
+class MixtureParameterMatrix(MixtureParameter):
+    """predictor = diag(param[allocation])  (parameter.py:474-538); never formed on the GPU path."""
+
+    def predictor(self, state: dict):
+        from scipy import sparse
+
+        alloc = state[self.allocation]
+        if is_chain(alloc):
+            raise NotImplementedError("per-chain allocation: use gather_device (consumed structurally by the samplers)")
+        return sparse.diags(diagonals=state[self.param][np.asarray(alloc).astype(int)].flatten(), offsets=0, format="csc")
+
+    def get_grad_param_list(self) -> list:
+        return []

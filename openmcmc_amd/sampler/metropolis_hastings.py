@@ -1,10 +1,16 @@
 """Metropolis-Hastings samplers on chain-batched state (reference sampler/metropolis_hastings.py).
 
-Built this round: RandomWalk (untruncated) and ManifoldMALA for a parameter whose conditional model
-is one Normal with the parameter as response, a shared mean and a shared dense precision
-(Normal("x", mean="mu", precision="Q") -- BASELINE configs[3]).  Because the Hessian of that target
-is constant, chol(H/step^2) is factorised once per sampler instead of five times per update
-(SURVEY.md section 3.4); every chain then advances with level-3 BLAS on the d x C state matrix.
+Two routes:
+  * fused: RandomWalk (untruncated) and ManifoldMALA for a parameter whose conditional model is one Normal with
+    the parameter as response, a shared mean and a shared dense precision (Normal("x", mean="mu", precision="Q")
+    -- BASELINE configs[3]).  The Hessian of that target is constant, so chol(H/step^2) is factorised once per
+    sampler instead of five times per update and every chain advances with level-3 BLAS
+    on the d x C state matrix (omc_mala_step / omc_rw_step).
+  * generic: any model whose log_p the device can evaluate.  The proposal (omc_rw_propose: Gaussian or truncated
+    Gaussian random walk), the model log-density of the current and the proposed state, the accept test
+    (omc_mh_accept) and the per-chain merge of the two states (omc_chain_select) are separate launches over all
+    chains; `state_update_function` callbacks receive and return chain-batched state.  This is the route of
+    RandomWalkLoop over the knots of a basis and of ReversibleJump (BASELINE configs[4]).
 """
 
 from dataclasses import dataclass, field
@@ -66,22 +72,25 @@ class MetropolisHastings(MCMCSampler):
         self.accept_rate.attach(engine)
         return self
 
-    def _target(self, state):
-        """(Q device, mu device or None, d) of the Gaussian target, checking the supported structure."""
-        eng = self._need_engine()
-        if list(self.model.keys()) != [self.param]:
-            raise NotImplementedError("MH samplers are built for a parameter whose conditional model is its own Normal")
+    def _gaussian_target(self, state):
+        """Does the fused route apply?  (one Normal with the parameter as response, shared mean and precision)"""
+        if list(self.model.keys()) != [self.param] or np.size(self.step) != 1:
+            return False
         dist = self.model[self.param]
         if not isinstance(dist, Normal) or not isinstance(dist.precision, Identity) or not isinstance(dist.mean, Identity):
-            raise NotImplementedError("MH target must be Normal(param, mean=<shared>, precision=<shared matrix>)")
+            return False
+        return not (is_chain(state[dist.precision.form]) or is_chain(state[dist.mean.form]))
+
+    def _target(self, state):
+        """(Q device, mu device or None, d) of the Gaussian target of the fused route."""
+        eng = self._need_engine()
+        if not self._gaussian_target(state):
+            raise NotImplementedError("fused MH route needs Normal(param, mean=<shared>, precision=<shared matrix>) "
+                                      "and a scalar step")
+        dist = self.model[self.param]
         Q, mu = state[dist.precision.form], state[dist.mean.form]
-        if is_chain(Q) or is_chain(mu):
-            raise NotImplementedError("per-chain target parameters")
-        if np.size(self.step) != 1:
-            raise NotImplementedError("per-element step sizes")
-        d = Q.shape[0]
         mu = np.asarray(mu, dtype=np.float64).reshape(-1)
-        return eng.shared(Q), (eng.shared(mu) if mu.any() else None), d
+        return eng.shared(Q), (eng.shared(mu) if mu.any() else None), Q.shape[0]
 
     def _x(self, state):
         v = state[self.param]
@@ -89,27 +98,158 @@ class MetropolisHastings(MCMCSampler):
             raise NotImplementedError("MH samplers need a per-chain (d, 1) parameter")
         return v.vector()
 
+    # ------------------------------------------------------------------ generic route
+    def _accept_reject_proposal(self, current_state: dict, prop_state: dict, logp_pr_g_cr, logp_cr_g_pr, count=None,
+                                index=0, u=None, sub=0, trace=None) -> dict:
+        """metropolis_hastings.py:127-173 for every chain at once: log_alpha = lp' + q_rev - (lp + q_fwd), accept iff
+        log U < log_alpha, then current_state takes the proposed value of every entry that differs, chain by chain.
+        `count`/`index` gate the chains taking part (a loop over the columns of a ragged parameter)."""
+        eng = self._need_engine()
+        lp_cur = self.model.log_p(current_state, engine=eng)
+        lp_prop = self.model.log_p(prop_state, engine=eng)
+        log_alpha = eng.empty(eng.n_chains) if trace is not None else None
+        acc = eng.mh_accept(lp_cur, lp_prop, _as_chain_tensor(eng, logp_pr_g_cr), _as_chain_tensor(eng, logp_cr_g_pr),
+                            count=count, index=index, u=u, draw_index=self._draw_index(), sub=sub,
+                            accept_count=self.accept_rate.accept, proposal_count=self.accept_rate.proposal,
+                            log_alpha=log_alpha)
+        if trace is not None:
+            trace.update(log_alpha=log_alpha, accept=acc, lp_cur=lp_cur, lp_prop=lp_prop)
+        for key, value in prop_state.items():
+            cur = current_state.get(key)
+            if value is cur or not is_chain(value):
+                continue
+            if not is_chain(cur) or cur.data.shape != value.data.shape:
+                raise NotImplementedError(f"proposed state entry '{key}' changes kind or padded shape")
+            eng.chain_select(acc, value.storage(), cur.storage())
+        return current_state
+
+
+def _as_chain_tensor(engine, value):
+    """Proposal log-density contributions may be Python floats (0.0 from a callback) or (C,) tensors."""
+    if value is None or hasattr(value, "data_ptr"):
+        return value
+    v = float(value)
+    return None if v == 0.0 else engine.full((engine.n_chains,), v)
+
+
+def _add_contribution(engine, total, extra):
+    """total (a (C,) tensor) += extra (float or (C,) tensor)."""
+    if hasattr(extra, "data_ptr"):
+        total += extra
+    elif float(extra) != 0.0:
+        total += float(extra)
+    return total
+
 
 @dataclass
 class RandomWalk(MetropolisHastings):
-    """Gaussian random-walk proposal (metropolis_hastings.py:176-269), untruncated."""
+    """(Truncated) Gaussian random-walk proposal (metropolis_hastings.py:176-269).
+
+    `state_update_function(prop_state, param_index) -> (prop_state, logq_fwd_extra, logq_rev_extra)` is called with
+    chain-batched state (ChainArray entries) and may return floats or (C,) tensors for the two extras."""
 
     domain_limits: np.ndarray = None
     state_update_function: Callable = None
 
+    def __post_init__(self):
+        # metropolis_hastings.py:201-210: keep the FULL model when a state_update_function may change other entries
+        if self.state_update_function is None:
+            self.model = self.model.conditional(self.param)
+        self._init_runtime()
+        self.step = np.array(self.step, ndmin=2)
+        self.inject_uniform = None
+        self.trace = None  # test hook: a dict that receives the internals of the last proposal / decision
+
+    def _blocks_per_proposal(self, p):
+        return (p + 1) // 2 + 1  # Philox blocks for p proposal draws, plus one for the accept uniform
+
+    def proposal(self, current_state: dict, param_index: int = None, inject=None):
+        """metropolis_hastings.py:212-269 for every chain; returns (prop_state, logq_fwd (C,), logq_rev (C,))."""
+        eng = self._need_engine()
+        x = current_state[self.param]
+        if not is_chain(x):
+            raise NotImplementedError("RandomWalk needs a per-chain parameter")
+        p, n_rep = x.shape
+        if param_index is None and n_rep != 1:
+            raise NotImplementedError("whole-matrix proposals for a replicated parameter: use RandomWalkLoop")
+        step = self.step
+        if step.shape[1] != 1:
+            if param_index is None:
+                raise NotImplementedError("(p, n) step sizes without a column index")
+            step = step[:, [param_index]]
+        cache = getattr(self, "_dev_consts", None)
+        if cache is None:
+            cache = self._dev_consts = {}
+        skey = ("step", 0 if self.step.shape[1] == 1 else param_index)
+        if skey not in cache:
+            cache[skey] = eng.to_device(np.ascontiguousarray(step.reshape(-1)))
+        if self.domain_limits is not None and "lim" not in cache:
+            lim = np.asarray(self.domain_limits, dtype=np.float64).reshape(-1, 2)
+            if lim.shape[0] != p:
+                raise ValueError("domain_limits must have one (lower, upper) row per element of the parameter")
+            cache["lim"] = (eng.to_device(lim[:, 0].copy()), eng.to_device(lim[:, 1].copy()))
+        lower, upper = cache.get("lim", (None, None))
+        col = 0 if param_index is None else int(param_index)
+        ragged_cols = x.ragged is not None and x.ragged[1] == 1
+        data = x.data if x.data.is_contiguous() else x.data.contiguous()
+        z = data.clone()
+        sub = col * self._blocks_per_proposal(p)
+        lq_f, lq_r = eng.rw_propose(data, z, cache[skey], lower, upper, column=col if n_rep > 1 or ragged_cols else None,
+                                    count=x.count(current_state) if ragged_cols else None, inject=inject,
+                                    draw_index=self._draw_index(), sub=sub)
+        prop_state = dict(current_state)  # shallow: only the entries a proposal replaces are new objects
+        prop_state[self.param] = x.like(z)
+        if callable(self.state_update_function):
+            prop_state, f_extra, r_extra = self.state_update_function(prop_state, param_index)
+            lq_f, lq_r = _add_contribution(eng, lq_f, f_extra), _add_contribution(eng, lq_r, r_extra)
+        return prop_state, lq_f, lq_r
+
+    def _generic_step(self, current_state, param_index=None):
+        x = current_state[self.param]
+        p = x.shape[0]
+        col = 0 if param_index is None else int(param_index)
+        inject = self.inject(self, self._sweep, param_index) if self.inject is not None else None
+        u = self.inject_uniform(self, self._sweep, param_index) if self.inject_uniform is not None else None
+        prop_state, lq_f, lq_r = self.proposal(current_state, param_index, inject=inject)
+        ragged_cols = x.ragged is not None and x.ragged[1] == 1
+        trace = None
+        if self.trace is not None:
+            trace = {"z": prop_state[self.param].data.clone(), "lq_fwd": lq_f.clone(), "lq_rev": lq_r.clone()}
+            self.trace.setdefault("steps", []).append(trace)
+        return self._accept_reject_proposal(current_state, prop_state, lq_f, lq_r,
+                                            count=x.count(current_state) if ragged_cols else None, index=col, u=u,
+                                            sub=col * self._blocks_per_proposal(p) + (p + 1) // 2, trace=trace)
+
     def sample(self, current_state: dict) -> dict:
         eng = self._need_engine()
-        if self.domain_limits is not None or self.state_update_function is not None:
-            raise NotImplementedError("truncated proposals / state_update_function: later round")
-        Q, mu, d = self._target(current_state)
-        if self._plan is None:
-            self._plan = eng.dense_cholesky(Q, 1.0)  # chol(Q) for log p (gmrf.py:339)
-        LQ, sl = self._plan
-        z = self.inject(self, self._sweep) if self.inject is not None else None
-        u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
-        eng.rw_step(mu, LQ, sl, float(self.step.item()), self._x(current_state), z=z, u=u,
-                    draw_index=self._draw_index(), accept_count=self.accept_rate.accept,
-                    proposal_count=self.accept_rate.proposal)
+        if self.domain_limits is None and self.state_update_function is None and self._gaussian_target(current_state):
+            Q, mu, d = self._target(current_state)
+            if self._plan is None:
+                self._plan = eng.dense_cholesky(Q, 1.0)  # chol(Q) for log p (gmrf.py:339)
+            LQ, sl = self._plan
+            z = self.inject(self, self._sweep) if self.inject is not None else None
+            u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
+            eng.rw_step(mu, LQ, sl, float(self.step.item()), self._x(current_state), z=z, u=u,
+                        draw_index=self._draw_index(), accept_count=self.accept_rate.accept,
+                        proposal_count=self.accept_rate.proposal)
+        else:
+            current_state = self._generic_step(current_state)
+        self._sweep += 1
+        return current_state
+
+
+@dataclass
+class RandomWalkLoop(RandomWalk):
+    """One random-walk step per column of the parameter (metropolis_hastings.py:272-289).  For a ragged parameter
+    the loop runs to the largest live length over the chains; chains with fewer columns sit the extra steps out."""
+
+    def sample(self, current_state: dict) -> dict:
+        x = current_state[self.param]
+        n_cols = x.shape[1]
+        if x.ragged is not None and x.ragged[1] == 1:
+            n_cols = int(x.count(current_state).max().item())
+        for param_index in range(n_cols):
+            current_state = self._generic_step(current_state, param_index)
         self._sweep += 1
         return current_state
 

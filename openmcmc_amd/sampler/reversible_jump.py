@@ -1,0 +1,141 @@
+"""Reversible-jump sampler on chain-batched, ragged state (reference sampler/reversible_jump.py).
+
+Every chain makes its own birth or death move in the same launches:
+  omc_rj_move                 move type, p_birth / p_death, deletion index          (reversible_jump.py:310-373, 173)
+  Distribution.rvs            the new element of each associated parameter          (:130)
+  omc_ragged_resize           np.concatenate / np.delete on the padded arrays       (:131, :175)
+  user callbacks              state_birth_function / state_death_function           (:133-134, :178-181)
+  omc_design_gram_batched +
+  omc_rj_matched_transition   matched coefficient transition and its densities      (:195-308)
+  Model.log_p x 2, omc_mh_accept, omc_chain_select                                  (metropolis_hastings.py:127-173)
+
+Batched callback convention (the reference calls ONE of the two callbacks for its single chain):
+  * `state_birth_function(current_state, prop_state)` is called every sweep and must bring the dependent entries
+    of prop_state in line with the resized associated parameters for EVERY chain -- recomputing a basis matrix
+    from the proposed knots does that for births and deaths alike;
+  * `state_death_function(current_state, prop_state, deletion_index)`, if given, is called after it with the (C,)
+    int64 deletion indices (-1 on chains that make a birth) for models that delete rather than recompute;
+  * `prop_state["__rj_move__"]` holds {"birth": int32 (C,), "deletion_index": int64 (C,)} for both.
+Allocation vectors of mixture parameters tied to the jump parameter (tests/test_reversible_jump.py:86-87) stay
+valid without a callback when they are all-zero: the padding already holds zeros.
+"""
+
+from dataclasses import dataclass
+from typing import Callable, Union
+
+import numpy as np
+
+from openmcmc_amd.chains import ChainArray, is_chain
+from openmcmc_amd.distribution.distribution import Uniform
+from openmcmc_amd.sampler.metropolis_hastings import MetropolisHastings, _add_contribution
+
+# Philox sub-streams within one ReversibleJump.sample call (block numbers; omc_rj_move owns 0..63)
+_SUB_ASSOCIATED, _SUB_MATCH, _SUB_ACCEPT = 64, 96, 97
+
+
+@dataclass
+class ReversibleJump(MetropolisHastings):
+    """reversible_jump.py:24-373; `param` is a per-chain (1, 1) count, `associated_params` ragged ChainArrays whose
+    live length it is."""
+
+    associated_params: Union[list, str, None] = None
+    n_max: Union[int, None] = None
+    birth_probability: float = 0.5
+    state_birth_function: Union[Callable, None] = None
+    state_death_function: Union[Callable, None] = None
+    matching_params: Union[dict, None] = None
+
+    def __post_init__(self):
+        # reversible_jump.py:66-74: the WHOLE model stays attached
+        self._init_runtime()
+        self.step = np.array(self.step, ndmin=2)
+        self.inject_uniform = None
+        self.trace = None
+        # test hooks: callables (sampler, sweep) -> device tensors replaying the reference's draws
+        self.inject_move = None       # (u (C,), deletion index int64 (C,))
+        self.inject_associated = None  # {key: uniforms (C, p)}
+        self.inject_match = None      # (C,) uniform (limits) or normal draw of the matched coefficient
+        if isinstance(self.associated_params, str):
+            self.associated_params = [self.associated_params]
+        if self.associated_params is None:
+            self.associated_params = []
+
+    # ------------------------------------------------------------------ proposal
+    def proposal(self, current_state: dict, param_index: int = None):
+        import torch
+
+        eng = self._need_engine()
+        n_cur = current_state[self.param]
+        if not is_chain(n_cur) or n_cur.size != 1:
+            raise NotImplementedError("the jump parameter must be a per-chain (1, 1) count")
+        count = n_cur.scalar()
+        di, t = self._draw_index(), self._sweep
+        u_move, idx = self.inject_move(self, t) if self.inject_move is not None else (None, None)
+        birth, p_birth, p_death, del_index = eng.rj_move(count.to(torch.int64), int(self.n_max),
+                                                         float(self.birth_probability), u=u_move, idx=idx, draw_index=di)
+        is_birth = birth.to(torch.bool)
+        prop_state = dict(current_state)
+        prop_state[self.param] = ChainArray((count + torch.where(is_birth, 1.0, -1.0)).reshape(-1, 1, 1))
+        prop_state["__rj_move__"] = {"birth": birth, "deletion_index": del_index}
+        log_prop_density = 0.0
+        inj_assoc = self.inject_associated(self, t) if self.inject_associated is not None else {}
+        for j, key in enumerate(self.associated_params):
+            dist, cur = self.model[key], current_state[key]
+            if not is_chain(cur) or cur.ragged is None or cur.ragged[0] != self.param:
+                raise NotImplementedError(f"associated parameter '{key}' must be a ragged ChainArray counted by '{self.param}'")
+            if not isinstance(dist, Uniform):
+                raise NotImplementedError("associated parameters with a non-Uniform prior")
+            new = dist.rvs(current_state, n=1, engine=eng, draw_index=di, sub=_SUB_ASSOCIATED + 2 * j,
+                           inject=inj_assoc.get(key))  # reversible_jump.py:130
+            prop_state[key] = cur.like(eng.ragged_resize(cur.data, count, birth, del_index, axis=cur.ragged[1],
+                                                         new_vals=new.data.reshape(eng.n_chains, -1)))
+            log_prop_density += dist.log_p_per_replicate(current_state)  # log_p(..., by_observation=True)[-1], :132,143
+        lq_f, lq_r = eng.zeros(eng.n_chains), eng.zeros(eng.n_chains)
+        if callable(self.state_birth_function):
+            prop_state, f_extra, r_extra = self.state_birth_function(current_state, prop_state)
+            lq_f, lq_r = _add_contribution(eng, lq_f, f_extra), _add_contribution(eng, lq_r, r_extra)
+        if callable(self.state_death_function):
+            prop_state, f_extra, r_extra = self.state_death_function(current_state, prop_state, del_index)
+            lq_f, lq_r = _add_contribution(eng, lq_f, f_extra), _add_contribution(eng, lq_r, r_extra)
+        if self.matching_params is not None:
+            prop_state = self._matched_transition(current_state, prop_state, count, birth, del_index, lq_f, lq_r)
+        # reversible_jump.py:142-144 (birth) and 189-191 (death)
+        lpb, lpd = torch.log(p_birth), torch.log(p_death)
+        lq_f += torch.where(is_birth, lpb + log_prop_density, lpd)
+        lq_r += torch.where(is_birth, lpd, lpb + log_prop_density)
+        del prop_state["__rj_move__"]
+        if self.trace is not None:
+            self.trace.update(birth=birth, deletion_index=del_index, lq_fwd=lq_f.clone(), lq_rev=lq_r.clone(),
+                              prop={k: prop_state[k].data.clone() for k in self._changed_keys()})
+        return prop_state, lq_f, lq_r
+
+    def _changed_keys(self):
+        keys = list(self.associated_params)
+        if self.matching_params is not None:
+            keys.append(self.matching_params["variable"])
+        return keys
+
+    def _matched_transition(self, current_state, prop_state, count, birth, del_index, lq_f, lq_r):
+        """reversible_jump.py:195-308 for every chain (omc_rj_matched_transition)."""
+        eng = self.engine
+        vector, matrix = self.matching_params["variable"], self.matching_params["matrix"]
+        scale, limits = float(self.matching_params["scale"]), self.matching_params["limits"]
+        coef, B_cur, B_prop = current_state[vector], current_state[matrix], prop_state[matrix]
+        if not (is_chain(coef) and is_chain(B_cur) and is_chain(B_prop)) or coef.shape[1] != 1:
+            raise NotImplementedError("matched transitions need per-chain coefficient vector and basis matrices")
+        gram_cur, _ = eng.design_gram_batched(B_cur.columns())
+        gram_prop, _ = eng.design_gram_batched(B_prop.columns())
+        inject = self.inject_match(self, self._sweep) if self.inject_match is not None else None
+        out = eng.rj_matched_transition(gram_cur, gram_prop, count, birth, del_index, coef.vector(), scale, limits, lq_f, lq_r,
+                                        inject=inject, draw_index=self._draw_index(), sub=_SUB_MATCH)
+        prop_state[vector] = coef.like(out.unsqueeze(2))
+        return prop_state
+
+    # ------------------------------------------------------------------ sample
+    def sample(self, current_state: dict) -> dict:
+        prop_state, lq_f, lq_r = self.proposal(current_state)
+        u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
+        current_state = self._accept_reject_proposal(current_state, prop_state, lq_f, lq_r, u=u, sub=_SUB_ACCEPT,
+                                                     trace=self.trace)
+        self._sweep += 1
+        return current_state

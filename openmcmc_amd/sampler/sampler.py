@@ -59,17 +59,26 @@ class MCMCSampler(ABC):
     def init_store(self, current_state: dict, store: dict, n_iterations: int) -> dict:
         """store[param]: (n_iterations, C, size) device tensor, NaN-filled (sampler.py:69-87; the
         reference's (size, n_iterations) per chain, iteration-major so a draw can be written into its
-        slab directly)."""
+        slab directly).  A variable-size parameter gets max_variable_size rows, NaN beyond its live length."""
         eng = self._need_engine()
-        if self.max_variable_size is not None:
-            raise NotImplementedError("variable-size parameters (reversible jump): later round")
-        size = current_state[self.param].size
+        if isinstance(self.max_variable_size, tuple):
+            raise NotImplementedError("tuple max_variable_size (matrix-valued variable-size parameters)")
+        size = current_state[self.param].size if self.max_variable_size is None else int(self.max_variable_size)
         store[self.param] = eng.full((n_iterations, eng.n_chains, size), float("nan"))
         return store
 
     def store(self, current_state: dict, store: dict, iteration: int) -> dict:
         """sampler.py:89-118."""
-        store[self.param][iteration].copy_(current_state[self.param].data.reshape(self.engine.n_chains, -1))
+        value = current_state[self.param]
+        flat = value.data.reshape(self.engine.n_chains, -1)
+        slab = store[self.param][iteration]
+        if value.ragged is None:
+            slab.copy_(flat)
+        else:  # live entries, NaN beyond (the reference leaves its NaN fill there, sampler.py:116)
+            import torch
+
+            live = torch.arange(flat.shape[1], device=flat.device).unsqueeze(0) < value.count(current_state).unsqueeze(1)
+            slab[:, : flat.shape[1]] = torch.where(live, flat, torch.full_like(flat, float("nan")))
         return store
 
 
@@ -105,12 +114,14 @@ class NormalNormal(MCMCSampler):
         if prior.domain_response_lower is not None or prior.domain_response_upper is not None:
             raise NotImplementedError("truncated Gaussian conditional (gmrf.gibbs_canonical_truncated_normal): next round")
         n = state[self.param].shape[0]
+        if prior.is_mixture:
+            return self._ragged_plan(state, n)
         pieces = []  # one per distribution: what Q and b receive from it
         for key, dist in self.model.items():
             if not isinstance(dist, Normal):
                 raise TypeError("NormalNormal handles Normal distributions only")
             st = dist.structure(state)
-            piece = {"key": key, "dist": dist, "st": st, "design": None}
+            piece = {"key": key, "dist": dist, "st": st, "design": None, "offset": False}
             if self._is_response[key]:
                 mean = dist.mean.predictor(state)  # sampler.py:183: b += Q_rsp @ mean
                 if is_chain(mean):
@@ -126,9 +137,12 @@ class NormalNormal(MCMCSampler):
                     A = state[dist.mean.form[self.param]]
                     if not _is_identity(A, n):
                         piece["design"] = A
-                    rest = dist.mean.predictor_conditional(state, term_to_exclude=self.param)
-                    if is_chain(rest):
-                        raise NotImplementedError("per-chain offsets in the response mean (mixed models): later round")
+                    if dist.mean.has_chain_terms(state, exclude=self.param):
+                        # per-chain offset d_c in y - d_c (e.g. a basis expansion B_c beta_c next to the GMRF):
+                        # evaluated on the device every sweep and fed to the solve as a per-chain rhs
+                        piece["offset"], rest = True, 0.0
+                    else:
+                        rest = dist.mean.predictor_conditional(state, term_to_exclude=self.param)
                 y = state[key]
                 if is_chain(y):
                     raise NotImplementedError("per-chain response")
@@ -142,15 +156,42 @@ class NormalNormal(MCMCSampler):
 
     def _tridiag_plan(self, state, n, pieces):
         eng = self.engine
-        terms, keys = [], []
+        terms, keys, offsets = [], [], []
         for pc in pieces:
             st = pc["st"]
+            if pc["offset"]:
+                if st.diag is not None or st.off is not None:
+                    raise NotImplementedError("per-chain offset under a non-identity response precision")
+                offsets.append((pc["dist"], st.scale_key))
             cache = eng.model_cache(pc["dist"], state, st, pc["center"])
             scale = _as_chain_scalar(eng, state, st.scale_key) if st.scale_key is not None else None
             terms.append({"diag": cache["diag"], "off": cache["off"], "rhs": cache["rhs"], "center": cache["center"],
                           "scale": None if scale is None else scale.scalar()})
             keys.append(pc["key"])
-        return {"kind": "tridiag", "n": n, "terms_list": terms, "terms": eng.tridiag_terms(terms, n), "keys": keys}
+        return {"kind": "tridiag", "n": n, "terms_list": terms, "terms": eng.tridiag_terms(terms, n), "keys": keys,
+                "offsets": offsets}
+
+    def _ragged_plan(self, state, n_max):
+        """Small variable-size parameter with a mixture prior (diagonal precision picked by an allocation) and
+        regression likelihoods whose design matrix is per chain: Q_c = diag(d_c) + tau_c B_c' W B_c on the live
+        block (sampler.py:176-192 with parameter.py:501, location_scale.py:238-241)."""
+        likes = []
+        for key, dist in self.model.items():
+            if key == self.param:
+                continue
+            if not isinstance(dist, Normal) or not isinstance(dist.mean, LinearCombination):
+                raise NotImplementedError("ragged NormalNormal needs LinearCombination likelihood means")
+            st = dist.structure(state)
+            if st.diag is False or st.off is not None:
+                raise NotImplementedError("regression likelihood needs a diagonal response precision")
+            if not is_chain(state[dist.mean.form[self.param]]):
+                raise NotImplementedError("ragged parameter with a shared design matrix")
+            if is_chain(state[key]) or state[key].shape[1] != 1:
+                raise NotImplementedError("per-chain or replicated response")
+            likes.append((key, dist, st))
+        if len(likes) != 1:
+            raise NotImplementedError("ragged NormalNormal: exactly one likelihood term")
+        return {"kind": "ragged", "n": n_max, "like": likes[0], "terms_list": [], "keys": []}
 
     def _dense_plan(self, state, n, pieces):
         """Q_c = sum_k s_k[c] M_k with dense M_k: prior precision as is, a regression likelihood as the
@@ -158,6 +199,8 @@ class NormalNormal(MCMCSampler):
         eng = self.engine
         terms, keys = [], []
         for pc in pieces:
+            if pc["offset"]:
+                raise NotImplementedError("per-chain offsets on the dense route")
             st, A = pc["st"], pc["design"]
             center = eng.to_device(pc["center"].reshape(-1))
             if A is None:
@@ -194,15 +237,46 @@ class NormalNormal(MCMCSampler):
         eng = self._need_engine()
         p = self.plan(current_state)
         n = p["n"]
-        x = eng.empty(eng.n_chains, n) if out is None else out
         z = self.inject(self, self._sweep) if self.inject is not None else None
+        if p["kind"] == "ragged":
+            return self._sample_ragged(current_state, p, z)
+        x = eng.empty(eng.n_chains, n) if out is None else out
         if p["kind"] == "tridiag":
-            eng.tridiag_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())
+            rhs_chain = None
+            for dist, scale_key in p["offsets"]:  # b_c -= tau_c * d_c  (sampler.py:190-192)
+                scale = current_state[scale_key].scalar() if scale_key is not None else None
+                t = dist.mean.predictor_device(current_state, eng, exclude=self.param, alpha=-1.0, chain_scale=scale)
+                rhs_chain = t if rhs_chain is None else rhs_chain + t
+            eng.tridiag_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
         else:
             eng.dense_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())
         current_state[self.param] = ChainArray(x)
         self._sweep += 1
         return current_state
+
+    def _sample_ragged(self, state, p, z):
+        eng = self.engine
+        key, dist, st = p["like"]
+        prior = self.model[self.param]
+        cur = state[self.param]
+        _, pmean, pprec, count = prior.mixture_pieces(state, eng)
+        B = state[dist.mean.form[self.param]]
+        w = None if st.diag is None else eng.shared(st.diag)
+        y = eng.shared(np.asarray(state[key], dtype=np.float64).reshape(-1))
+        rest = None
+        if dist.mean.has_chain_terms(state, exclude=self.param):
+            rest = dist.mean.predictor_device(state, eng, exclude=self.param)
+        else:
+            host = dist.mean.predictor_conditional(state, term_to_exclude=self.param)
+            if not isinstance(host, int):
+                y = eng.to_device(np.asarray(state[key], dtype=np.float64).reshape(-1) - np.asarray(host).reshape(-1))
+        gram, rhs = eng.design_gram_batched(B.columns(), w=w, resid_shared=y, resid_chain=rest)
+        scale = _as_chain_scalar(eng, state, st.scale_key).scalar() if st.scale_key is not None else None
+        x = eng.small_sample_canonical(gram, rhs, pprec, lik_scale=scale, prior_mean=pmean, count=count, z=z,
+                                       draw_index=self._draw_index())
+        state[self.param] = cur.like(x.unsqueeze(2))
+        self._sweep += 1
+        return state
 
 
 @dataclass

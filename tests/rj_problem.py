@@ -1,0 +1,92 @@
+"""The cfg5-shaped model (GMRF + Gaussian-kernel basis with a reversible-jump number of
+knots) written against openmcmc_amd's mirror of the reference API.  This is USER model code: what
+tests/golden/make_golden_rj.py writes against the reference, here on chain-batched state.  Shared by the GPU
+tests and benchmarks/cfg5_rj_gmrf.py."""
+
+import math
+
+import numpy as np
+from scipy import sparse
+
+
+def make_basis_host(X, theta):
+    """The same basis for one chain in numpy ((n, 1) locations, (1, k) knots): what the CPU oracle is given."""
+    return np.exp(-((X - theta) ** 2) / 2.0) / math.sqrt(2 * math.pi)
+
+
+def make_basis(state, X_dev):
+    """B[c, i, k] = phi(X_i - theta[c, k]) for the live knots of chain c, zero columns beyond: the batched form of
+    the reference test's make_basis (tests/test_reversible_jump.py:24-40, unit scales).  Returned as an (n, k_max)
+    ChainArray kept column-major per chain (what the per-chain design kernels read)."""
+    import torch
+
+    from openmcmc_amd.chains import ChainArray
+
+    theta = state["theta"]
+    th = theta.data[:, 0, :]                                    # (C, k_max)
+    live = torch.arange(th.shape[1], device=th.device).unsqueeze(0) < theta.count(state).unsqueeze(1)
+    d = X_dev.reshape(1, 1, -1) - th.unsqueeze(2)               # (C, k_max, n)
+    B = torch.exp(-(d * d) / 2.0) / math.sqrt(2 * math.pi) * live.unsqueeze(2)
+    return ChainArray(B.transpose(1, 2), ragged=(theta.ragged[0], 1))
+
+
+def build(y, X, P, n_max, engine_device, n_chains, init_theta, init_beta, init_k):
+    """(model, state, samplers): the model of make_golden_rj.rj_gmrf_problem on `n_chains` chains."""
+    import torch
+
+    from openmcmc_amd.chains import ChainArray, ragged_from_lists
+    from openmcmc_amd.distribution.distribution import Gamma, Poisson, Uniform
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import LinearCombination, MixtureParameterMatrix, MixtureParameterVector, ScaledMatrix
+    from openmcmc_amd.sampler.metropolis_hastings import RandomWalkLoop
+    from openmcmc_amd.sampler.reversible_jump import ReversibleJump
+    from openmcmc_amd.sampler.sampler import NormalGamma, NormalNormal
+
+    n = y.size
+    dev = engine_device
+    X_dev = torch.as_tensor(np.asarray(X, dtype=np.float64).reshape(-1), device=dev)
+    mdl = Model(
+        [
+            Normal("y", mean=LinearCombination({"beta": "B", "b": "A"}), precision=ScaledMatrix("P_tau", "tau")),
+            Normal("b", mean="mu_b", precision=ScaledMatrix("P_lambda", "lambda")),
+            Normal("beta", mean=MixtureParameterVector("mu_beta", "alloc_beta"),
+                   precision=MixtureParameterMatrix("tau_beta", "alloc_beta")),
+            Poisson("n_basis", rate="rho"),
+            Uniform("theta", domain_response_lower=np.array([[-10.0]]), domain_response_upper=np.array([[10.0]])),
+            Gamma("lambda", shape="a_lam", rate="b_lam"),
+            Gamma("tau", shape="a_tau", rate="b_tau"),
+        ]
+    )
+    mdl.response = {"y": "mean"}
+
+    def move_function(state, col):          # state_update_function of RandomWalkLoop
+        state["B"] = make_basis(state, X_dev)
+        return state, 0.0, 0.0
+
+    def birth_function(cur, prop):          # state_birth_function: births and deaths alike (see reversible_jump.py)
+        prop["B"] = make_basis(prop, X_dev)
+        return prop, 0.0, 0.0
+
+    state = {
+        "y": np.asarray(y, dtype=np.float64).reshape(n, 1), "X": np.asarray(X, dtype=np.float64).reshape(n, 1),
+        "A": sparse.eye(n, format="csc"), "P_tau": sparse.eye(n, format="csc"), "P_lambda": sparse.csc_matrix(P),
+        "mu_b": np.zeros((n, 1)), "mu_beta": np.zeros((1, 1)), "tau_beta": 0.25 * np.ones((1, 1)), "rho": 5.0,
+        "a_lam": 10.0, "b_lam": 1.0, "a_tau": 1.0, "b_tau": 1.0, "lambda": 100.0, "tau": 10.0, "b": np.zeros((n, 1)),
+        "n_basis": ChainArray(torch.as_tensor(np.asarray(init_k, dtype=np.float64), device=dev).reshape(-1, 1, 1)),
+        "theta": ragged_from_lists(init_theta, n_max, 1, "n_basis", dev),
+        "beta": ragged_from_lists(init_beta, n_max, 0, "n_basis", dev),
+        "alloc_beta": ragged_from_lists([np.zeros(int(k)) for k in init_k], n_max, 0, "n_basis", dev),
+    }  # fmt: skip
+    state["B"] = make_basis(state, X_dev)
+    samplers = [
+        NormalNormal("b", mdl),
+        NormalNormal("beta", mdl, max_variable_size=n_max),
+        NormalGamma("lambda", mdl),
+        NormalGamma("tau", mdl),
+        RandomWalkLoop("theta", mdl, step=np.array(0.2), max_variable_size=n_max, domain_limits=np.array([[-10.0, 10.0]]),
+                       state_update_function=move_function),
+        ReversibleJump("n_basis", mdl, associated_params=["theta"], n_max=n_max, state_birth_function=birth_function,
+                       matching_params={"variable": "beta", "matrix": "B", "scale": 1.0, "limits": [-10.0, 10.0]}),
+    ]
+    return mdl, state, samplers

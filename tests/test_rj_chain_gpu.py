@@ -1,0 +1,167 @@
+"""End-to-end parity of the reversible-jump + GMRF model (BASELINE configs[4], SURVEY.md section 8d cfg5 at a size
+the reference finishes in seconds): five chains with different starting dimensions run TOGETHER through the
+mirror API, every draw the reference consumed injected from the golden tape
+(tests/golden/rj_gmrf_chain.npz, made by tests/golden/make_golden_rj.py running the reference).
+Pass: the per-chain (move, deletion index, n_basis) trace and the accept decisions are identical, the knots,
+coefficients, field, hyper-parameters and log-posterior agree to 1e-9 over 150 sweeps."""
+
+import numpy as np
+import pytest
+
+from rj_problem import build, make_basis_host
+
+pytestmark = pytest.mark.gpu
+
+
+def _nan0(a, fill=0.5):
+    return np.where(np.isnan(a), fill, a)
+
+
+def run_with_tape(G, chains, n_iter, trace_sweeps=()):
+    import torch
+
+    from openmcmc_amd.mcmc import MCMC
+
+    n, n_max = int(G["n"]), int(G["n_max"])
+    C = len(chains)
+    P = np.diag(G["P_diag"]) + np.diag(G["P_off"], 1) + np.diag(G["P_off"], -1)
+    k0 = G["init_k"][chains]
+    init_theta = [G["init_theta"][c][: int(k)] for c, k in zip(chains, k0)]
+    init_beta = [G["init_beta"][c][: int(k)] for c, k in zip(chains, k0)]
+    dev = torch.device("cuda", 0)
+    mdl, state, samplers = build(G["y"], G["X"], P, n_max, dev, C, init_theta, init_beta, k0)
+    tape = {k[5:]: G[k][chains] for k in G.files if k.startswith("tape_")}
+
+    def t(a):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+
+    s_b, s_beta, s_lam, s_tau, s_rw, s_rj = samplers
+    s_b.inject = lambda s, it: t(tape["z_b"][:, it])
+    s_beta.inject = lambda s, it: t(_nan0(tape["z_beta"][:, it], 0.0))
+    s_lam.inject = lambda s, it: t(tape["g"][:, it, 0])
+    s_tau.inject = lambda s, it: t(tape["g"][:, it, 1])
+    s_rw.inject = lambda s, it, j: t(_nan0(tape["rw_u"][:, it, j]).reshape(C, 1))
+    s_rw.inject_uniform = lambda s, it, j: t(_nan0(tape["rw_acc_u"][:, it, j]))
+    s_rj.inject_move = lambda s, it: (t(_nan0(tape["rj_move_u"][:, it])),
+                                      torch.as_tensor(np.maximum(tape["rj_idx"][:, it], 0).astype(np.int64), device=dev))
+    s_rj.inject_associated = lambda s, it: {"theta": t(_nan0(tape["rj_theta_u"][:, it]).reshape(C, 1))}
+    s_rj.inject_match = lambda s, it: t(_nan0(tape["rj_beta_u"][:, it]))
+    s_rj.inject_uniform = lambda s, it: t(_nan0(tape["rj_acc_u"][:, it]))
+    M = MCMC(state, samplers, model=mdl, n_burn=0, n_iter=n_iter, n_chains=C)
+    return M, samplers, tape
+
+
+def matched_transition_conditioning(G, c, n_iter):
+    """Largest condition number of the systems X'X + 1e-10 I that the matched birth/death transitions of chain c
+    solve (reversible_jump.py:240-242, 290-292), from a replay of the chain on the CPU oracle (which is pinned to
+    the reference by tests/test_oracle_golden.py)."""
+    from oracle import rj_sweep_ref
+
+    n_max = int(G["n_max"])
+    P = np.diag(G["P_diag"]) + np.diag(G["P_off"], 1) + np.diag(G["P_off"], -1)
+    conds = []
+    birth, death = rj_sweep_ref.matched_birth, rj_sweep_ref.matched_death
+
+    def spy_birth(B_cur, B_prop, *a):
+        conds.append(np.linalg.cond(B_prop.T @ B_prop + 1e-10 * np.eye(B_prop.shape[1])))
+        return birth(B_cur, B_prop, *a)
+
+    def spy_death(B_cur, B_prop, *a):
+        conds.append(np.linalg.cond(B_cur.T @ B_cur + 1e-10 * np.eye(B_cur.shape[1])))
+        return death(B_cur, B_prop, *a)
+
+    rj_sweep_ref.matched_birth, rj_sweep_ref.matched_death = spy_birth, spy_death
+    try:
+        k0 = int(G["init_k"][c])
+        tape = {k[5:]: G[k][c] for k in G.files if k.startswith("tape_")}
+        model = rj_sweep_ref.RjGmrfModel(G["y"], G["X"], P, make_basis_host, n_max)
+        rj_sweep_ref.rj_gmrf_chain(model, {"theta": G["init_theta"][c][:k0], "beta": G["init_beta"][c][:k0]}, tape, n_iter)
+    finally:
+        rj_sweep_ref.matched_birth, rj_sweep_ref.matched_death = birth, death
+    return max(conds)
+
+
+def test_rj_gmrf_chain_matches_reference(golden):
+    G = golden("rj_gmrf_chain")
+    chains = np.arange(G["init_k"].shape[0])
+    n_iter = int(G["n_iter"])
+    M, samplers, tape = run_with_tape(G, chains, n_iter)
+    M.run_mcmc()
+    got = M.collect()
+    # INT / index path: dimension trace identical
+    assert np.array_equal(got["n_basis"], G["store_n_basis"])
+    for key in ("theta", "beta"):
+        ref = G["store_" + key]
+        assert np.array_equal(np.isnan(got[key]), np.isnan(ref)), key  # NaN padding beyond the live length
+    keys = ("theta", "beta", "b", "lambda", "tau", "log_post", "y")
+    err = {}
+    for key in keys:
+        ref = G["store_" + key]
+        e = np.abs(got[key] - ref) / np.maximum(1.0, np.abs(ref))
+        err[key] = np.nanmax(e.reshape(len(chains), -1), axis=1)  # worst per chain over entries and sweeps
+    print("worst relative differences per chain over 150 sweeps:", {k: v.tolist() for k, v in err.items()})
+    # Bar: 1e-10.  The matched birth/death transition solves with X'X + 1e-10 I; when two knots nearly coincide that
+    # system has condition number 1e6..1e8, and the reference's own output is then only accurate to cond * eps:
+    # at the one such move of these chains (chain 3, sweep 146, cond 1.4e8) the reference is 7.8e-9 away from the
+    # exact-arithmetic answer (mpmath), and the difference propagates to the next sweeps through b and beta.  A
+    # chain that exceeds 1e-10 must therefore stay within cond_max * eps of the reference, cond_max taken from a
+    # replay of that chain on the oracle.  (test_matched_transition_accuracy_when_ill_conditioned compares the
+    # kernel with exact arithmetic directly.)
+    for c in chains:
+        if all(err[k][c] < 1e-10 for k in keys):
+            continue
+        cond = matched_transition_conditioning(G, int(c), n_iter)
+        for key in keys:
+            assert err[key][c] < 1e-10 + cond * 2.2e-16, (key, int(c), err[key][c], cond)
+    # accept counters of both Metropolis-Hastings samplers (INT)
+    s_rw, s_rj = samplers[4], samplers[5]
+    assert np.array_equal(s_rw.accept_rate.accept.cpu().numpy(), G["accept_rw"][:, 0].astype(np.int64))
+    assert np.array_equal(s_rw.accept_rate.proposal.cpu().numpy(), G["accept_rw"][:, 1].astype(np.int64))
+    assert np.array_equal(s_rj.accept_rate.accept.cpu().numpy(), G["accept_rj"][:, 0].astype(np.int64))
+    assert np.array_equal(s_rj.accept_rate.proposal.cpu().numpy(), G["accept_rj"][:, 1].astype(np.int64))
+
+
+def test_rj_internals_match_reference_per_sweep(golden):
+    """The MH internals the reference computed (proposal densities, log acceptance ratio, proposed coefficients)
+    for the first sweeps, chain by chain: localises a disagreement that the end-to-end test would only show as a
+    diverged chain."""
+    G = golden("rj_gmrf_chain")
+    chains = np.arange(G["init_k"].shape[0])
+    n_sweeps = 12
+    M, samplers, tape = run_with_tape(G, chains, n_sweeps)
+    s_rw, s_rj = samplers[4], samplers[5]
+    state = M.state
+    for it in range(n_sweeps):
+        s_rw.trace, s_rj.trace = {}, {}
+        for smp in samplers:
+            state = smp.sample(state)
+        M.engine.check_status()
+        # random-walk loop over the knots
+        for j, step in enumerate(s_rw.trace["steps"]):
+            ref_la = tape["rw_log_accept"][:, it, j]
+            act = ~np.isnan(ref_la)
+            got_la = step["log_alpha"].cpu().numpy()
+            assert np.all(np.isnan(got_la[~act]))
+            for name, ref in (("lq_fwd", tape["rw_lq_fwd"][:, it, j]), ("lq_rev", tape["rw_lq_rev"][:, it, j])):
+                g = step[name].cpu().numpy()
+                assert np.max(np.abs(g[act] - ref[act]) / np.maximum(1.0, np.abs(ref[act])), initial=0.0) < 1e-10, (it, j, name)
+            z = step["z"][:, 0, j].cpu().numpy()
+            assert np.max(np.abs(z[act] - tape["rw_z"][act, it, j]), initial=0.0) < 1e-10
+            # the log acceptance ratio is a difference of two log-posteriors of size ~1e2: absolute bar
+            assert np.max(np.abs(got_la[act] - ref_la[act]), initial=0.0) < 1e-8, (it, j)
+            exp_acc = np.log(_nan0(tape["rw_acc_u"][:, it, j])) < np.where(act, ref_la, -np.inf)
+            assert np.array_equal(step["accept"].cpu().numpy().astype(bool), exp_acc)
+        # reversible jump
+        tr = s_rj.trace
+        assert np.array_equal(tr["birth"].cpu().numpy(), tape["rj_birth"][:, it].astype(np.int32))
+        ref_idx = tape["rj_idx"][:, it].astype(np.int64)
+        assert np.array_equal(tr["deletion_index"].cpu().numpy(), ref_idx)
+        for name, ref in (("lq_fwd", tape["rj_lq_fwd"][:, it]), ("lq_rev", tape["rj_lq_rev"][:, it])):
+            g = tr[name].cpu().numpy()
+            assert np.max(np.abs(g - ref) / np.maximum(1.0, np.abs(ref))) < 1e-9, (it, name)
+        for key, ref in (("beta", tape["rj_prop_beta"][:, it]), ("theta", tape["rj_prop_theta"][:, it])):
+            g = tr["prop"][key].reshape(len(chains), -1).cpu().numpy()
+            live = ~np.isnan(ref)
+            assert np.max(np.abs(g[live] - ref[live]) / np.maximum(1.0, np.abs(ref[live]))) < 1e-9, (it, key)
+            assert not g[~live].any()
+        assert np.max(np.abs(tr["log_alpha"].cpu().numpy() - tape["rj_log_accept"][:, it])) < 1e-8, it

@@ -345,6 +345,67 @@ def test_matched_transitions_match_oracle(limits):
     eng.close()
 
 
+def test_matched_transition_accuracy_when_ill_conditioned():
+    """Two knots 0.00025 apart make X'X + 1e-10 I nearly singular (cond ~ 1e8): the reference's LU solve is then only
+    accurate to ~1e-8, so agreement with it cannot be the bar.  Here the kernel is compared with EXACT arithmetic
+    (mpmath, 60 digits): it must be at least as accurate as the reference's algorithm (the oracle), up to a factor."""
+    import mpmath as mp
+    import torch
+
+    from oracle import rj_sweep_ref
+
+    mp.mp.dps = 60
+    n, kmax = 48, 6
+    X = np.linspace(-10, 10, n)
+    theta = np.array([-6.1, -0.7, -0.70025, 3.3, 7.9])
+    beta = np.array([2.5, -1.3, 3.1, 0.4, -2.2])
+    k, idx = theta.size, 2
+
+    def basis(th):
+        return np.exp(-0.5 * (X[:, None] - th[None, :]) ** 2) / np.sqrt(2 * np.pi)
+
+    cur = basis(theta)
+    prop = np.delete(cur, idx, axis=1)
+    ref_out, ref_f, _ = rj_sweep_ref.matched_death(cur, prop, beta.reshape(k, 1), 1.0, (-10.0, 10.0), idx)
+    Bm = mp.matrix(cur.tolist())
+    Mm = Bm.T * Bm + mp.mpf("1e-10") * mp.eye(k)
+    Rm = Bm.T * mp.matrix(prop.tolist())
+    cols = [mp.lu_solve(Mm, Rm[:, j]) for j in range(k - 1)]
+    F = mp.zeros(k, k)
+    for i in range(k):
+        jj = 0
+        for j in range(k):
+            if j == idx:
+                F[i, j] = 1 if i == idx else 0
+            else:
+                F[i, j] = cols[jj][i]
+                jj += 1
+    mu = mp.lu_solve(F, mp.matrix(beta.tolist()))
+    exact = np.array([float(mu[i]) for i in range(k) if i != idx])
+    exact_f = float(mp.log(mp.det(F)))
+    C = 2
+    eng = make_engine(C)
+    Bc, Bp = np.zeros((C, kmax, n)), np.zeros((C, kmax, n))
+    Bc[:, :k], Bp[:, : k - 1] = cur.T, prop.T
+    coef = np.zeros((C, kmax))
+    coef[:, :k] = beta
+    gc, _ = eng.design_gram_batched(eng.to_device(Bc))
+    gp, _ = eng.design_gram_batched(eng.to_device(Bp))
+    lqf, lqr = eng.zeros(C), eng.zeros(C)
+    got = eng.rj_matched_transition(gc, gp, eng.full((C,), float(k)), torch.zeros(C, dtype=torch.int32, device="cuda"),
+                                    torch.full((C,), idx, dtype=torch.int64, device="cuda"), eng.to_device(coef), 1.0,
+                                    (-10.0, 10.0), lqf, lqr)
+    eng.check_status()
+    g = got.cpu().numpy()[0, : k - 1]
+    err_ref = np.max(np.abs(ref_out.ravel() - exact))
+    err_gpu = np.max(np.abs(g - exact))
+    cond = np.linalg.cond(cur.T @ cur + 1e-10 * np.eye(k))
+    print(f"cond {cond:.3g}: |reference - exact| = {err_ref:.3g}, |kernel - exact| = {err_gpu:.3g}")
+    assert cond > 1e7 and err_gpu < 4 * err_ref + cond * 1e-17
+    assert abs(lqf.cpu().numpy()[0] - exact_f) < 4 * abs(ref_f - exact_f) + cond * 1e-17
+    eng.close()
+
+
 def test_ragged_log_densities():
     from scipy import stats
 
