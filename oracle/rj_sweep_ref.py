@@ -141,7 +141,7 @@ class RjGmrfModel:
             fwd = f + np.log(p_birth) + log_prior_theta
             rev = r + np.log(p_death)
         else:
-            idx = int(idx)
+            idx = int(idx) % k  # recorded tapes hold the index itself; synthetic tapes any non-negative integer
             prop["theta"] = np.delete(st["theta"], obj=idx, axis=1)
             prop["B"] = np.delete(st["B"], obj=idx, axis=1)
             prop["beta"], f, r = matched_death(st["B"], prop["B"], st["beta"], self.match_scale, self.match_limits, idx)
@@ -149,7 +149,8 @@ class RjGmrfModel:
             rev = r + np.log(p_birth) + log_prior_theta
         log_accept = self.log_p(prop) + rev - (self.log_p(st) + fwd)
         if trace is not None:
-            trace.update({"rj_birth": float(birth), "rj_lq_fwd": fwd, "rj_lq_rev": rev, "rj_log_accept": log_accept,
+            trace.update({"rj_birth": float(birth), "rj_idx": -1 if birth else idx, "rj_lq_fwd": fwd, "rj_lq_rev": rev,
+                          "rj_log_accept": log_accept,
                           "rj_prop_beta": prop["beta"].ravel().copy(), "rj_prop_theta": prop["theta"].ravel().copy()})
         accepted = bool(np.log(u_acc) < log_accept)
         return (prop if accepted else st), accepted

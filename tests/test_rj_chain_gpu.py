@@ -18,19 +18,24 @@ def _nan0(a, fill=0.5):
 
 
 def run_with_tape(G, chains, n_iter, trace_sweeps=()):
-    import torch
-
-    from openmcmc_amd.mcmc import MCMC
-
-    n, n_max = int(G["n"]), int(G["n_max"])
-    C = len(chains)
+    n_max = int(G["n_max"])
     P = np.diag(G["P_diag"]) + np.diag(G["P_off"], 1) + np.diag(G["P_off"], -1)
     k0 = G["init_k"][chains]
     init_theta = [G["init_theta"][c][: int(k)] for c, k in zip(chains, k0)]
     init_beta = [G["init_beta"][c][: int(k)] for c, k in zip(chains, k0)]
-    dev = torch.device("cuda", 0)
-    mdl, state, samplers = build(G["y"], G["X"], P, n_max, dev, C, init_theta, init_beta, k0)
     tape = {k[5:]: G[k][chains] for k in G.files if k.startswith("tape_")}
+    return mcmc_with_tape(G["y"], G["X"], P, n_max, init_theta, init_beta, k0, tape, n_iter)
+
+
+def mcmc_with_tape(y, X, P, n_max, init_theta, init_beta, k0, tape, n_iter):
+    """MCMC over len(k0) chains with every draw injected from `tape` (arrays with a leading chain axis)."""
+    import torch
+
+    from openmcmc_amd.mcmc import MCMC
+
+    C = len(k0)
+    dev = torch.device("cuda", 0)
+    mdl, state, samplers = build(y, X, P, n_max, dev, C, init_theta, init_beta, k0)
 
     def t(a):
         return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
@@ -165,3 +170,49 @@ def test_rj_internals_match_reference_per_sweep(golden):
             assert np.max(np.abs(g[live] - ref[live]) / np.maximum(1.0, np.abs(ref[live]))) < 1e-9, (it, key)
             assert not g[~live].any()
         assert np.max(np.abs(tr["log_alpha"].cpu().numpy() - tape["rj_log_accept"][:, it])) < 1e-8, it
+
+
+def test_rj_gmrf_full_size_matches_oracle():
+    """BASELINE configs[4] sizes (n = 5000 nodes, n_max = 20): three chains with different starting dimensions for a
+    few sweeps against the CPU oracle on a synthetic draw tape (the reference needs 80 ms per chain-update here, the
+    oracle about as long, so the full 512-chain workload is only timed: benchmarks/cfg5_rj_gmrf.py)."""
+    from scipy import sparse
+
+    from oracle import gmrf_ref, rj_sweep_ref
+
+    n, n_max, S = 5000, 20, 4
+    rng = np.random.default_rng(77)
+    X = np.linspace(-10, 10, n)
+    y = (make_basis_host(X.reshape(n, 1), np.array([[-6.0, -1.0, 4.5]])) @ np.array([[3.0], [-2.0], [4.0]])).ravel()
+    y = y + 0.05 * np.cumsum(rng.standard_normal(n)) * np.sqrt(48.0 / n) + 0.1 * rng.standard_normal(n)
+    P = sparse.lil_matrix(gmrf_ref.rw1_precision(np.arange(float(n))))
+    P[0, 0] += 1e-3
+    P = P.tocsc()
+    k0 = np.array([1.0, 7.0, 20.0])
+    C = k0.size
+    init_theta = [rng.uniform(-10, 10, size=int(k)) for k in k0]
+    init_beta = [rng.standard_normal(int(k)) for k in k0]
+    tape = {"z_b": rng.standard_normal((C, S, n)), "z_beta": rng.standard_normal((C, S, n_max)),
+            "g": np.stack([rng.standard_gamma(10 + n / 2, size=(C, S)), rng.standard_gamma(1 + n / 2, size=(C, S))], axis=2),
+            "rw_u": rng.random((C, S, n_max)), "rw_acc_u": rng.random((C, S, n_max)), "rj_move_u": rng.random((C, S)),
+            "rj_theta_u": rng.random((C, S)), "rj_beta_u": rng.random((C, S)), "rj_acc_u": rng.random((C, S)),
+            "rj_idx": rng.integers(0, 1 << 20, size=(C, S)).astype(float)}
+    model = rj_sweep_ref.RjGmrfModel(y, X, P, make_basis_host, n_max)
+    stores, idx_used = [], np.zeros((C, S))
+    for c in range(C):
+        st, traces, _ = rj_sweep_ref.rj_gmrf_chain(model, {"theta": init_theta[c], "beta": init_beta[c]},
+                                                   {k: v[c] for k, v in tape.items()}, S)
+        stores.append(st)
+        idx_used[c] = [max(t["rj_idx"], 0) for t in traces]
+    tape["rj_idx"] = idx_used
+    M, samplers, _ = mcmc_with_tape(y, X, P, n_max, init_theta, init_beta, k0, tape, S)
+    M.run_mcmc()
+    got = M.collect()
+    for c in range(C):
+        assert np.array_equal(got["n_basis"][c], stores[c]["n_basis"])
+        for key in ("theta", "beta", "b", "lambda", "tau", "log_post", "y"):
+            ref = stores[c][key]
+            assert np.array_equal(np.isnan(got[key][c]), np.isnan(ref)), key
+            live = ~np.isnan(ref)
+            err = np.max(np.abs(got[key][c][live] - ref[live]) / np.maximum(1.0, np.abs(ref[live])))
+            assert err < 1e-9, (c, key, err)
