@@ -33,10 +33,12 @@ P[0, 0] += 1e-3
 k0 = np.clip(rng.poisson(5, size=C), 1, n_max)                       # n_basis ~ Poisson(5), theta ~ U(-10, 10)
 init_theta = [rng.uniform(-10, 10, size=k) for k in k0]
 init_beta = [rng.standard_normal(k) for k in k0]
-dev = torch.device("cuda", 0)
-mdl, state, samplers = build(y, X, P.tocsc(), n_max, dev, C, init_theta, init_beta, k0.astype(float))
+from openmcmc_amd.engine import Engine
+
+eng = Engine(C, seed=a.seed)
+mdl, state, samplers = build(y, X, P.tocsc(), n_max, eng, init_theta, init_beta, k0.astype(float))
 total = a.warmup + a.steps
-M = MCMC(state, samplers, model=mdl, n_burn=a.warmup, n_iter=a.steps, n_chains=C, seed=a.seed)
+M = MCMC(state, samplers, model=mdl, n_burn=a.warmup, n_iter=a.steps, n_chains=C, seed=a.seed, engine=eng)
 # time the stored iterations only: run the burn-in, then the rest
 M_n_iter = M.n_iter
 M.n_iter = 0

@@ -296,6 +296,13 @@ omc_status omc_ragged_resize(omc_ctx* ctx, int64_t rows, int64_t kmax, const dou
                              const int64_t* del_index, const double* new_vals, const double* src, double* dst,
                              int64_t chain_stride, int64_t row_stride, int64_t col_stride);
 
+/* Gaussian-kernel basis on per-chain knots, the design matrix of the reference's reversible-jump example
+ * (tests/test_reversible_jump.py:24-40: norm.pdf(X, loc=knot, scale=scale) per column):
+ *   B[c][j][i] = exp(-t^2/2) / sqrt(2 pi) / s,  t = (X[i] - knots[c][j]) / s,  s = scales[c][j] or scale0 (scales NULL)
+ *   for j < count[c], 0 beyond.  column >= 0 rewrites only that column (one knot moved), -1 all of them.      */
+omc_status omc_gaussian_basis(omc_ctx* ctx, int64_t n, int64_t kmax, const double* X, const double* knots,
+                              const double* scales, double scale0, const double* count, int64_t column, double* B);
+
 /* Per-chain design matrices B_c (n x kmax; column j of chain c contiguous at B[(c*kmax + j)*n]):
  *   omc_design_predict_batched: out[c] = chain_scale[c] * (alpha * B_c coef_c + add_chain[c] + add_shared)
  *     (LinearCombination.predictor / predictor_conditional, parameter.py:162-197, for a basis that depends on
@@ -303,12 +310,14 @@ omc_status omc_ragged_resize(omc_ctx* ctx, int64_t rows, int64_t kmax, const dou
  *     add_chain [C][n], add_shared [n], chain_scale [C] may be NULL;
  *   omc_design_gram_batched:    gram[c] = B_c' diag(w) B_c (kmax x kmax, row-major),
  *     rhs[c] = B_c' diag(w) (resid_shared - resid_chain[c])   (location_scale.py:238-241, sampler.py:192);
- *     w [n] shared or NULL = ones; resid_* / rhs may be NULL.  kmax <= 36.                                  */
+ *     w [n] shared or NULL = ones; resid_* / rhs may be NULL; count [C] (NULL = kmax): only the leading count[c]
+ *     columns are live, the rest of gram / rhs is written as 0.  kmax <= 36.                                 */
 omc_status omc_design_predict_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* coef,
                                       const double* add_chain, const double* add_shared, double alpha,
                                       const double* chain_scale, double* out);
 omc_status omc_design_gram_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* w,
-                                   const double* resid_shared, const double* resid_chain, double* gram, double* rhs);
+                                   const double* resid_shared, const double* resid_chain, const double* count,
+                                   double* gram, double* rhs);
 
 /* NormalNormal.sample (sampler.py:176-197 -> gmrf.py:167-198) for a small ragged parameter:
  *   Q_c = diag(prior_prec[c]) + lik_scale[c]*gram[c],  b_c = prior_prec[c]*prior_mean[c] + lik_scale[c]*gram_rhs[c]

@@ -139,38 +139,65 @@ __global__ void k_design_predict_batched(int64_t C, int64_t n, int64_t kmax, con
   }
 }
 
-// Gram matrix B'WB (kmax x kmax) and B'W r (kmax) of one chain per workgroup.  The residual is
-// carried as column kmax of the tile, pairs (a, b) are distributed over the threads.
+// Gaussian-kernel basis B[c][j][i] = phi((X_i - knot_cj) / scale_cj) / scale_cj for the live knots, zero beyond;
+// column >= 0 rewrites only that column (a random-walk move of one knot)
+__global__ void k_gaussian_basis(int64_t C, int64_t n, int64_t kmax, const double* X, const double* knots,
+                                 const double* scales, double scale0, const double* count, int64_t column, double* B) {
+  const int64_t c = blockIdx.z;
+  const int64_t j = column >= 0 ? column : (int64_t)blockIdx.y;
+  const bool live = !count || (double)j < count[c];
+  const double th = knots[c * kmax + j];
+  const double sc = scales ? scales[c * kmax + j] : scale0;
+  double* out = B + (c * kmax + j) * n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double v = 0.0;
+    if (live) {
+      const double t = (X[i] - th) / sc;
+      v = exp(-(t * t) / 2.0) / 2.5066282746310002 / sc;  // scipy norm.pdf: exp(-x^2/2)/sqrt(2 pi), then / scale
+    }
+    out[i] = v;
+  }
+}
+
+// Gram matrix B'WB (kmax x kmax) and B'W r (kmax) of one chain per workgroup.  Only the live columns
+// (count[c] of them) are staged; the residual rides along as one more tile column.  Work items are
+// (pair (a <= b), row slice): with few live columns the 256 threads split the rows of a tile between them
+// and the slices are summed in a fixed order at the end, so the result does not depend on scheduling.
 #define GRAM_TR 128
 __global__ void __launch_bounds__(256) k_design_gram_batched(int64_t n, int64_t kmax, const double* B, const double* w,
                                                              const double* resid_shared, const double* resid_chain,
-                                                             double* gram, double* rhs) {
-  extern __shared__ double tile[];  // (kmax + 2) x (GRAM_TR + 1): columns, residual, weights
+                                                             const double* count, double* gram, double* rhs) {
+  extern __shared__ double tile[];  // (kmax + 1) x (GRAM_TR + 1) columns + residual, then weights[GRAM_TR]
   const int64_t c = blockIdx.x;
   const double* Bc = B + c * kmax * n;
-  const int K1 = (int)kmax + 1;
+  const int k = count ? (int)count[c] : (int)kmax;   // live columns
+  const int K1 = k + 1;                              // + residual
   const int ld = GRAM_TR + 1;
-  double* wt = tile + (int64_t)K1 * ld;
+  double* wt = tile + ((int64_t)kmax + 1) * ld;
   const int n_pairs = K1 * (K1 + 1) / 2;
-  double acc[3] = {0.0, 0.0, 0.0};  // kmax <= 36 -> at most 3 pairs per thread
-  int pa[3], pb[3];
+  const int S = n_pairs >= 256 ? 1 : 256 / n_pairs;  // row slices
+  const int items = n_pairs * S;
+  double acc[3] = {0.0, 0.0, 0.0};  // kmax <= 36 -> at most 3 items per thread
+  int pa[3], pb[3], ps[3];
   for (int q = 0; q < 3; ++q) {
-    int pidx = (int)threadIdx.x + q * 256;
-    pa[q] = pb[q] = -1;
-    if (pidx < n_pairs) {  // unrank (a <= b) from the row-major upper triangle
-      int a = 0, rem = pidx;
+    const int item = (int)threadIdx.x + q * 256;
+    pa[q] = pb[q] = -1; ps[q] = 0;
+    if (item < items) {  // unrank (a <= b) from the row-major upper triangle
+      int a = 0, rem = item % n_pairs;
       while (rem >= K1 - a) { rem -= K1 - a; ++a; }
-      pa[q] = a; pb[q] = a + rem;
+      pa[q] = a; pb[q] = a + rem; ps[q] = item / n_pairs;
     }
   }
+  for (int t = threadIdx.x; t < kmax * kmax; t += 256) gram[c * kmax * kmax + t] = 0.0;
+  if (rhs) for (int t = threadIdx.x; t < kmax; t += 256) rhs[c * kmax + t] = 0.0;
   for (int64_t i0 = 0; i0 < n; i0 += GRAM_TR) {
     const int len = (int)((n - i0 < GRAM_TR) ? n - i0 : GRAM_TR);
     for (int t = threadIdx.x; t < K1 * GRAM_TR; t += 256) {
       const int col = t / GRAM_TR, i = t % GRAM_TR;
       double v = 0.0;
       if (i < len)
-        v = (col < kmax) ? Bc[(int64_t)col * n + i0 + i]
-                         : (resid_shared ? resid_shared[i0 + i] : 0.0) - (resid_chain ? resid_chain[c * n + i0 + i] : 0.0);
+        v = (col < k) ? Bc[(int64_t)col * n + i0 + i]
+                      : (resid_shared ? resid_shared[i0 + i] : 0.0) - (resid_chain ? resid_chain[c * n + i0 + i] : 0.0);
       tile[col * ld + i] = v;
     }
     for (int i = threadIdx.x; i < GRAM_TR; i += 256) wt[i] = (i < len) ? (w ? w[i0 + i] : 1.0) : 0.0;
@@ -180,18 +207,30 @@ __global__ void __launch_bounds__(256) k_design_gram_batched(int64_t n, int64_t 
       const double* ta = tile + pa[q] * ld;
       const double* tb = tile + pb[q] * ld;
       double s = acc[q];
-      for (int i = 0; i < GRAM_TR; ++i) s = fma(ta[i] * wt[i], tb[i], s);
+      for (int i = ps[q]; i < GRAM_TR; i += S) s = fma(ta[i] * wt[i], tb[i], s);
       acc[q] = s;
     }
     __syncthreads();
   }
+  // sum the row slices (the tile is free now: S x n_pairs partials)
+  if (S > 1) {
+    if (pa[0] >= 0) tile[ps[0] * n_pairs + ((int)threadIdx.x % n_pairs)] = acc[0];
+    __syncthreads();
+    if ((int)threadIdx.x < n_pairs) {
+      double s = 0.0;
+      for (int sl = 0; sl < S; ++sl) s += tile[sl * n_pairs + threadIdx.x];
+      acc[0] = s;
+    } else {
+      pa[0] = -1;
+    }
+  }
   for (int q = 0; q < 3; ++q) {
     if (pa[q] < 0) continue;
     const int a = pa[q], b = pb[q];
-    if (b < kmax) {
+    if (b < k) {
       gram[c * kmax * kmax + a * kmax + b] = acc[q];
       gram[c * kmax * kmax + b * kmax + a] = acc[q];
-    } else if (a < kmax && rhs) {
+    } else if (a < k && rhs) {
       rhs[c * kmax + a] = acc[q];
     }
   }
@@ -489,6 +528,19 @@ omc_status omc_ragged_resize(omc_ctx* ctx, int64_t rows, int64_t kmax, const dou
   return OMC_OK;
 }
 
+omc_status omc_gaussian_basis(omc_ctx* ctx, int64_t n, int64_t kmax, const double* X, const double* knots,
+                              const double* scales, double scale0, const double* count, int64_t column, double* B) {
+  if (!ctx || n < 1 || kmax < 1 || !X || !knots || !B || column >= kmax || (!scales && !(scale0 > 0.0)))
+    return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  unsigned gx = grid1(n, 256);
+  if (gx > 32) gx = 32;
+  hipLaunchKernelGGL(k_gaussian_basis, dim3(gx, column >= 0 ? 1u : (unsigned)kmax, (unsigned)ctx->n_chains), dim3(256), 0,
+                     ctx->stream, ctx->n_chains, n, kmax, X, knots, scales, scale0, count, column, B);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
 omc_status omc_design_predict_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* coef,
                                       const double* add_chain, const double* add_shared, double alpha,
                                       const double* chain_scale, double* out) {
@@ -503,12 +555,13 @@ omc_status omc_design_predict_batched(omc_ctx* ctx, int64_t n, int64_t kmax, con
 }
 
 omc_status omc_design_gram_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* w,
-                                   const double* resid_shared, const double* resid_chain, double* gram, double* rhs) {
+                                   const double* resid_shared, const double* resid_chain, const double* count,
+                                   double* gram, double* rhs) {
   if (!ctx || n < 1 || kmax < 1 || kmax > 36 || !B || !gram) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   const size_t lds = (size_t)((kmax + 1) * (GRAM_TR + 1) + GRAM_TR) * sizeof(double);
   hipLaunchKernelGGL(k_design_gram_batched, dim3((unsigned)ctx->n_chains), dim3(256), lds, ctx->stream, n, kmax, B, w,
-                     resid_shared, resid_chain, gram, rhs);
+                     resid_shared, resid_chain, count, gram, rhs);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

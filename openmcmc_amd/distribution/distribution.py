@@ -150,8 +150,11 @@ class Uniform(Distribution):
         lo = np.broadcast_to(self.domain_response_lower, (p, 1)).reshape(-1)
         rng = self.domain_range(state).reshape(-1)
         u = None if inject is None else inject.reshape(engine.n_chains, p * n).contiguous()
-        draw = engine.uniform_draw(engine.to_device(np.repeat(lo, n)), engine.to_device(np.repeat(rng, n)), inject=u,
-                                   draw_index=draw_index, sub=sub)
+        consts = self.__dict__.setdefault("_dev_consts", {})
+        if (p, n) not in consts:  # uploaded once: a host-to-device copy per call would stall the launch queue
+            consts[(p, n)] = (engine.to_device(np.repeat(lo, n)), engine.to_device(np.repeat(rng, n)))
+        lo_d, rng_d = consts[(p, n)]
+        draw = engine.uniform_draw(lo_d, rng_d, inject=u, draw_index=draw_index, sub=sub)
         return ChainArray(draw.reshape(engine.n_chains, p, n))
 
 

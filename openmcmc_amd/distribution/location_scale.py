@@ -106,13 +106,19 @@ class Normal(Distribution):
             M, scale_key = state[self.precision.form], None
         if is_chain(M):
             raise NotImplementedError("per-chain precision matrices")
+        memo = self.__dict__.setdefault("_structure_memo", {})
+        hit = memo.get(id(M))
+        if hit is not None and hit.matrix is M and hit.scale_key == scale_key:
+            return hit  # shared matrices are immutable: the band extraction is done once, not every log_p
         if M.shape[0] != M.shape[1]:
             raise ValueError("Matrix is not square")
         n = M.shape[0]
         bands = tridiagonal_bands(M, n)
         diag, off = bands if bands is not None else (False, False)  # False = not tridiagonal
         d = M.diagonal() if sparse.issparse(M) else np.diag(np.asarray(M))
-        return NormalStructure(n=n, matrix=M, scale_key=scale_key, diag=diag, off=off, n_pos=int(np.sum(d > 0)))
+        st = NormalStructure(n=n, matrix=M, scale_key=scale_key, diag=diag, off=off, n_pos=int(np.sum(d > 0)))
+        memo[id(M)] = st
+        return st
 
     def chain_and_center(self, state):
         """(x, m): the per-chain vector and the shared vector such that the residual of the Gaussian

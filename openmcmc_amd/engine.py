@@ -472,6 +472,16 @@ class Engine:
                                     C.c_void_p(dst.data_ptr()), st[0], rs, js))
         return dst
 
+    def gaussian_basis(self, X, knots, out, count=None, scales=None, scale=1.0, column=None):
+        """Gaussian-kernel basis on per-chain knots written into out (C, kmax, n); column: rewrite only that column."""
+        Cn, kmax, n = out.shape
+        if not out.is_contiguous():
+            raise ValueError("out must be a contiguous (C, kmax, n) tensor")
+        check(lib.omc_gaussian_basis(self._ctx, n, kmax, self._vec(X, n), self._p(knots, Cn, kmax), self._p(scales),
+                                     float(scale), self._chain_scalar(count), -1 if column is None else int(column),
+                                     self._p(out.view(Cn, -1))))
+        return out
+
     def design_predict_batched(self, B, coef, add_chain=None, add_shared=None, alpha=1.0, chain_scale=None, out=None):
         """out[c] = chain_scale[c] * (alpha * B_c coef_c + add_chain[c] + add_shared);
         B: (C, kmax, n) contiguous (column j of chain c contiguous)."""
@@ -484,8 +494,9 @@ class Engine:
                                              self._chain_scalar(chain_scale), self._p(out)))
         return out
 
-    def design_gram_batched(self, B, w=None, resid_shared=None, resid_chain=None):
-        """(gram (C, kmax, kmax), rhs (C, kmax) or None) = (B_c' W B_c, B_c' W (resid_shared - resid_chain[c]))."""
+    def design_gram_batched(self, B, w=None, resid_shared=None, resid_chain=None, count=None):
+        """(gram (C, kmax, kmax), rhs (C, kmax) or None) = (B_c' W B_c, B_c' W (resid_shared - resid_chain[c]));
+        count (C,): only the leading count[c] columns of chain c are live (the rest of the outputs is 0)."""
         Cn, kmax, n = B.shape
         if not B.is_contiguous():
             raise ValueError("B must be a contiguous (C, kmax, n) tensor")
@@ -493,8 +504,8 @@ class Engine:
         want_rhs = resid_shared is not None or resid_chain is not None
         rhs = self.empty(Cn, kmax) if want_rhs else None
         check(lib.omc_design_gram_batched(self._ctx, n, kmax, self._p(B.view(Cn, -1)), self._vec(w, n),
-                                          self._vec(resid_shared, n), self._p(resid_chain), self._p(gram.view(Cn, -1)),
-                                          self._p(rhs)))
+                                          self._vec(resid_shared, n), self._p(resid_chain), self._chain_scalar(count),
+                                          self._p(gram.view(Cn, -1)), self._p(rhs)))
         return gram, rhs
 
     def small_sample_canonical(self, gram, gram_rhs, prior_prec, lik_scale=None, prior_mean=None, count=None, z=None,

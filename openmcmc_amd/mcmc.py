@@ -35,6 +35,7 @@ class MCMC:
     device: int = 0
     chain_id_offset: int = 0
     fuse: bool = True
+    engine: object = None  # an existing Engine (e.g. one that user callbacks already hold); default: a new one
     store: dict = field(default_factory=dict, init=False)
 
     def __post_init__(self):
@@ -45,7 +46,10 @@ class MCMC:
             if sparse.issparse(term) or is_chain(term):
                 continue
             self.state[key] = host_2d(term)
-        self.engine = Engine(self.n_chains, seed=self.seed, device=self.device, chain_id_offset=self.chain_id_offset)
+        if self.engine is None:
+            self.engine = Engine(self.n_chains, seed=self.seed, device=self.device, chain_id_offset=self.chain_id_offset)
+        elif self.engine.n_chains != self.n_chains:
+            raise ValueError("engine holds a different number of chains")
         eng, C = self.engine, self.n_chains
         ns = len(self.samplers)
         for pos, sampler in enumerate(self.samplers):

@@ -212,8 +212,7 @@ class MixtureParameter(Parameter, ABC):
         alloc, par = state[self.allocation], state[self.param]
         if not is_chain(alloc) or is_chain(par):
             raise NotImplementedError("mixture parameters need a per-chain allocation and a shared parameter vector")
-        return engine.mixture_gather(engine.shared(np.asarray(par, dtype=np.float64).reshape(-1)), alloc.vector(),
-                                     count=alloc.count(state), fill=fill)
+        return engine.mixture_gather(engine.shared(par).reshape(-1), alloc.vector(), count=alloc.count(state), fill=fill)
 
 
 @dataclass

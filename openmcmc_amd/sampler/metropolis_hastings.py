@@ -100,12 +100,16 @@ class MetropolisHastings(MCMCSampler):
 
     # ------------------------------------------------------------------ generic route
     def _accept_reject_proposal(self, current_state: dict, prop_state: dict, logp_pr_g_cr, logp_cr_g_pr, count=None,
-                                index=0, u=None, sub=0, trace=None) -> dict:
+                                index=0, u=None, sub=0, trace=None, lp_cur=None) -> dict:
         """metropolis_hastings.py:127-173 for every chain at once: log_alpha = lp' + q_rev - (lp + q_fwd), accept iff
         log U < log_alpha, then current_state takes the proposed value of every entry that differs, chain by chain.
-        `count`/`index` gate the chains taking part (a loop over the columns of a ragged parameter)."""
+        `count`/`index` gate the chains taking part (a loop over the columns of a ragged parameter).
+        `lp_cur`: the model log-density of current_state if the caller already has it (the reference recomputes it
+        for every proposal; inside a loop over columns it is the value selected at the previous step); it is
+        updated in place to the log-density of the returned state and kept in self._lp_state."""
         eng = self._need_engine()
-        lp_cur = self.model.log_p(current_state, engine=eng)
+        if lp_cur is None:
+            lp_cur = self.model.log_p(current_state, engine=eng)
         lp_prop = self.model.log_p(prop_state, engine=eng)
         log_alpha = eng.empty(eng.n_chains) if trace is not None else None
         acc = eng.mh_accept(lp_cur, lp_prop, _as_chain_tensor(eng, logp_pr_g_cr), _as_chain_tensor(eng, logp_cr_g_pr),
@@ -113,7 +117,7 @@ class MetropolisHastings(MCMCSampler):
                             accept_count=self.accept_rate.accept, proposal_count=self.accept_rate.proposal,
                             log_alpha=log_alpha)
         if trace is not None:
-            trace.update(log_alpha=log_alpha, accept=acc, lp_cur=lp_cur, lp_prop=lp_prop)
+            trace.update(log_alpha=log_alpha, accept=acc, lp_cur=lp_cur.clone(), lp_prop=lp_prop)
         for key, value in prop_state.items():
             cur = current_state.get(key)
             if value is cur or not is_chain(value):
@@ -121,6 +125,8 @@ class MetropolisHastings(MCMCSampler):
             if not is_chain(cur) or cur.data.shape != value.data.shape:
                 raise NotImplementedError(f"proposed state entry '{key}' changes kind or padded shape")
             eng.chain_select(acc, value.storage(), cur.storage())
+        eng.chain_select(acc, lp_prop, lp_cur)
+        self._lp_state = lp_cur
         return current_state
 
 
@@ -204,7 +210,7 @@ class RandomWalk(MetropolisHastings):
             lq_f, lq_r = _add_contribution(eng, lq_f, f_extra), _add_contribution(eng, lq_r, r_extra)
         return prop_state, lq_f, lq_r
 
-    def _generic_step(self, current_state, param_index=None):
+    def _generic_step(self, current_state, param_index=None, lp_cur=None):
         x = current_state[self.param]
         p = x.shape[0]
         col = 0 if param_index is None else int(param_index)
@@ -218,7 +224,8 @@ class RandomWalk(MetropolisHastings):
             self.trace.setdefault("steps", []).append(trace)
         return self._accept_reject_proposal(current_state, prop_state, lq_f, lq_r,
                                             count=x.count(current_state) if ragged_cols else None, index=col, u=u,
-                                            sub=col * self._blocks_per_proposal(p) + (p + 1) // 2, trace=trace)
+                                            sub=col * self._blocks_per_proposal(p) + (p + 1) // 2, trace=trace,
+                                            lp_cur=lp_cur)
 
     def sample(self, current_state: dict) -> dict:
         eng = self._need_engine()
@@ -248,8 +255,10 @@ class RandomWalkLoop(RandomWalk):
         n_cols = x.shape[1]
         if x.ragged is not None and x.ragged[1] == 1:
             n_cols = int(x.count(current_state).max().item())
+        lp = None  # log-density of the current state, carried from one column to the next
         for param_index in range(n_cols):
-            current_state = self._generic_step(current_state, param_index)
+            current_state = self._generic_step(current_state, param_index, lp_cur=lp)
+            lp = self._lp_state
         self._sweep += 1
         return current_state
 

@@ -262,7 +262,7 @@ class NormalNormal(MCMCSampler):
         _, pmean, pprec, count = prior.mixture_pieces(state, eng)
         B = state[dist.mean.form[self.param]]
         w = None if st.diag is None else eng.shared(st.diag)
-        y = eng.shared(np.asarray(state[key], dtype=np.float64).reshape(-1))
+        y = eng.shared(state[key]).reshape(-1)  # cached by the identity of the state's own array
         rest = None
         if dist.mean.has_chain_terms(state, exclude=self.param):
             rest = dist.mean.predictor_device(state, eng, exclude=self.param)
@@ -270,7 +270,7 @@ class NormalNormal(MCMCSampler):
             host = dist.mean.predictor_conditional(state, term_to_exclude=self.param)
             if not isinstance(host, int):
                 y = eng.to_device(np.asarray(state[key], dtype=np.float64).reshape(-1) - np.asarray(host).reshape(-1))
-        gram, rhs = eng.design_gram_batched(B.columns(), w=w, resid_shared=y, resid_chain=rest)
+        gram, rhs = eng.design_gram_batched(B.columns(), w=w, resid_shared=y, resid_chain=rest, count=B.count(state))
         scale = _as_chain_scalar(eng, state, st.scale_key).scalar() if st.scale_key is not None else None
         x = eng.small_sample_canonical(gram, rhs, pprec, lik_scale=scale, prior_mean=pmean, count=count, z=z,
                                        draw_index=self._draw_index())

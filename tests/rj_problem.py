@@ -14,24 +14,27 @@ def make_basis_host(X, theta):
     return np.exp(-((X - theta) ** 2) / 2.0) / math.sqrt(2 * math.pi)
 
 
-def make_basis(state, X_dev):
+def make_basis(state, X_dev, engine, column=None):
     """B[c, i, k] = phi(X_i - theta[c, k]) for the live knots of chain c, zero columns beyond: the batched form of
-    the reference test's make_basis (tests/test_reversible_jump.py:24-40, unit scales).  Returned as an (n, k_max)
-    ChainArray kept column-major per chain (what the per-chain design kernels read)."""
-    import torch
-
+    the reference test's make_basis (tests/test_reversible_jump.py:24-40, unit scales), by the library's
+    Gaussian-kernel basis kernel.  Returned as an (n, k_max) ChainArray kept column-major per chain (what the
+    per-chain design kernels read).  With `column` only that column is recomputed (one knot moved); the other
+    columns are carried over from state["B"]."""
     from openmcmc_amd.chains import ChainArray
 
     theta = state["theta"]
-    th = theta.data[:, 0, :]                                    # (C, k_max)
-    live = torch.arange(th.shape[1], device=th.device).unsqueeze(0) < theta.count(state).unsqueeze(1)
-    d = X_dev.reshape(1, 1, -1) - th.unsqueeze(2)               # (C, k_max, n)
-    B = torch.exp(-(d * d) / 2.0) / math.sqrt(2 * math.pi) * live.unsqueeze(2)
-    return ChainArray(B.transpose(1, 2), ragged=(theta.ragged[0], 1))
+    C, _, k_max = theta.data.shape
+    if column is None or "B" not in state:
+        out, column = engine.empty(C, k_max, X_dev.numel()), None
+    else:
+        out = state["B"].columns().clone()
+    engine.gaussian_basis(X_dev, theta.data[:, 0, :], out, count=theta.count(state), scale=1.0, column=column)
+    return ChainArray(out.transpose(1, 2), ragged=(theta.ragged[0], 1))
 
 
-def build(y, X, P, n_max, engine_device, n_chains, init_theta, init_beta, init_k):
-    """(model, state, samplers): the model of make_golden_rj.rj_gmrf_problem on `n_chains` chains."""
+def build(y, X, P, n_max, engine, init_theta, init_beta, init_k):
+    """(model, state, samplers): the model of make_golden_rj.rj_gmrf_problem on the chains of `engine`
+    (pass the same engine to MCMC)."""
     import torch
 
     from openmcmc_amd.chains import ChainArray, ragged_from_lists
@@ -44,7 +47,7 @@ def build(y, X, P, n_max, engine_device, n_chains, init_theta, init_beta, init_k
     from openmcmc_amd.sampler.sampler import NormalGamma, NormalNormal
 
     n = y.size
-    dev = engine_device
+    dev = engine.device
     X_dev = torch.as_tensor(np.asarray(X, dtype=np.float64).reshape(-1), device=dev)
     mdl = Model(
         [
@@ -60,12 +63,27 @@ def build(y, X, P, n_max, engine_device, n_chains, init_theta, init_beta, init_k
     )
     mdl.response = {"y": "mean"}
 
-    def move_function(state, col):          # state_update_function of RandomWalkLoop
-        state["B"] = make_basis(state, X_dev)
+    scratch = {}
+
+    def move_function(state, col):          # state_update_function of RandomWalkLoop: knot `col` moved
+        # The proposed basis differs from the current one in column `col` only.  It lives in one scratch buffer that
+        # is cloned from the current basis at the first knot of a sweep and afterwards re-synchronised by copying
+        # back the single column the previous step may have left different (RandomWalkLoop visits 0, 1, 2, ...),
+        # so a knot costs one column of traffic instead of a copy of the whole (C, k_max, n) basis.
+        store = state["B"].columns()        # the CURRENT basis: `state` is a shallow copy of the current state
+        buf = scratch.get("buf")
+        if buf is None or buf.shape != store.shape or col == 0 or scratch.get("last") != col - 1:
+            buf = scratch["buf"] = store.clone()
+        else:
+            buf[:, col - 1, :].copy_(store[:, col - 1, :])
+        theta = state["theta"]
+        engine.gaussian_basis(X_dev, theta.data[:, 0, :], buf, count=theta.count(state), scale=1.0, column=col)
+        scratch["last"] = col
+        state["B"] = state["B"].like(buf.transpose(1, 2))
         return state, 0.0, 0.0
 
     def birth_function(cur, prop):          # state_birth_function: births and deaths alike (see reversible_jump.py)
-        prop["B"] = make_basis(prop, X_dev)
+        prop["B"] = make_basis(prop, X_dev, engine)
         return prop, 0.0, 0.0
 
     state = {
@@ -78,7 +96,7 @@ def build(y, X, P, n_max, engine_device, n_chains, init_theta, init_beta, init_k
         "beta": ragged_from_lists(init_beta, n_max, 0, "n_basis", dev),
         "alloc_beta": ragged_from_lists([np.zeros(int(k)) for k in init_k], n_max, 0, "n_basis", dev),
     }  # fmt: skip
-    state["B"] = make_basis(state, X_dev)
+    state["B"] = make_basis(state, X_dev, engine)
     samplers = [
         NormalNormal("b", mdl),
         NormalNormal("beta", mdl, max_variable_size=n_max),

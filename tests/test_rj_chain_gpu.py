@@ -33,9 +33,12 @@ def mcmc_with_tape(y, X, P, n_max, init_theta, init_beta, k0, tape, n_iter):
 
     from openmcmc_amd.mcmc import MCMC
 
+    from openmcmc_amd.engine import Engine
+
     C = len(k0)
-    dev = torch.device("cuda", 0)
-    mdl, state, samplers = build(y, X, P, n_max, dev, C, init_theta, init_beta, k0)
+    eng = Engine(C)
+    dev = eng.device
+    mdl, state, samplers = build(y, X, P, n_max, eng, init_theta, init_beta, k0)
 
     def t(a):
         return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
@@ -52,7 +55,7 @@ def mcmc_with_tape(y, X, P, n_max, init_theta, init_beta, k0, tape, n_iter):
     s_rj.inject_associated = lambda s, it: {"theta": t(_nan0(tape["rj_theta_u"][:, it]).reshape(C, 1))}
     s_rj.inject_match = lambda s, it: t(_nan0(tape["rj_beta_u"][:, it]))
     s_rj.inject_uniform = lambda s, it: t(_nan0(tape["rj_acc_u"][:, it]))
-    M = MCMC(state, samplers, model=mdl, n_burn=0, n_iter=n_iter, n_chains=C)
+    M = MCMC(state, samplers, model=mdl, n_burn=0, n_iter=n_iter, n_chains=C, engine=eng)
     return M, samplers, tape
 
 
