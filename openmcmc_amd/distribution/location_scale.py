@@ -134,7 +134,7 @@ class Normal(Distribution):
             return mean, np.asarray(resp, dtype=np.float64)
         raise NotImplementedError("Normal with response and mean both per-chain (or both shared) on the GPU path")
 
-    def residual_quad(self, state, engine, st=None):
+    def residual_quad(self, state, engine, st=None, replicates=False):
         """(C,) tensor r' M r with r = response - mean, M the unscaled precision matrix: the sufficient
         statistic of NormalGamma.sample (sampler.py:276,284) and of log_p (gmrf.py:343-344)."""
         st = self.structure(state) if st is None else st
@@ -155,12 +155,23 @@ class Normal(Distribution):
         if st.diag is False:
             raise NotImplementedError("quadratic form with a dense precision matrix: later round")
         x, m = self.chain_and_center(state)
-        if m.shape[1] != 1 or x.shape[1] != 1:
+        if x.shape[1] != 1:
+            raise NotImplementedError("replicated per-chain side of a Normal")
+        n_rep = m.shape[1]
+        if n_rep != 1 and not replicates:
+            # NormalGamma's b* = r'Pr is a scalar only for one replicate (the reference's .item() raises, sampler.py:284)
             raise NotImplementedError("replicated responses")
+        const = 0.0
+        if n_rep != 1:
+            # sum_r (y_r - x)'M(y_r - x) = n_rep (x - ybar)'M(x - ybar) + sum_r (y_r - ybar)'M(y_r - ybar)
+            ybar = m.mean(axis=1, keepdims=True)
+            dev = m - ybar
+            const = float(np.sum(dev * (st.matrix @ dev)))
+            m = ybar
         cache = engine.model_cache(self, state, st, m)
         quad = engine.empty(1, engine.n_chains)
         engine.tridiag_quadform(st.n, cache["terms_unit"], x.vector(), quad)
-        return quad[0]
+        return quad[0] if n_rep == 1 else quad[0] * float(n_rep) + const
 
     # ------------------------------------------------------------------ log density
     def log_p(self, state: dict, by_observation: bool = False, engine=None, out=None, accumulate=False):
@@ -175,13 +186,16 @@ class Normal(Distribution):
             engine.diag_gauss_logpdf(x, prec, out, mean=mean, count=count, accumulate=accumulate)
             return out
         st = self.structure(state)
-        quad = self.residual_quad(state, engine, st)
+        quad = self.residual_quad(state, engine, st, replicates=True)
         if st.scale_key is not None and not is_chain(state[st.scale_key]):
             raise NotImplementedError("shared precision scalar")
         scale = state[st.scale_key].scalar() if st.scale_key is not None else None
         logdet = engine.matrix_logdet(st)
+        resp = state[self.response]
+        n_rep = 1 if is_chain(resp) else resp.shape[1]  # the log-density is summed over replicate columns (gmrf.py:346-348)
         out = engine.empty(engine.n_chains) if out is None else out
-        engine.scaled_gauss_logpdf(st.n, scale, logdet, quad, out, accumulate=accumulate)
+        engine.scaled_gauss_logpdf(st.n * n_rep, scale, logdet if n_rep == 1 else logdet * float(n_rep), quad, out,
+                                   accumulate=accumulate)
         return out
 
     def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):

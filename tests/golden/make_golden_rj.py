@@ -3,7 +3,7 @@ RUNNING the reference (openMCMC v1.0.7) in the build container:
 
     PYTHONPATH=/root/reference/src python3 tests/golden/make_golden_rj.py
 
-Writes truncnorm.npz and rj_gmrf_chain.npz.  Fixtures hold data only: inputs, the draws the
+Writes truncnorm.npz, rj_gmrf_chain.npz and example2.npz (pass names to regenerate a subset).  Fixtures hold data only: inputs, the draws the
 reference consumed, and what it produced.  Recorded-draw convention for the new kinds (SURVEY.md
 section 8c, re-checked at the top of gen_truncnorm):
 
@@ -308,8 +308,56 @@ def gen_rj_gmrf_chain():
     np.savez_compressed(os.path.join(OUT, "rj_gmrf_chain.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- example 2
+def gen_example2():
+    """examples/2_samplers.ipynb verbatim: five replicated observations y (1, 5) of a scalar h, samplers
+    RandomWalk('h', step=5.0) and NormalNormal('h'), 300 iterations each, recorded draws."""
+    from openmcmc.sampler.metropolis_hastings import RandomWalk
+
+    def fresh():
+        mdl = Model([Normal("y", mean="h", precision="tau"), Normal("h", mean="mu", precision="lambda")])
+        st = {"y": np.array([150, 155, 190, 160, 173], ndmin=2), "h": np.array(200, ndmin=2),
+              "tau": np.array(1 / 200, ndmin=2), "mu": np.array(160, ndmin=2), "lambda": np.array(1 / 100, ndmin=2)}
+        return mdl, st
+
+    out = {"y": np.array([150.0, 155, 190, 160, 173]), "h0": 200.0, "tau": 1 / 200, "mu": 160.0, "lambda": 1 / 100,
+           "n_iter": 300, "step": 5.0}
+    rng = np.random.default_rng(64)
+    zs, us = [], []
+
+    def _norm(loc=0, scale=1, size=None, **_):
+        z = rng.standard_normal(size)
+        zs.append(np.asarray(z, dtype=float).reshape(-1))
+        return loc + z * scale
+
+    def _uniform(loc=0, scale=1, size=None, **_):
+        u = rng.random(size)
+        us.append(float(u))
+        return loc + u * scale
+
+    saved = (stats.norm.rvs, stats.uniform.rvs)
+    stats.norm.rvs, stats.uniform.rvs = _norm, _uniform
+    try:
+        mdl, st = fresh()
+        smp = RandomWalk("h", model=mdl, step=5.0)
+        M = MCMC(st, [smp], model=mdl, n_burn=0, n_iter=300)
+        M.run_mcmc()
+        out["rw_z"], out["rw_u"] = np.concatenate(zs), np.array(us)
+        out["rw_store_h"], out["rw_log_post"] = M.store["h"], M.store["log_post"]
+        out["rw_accept"] = np.array([smp.accept_rate.count["accept"], smp.accept_rate.count["proposal"]], dtype=float)
+        zs.clear(), us.clear()
+        mdl, st = fresh()
+        M = MCMC(st, [NormalNormal("h", model=mdl)], model=mdl, n_burn=0, n_iter=300)
+        M.run_mcmc()
+        out["nn_z"] = np.concatenate(zs)
+        out["nn_store_h"], out["nn_log_post"] = M.store["h"], M.store["log_post"]
+    finally:
+        stats.norm.rvs, stats.uniform.rvs = saved
+    np.savez_compressed(os.path.join(OUT, "example2.npz"), **out)
+
+
 if __name__ == "__main__":
-    gen_truncnorm()
-    gen_rj_gmrf_chain()
-    for f in ("truncnorm.npz", "rj_gmrf_chain.npz"):
-        print(f, os.path.getsize(os.path.join(OUT, f)))
+    which = sys.argv[1:] or ["truncnorm", "rj_gmrf_chain", "example2"]
+    for name in which:
+        {"truncnorm": gen_truncnorm, "rj_gmrf_chain": gen_rj_gmrf_chain, "example2": gen_example2}[name]()
+        print(name + ".npz", os.path.getsize(os.path.join(OUT, name + ".npz")))

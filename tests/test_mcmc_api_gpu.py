@@ -256,3 +256,50 @@ def test_on_device_posterior_summaries(golden):
         mean, var = M.summary(key, pooled=True)
         flat = np.transpose(arr, (1, 0, 2)).reshape(arr.shape[1], -1)
         assert relerr(mean, flat.mean(axis=1)) < 1e-12 and relerr(var, flat.var(axis=1, ddof=1)) < 1e-10
+
+
+def test_example2_samplers_replay_reference(golden):
+    """examples/2_samplers.ipynb verbatim through the mirror API: a scalar h observed five times (y is (1, 5):
+    replicated response), RandomWalk('h', step=5.0) on the generic Metropolis-Hastings route and
+    NormalNormal('h'); 300 iterations each with the reference's recorded draws."""
+    import torch
+
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.sampler.metropolis_hastings import RandomWalk
+    from openmcmc_amd.sampler.sampler import NormalNormal
+
+    G = golden("example2")
+    n_iter = int(G["n_iter"])
+
+    def fresh():
+        mdl = Model([Normal("y", mean="h", precision="tau"), Normal("h", mean="mu", precision="lambda")])
+        st = {"y": np.array(G["y"], ndmin=2), "h": np.array(float(G["h0"]), ndmin=2), "tau": np.array(float(G["tau"]), ndmin=2),
+              "mu": np.array(float(G["mu"]), ndmin=2), "lambda": np.array(float(G["lambda"]), ndmin=2)}
+        return mdl, st
+
+    C = 3  # three identical chains fed the same draws: every one must reproduce the reference
+    dev = torch.device("cuda", 0)
+    mdl, st = fresh()
+    smp = RandomWalk("h", model=mdl, step=float(G["step"]))
+    smp.inject = lambda s, it, j: torch.full((C, 1), float(G["rw_z"][it]), dtype=torch.float64, device=dev)
+    smp.inject_uniform = lambda s, it, j: torch.full((C,), float(G["rw_u"][it]), dtype=torch.float64, device=dev)
+    M = MCMC(st, [smp], model=mdl, n_burn=0, n_iter=n_iter, n_chains=C)
+    M.run_mcmc()
+    got = M.collect()
+    for c in range(C):
+        assert np.max(np.abs(got["h"][c] - G["rw_store_h"]) / np.abs(G["rw_store_h"])) < 1e-12
+        assert np.max(np.abs(got["log_post"][c] - G["rw_log_post"]) / np.abs(G["rw_log_post"])) < 1e-10
+    assert smp.accept_rate.accept.cpu().numpy().tolist() == [int(G["rw_accept"][0])] * C
+    assert smp.accept_rate.proposal.cpu().numpy().tolist() == [int(G["rw_accept"][1])] * C
+
+    mdl, st = fresh()
+    nn = NormalNormal("h", model=mdl)
+    nn.inject = lambda s, it: torch.full((C, 1), float(G["nn_z"][it]), dtype=torch.float64, device=dev)
+    M = MCMC(st, [nn], model=mdl, n_burn=0, n_iter=n_iter, n_chains=C)
+    M.run_mcmc()
+    got = M.collect()
+    for c in range(C):
+        assert np.max(np.abs(got["h"][c] - G["nn_store_h"]) / np.abs(G["nn_store_h"])) < 1e-10
+        assert np.max(np.abs(got["log_post"][c] - G["nn_log_post"]) / np.abs(G["nn_log_post"])) < 1e-10
