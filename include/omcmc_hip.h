@@ -253,6 +253,29 @@ omc_status omc_rj_move(omc_ctx* ctx, int64_t n_max, double birth_probability, co
                        const double* u_inject, const int64_t* idx_inject, uint64_t draw_index,
                        int32_t* birth_out, double* p_birth_out, double* p_death_out, int64_t* del_index_out);
 
+/* ---- truncated Gaussian full conditional ------------------------------------
+ * gmrf.gibbs_canonical_truncated_normal (gmrf.py:201-266), the branch NormalNormal.sample takes when the
+ * parameter's prior has domain limits (sampler.py:199-205): ONE scan of single-site updates in index order,
+ *   x_i ~ N_[lower_i, upper_i]( (b_i - sum_j Q_ij x_j + Q_ii x_i) / Q_ii, 1/Q_ii ),  x_j already updated for j < i,
+ * each by inverse CDF of a uniform (gmrf.py:264 -> scipy truncnorm.rvs == ppf(U)).  x is updated in place
+ * (the scan starts from the current state).  Q and b in the same "shared structure x per-chain scalar" forms as
+ * the untruncated entry points; lower / upper: device [n] (NULL = unbounded on that side).
+ * u_inject [C][ld_u] injected uniforms; in-kernel uniforms are Philox blocks i/2 of (seed, chain, draw_index).
+ * The scan is sequential in i by definition, the parallelism is over chains (tridiagonal: one lane per chain;
+ * dense: one wave per chain, p <= 8192).                                                                    */
+omc_status omc_tridiag_gibbs_truncated(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
+                                       const double* rhs_chain, int64_t ld_rhs, const double* lower,
+                                       const double* upper, const double* u_inject, int64_t ld_u,
+                                       uint64_t draw_index, double* x, int64_t ld_x);
+omc_status omc_dense_gibbs_truncated(omc_ctx* ctx, int64_t p, const omc_dense_terms* terms,
+                                     const double* rhs_chain, int64_t ld_rhs, const double* lower,
+                                     const double* upper, const double* u_inject, int64_t ld_u,
+                                     uint64_t draw_index, double* x, int64_t ld_x);
+/* Normal.log_p returns -inf when the response lies outside [lower, upper] (location_scale.py:162-188):
+ *   out[c] = -inf for every chain with an element of x[c] below lower or above upper; other chains untouched. */
+omc_status omc_domain_penalty(omc_ctx* ctx, int64_t n, const double* x, int64_t ld, const double* lower,
+                              const double* upper, double* out);
+
 /* ---- generic Metropolis-Hastings blocks, ragged state, reversible-jump transitions ----------------
  * Ragged parameters (dimension changes under reversible jump: knots, their coefficients, the basis)
  * are held padded to n_max with zeros; count[c] -- the float64 the reference keeps in

@@ -106,6 +106,11 @@ SIGNATURES = {
     "omc_gamma_logpdf": (i32, [C.c_void_p, c_dp, C.c_double, C.c_double, c_dp, i32]),
     "omc_rj_move": (i32, [C.c_void_p, i64, C.c_double, c_dp, c_dp, c_dp, u64, c_dp, c_dp, c_dp, c_dp]),
     "omc_store_moments": (i32, [C.c_void_p, i64, i64, c_dp, i32, c_dp, c_dp]),
+    "omc_tridiag_gibbs_truncated": (
+        i32, [C.c_void_p, i64, C.POINTER(TridiagTerms), c_dp, i64, c_dp, c_dp, c_dp, i64, u64, c_dp, i64]),
+    "omc_dense_gibbs_truncated": (
+        i32, [C.c_void_p, i64, C.POINTER(DenseTerms), c_dp, i64, c_dp, c_dp, c_dp, i64, u64, c_dp, i64]),
+    "omc_domain_penalty": (i32, [C.c_void_p, i64, c_dp, i64, c_dp, c_dp, c_dp]),
     "omc_rw_propose": (
         i32,
         [C.c_void_p, i64, c_dp, i64, i64, c_dp, i64, c_dp, c_dp, c_dp, i64, c_dp, u64, u32, c_dp, i64, i64, c_dp, c_dp],

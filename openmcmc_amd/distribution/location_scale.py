@@ -57,8 +57,9 @@ class NormalStructure:
 
 @dataclass
 class Normal(Distribution):
-    """Multivariate normal in mean/precision form.  Truncation limits are accepted for API parity
-    but the truncated conditional sampler is not built yet."""
+    """Multivariate normal in mean/precision form.  Truncation limits on the response make NormalNormal sample
+    its conditional by single-site truncated updates and log_p return -inf outside the domain, as in the reference
+    (sampler.py:199-205, location_scale.py:162-188)."""
 
     mean: Union[str, Identity, LinearCombination, MixtureParameterVector]
     precision: Union[str, Identity, ScaledMatrix, MixtureParameterMatrix]
@@ -196,7 +197,21 @@ class Normal(Distribution):
         out = engine.empty(engine.n_chains) if out is None else out
         engine.scaled_gauss_logpdf(st.n * n_rep, scale, logdet if n_rep == 1 else logdet * float(n_rep), quad, out,
                                    accumulate=accumulate)
+        if (self.domain_response_lower is not None or self.domain_response_upper is not None) and is_chain(resp):
+            # location_scale.py:162-164: -inf for a response outside its domain (the un-normalised density otherwise)
+            lo, hi = self._domain_device(engine, st.n)
+            engine.domain_penalty(resp.vector(), out, lower=lo, upper=hi)
         return out
+
+    def _domain_device(self, engine, n):
+        memo = self.__dict__.setdefault("_domain_memo", {})
+        if n not in memo:
+            def vec(v):
+                if v is None:
+                    return None
+                return engine.to_device(np.broadcast_to(np.asarray(v, dtype=np.float64).reshape(-1, 1), (n, 1)).reshape(-1).copy())
+            memo[n] = (vec(self.domain_response_lower), vec(self.domain_response_upper))
+        return memo[n]
 
     def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):
         """One draw per chain from N(mean, (scale * M)^-1) (location_scale.py:252-272 -> gmrf.py:29-61),

@@ -399,6 +399,33 @@ class Engine:
                               C.c_void_p(dele.data_ptr())))
         return birth, pb, pd, dele
 
+    # ------------------------------------------------------------------ truncated Gaussian conditional
+    def tridiag_gibbs_truncated(self, n, terms, x, lower=None, upper=None, u=None, rhs_chain=None, draw_index=0):
+        """One in-place scan of gmrf.gibbs_canonical_truncated_normal on x (C, n); lower / upper: device (n,) or None."""
+        T = terms if isinstance(terms, _abi.TridiagTerms) else self.tridiag_terms(terms, n)
+        Cn = self.n_chains
+        ld = lambda t: 0 if t is None else t.stride(0)  # noqa: E731
+        check(lib.omc_tridiag_gibbs_truncated(self._ctx, n, C.byref(T), self._p(rhs_chain, Cn, n), ld(rhs_chain),
+                                              self._vec(lower, n), self._vec(upper, n), self._p(u, Cn, n), ld(u),
+                                              int(draw_index), self._p(x, Cn, n), ld(x)))
+        return x
+
+    def dense_gibbs_truncated(self, p, terms, x, lower=None, upper=None, u=None, rhs_chain=None, draw_index=0):
+        T = terms if isinstance(terms, _abi.DenseTerms) else self.dense_terms(terms, p)
+        Cn = self.n_chains
+        ld = lambda t: 0 if t is None else t.stride(0)  # noqa: E731
+        check(lib.omc_dense_gibbs_truncated(self._ctx, p, C.byref(T), self._p(rhs_chain, Cn, p), ld(rhs_chain),
+                                            self._vec(lower, p), self._vec(upper, p), self._p(u, Cn, p), ld(u),
+                                            int(draw_index), self._p(x, Cn, p), ld(x)))
+        return x
+
+    def domain_penalty(self, x, out, lower=None, upper=None):
+        """out[c] = -inf where any element of x[c] (C, n) lies outside [lower, upper]."""
+        Cn, n = x.shape
+        check(lib.omc_domain_penalty(self._ctx, n, self._p(x, Cn, n), x.stride(0), self._vec(lower, n), self._vec(upper, n),
+                                     self._chain_scalar(out)))
+        return out
+
     # ------------------------------------------------------------------ generic MH / ragged state / RJ transitions
     def _i32(self, t):
         torch = _torch()

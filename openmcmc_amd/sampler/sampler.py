@@ -111,10 +111,10 @@ class NormalNormal(MCMCSampler):
         prior = self.model[self.param]
         if not isinstance(prior, Normal):
             raise TypeError("NormalNormal needs a Normal prior on the parameter")
-        if prior.domain_response_lower is not None or prior.domain_response_upper is not None:
-            raise NotImplementedError("truncated Gaussian conditional (gmrf.gibbs_canonical_truncated_normal): next round")
         n = state[self.param].shape[0]
         if prior.is_mixture:
+            if prior.domain_response_lower is not None or prior.domain_response_upper is not None:
+                raise NotImplementedError("truncated prior on a variable-size parameter")
             return self._ragged_plan(state, n)
         pieces = []  # one per distribution: what Q and b receive from it
         for key, dist in self.model.items():
@@ -161,7 +161,25 @@ class NormalNormal(MCMCSampler):
                 piece["center"] = y - rest
             pieces.append(piece)
         tridiagonal = all(pc["design"] is None and pc["st"].diag is not False and pc["st"].n == n for pc in pieces)
-        return self._tridiag_plan(state, n, pieces) if tridiagonal else self._dense_plan(state, n, pieces)
+        plan = self._tridiag_plan(state, n, pieces) if tridiagonal else self._dense_plan(state, n, pieces)
+        plan["limits"] = self._domain_limits(prior, n)
+        return plan
+
+    def _domain_limits(self, prior, n):
+        """(lower, upper) device vectors of the prior's truncation, or None when there is none: then the conditional
+        is sampled exactly (sampler.py:196-197); otherwise by one scan of single-site truncated updates
+        (sampler.py:199-205 -> gmrf.gibbs_canonical_truncated_normal, which itself falls back to the exact draw when
+        both limits are infinite, gmrf.py:231-232)."""
+        lo, hi = prior.domain_response_lower, prior.domain_response_upper
+        if lo is None and hi is None:
+            return None
+        lo = np.full(n, -np.inf) if lo is None else np.broadcast_to(np.asarray(lo, dtype=np.float64).reshape(-1, 1), (n, 1)).reshape(-1)
+        hi = np.full(n, np.inf) if hi is None else np.broadcast_to(np.asarray(hi, dtype=np.float64).reshape(-1, 1), (n, 1)).reshape(-1)
+        if np.any(lo >= hi):
+            raise ValueError("Error lower bound must be strictly less than upper bound")  # gmrf.py:149-150
+        if np.all(np.isneginf(lo)) and np.all(np.isposinf(hi)):
+            return None
+        return self.engine.to_device(lo.copy()), self.engine.to_device(hi.copy())
 
     def _replicated_structure(self, key, st, n_rep):
         """The structure of n_rep * M (kept on the sampler so the device cache sees one stable matrix object)."""
@@ -213,7 +231,7 @@ class NormalNormal(MCMCSampler):
             likes.append((key, dist, st))
         if len(likes) != 1:
             raise NotImplementedError("ragged NormalNormal: exactly one likelihood term")
-        return {"kind": "ragged", "n": n_max, "like": likes[0], "terms_list": [], "keys": []}
+        return {"kind": "ragged", "n": n_max, "like": likes[0], "terms_list": [], "keys": [], "limits": None}
 
     def _dense_plan(self, state, n, pieces):
         """Q_c = sum_k s_k[c] M_k with dense M_k: prior precision as is, a regression likelihood as the
@@ -263,12 +281,18 @@ class NormalNormal(MCMCSampler):
         if p["kind"] == "ragged":
             return self._sample_ragged(current_state, p, z)
         x = eng.empty(eng.n_chains, n) if out is None else out
-        if p["kind"] == "tridiag":
-            rhs_chain = None
-            for dist, scale_key in p["offsets"]:  # b_c -= tau_c * d_c  (sampler.py:190-192)
-                scale = current_state[scale_key].scalar() if scale_key is not None else None
-                t = dist.mean.predictor_device(current_state, eng, exclude=self.param, alpha=-1.0, chain_scale=scale)
-                rhs_chain = t if rhs_chain is None else rhs_chain + t
+        rhs_chain = None
+        for dist, scale_key in p.get("offsets", ()):  # b_c -= tau_c * d_c  (sampler.py:190-192)
+            scale = current_state[scale_key].scalar() if scale_key is not None else None
+            t = dist.mean.predictor_device(current_state, eng, exclude=self.param, alpha=-1.0, chain_scale=scale)
+            rhs_chain = t if rhs_chain is None else rhs_chain + t
+        if p["limits"] is not None:
+            # truncated prior: the scan starts from the current value and `z` carries the injected UNIFORMS
+            lower, upper = p["limits"]
+            x.copy_(current_state[self.param].vector())
+            gibbs = eng.tridiag_gibbs_truncated if p["kind"] == "tridiag" else eng.dense_gibbs_truncated
+            gibbs(n, p["terms"], x, lower=lower, upper=upper, u=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
+        elif p["kind"] == "tridiag":
             eng.tridiag_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
         else:
             eng.dense_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())

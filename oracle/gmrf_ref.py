@@ -92,3 +92,27 @@ def gauss_logpdf(x, mu, Q, by_observation=False):
     w = L.T @ (x - mu)
     lp = 0.5 * (logdet - d * np.log(2 * np.pi) - np.sum(np.power(w, 2), axis=0))
     return lp if by_observation else np.sum(lp)
+
+
+def gibbs_truncated_scan(b, Q, x, lower, upper, u):
+    """One scan of single-site truncated-normal updates in index order  [gmrf.py:201-266], the uniforms `u` behind
+    scipy's truncnorm.rvs supplied (one per coordinate).  Both limits infinite -> the caller uses draw_canonical
+    (gmrf.py:231-232).  Returns the updated copy of x."""
+    from oracle import truncnorm_ref
+
+    x = np.array(x, dtype=float).reshape(-1, 1)
+    b = np.asarray(b, dtype=float).reshape(-1, 1)
+    p = x.size
+    lower = np.broadcast_to(np.asarray(-np.inf if lower is None else lower, dtype=float).reshape(-1, 1), (p, 1))
+    upper = np.broadcast_to(np.asarray(np.inf if upper is None else upper, dtype=float).reshape(-1, 1), (p, 1))
+    u = np.asarray(u, dtype=float).reshape(-1)
+    Qd = Q.toarray() if sparse.issparse(Q) else np.asarray(Q, dtype=float)
+    if p == 1:  # gmrf.py:244-247
+        return np.array(truncnorm_ref.truncated_normal_rv(b / Qd, 1 / np.sqrt(Qd), lower, upper, u[0]), ndmin=2)
+    for i in range(p):  # gmrf.py:254-264
+        Q_ii = Qd[i, i]
+        v_i = 1 / Q_ii
+        row = (Q.getrow(i) @ x) if sparse.issparse(Q) else (Qd[i, :] @ x)
+        cond_mean = v_i * (b[i] - row + Q_ii * x[i])
+        x[i] = truncnorm_ref.truncated_normal_rv(np.ravel(cond_mean)[0], np.sqrt(v_i), lower[i, 0], upper[i, 0], u[i])
+    return x

@@ -356,8 +356,93 @@ def gen_example2():
     np.savez_compressed(os.path.join(OUT, "example2.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- truncated conditional
+def gen_truncated_conditional():
+    """gmrf.gibbs_canonical_truncated_normal (gmrf.py:201-266) called directly on tridiagonal (sparse) and dense
+    precisions, and NormalNormal.sample with a truncated prior (sampler.py:199-205) inside the example-4 model
+    for a few sweeps; the uniforms behind truncnorm.rvs are recorded."""
+    from openmcmc.parameter import LinearCombination, ScaledMatrix
+
+    out = {}
+    rng = np.random.default_rng(91)
+    used = []
+
+    def _trunc(a, b, loc=0, scale=1, size=None, **_):
+        u = rng.random(size)
+        used.append(np.asarray(u, dtype=float).reshape(-1))
+        return stats.truncnorm.ppf(u, a, b) * scale + loc
+
+    saved = stats.truncnorm.rvs
+    stats.truncnorm.rvs = _trunc
+    try:
+        cases = []
+        for n in (1, 2, 9, 40):
+            P = sparse.csc_matrix(gmrf.precision_irregular(np.arange(float(n)))) if n > 1 else sparse.csc_matrix(np.array([[1.0]]))
+            Q = (3.0 * P + 0.7 * sparse.identity(n, format="csc")).tocsc()
+            for lower, upper in ((0.5, 0.7), (-np.inf, 0.2), (-0.3, np.inf), (-4.0, 5.0)):
+                cases.append(("tri", n, Q, lower, upper))
+        for p_ in (1, 5, 12):
+            A = rng.standard_normal((p_, 2 * p_ + 2))
+            Q = A @ A.T / (2 * p_ + 2) + 0.5 * np.eye(p_)
+            for lower, upper in ((0.5, 0.7), (-1.0, np.inf)):
+                cases.append(("dense", p_, (Q + Q.T) / 2, lower, upper))
+        out["n_cases"] = len(cases)
+        for ci, (kind, n, Q, lower, upper) in enumerate(cases):
+            b = rng.standard_normal((n, 1)) * 2
+            x0 = np.full((n, 1), 0.6) if (lower, upper) == (0.5, 0.7) else rng.uniform(max(lower, -1), min(upper, 1), size=(n, 1))
+            used.clear()
+            x = gmrf.gibbs_canonical_truncated_normal(b=b.copy(), Q=Q, x=x0.copy(), lower=lower, upper=upper)
+            k = f"c{ci}_"
+            Qd = Q.toarray() if sparse.issparse(Q) else Q
+            out[k + "kind"], out[k + "n"], out[k + "Q"], out[k + "b"], out[k + "x0"] = kind, n, Qd, b.ravel(), x0.ravel()
+            out[k + "lower"], out[k + "upper"] = lower, upper
+            out[k + "u"], out[k + "x"] = np.concatenate(used), np.asarray(x).ravel()
+        # NormalNormal with a truncated prior inside the example-4 model (sparse route)
+        n, n_sweeps = 30, 8
+        t = np.arange(n) * 60.0 / n
+        y = np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + np.random.default_rng(3).standard_normal(n)
+        P = sparse.csc_matrix(gmrf.precision_irregular(np.arange(float(n)))).tolil()
+        P[0, 0] += 1e-3
+        mdl = Model([
+            Normal("y", mean=LinearCombination(form={"b": "A"}), precision=ScaledMatrix(matrix="P_tau", scalar="tau")),
+            Normal("b", mean="mu", precision=ScaledMatrix(matrix="P_lambda", scalar="lambda"), domain_response_lower=np.array(1.5)),
+            Gamma("lambda", shape="a_lam", rate="b_lam"), Gamma("tau", shape="a_tau", rate="b_tau")])
+        st = {"y": y.copy(), "b": np.maximum(y, 2.0), "mu": np.zeros(n), "lambda": 100, "P_lambda": P.tocsc(), "a_lam": 10,
+              "b_lam": 1, "tau": 1, "P_tau": sparse.csc_matrix(np.eye(n)), "a_tau": 1, "b_tau": 1,
+              "A": sparse.identity(n, format="csc")}
+        gs = []
+
+        def _gamma(a, loc=0, scale=1, size=None, **_):
+            g = rng.standard_gamma(np.asarray(a, dtype=np.float64), size=size)
+            gs.append(float(np.asarray(g).reshape(-1)[0]))
+            return loc + g * scale
+
+        saved_g = stats.gamma.rvs
+        stats.gamma.rvs = _gamma
+        used.clear()
+        try:
+            M = MCMC(st, [NormalNormal("b", mdl), NormalGamma("lambda", mdl), NormalGamma("tau", mdl)], model=mdl, n_burn=0,
+                     n_iter=n_sweeps)
+            M.run_mcmc()
+        finally:
+            stats.gamma.rvs = saved_g
+        Pd = P.toarray()
+        out["mc_n"], out["mc_sweeps"], out["mc_y"], out["mc_b0"], out["mc_lower"] = n, n_sweeps, y, np.maximum(y, 2.0), 1.5
+        out["mc_P_diag"], out["mc_P_off"] = np.diag(Pd).copy(), np.diag(Pd, -1).copy()
+        out["mc_u"] = np.concatenate(used).reshape(n_sweeps, n)
+        out["mc_g"] = np.array(gs).reshape(n_sweeps, 2)
+        for key in ("b", "lambda", "tau", "log_post"):
+            out["mc_store_" + key] = np.asarray(M.store[key])
+    finally:
+        stats.truncnorm.rvs = saved
+    np.savez_compressed(os.path.join(OUT, "truncated_conditional.npz"), **out)
+
+
+GENERATORS = {"truncnorm": gen_truncnorm, "rj_gmrf_chain": gen_rj_gmrf_chain, "example2": gen_example2,
+              "truncated_conditional": gen_truncated_conditional}
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["truncnorm", "rj_gmrf_chain", "example2"]
+    which = sys.argv[1:] or list(GENERATORS)
     for name in which:
-        {"truncnorm": gen_truncnorm, "rj_gmrf_chain": gen_rj_gmrf_chain, "example2": gen_example2}[name]()
+        GENERATORS[name]()
         print(name + ".npz", os.path.getsize(os.path.join(OUT, name + ".npz")))
