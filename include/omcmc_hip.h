@@ -253,6 +253,32 @@ omc_status omc_rj_move(omc_ctx* ctx, int64_t n_max, double birth_probability, co
                        const double* u_inject, const int64_t* idx_inject, uint64_t draw_index,
                        int32_t* birth_out, double* p_birth_out, double* p_death_out, int64_t* del_index_out);
 
+/* ---- banded precisions of any bandwidth (RW2, seasonal, lattice GMRFs) --------
+ * The same conditional draw as omc_tridiag_sample_canonical for Q_c = sum_k scale[k][c] * M_k with every M_k
+ * symmetric of bandwidth bw[k] <= w (w <= 128), factorised in natural order (the reference's unpermuted SuperLU /
+ * LAPACK route, gmrf.py:489-520, so the draw matches path-wise for the same z):
+ *   band[k]  [(bw[k]+1) x n], band[k][d*n + i] = M_k[i+d, i] (d-th sub-diagonal contiguous, as scipy's
+ *            M.diagonal(-d) padded to n); NULL = identity (bw 0);
+ *   rhs[k]   [n] shared M_k m_k or NULL;  scale[k] [C] or NULL = 1;
+ *   x = Q^{-1} b + L^{-T} z; mean (optional) = Q^{-1} b; logdet (optional) [C] = log det Q_c.
+ * Uses a per-context workspace of C * n * (w+1) doubles for the factor.                                      */
+typedef struct {
+  int32_t n_terms;
+  const double* band[OMC_MAX_TERMS];
+  int32_t bw[OMC_MAX_TERMS];
+  const double* rhs[OMC_MAX_TERMS];
+  const double* scale[OMC_MAX_TERMS];
+} omc_band_terms;
+
+omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const omc_band_terms* terms,
+                                     const double* rhs_chain, int64_t ld_rhs, const double* z_inject, int64_t ld_z,
+                                     uint64_t draw_index, double* x, int64_t ld_x, double* mean, int64_t ld_mean,
+                                     double* logdet);
+/* quad[c] = (x_c - center)' M (x_c - center) for one shared band matrix (NormalGamma.sample sampler.py:276,284;
+ * Normal.log_p gmrf.py:343-344); band NULL with w = 0 is the identity, center NULL = 0.                      */
+omc_status omc_band_quadform(omc_ctx* ctx, int64_t n, int64_t w, const double* band, const double* center,
+                             const double* x, int64_t ld, double* quad);
+
 /* ---- truncated Gaussian full conditional ------------------------------------
  * gmrf.gibbs_canonical_truncated_normal (gmrf.py:201-266), the branch NormalNormal.sample takes when the
  * parameter's prior has domain limits (sampler.py:199-205): ONE scan of single-site updates in index order,

@@ -44,6 +44,18 @@ class DenseTerms(C.Structure):
     ]
 
 
+class BandTerms(C.Structure):
+    """omc_band_terms."""
+
+    _fields_ = [
+        ("n_terms", i32),
+        ("band", c_dp * OMC_MAX_TERMS),
+        ("bw", i32 * OMC_MAX_TERMS),
+        ("rhs", c_dp * OMC_MAX_TERMS),
+        ("scale", c_dp * OMC_MAX_TERMS),
+    ]
+
+
 class GammaBlock(C.Structure):
     """omc_gamma_block."""
 
@@ -106,6 +118,9 @@ SIGNATURES = {
     "omc_gamma_logpdf": (i32, [C.c_void_p, c_dp, C.c_double, C.c_double, c_dp, i32]),
     "omc_rj_move": (i32, [C.c_void_p, i64, C.c_double, c_dp, c_dp, c_dp, u64, c_dp, c_dp, c_dp, c_dp]),
     "omc_store_moments": (i32, [C.c_void_p, i64, i64, c_dp, i32, c_dp, c_dp]),
+    "omc_band_sample_canonical": (
+        i32, [C.c_void_p, i64, i64, C.POINTER(BandTerms), c_dp, i64, c_dp, i64, u64, c_dp, i64, c_dp, i64, c_dp]),
+    "omc_band_quadform": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, i64, c_dp]),
     "omc_tridiag_gibbs_truncated": (
         i32, [C.c_void_p, i64, C.POINTER(TridiagTerms), c_dp, i64, c_dp, c_dp, c_dp, i64, u64, c_dp, i64]),
     "omc_dense_gibbs_truncated": (

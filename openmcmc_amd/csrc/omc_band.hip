@@ -1,0 +1,290 @@
+// Banded precisions of any bandwidth w (RW2 / seasonal / lattice GMRFs):
+// gmrf.sample_normal_canonical (gmrf.py:167-198) with Q_c = sum_k s_k[c] M_k, every M_k symmetric with
+// bandwidth <= w, factorised in NATURAL order like the reference's unpermuted SuperLU / LAPACK route
+// (gmrf.py:489-520), so that the draw matches the reference path-wise for the same z.
+//
+// One workgroup (16 x 16 threads) per chain.  Right-looking banded Cholesky on a ring of the w+1 "open"
+// columns held in LDS: column j is scaled by 1/sqrt(pivot), written to the per-chain factor workspace
+// (column-major band: column j = w+1 contiguous doubles), used to update the (w x w)/2 trailing entries of
+// the ring (threads tile the (a, b) square, no integer division), and its ring slot is reloaded with column
+// j+w+1.  The forward substitution rides along (the right-hand side is one more ring).  The backward pass
+// solves L'x = u + z (mean and draw share one pass: x = L^-T L^-1 b + L^-T z) with the dot product over the
+// band spread over the lanes.  Two barriers per column; the work per column is O(w^2), so the cost is the
+// band flops n w^2 for wide bands and barrier latency for narrow ones (tridiagonal models take the segmented
+// kernel of omc_tridiag.hip instead).
+#include <math.h>
+
+#include "omc_common.h"
+
+omc_status omc_ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need);  // omc_dense.hip
+
+#define BAND_WMAX 128
+#define BAND_TX 16
+#define BAND_TY 16
+
+struct BandTermsDev {
+  int n_terms;
+  const double* band[OMC_MAX_TERMS];  // [ (bw+1) x n ], band[d*n + i] = M[i+d, i]; NULL = identity
+  int bw[OMC_MAX_TERMS];
+  const double* rhs[OMC_MAX_TERMS];
+  const double* scale[OMC_MAX_TERMS];
+};
+
+__device__ __forceinline__ double band_entry(const BandTermsDev& T, const double* s, int64_t n, int64_t col, int d) {
+  // Q[col + d, col]
+  if (col + d >= n) return 0.0;
+  double v = 0.0;
+#pragma unroll
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+    if (k < T.n_terms) {
+      if (T.band[k]) {
+        if (d <= T.bw[k]) v = fma(s[k], T.band[k][(int64_t)d * n + col], v);
+      } else if (d == 0) {
+        v += s[k];
+      }
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ double band_rhs(const BandTermsDev& T, const double* s, int64_t n, int64_t col, const double* rc) {
+  if (col >= n) return 0.0;
+  double b = rc ? rc[col] : 0.0;
+#pragma unroll
+  for (int k = 0; k < OMC_MAX_TERMS; ++k)
+    if (k < T.n_terms && T.rhs[k]) b = fma(s[k], T.rhs[k][col], b);
+  return b;
+}
+
+__global__ void __launch_bounds__(BAND_TX* BAND_TY) k_band_sample(int64_t C, int64_t chain_offset, int64_t n, int w,
+                                                                   BandTermsDev T, const double* rhs_chain, int64_t ld_rhs,
+                                                                   const double* z_in, int64_t ld_z, omc_rng_key key,
+                                                                   double* Lws, double* x, int64_t ld_x, double* mean,
+                                                                   int64_t ld_mean, double* logdet, long long* bad) {
+  extern __shared__ double sm[];
+  const int W1 = w + 1;
+  double* ring = sm;                    // W1 x W1: ring[(col % W1) * W1 + d] = open entry Q[col + d, col]
+  double* rring = ring + (int64_t)W1 * W1;  // W1: open right-hand side
+  double* lcol = rring + W1;            // W1: the column being eliminated
+  double* misc = lcol + W1;             // [0] u_j, [1] fail flag
+  const int64_t c = blockIdx.x;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tid = ty * BAND_TX + tx;
+  const int nthreads = BAND_TX * BAND_TY;
+  double s[OMC_MAX_TERMS];
+#pragma unroll
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) s[k] = (k < T.n_terms && T.scale[k]) ? T.scale[k][c] : 1.0;
+  double* Lc = Lws + c * n * W1;
+  double* xc = x + c * ld_x;
+
+  // open the first w+1 columns
+  for (int t = tid; t < W1 * W1; t += nthreads) {
+    const int col = t / W1, d = t % W1;
+    ring[col * W1 + d] = band_entry(T, s, n, col, d);
+  }
+  const double* rc = rhs_chain ? rhs_chain + c * ld_rhs : nullptr;
+  for (int t = tid; t < W1; t += nthreads) rring[t] = band_rhs(T, s, n, t, rc);
+  if (tid == 0) misc[1] = 0.0;
+  __syncthreads();
+
+  double ld_acc = 0.0;
+  // entries of the column that will be opened at the END of step j (column j + w + 1) are fetched one step ahead,
+  // so the global-load latency hides behind a whole elimination step instead of stalling every barrier
+  double pre = 0.0;
+  if (tid < W1) pre = band_entry(T, s, n, (int64_t)W1, tid);
+  else if (tid == W1) pre = band_rhs(T, s, n, (int64_t)W1, rc);
+  for (int64_t j = 0; j < n; ++j) {
+    const int slot = (int)(j % W1);
+    double pre_next = 0.0;
+    if (tid < W1) pre_next = band_entry(T, s, n, j + 1 + W1, tid);
+    else if (tid == W1) pre_next = band_rhs(T, s, n, j + 1 + W1, rc);
+    const double pivot = ring[slot * W1];
+    const bool ok = pivot > 0.0;
+    const double ljj = ok ? sqrt(pivot) : 1.0;
+    if (tid < W1) {
+      const double l = (tid == 0) ? ljj : ring[slot * W1 + tid] / ljj;
+      lcol[tid] = l;
+      Lc[j * W1 + tid] = l;
+    }
+    if (tid == 0) {
+      const double u = rring[slot] / ljj;
+      misc[0] = u;
+      xc[j] = u;  // forward-substituted right-hand side, overwritten by the draw in the backward pass
+      if (!ok) misc[1] = 1.0;
+      ld_acc += log(pivot);
+    }
+    __syncthreads();
+    // trailing update: Q[j+a, j+b] -= l_a l_b, 1 <= b <= a <= w, and the right-hand side
+    for (int a = 1 + ty; a <= w; a += BAND_TY) {
+      const double la = lcol[a];
+      for (int b = 1 + tx; b <= a; b += BAND_TX) {
+        const int cslot = (int)((j + b) % W1);
+        ring[cslot * W1 + (a - b)] = fma(-la, lcol[b], ring[cslot * W1 + (a - b)]);
+      }
+    }
+    if (tid >= 1 && tid <= w) {
+      const int rslot = (int)((j + tid) % W1);
+      rring[rslot] = fma(-lcol[tid], misc[0], rring[rslot]);
+    }
+    // the eliminated column's slot takes column j + w + 1 (fetched during the previous step)
+    if (tid < W1) ring[slot * W1 + tid] = pre;
+    else if (tid == W1) rring[slot] = pre;
+    pre = pre_next;
+    __syncthreads();
+  }
+  const bool failed = misc[1] != 0.0;
+  if (tid == 0) {
+    if (logdet) logdet[c] = ld_acc;
+    if (failed) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+  }
+  __syncthreads();
+  if (failed) {
+    for (int64_t i = tid; i < n; i += nthreads) xc[i] = NAN;
+    return;
+  }
+
+  // t = u + z (all threads), mean needs u alone: keep it in the mean buffer
+  double* mc = mean ? mean + c * ld_mean : nullptr;
+  for (int64_t i = tid; i < n; i += nthreads) {
+    double z;
+    if (z_in) {
+      z = z_in[c * ld_z + i];
+    } else {
+      double n0, n1;
+      omc_normal_pair(omc_rng_block(key, chain_offset + c, (uint32_t)(i >> 1)), n0, n1);
+      z = (i & 1) ? n1 : n0;
+    }
+    const double u = xc[i];
+    if (mc) mc[i] = u;
+    xc[i] = u + z;
+  }
+  __syncthreads();
+
+  // backward pass  L' x = t:  x_j = (t_j - sum_{d=1..w} L[j+d, j] x_{j+d}) / L_jj ;  ring of the last w solutions
+  double* xr = ring;        // W1 entries: x_{col} at xr[col % W1]
+  double* mr = ring + W1;   // the same for the mean
+  double* red = ring + 2 * W1;  // per-wave partial sums (2 x 4)
+  for (int t = tid; t < 2 * W1; t += nthreads) ring[t] = 0.0;
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n_waves = (w + 63) / 64;  // waves that carry band entries (w <= 128 -> at most 2)
+  const int d = tid + 1;  // band offset handled by this thread
+  // the factor column and the right-hand side of step j - 1 are fetched while step j is reduced
+  double l_cur = (d <= w) ? Lc[(n - 1) * W1 + d] : 0.0;
+  double ljj_cur = 0.0, t_cur = 0.0, tm_cur = 0.0;
+  if (tid == 0) {
+    ljj_cur = Lc[(n - 1) * W1];
+    t_cur = xc[n - 1];
+    if (mc) tm_cur = mc[n - 1];
+  }
+  for (int64_t j = n - 1; j >= 0; --j) {
+    double l_next = 0.0, ljj_next = 0.0, t_next = 0.0, tm_next = 0.0;
+    if (j > 0) {
+      if (d <= w) l_next = Lc[(j - 1) * W1 + d];
+      if (tid == 0) {
+        ljj_next = Lc[(j - 1) * W1];
+        t_next = xc[j - 1];
+        if (mc) tm_next = mc[j - 1];
+      }
+    }
+    double px = 0.0, pm = 0.0;
+    if (d <= w && j + d < n) {
+      const int sl = (int)((j + d) % W1);
+      px = l_cur * xr[sl];
+      if (mc) pm = l_cur * mr[sl];
+    }
+    if (wave < n_waves || wave == 0) {
+#pragma unroll
+      for (int sh = 32; sh > 0; sh >>= 1) {
+        px += __shfl_xor(px, sh, 64);
+        pm += __shfl_xor(pm, sh, 64);
+      }
+      if (lane == 0) { red[wave] = px; red[4 + wave] = pm; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double sx = red[0], smn = red[4];
+      if (n_waves > 1) { sx += red[1]; smn += red[5]; }
+      const double xv = (t_cur - sx) / ljj_cur;
+      xc[j] = xv;
+      xr[j % W1] = xv;
+      if (mc) {
+        const double mv = (tm_cur - smn) / ljj_cur;
+        mc[j] = mv;
+        mr[j % W1] = mv;
+      }
+    }
+    l_cur = l_next; ljj_cur = ljj_next; t_cur = t_next; tm_cur = tm_next;
+    __syncthreads();
+  }
+}
+
+// quad[c] = (x_c - m)' M (x_c - m) for a shared band matrix (NormalGamma.sample sampler.py:276,284; gmrf.py:343-344)
+__global__ void __launch_bounds__(256) k_band_quadform(int64_t C, int64_t n, int w, const double* band, const double* center,
+                                                       const double* x, int64_t ld, double* quad) {
+  __shared__ double red[4];
+  const int64_t c = blockIdx.x;
+  const double* xc = x + c * ld;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const double ri = xc[i] - (center ? center[i] : 0.0);
+    double row = (band ? band[i] : 1.0) * ri;
+    for (int d = 1; d <= w && i + d < n; ++d) {
+      const double rj = xc[i + d] - (center ? center[i + d] : 0.0);
+      row = fma(2.0 * band[(int64_t)d * n + i], rj, row);
+    }
+    acc = fma(ri, row, acc);
+  }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) acc += __shfl_xor(acc, sh, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) quad[c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+extern "C" {
+
+omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const omc_band_terms* terms,
+                                     const double* rhs_chain, int64_t ld_rhs, const double* z_inject, int64_t ld_z,
+                                     uint64_t draw_index, double* x, int64_t ld_x, double* mean, int64_t ld_mean,
+                                     double* logdet) {
+  if (!ctx || n < 1 || w < 0 || w > BAND_WMAX || !terms || terms->n_terms < 1 || terms->n_terms > OMC_MAX_TERMS || !x ||
+      ld_x < n || (rhs_chain && ld_rhs < n) || (z_inject && ld_z < n) || (mean && ld_mean < n))
+    return OMC_INVALID_ARG;
+  BandTermsDev T;
+  T.n_terms = terms->n_terms;
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+    const bool on = k < terms->n_terms;
+    T.band[k] = on ? terms->band[k] : nullptr;
+    T.bw[k] = on ? (int)terms->bw[k] : 0;
+    T.rhs[k] = on ? terms->rhs[k] : nullptr;
+    T.scale[k] = on ? terms->scale[k] : nullptr;
+    if (on && (terms->bw[k] < 0 || terms->bw[k] > w)) return OMC_INVALID_ARG;
+  }
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  const size_t need = (size_t)ctx->n_chains * n * (w + 1) * sizeof(double);
+  omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->workspace, &ctx->workspace_bytes, need);
+  if (st != OMC_OK) return st;
+  const int W1 = (int)w + 1;
+  size_t lds = ((size_t)W1 * W1 + 2 * W1 + 2) * sizeof(double);
+  const size_t lds_back = (size_t)(2 * W1 + 8) * sizeof(double);
+  if (lds < lds_back) lds = lds_back;
+  hipLaunchKernelGGL(k_band_sample, dim3((unsigned)ctx->n_chains), dim3(BAND_TX, BAND_TY), lds, ctx->stream, ctx->n_chains,
+                     ctx->chain_offset, n, (int)w, T, rhs_chain, ld_rhs, z_inject, ld_z,
+                     omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), ctx->workspace, x, ld_x, mean, ld_mean, logdet,
+                     ctx->d_bad_chain);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_band_quadform(omc_ctx* ctx, int64_t n, int64_t w, const double* band, const double* center, const double* x,
+                             int64_t ld, double* quad) {
+  if (!ctx || n < 1 || w < 0 || (w > 0 && !band) || !x || ld < n || !quad) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_band_quadform, dim3((unsigned)ctx->n_chains), dim3(256), 0, ctx->stream, ctx->n_chains, n, (int)w, band,
+                     center, x, ld, quad);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+}  // extern "C"

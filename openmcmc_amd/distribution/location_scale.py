@@ -43,6 +43,31 @@ def tridiagonal_bands(M, n):
     return diag, off
 
 
+BAND_MAX = 128  # widest band the band kernel takes (omc_band_sample_canonical)
+
+
+def band_storage(M, n):
+    """(w+1, n) array with row d = the d-th sub-diagonal of the symmetric matrix M padded with zeros (the layout of
+    omc_band_terms), or None when the bandwidth exceeds BAND_MAX or a band factorisation would not pay (w+1 >= n/2)."""
+    if sparse.issparse(M):
+        coo = M.tocoo()
+        w = int(np.max(np.abs(coo.row - coo.col))) if coo.nnz else 0
+    else:
+        A = np.asarray(M)
+        nz = np.nonzero(A)
+        w = int(np.max(np.abs(nz[0] - nz[1]))) if nz[0].size else 0
+    if w > BAND_MAX or (w + 1) * 2 > n:
+        return None
+    out = np.zeros((w + 1, n))
+    for d in range(w + 1):
+        lower = M.diagonal(-d) if sparse.issparse(M) else np.diag(np.asarray(M), -d)
+        upper = M.diagonal(d) if sparse.issparse(M) else np.diag(np.asarray(M), d)
+        if not np.array_equal(lower, upper):
+            raise ValueError("precision matrix is not symmetric")
+        out[d, : n - d] = lower
+    return out
+
+
 @dataclass
 class NormalStructure:
     """What the samplers need to know about one Normal: precision = scale * M."""
@@ -50,9 +75,21 @@ class NormalStructure:
     n: int
     matrix: object          # host matrix M (n x n)
     scale_key: object       # state label of the scalar, or None (scale 1)
-    diag: object            # tridiagonal bands of M (None, None) if M is the identity
+    diag: object            # tridiagonal bands of M (None, None) if M is the identity; False = wider than tridiagonal
     off: object
     n_pos: int              # #{diag(M) > 0}  (sampler.py:283)
+    band: object = None     # (w+1, n) band storage when M is banded but wider than tridiagonal, else None
+
+    def band_rows(self):
+        """Band storage of M whatever its structure class (identity -> None = the kernels' identity)."""
+        if self.diag is False:
+            return self.band
+        if self.diag is None and self.off is None:
+            return None
+        diag = np.ones(self.n) if self.diag is None else self.diag
+        if self.off is None:
+            return diag.reshape(1, -1).copy()
+        return np.stack([diag, np.concatenate([self.off, [0.0]])])
 
 
 @dataclass
@@ -117,7 +154,8 @@ class Normal(Distribution):
         bands = tridiagonal_bands(M, n)
         diag, off = bands if bands is not None else (False, False)  # False = not tridiagonal
         d = M.diagonal() if sparse.issparse(M) else np.diag(np.asarray(M))
-        st = NormalStructure(n=n, matrix=M, scale_key=scale_key, diag=diag, off=off, n_pos=int(np.sum(d > 0)))
+        st = NormalStructure(n=n, matrix=M, scale_key=scale_key, diag=diag, off=off, n_pos=int(np.sum(d > 0)),
+                             band=band_storage(M, n) if bands is None else None)
         memo[id(M)] = st
         return st
 
@@ -154,7 +192,15 @@ class Normal(Distribution):
             engine.weighted_resid_sq(engine.shared(resp).reshape(-1), fitted, quad, w=w)
             return quad
         if st.diag is False:
-            raise NotImplementedError("quadratic form with a dense precision matrix: later round")
+            if st.band is None:
+                raise NotImplementedError("quadratic form with a dense precision matrix: later round")
+            x, m = self.chain_and_center(state)
+            if m.shape[1] != 1 or x.shape[1] != 1:
+                raise NotImplementedError("replicated responses under a banded precision")
+            cache = engine.band_cache(self, st, m)
+            quad = engine.empty(engine.n_chains)
+            engine.band_quadform(st.n, cache["band"], x.vector(), quad, center=cache["center"])
+            return quad
         x, m = self.chain_and_center(state)
         if x.shape[1] != 1:
             raise NotImplementedError("replicated per-chain side of a Normal")

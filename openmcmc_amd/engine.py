@@ -321,8 +321,13 @@ class Engine:
         if hit is not None and hit[0] is st.matrix:
             return hit[1]
         if st.diag is False:
-            raise NotImplementedError("log det of a dense precision matrix: later round")
-        if st.diag is None and st.off is None:
+            if st.band is None:
+                raise NotImplementedError("log det of a dense precision matrix: later round")
+            # banded: one factorisation of M itself on the device (every chain computes the same number)
+            x, out = self.empty(self.n_chains, st.n), self.empty(self.n_chains)
+            self.band_sample_canonical(st.n, [{"band": self.to_device(st.band)}], x, logdet_out=out)
+            ld = out[:1].clone()
+        elif st.diag is None and st.off is None:
             ld = self.zeros(1)
         else:
             diag = self.to_device(st.diag) if st.diag is not None else self.full((st.n,), 1.0)
@@ -343,6 +348,23 @@ class Engine:
         t = self.to_device(np.ascontiguousarray(dense, dtype=np.float64))
         self._shared_cache[id(array)] = (array, t)
         return t
+
+    def band_cache(self, dist, st, center):
+        """Device copies of a banded Normal's shared pieces: band rows of M, the vector m its residual is taken around
+        and M m (host product, once per model)."""
+        if not hasattr(self, "_band_cache"):
+            self._band_cache = {}
+        key = (id(dist), id(st.matrix))
+        c_host = np.ascontiguousarray(center, dtype=np.float64).reshape(-1)
+        hit = self._band_cache.get(key)
+        if hit is not None and np.array_equal(hit["center_host"], c_host):
+            return hit
+        rows = st.band_rows()
+        entry = {"band": None if rows is None else self.to_device(rows), "center_host": c_host,
+                 "center": self.to_device(c_host) if c_host.any() else None,
+                 "rhs": self.to_device(np.asarray(st.matrix @ c_host).reshape(-1)) if c_host.any() else None}
+        self._band_cache[key] = entry
+        return entry
 
     def model_cache(self, dist, state, st, center):
         """Device copies of one Normal's shared pieces (bands of M, the vector m its residual is taken
@@ -398,6 +420,44 @@ class Engine:
                               int(draw_index), C.c_void_p(birth.data_ptr()), self._p(pb), self._p(pd),
                               C.c_void_p(dele.data_ptr())))
         return birth, pb, pd, dele
+
+    # ------------------------------------------------------------------ banded precisions
+    def band_terms(self, terms, n):
+        """terms: list of dicts with optional keys band ((bw+1, n) shared tensor, sub-diagonal d in row d; None =
+        identity), rhs ((n,) shared), scale ((C,) per chain).  Returns (struct, overall bandwidth)."""
+        if not 1 <= len(terms) <= _abi.OMC_MAX_TERMS:
+            raise ValueError("1..4 terms supported")
+        T = _abi.BandTerms()
+        T.n_terms = len(terms)
+        keep, w = [], 0
+        for k, t in enumerate(terms):
+            band = t.get("band")
+            if band is not None:
+                if band.dim() != 2 or band.shape[1] != n or not band.is_contiguous():
+                    raise ValueError("band must be a contiguous (bw+1, n) tensor")
+                T.bw[k] = band.shape[0] - 1
+                w = max(w, band.shape[0] - 1)
+            T.band[k] = self._p(band)
+            T.rhs[k] = self._vec(t.get("rhs"), n)
+            T.scale[k] = self._chain_scalar(t.get("scale"))
+            keep.append(dict(t))
+        T._keep = keep
+        return T, w
+
+    def band_sample_canonical(self, n, terms, x_out, z=None, rhs_chain=None, draw_index=0, mean_out=None, logdet_out=None):
+        T, w = terms if isinstance(terms, tuple) else self.band_terms(terms, n)
+        Cn = self.n_chains
+        ld = lambda t: 0 if t is None else t.stride(0)  # noqa: E731
+        check(lib.omc_band_sample_canonical(self._ctx, n, w, C.byref(T), self._p(rhs_chain, Cn, n), ld(rhs_chain),
+                                            self._p(z, Cn, n), ld(z), int(draw_index), self._p(x_out, Cn, n), ld(x_out),
+                                            self._p(mean_out, Cn, n), ld(mean_out), self._chain_scalar(logdet_out)))
+        return x_out
+
+    def band_quadform(self, n, band, x, quad_out, center=None):
+        w = 0 if band is None else band.shape[0] - 1
+        check(lib.omc_band_quadform(self._ctx, n, w, self._p(band), self._vec(center, n), self._p(x, self.n_chains, n),
+                                    x.stride(0), self._chain_scalar(quad_out)))
+        return quad_out
 
     # ------------------------------------------------------------------ truncated Gaussian conditional
     def tridiag_gibbs_truncated(self, n, terms, x, lower=None, upper=None, u=None, rhs_chain=None, draw_index=0):

@@ -161,7 +161,14 @@ class NormalNormal(MCMCSampler):
                 piece["center"] = y - rest
             pieces.append(piece)
         tridiagonal = all(pc["design"] is None and pc["st"].diag is not False and pc["st"].n == n for pc in pieces)
-        plan = self._tridiag_plan(state, n, pieces) if tridiagonal else self._dense_plan(state, n, pieces)
+        banded = all(pc["design"] is None and pc["st"].n == n and (pc["st"].diag is not False or pc["st"].band is not None)
+                     for pc in pieces)
+        if tridiagonal:
+            plan = self._tridiag_plan(state, n, pieces)
+        elif banded:
+            plan = self._band_plan(state, n, pieces)
+        else:
+            plan = self._dense_plan(state, n, pieces)
         plan["limits"] = self._domain_limits(prior, n)
         return plan
 
@@ -233,6 +240,24 @@ class NormalNormal(MCMCSampler):
             raise NotImplementedError("ragged NormalNormal: exactly one likelihood term")
         return {"kind": "ragged", "n": n_max, "like": likes[0], "terms_list": [], "keys": [], "limits": None}
 
+    def _band_plan(self, state, n, pieces):
+        """Q_c = sum_k s_k[c] M_k with banded M_k wider than tridiagonal (RW2, seasonal, lattice GMRFs): natural-order
+        band Cholesky per chain (omc_band_sample_canonical)."""
+        eng = self.engine
+        terms, keys = [], []
+        for pc in pieces:
+            if pc["offset"] or pc.get("replicated"):
+                raise NotImplementedError("per-chain offsets / replicated responses on the band route")
+            st = pc["st"]
+            cache = eng.band_cache(pc["dist"], st, pc["center"])
+            scale = _as_chain_scalar(eng, state, st.scale_key) if st.scale_key is not None else None
+            rhs = cache["rhs"]
+            if rhs is None and cache["center"] is not None:
+                rhs = cache["center"]  # identity matrix: M m = m
+            terms.append({"band": cache["band"], "rhs": rhs, "scale": None if scale is None else scale.scalar()})
+            keys.append(pc["key"])
+        return {"kind": "band", "n": n, "terms_list": terms, "terms": eng.band_terms(terms, n), "keys": keys}
+
     def _dense_plan(self, state, n, pieces):
         """Q_c = sum_k s_k[c] M_k with dense M_k: prior precision as is, a regression likelihood as the
         Gram matrix A' W A (one fp64 GEMM at plan time) -- sampler.py:185-192, location_scale.py:238-241."""
@@ -290,10 +315,14 @@ class NormalNormal(MCMCSampler):
             # truncated prior: the scan starts from the current value and `z` carries the injected UNIFORMS
             lower, upper = p["limits"]
             x.copy_(current_state[self.param].vector())
+            if p["kind"] == "band":
+                raise NotImplementedError("truncated conditional under a banded precision wider than tridiagonal")
             gibbs = eng.tridiag_gibbs_truncated if p["kind"] == "tridiag" else eng.dense_gibbs_truncated
             gibbs(n, p["terms"], x, lower=lower, upper=upper, u=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
         elif p["kind"] == "tridiag":
             eng.tridiag_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
+        elif p["kind"] == "band":
+            eng.band_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())
         else:
             eng.dense_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())
         current_state[self.param] = ChainArray(x)

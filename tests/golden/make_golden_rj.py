@@ -438,7 +438,52 @@ def gen_truncated_conditional():
     np.savez_compressed(os.path.join(OUT, "truncated_conditional.npz"), **out)
 
 
-GENERATORS = {"truncnorm": gen_truncnorm, "rj_gmrf_chain": gen_rj_gmrf_chain, "example2": gen_example2,
+# ----------------------------------------------------------------------------- banded precision (RW2)
+def gen_band_chain():
+    """Full MCMC.run_mcmc of the example-4 model with a SECOND-order random-walk prior (pentadiagonal precision
+    D2'D2 + 1e-3 I, sparse route): NormalNormal + both NormalGamma updates + log_post, recorded draws."""
+    from openmcmc.parameter import LinearCombination, ScaledMatrix
+
+    n, n_burn, n_iter = 45, 2, 10
+    t = np.arange(n) * 60.0 / n
+    y = np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + 0.3 * np.random.default_rng(8).standard_normal(n)
+    D = sparse.diags([np.ones(n - 2), -2 * np.ones(n - 2), np.ones(n - 2)], offsets=[0, 1, 2], shape=(n - 2, n))
+    P = (D.T @ D + 1e-3 * sparse.identity(n)).tocsc()
+    mdl = Model([
+        Normal("y", mean=LinearCombination(form={"b": "A"}), precision=ScaledMatrix(matrix="P_tau", scalar="tau")),
+        Normal("b", mean="mu", precision=ScaledMatrix(matrix="P_lambda", scalar="lambda")),
+        Gamma("lambda", shape="a_lam", rate="b_lam"), Gamma("tau", shape="a_tau", rate="b_tau")])
+    st = {"y": y.copy(), "b": y.copy(), "mu": np.full(n, 0.3), "lambda": 50, "P_lambda": P, "a_lam": 10, "b_lam": 1, "tau": 1,
+          "P_tau": sparse.csc_matrix(np.eye(n)), "a_tau": 1, "b_tau": 1, "A": sparse.identity(n, format="csc")}
+    rng = np.random.default_rng(17)
+    zs, gs = [], []
+
+    def _norm(loc=0, scale=1, size=None, **_):
+        z = rng.standard_normal(size)
+        zs.append(np.asarray(z, dtype=float).reshape(-1))
+        return loc + z * scale
+
+    def _gamma(a, loc=0, scale=1, size=None, **_):
+        g = rng.standard_gamma(np.asarray(a, dtype=np.float64), size=size)
+        gs.append(float(np.asarray(g).reshape(-1)[0]))
+        return loc + g * scale
+
+    saved = (stats.norm.rvs, stats.gamma.rvs)
+    stats.norm.rvs, stats.gamma.rvs = _norm, _gamma
+    try:
+        M = MCMC(st, [NormalNormal("b", mdl), NormalGamma("lambda", mdl), NormalGamma("tau", mdl)], model=mdl, n_burn=n_burn,
+                 n_iter=n_iter)
+        M.run_mcmc()
+    finally:
+        stats.norm.rvs, stats.gamma.rvs = saved
+    out = {"n": n, "n_burn": n_burn, "n_iter": n_iter, "y": y, "P": P.toarray(), "mu": 0.3,
+           "z": np.concatenate(zs).reshape(n_burn + n_iter, n), "g": np.array(gs).reshape(n_burn + n_iter, 2)}
+    for key in ("b", "lambda", "tau", "log_post"):
+        out["store_" + key] = np.asarray(M.store[key])
+    np.savez_compressed(os.path.join(OUT, "band_chain.npz"), **out)
+
+
+GENERATORS = {"band_chain": gen_band_chain, "truncnorm": gen_truncnorm, "rj_gmrf_chain": gen_rj_gmrf_chain, "example2": gen_example2,
               "truncated_conditional": gen_truncated_conditional}
 
 if __name__ == "__main__":

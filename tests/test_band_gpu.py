@@ -1,0 +1,157 @@
+"""Banded precisions of any bandwidth on the GPU: omc_band_sample_canonical /
+omc_band_quadform against the CPU oracle (natural-order sparse factorisation, as the reference) with injected
+draws, on RW2 precisions and random symmetric positive definite band matrices up to bandwidth 128."""
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def make_engine(C, **kw):
+    from openmcmc_amd.engine import Engine
+
+    return Engine(C, **kw)
+
+
+def band_of(M, w):
+    """(w+1, n) array, row d = d-th sub-diagonal padded with zeros (the ABI's layout)."""
+    M = M.toarray() if sparse.issparse(M) else np.asarray(M)
+    n = M.shape[0]
+    out = np.zeros((w + 1, n))
+    for d in range(w + 1):
+        out[d, : n - d] = np.diag(M, -d)
+    return out
+
+
+def rw2_precision(n):
+    """Second-order random walk: D2' D2 with D2 the second-difference operator (pentadiagonal), plus a small ridge."""
+    if n < 3:
+        return sparse.identity(n, format="csc") * 1.0
+    D = sparse.diags([np.ones(n - 2), -2 * np.ones(n - 2), np.ones(n - 2)], offsets=[0, 1, 2], shape=(n - 2, n))
+    return (D.T @ D + 1e-3 * sparse.identity(n)).tocsc()
+
+
+def random_band_spd(n, w, rng):
+    A = np.zeros((n, n))
+    for d in range(1, min(w, n - 1) + 1):
+        v = rng.standard_normal(n - d) * 0.5
+        A += np.diag(v, -d) + np.diag(v, d)
+    A += np.diag(np.abs(A).sum(axis=1) + 0.5 + rng.random(n))
+    return sparse.csc_matrix(A)
+
+
+def check_case(eng, M, w, rng, C):
+    from oracle import gmrf_ref
+
+    n = M.shape[0]
+    lam, tau = rng.random(C) * 3 + 0.5, rng.random(C) * 2 + 0.2
+    m = rng.standard_normal(n)
+    y = rng.standard_normal(n)
+    z = rng.standard_normal((C, n))
+    extra = rng.standard_normal((C, n)) * 0.3
+    terms = [{"band": eng.to_device(band_of(M, w)), "rhs": eng.to_device(M @ m), "scale": eng.to_device(lam)},
+             {"rhs": eng.to_device(y), "scale": eng.to_device(tau)}]
+    x, mu, ld = eng.empty(C, n), eng.empty(C, n), eng.empty(C)
+    eng.band_sample_canonical(n, terms, x, z=eng.to_device(z), rhs_chain=eng.to_device(extra), mean_out=mu, logdet_out=ld)
+    eng.check_status()
+    xg, mg, lg = x.cpu().numpy(), mu.cpu().numpy(), ld.cpu().numpy()
+    worst = 0.0
+    for c in range(C):
+        Q = (lam[c] * M + tau[c] * sparse.identity(n, format="csc")).tocsc()
+        b = (lam[c] * (M @ m) + tau[c] * y + extra[c]).reshape(n, 1)
+        xo, mo, L = gmrf_ref.draw_canonical(b, Q, z[c].reshape(n, 1))
+        logdet = 2 * np.sum(np.log(L.diagonal()))
+        scale = max(1.0, np.max(np.abs(xo)))
+        worst = max(worst, np.max(np.abs(xg[c] - xo.ravel())) / scale, np.max(np.abs(mg[c] - mo.ravel())) / scale,
+                    abs(lg[c] - logdet) / max(1.0, abs(logdet)))
+    # quadratic form
+    quad = eng.empty(C)
+    eng.band_quadform(n, terms[0]["band"], x, quad, center=eng.to_device(m))
+    r = xg - m[None, :]
+    exp = np.einsum("ci,ci->c", r, (M @ r.T).T)
+    worst = max(worst, np.max(np.abs(quad.cpu().numpy() - exp) / np.maximum(1.0, np.abs(exp))))
+    return worst
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 40, 301])
+def test_rw2_precision(n):
+    rng = np.random.default_rng(n)
+    C = 5
+    eng = make_engine(C)
+    worst = check_case(eng, rw2_precision(n), 2 if n >= 3 else 0, rng, C)
+    assert worst < 1e-8, worst  # RW2 + ridge is ill-conditioned (cond ~ n^4): compared at its conditioning
+    eng.close()
+
+
+@pytest.mark.parametrize("w,n", [(0, 7), (1, 9), (3, 3), (3, 50), (7, 8), (7, 130), (20, 21), (20, 400), (64, 200),
+                                  (100, 350), (128, 129), (128, 600)])
+def test_random_band_matrices(w, n):
+    rng = np.random.default_rng(100 * w + n)
+    C = 4
+    eng = make_engine(C)
+    worst = check_case(eng, random_band_spd(n, w, rng), w, rng, C)
+    assert worst < RTOL, worst
+    eng.close()
+
+
+def test_band_failure_latch_and_in_kernel_draws():
+    n, w, C = 60, 3, 3
+    rng = np.random.default_rng(3)
+    M = random_band_spd(n, w, rng)
+    eng = make_engine(C, seed=9)
+    band = eng.to_device(band_of(M, w))
+    x = eng.empty(C, n)
+    scale = eng.to_device(np.array([1.0, -1.0, 2.0]))  # chain 1: negative definite
+    eng.band_sample_canonical(n, [{"band": band, "scale": scale}], x)
+    with pytest.raises(np.linalg.LinAlgError, match="chain 1"):
+        eng.check_status()
+    eng2 = make_engine(C, seed=9)
+    a, b = eng2.empty(C, n), eng2.empty(C, n)
+    eng2.band_sample_canonical(n, [{"band": band}], a, draw_index=4)
+    eng2.band_sample_canonical(n, [{"band": band}], b, draw_index=4)
+    eng2.check_status()
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy()) and not np.array_equal(a[0].cpu().numpy(), a[1].cpu().numpy())
+    eng.close(), eng2.close()
+
+
+def test_rw2_smoother_replays_reference(golden):
+    """The example-4 model with a second-order random-walk prior (pentadiagonal precision) through MCMC.run_mcmc:
+    NormalNormal on the band route, NormalGamma with the band quadratic form, log_post with the band log-determinant;
+    the reference's draws injected (tests/golden/band_chain.npz)."""
+    import torch
+
+    from openmcmc_amd.distribution.distribution import Gamma
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import LinearCombination, ScaledMatrix
+    from openmcmc_amd.sampler.sampler import NormalGamma, NormalNormal
+
+    G = golden("band_chain")
+    n, n_burn, n_iter = int(G["n"]), int(G["n_burn"]), int(G["n_iter"])
+    mdl = Model([
+        Normal("y", mean=LinearCombination(form={"b": "A"}), precision=ScaledMatrix(matrix="P_tau", scalar="tau")),
+        Normal("b", mean="mu", precision=ScaledMatrix(matrix="P_lambda", scalar="lambda")),
+        Gamma("lambda", shape="a_lam", rate="b_lam"), Gamma("tau", shape="a_tau", rate="b_tau")])
+    st = {"y": G["y"].copy(), "b": G["y"].copy(), "mu": np.full(n, float(G["mu"])), "lambda": 50,
+          "P_lambda": sparse.csc_matrix(G["P"]), "a_lam": 10, "b_lam": 1, "tau": 1, "P_tau": sparse.csc_matrix(np.eye(n)),
+          "a_tau": 1, "b_tau": 1, "A": sparse.identity(n, format="csc")}
+    C = 2
+    dev = torch.device("cuda", 0)
+    samplers = [NormalNormal("b", mdl), NormalGamma("lambda", mdl), NormalGamma("tau", mdl)]
+    samplers[0].inject = lambda s, it: torch.as_tensor(np.tile(G["z"][it], (C, 1)), device=dev)
+    samplers[1].inject = lambda s, it: torch.full((C,), float(G["g"][it, 0]), dtype=torch.float64, device=dev)
+    samplers[2].inject = lambda s, it: torch.full((C,), float(G["g"][it, 1]), dtype=torch.float64, device=dev)
+    M = MCMC(st, samplers, model=mdl, n_burn=n_burn, n_iter=n_iter, n_chains=C)
+    assert samplers[0].plan(M.state)["kind"] == "band"
+    M.run_mcmc()
+    got = M.collect()
+    for c in range(C):
+        for key in ("b", "lambda", "tau", "log_post"):
+            ref = G["store_" + key]
+            err = np.max(np.abs(got[key][c] - ref) / np.maximum(1.0, np.abs(ref)))
+            assert err < 1e-9, (key, err)  # D2'D2 + 1e-3 I at n = 45 has condition number ~ 4e7

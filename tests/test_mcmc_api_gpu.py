@@ -132,10 +132,23 @@ def test_dense_prior_and_unsupported_structures():
     assert relerr(state["b"].chain(1).ravel(), xo.ravel()) < TOL
     with pytest.raises(RuntimeError):
         NormalNormal("b", mdl).sample(state)  # not bound to an engine
+    # a truncated prior on the dense route: one scan of single-site truncated updates, checked against the oracle
     trunc = Model([Normal("y", mean="b", precision=ScaledMatrix("P_tau", "tau")),
                    Normal("b", mean="mu", precision=ScaledMatrix("P", "lam"), domain_response_lower=np.zeros((n, 1)))])
-    with pytest.raises(NotImplementedError):
-        NormalNormal("b", trunc).bind(eng).sample(state)
+    tsmp = NormalNormal("b", trunc).bind(eng)
+    u = rng.random(n)
+    tsmp.inject = lambda s_, t: eng.to_device(np.tile(u, (2, 1)))
+    x0 = np.abs(state["b"].chain(1)) + 0.1
+    state["b"] = ChainArray(eng.to_device(np.tile(x0.reshape(1, n), (2, 1))))
+    state = tsmp.sample(state)
+    eng.check_status()
+    xt = gmrf_ref.gibbs_truncated_scan(2.0 * yv, 1.5 * dense + 2.0 * np.eye(n), x0, 0.0, None, u)
+    assert relerr(state["b"].chain(0).ravel(), xt.ravel()) < TOL and state["b"].chain(0).min() >= 0.0
+    with pytest.raises(ValueError):  # gmrf.py:149-150
+        bad = Model([Normal("y", mean="b", precision=ScaledMatrix("P_tau", "tau")),
+                     Normal("b", mean="mu", precision=ScaledMatrix("P", "lam"), domain_response_lower=np.array(1.0),
+                            domain_response_upper=np.array(0.5))])
+        NormalNormal("b", bad).bind(eng).sample(state)
     eng.close()
 
 
