@@ -3,7 +3,7 @@
 // bandwidth <= w, factorised in NATURAL order like the reference's unpermuted SuperLU / LAPACK route
 // (gmrf.py:489-520), so that the draw matches the reference path-wise for the same z.
 //
-// One workgroup (16 x 16 threads) per chain.  Right-looking banded Cholesky on a ring of the w+1 "open"
+// One workgroup per chain (16 x 16 threads; a single 8 x 8 wave for bandwidth <= 7).  Right-looking banded Cholesky on a ring of the w+1 "open"
 // columns held in LDS: column j is scaled by 1/sqrt(pivot), written to the per-chain factor workspace
 // (column-major band: column j = w+1 contiguous doubles), used to update the (w x w)/2 trailing entries of
 // the ring (threads tile the (a, b) square, no integer division), and its ring slot is reloaded with column
@@ -19,8 +19,13 @@
 omc_status omc_ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need);  // omc_dense.hip
 
 #define BAND_WMAX 128
-#define BAND_TX 16
-#define BAND_TY 16
+
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter, which would expose the latency of the prefetched global loads (and of the factor stores) on every
+// column; inside the two loops the threads communicate through LDS alone.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 struct BandTermsDev {
   int n_terms;
@@ -56,6 +61,7 @@ __device__ __forceinline__ double band_rhs(const BandTermsDev& T, const double* 
   return b;
 }
 
+template <int BAND_TX, int BAND_TY>
 __global__ void __launch_bounds__(BAND_TX* BAND_TY) k_band_sample(int64_t C, int64_t chain_offset, int64_t n, int w,
                                                                    BandTermsDev T, const double* rhs_chain, int64_t ld_rhs,
                                                                    const double* z_in, int64_t ld_z, omc_rng_key key,
@@ -87,54 +93,74 @@ __global__ void __launch_bounds__(BAND_TX* BAND_TY) k_band_sample(int64_t C, int
   if (tid == 0) misc[1] = 0.0;
   __syncthreads();
 
-  double ld_acc = 0.0;
+  double ld_mant = 1.0;
+  long long ld_exp = 0;
   // entries of the column that will be opened at the END of step j (column j + w + 1) are fetched one step ahead,
   // so the global-load latency hides behind a whole elimination step instead of stalling every barrier
   double pre = 0.0;
   if (tid < W1) pre = band_entry(T, s, n, (int64_t)W1, tid);
   else if (tid == W1) pre = band_rhs(T, s, n, (int64_t)W1, rc);
-  for (int64_t j = 0; j < n; ++j) {
-    const int slot = (int)(j % W1);
+  int slot = 0;  // j % W1, kept incrementally (a 64-bit modulo per access would dominate the step)
+  for (int64_t j = 0; j < n; ++j, slot = (slot + 1 == W1) ? 0 : slot + 1) {
     double pre_next = 0.0;
     if (tid < W1) pre_next = band_entry(T, s, n, j + 1 + W1, tid);
     else if (tid == W1) pre_next = band_rhs(T, s, n, j + 1 + W1, rc);
     const double pivot = ring[slot * W1];
     const bool ok = pivot > 0.0;
-    const double ljj = ok ? sqrt(pivot) : 1.0;
+    // 1/sqrt(pivot) by rsq + two Newton steps; the column is scaled by multiplication (fp64 sqrt and divisions
+    // on the serial path cost more than the whole trailing update for narrow bands)
+    double rinv = 1.0;
+    if (ok) {
+      const double g = __builtin_amdgcn_rsq(pivot);
+      const double h = 0.5 * g;
+      double sq = pivot * g;                 // ~ sqrt(pivot)
+      double e = fma(-sq, sq, pivot);
+      sq = fma(e, h, sq);
+      e = fma(-sq, sq, pivot);
+      sq = fma(e, h, sq);
+      rinv = omc_rcp_nr(sq);
+    }
     if (tid < W1) {
-      const double l = (tid == 0) ? ljj : ring[slot * W1 + tid] / ljj;
+      // the diagonal slot of the stored factor holds 1/L_jj (what the backward pass multiplies by)
+      const double l = (tid == 0) ? rinv : ring[slot * W1 + tid] * rinv;
       lcol[tid] = l;
       Lc[j * W1 + tid] = l;
     }
     if (tid == 0) {
-      const double u = rring[slot] / ljj;
+      const double u = rring[slot] * rinv;
       misc[0] = u;
       xc[j] = u;  // forward-substituted right-hand side, overwritten by the draw in the backward pass
       if (!ok) misc[1] = 1.0;
-      ld_acc += log(pivot);
+      // log det = sum log pivot, accumulated as a product with the exponent split off (one log at the end)
+      ld_mant *= __builtin_amdgcn_frexp_mant(ok ? pivot : 1.0);
+      ld_exp += __builtin_amdgcn_frexp_exp(ok ? pivot : 1.0);
+      ld_exp += __builtin_amdgcn_frexp_exp(ld_mant);
+      ld_mant = __builtin_amdgcn_frexp_mant(ld_mant);
     }
-    __syncthreads();
+    lds_barrier();
     // trailing update: Q[j+a, j+b] -= l_a l_b, 1 <= b <= a <= w, and the right-hand side
     for (int a = 1 + ty; a <= w; a += BAND_TY) {
       const double la = lcol[a];
       for (int b = 1 + tx; b <= a; b += BAND_TX) {
-        const int cslot = (int)((j + b) % W1);
+        int cslot = slot + b;
+        if (cslot >= W1) cslot -= W1;
         ring[cslot * W1 + (a - b)] = fma(-la, lcol[b], ring[cslot * W1 + (a - b)]);
       }
     }
     if (tid >= 1 && tid <= w) {
-      const int rslot = (int)((j + tid) % W1);
+      int rslot = slot + tid;
+      if (rslot >= W1) rslot -= W1;
       rring[rslot] = fma(-lcol[tid], misc[0], rring[rslot]);
     }
     // the eliminated column's slot takes column j + w + 1 (fetched during the previous step)
     if (tid < W1) ring[slot * W1 + tid] = pre;
     else if (tid == W1) rring[slot] = pre;
     pre = pre_next;
-    __syncthreads();
+    lds_barrier();
   }
   const bool failed = misc[1] != 0.0;
   if (tid == 0) {
-    if (logdet) logdet[c] = ld_acc;
+    if (logdet) logdet[c] = log(ld_mant) + (double)ld_exp * 0.69314718055994530942;
     if (failed) atomicMin((unsigned long long*)bad, (unsigned long long)c);
   }
   __syncthreads();
@@ -177,7 +203,8 @@ __global__ void __launch_bounds__(BAND_TX* BAND_TY) k_band_sample(int64_t C, int
     t_cur = xc[n - 1];
     if (mc) tm_cur = mc[n - 1];
   }
-  for (int64_t j = n - 1; j >= 0; --j) {
+  int bslot = (int)((n - 1) % W1);  // j % W1, kept incrementally
+  for (int64_t j = n - 1; j >= 0; --j, bslot = (bslot == 0) ? W1 - 1 : bslot - 1) {
     double l_next = 0.0, ljj_next = 0.0, t_next = 0.0, tm_next = 0.0;
     if (j > 0) {
       if (d <= w) l_next = Lc[(j - 1) * W1 + d];
@@ -189,7 +216,8 @@ __global__ void __launch_bounds__(BAND_TX* BAND_TY) k_band_sample(int64_t C, int
     }
     double px = 0.0, pm = 0.0;
     if (d <= w && j + d < n) {
-      const int sl = (int)((j + d) % W1);
+      int sl = bslot + d;
+      if (sl >= W1) sl -= W1;
       px = l_cur * xr[sl];
       if (mc) pm = l_cur * mr[sl];
     }
@@ -201,21 +229,21 @@ __global__ void __launch_bounds__(BAND_TX* BAND_TY) k_band_sample(int64_t C, int
       }
       if (lane == 0) { red[wave] = px; red[4 + wave] = pm; }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
       double sx = red[0], smn = red[4];
       if (n_waves > 1) { sx += red[1]; smn += red[5]; }
-      const double xv = (t_cur - sx) / ljj_cur;
+      const double xv = (t_cur - sx) * ljj_cur;  // ljj_cur holds 1/L_jj
       xc[j] = xv;
-      xr[j % W1] = xv;
+      xr[bslot] = xv;
       if (mc) {
-        const double mv = (tm_cur - smn) / ljj_cur;
+        const double mv = (tm_cur - smn) * ljj_cur;
         mc[j] = mv;
-        mr[j % W1] = mv;
+        mr[bslot] = mv;
       }
     }
     l_cur = l_next; ljj_cur = ljj_next; t_cur = t_next; tm_cur = tm_next;
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -269,10 +297,18 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
   size_t lds = ((size_t)W1 * W1 + 2 * W1 + 2) * sizeof(double);
   const size_t lds_back = (size_t)(2 * W1 + 8) * sizeof(double);
   if (lds < lds_back) lds = lds_back;
-  hipLaunchKernelGGL(k_band_sample, dim3((unsigned)ctx->n_chains), dim3(BAND_TX, BAND_TY), lds, ctx->stream, ctx->n_chains,
-                     ctx->chain_offset, n, (int)w, T, rhs_chain, ld_rhs, z_inject, ld_z,
-                     omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), ctx->workspace, x, ld_x, mean, ld_mean, logdet,
-                     ctx->d_bad_chain);
+  const omc_rng_key key = omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL);
+  if (w <= 7) {
+    // narrow band: one wave per chain -- the two barriers per column cost nothing inside a single wave, and the
+    // 8 x 8 thread tile already covers the (w x w)/2 update
+    hipLaunchKernelGGL((k_band_sample<8, 8>), dim3((unsigned)ctx->n_chains), dim3(8, 8), lds, ctx->stream, ctx->n_chains,
+                       ctx->chain_offset, n, (int)w, T, rhs_chain, ld_rhs, z_inject, ld_z, key, ctx->workspace, x, ld_x, mean,
+                       ld_mean, logdet, ctx->d_bad_chain);
+  } else {
+    hipLaunchKernelGGL((k_band_sample<16, 16>), dim3((unsigned)ctx->n_chains), dim3(16, 16), lds, ctx->stream, ctx->n_chains,
+                       ctx->chain_offset, n, (int)w, T, rhs_chain, ld_rhs, z_inject, ld_z, key, ctx->workspace, x, ld_x, mean,
+                       ld_mean, logdet, ctx->d_bad_chain);
+  }
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }
