@@ -43,6 +43,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->tridiag_seg = 0;
   c->stamps = nullptr;
   c->debug_zero_z = 0;
+  c->dense_use_rocsolver = 0;
   if (c->own_stream) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { omc_set_error("hipStreamCreate", e); delete c; return OMC_HIP_ERROR; }
@@ -107,6 +108,10 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "tridiag_seg")) {
     if (value != 0 && value != 8 && value != 10 && value != 16 && value != 20 && value != 32) return OMC_INVALID_ARG;
     ctx->tridiag_seg = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "dense_use_rocsolver")) {
+    ctx->dense_use_rocsolver = value != 0;
     return OMC_OK;
   }
   if (!strcmp(name, "debug_zero_z")) {

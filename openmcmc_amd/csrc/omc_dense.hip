@@ -219,6 +219,118 @@ __global__ void __launch_bounds__(256) k_tri_solve_batched(int64_t p, const doub
   for (int64_t i = tid; i < p; i += 256) x[i] = xs[i];
 }
 
+// ------------------------------------------------------------------------------------------
+// Batched Cholesky, left-looking by 64-column blocks (column-major, lower; the natural-order factor is unique, so
+// this is the reference's np.linalg.cholesky / LAPACK potrf result up to rounding, gmrf.py:481):
+//   for each block column J:   A[J:, J] -= L[J:, :J] L[J, :J]'        one strided-batched DGEMM over all chains
+//                              L_JJ = chol(A_JJ), A[J+1:, J] L_JJ^-T  k_chol_panel, one workgroup per chain
+// rocSOLVER's potrf_strided_batched spent 13 ms on 256 matrices of order 1000 (6.5 TFLOP/s: small-panel kernels
+// and a syr2k-based update); here the flops sit in 15 well-shaped batched GEMMs.
+#define CH_NB 64
+__global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int nb, double* Qall, int* info,
+                                                    long long* bad) {
+  __shared__ double D[CH_NB][CH_NB + 1];  // diagonal block, then its Cholesky factor (zero outside the live nb x nb)
+  __shared__ double LiT[CH_NB][CH_NB];    // transposed inverse of the factor (row t: column t of L_JJ^-1)
+  __shared__ double dinv[CH_NB];
+  __shared__ int failed;
+  const int64_t c = blockIdx.x;
+  double* A = Qall + c * p * p + j0 + j0 * p;  // panel origin: element (r, cc) at A[r + cc * p]
+  const int tid = threadIdx.x;
+  const int64_t m = p - j0;
+  for (int t = tid; t < CH_NB * CH_NB; t += 256) {
+    const int r = t % CH_NB, cc = t / CH_NB;
+    D[r][cc] = (cc <= r && r < nb) ? A[r + (int64_t)cc * p] : 0.0;
+  }
+  if (tid < CH_NB) dinv[tid] = 0.0;
+  if (tid == 0) failed = 0;
+  __syncthreads();
+  if (tid < 64) {
+    // unblocked right-looking Cholesky of the block by ONE wave (lane = row): no workgroup barriers on the
+    // 64-step serial path, only the wave's own in-order LDS traffic
+    const int r = tid;
+    for (int k = 0; k < nb; ++k) {
+      const double piv = D[k][k];
+      const bool ok = piv > 0.0;
+      const double sq = ok ? sqrt(piv) : 1.0;
+      const double rinv = 1.0 / sq;
+      double lr = 0.0;
+      if (r > k && r < nb) {
+        lr = D[r][k] * rinv;
+        D[r][k] = lr;
+      }
+      if (r == k) {
+        D[k][k] = sq;
+        dinv[k] = rinv;
+        if (!ok) failed = 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (r > k && r < nb)
+        for (int cc = k + 1; cc <= r; ++cc) D[r][cc] = fma(-lr, D[cc][k], D[r][cc]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  // inverse of the diagonal factor, one column per lane (forward substitution on e_j), stored transposed:
+  // LiT[t][cc] = (L_JJ^-1)[cc][t], so that the row update below reads 64 consecutive doubles per t
+  if (tid < 64) {
+    const int j = tid;
+    for (int i = 0; i < CH_NB; ++i) LiT[j][i] = 0.0;
+    if (j < nb) {
+      for (int i = j; i < nb; ++i) {
+        double acc = (i == j) ? 1.0 : 0.0;
+        for (int t = j; t < i; ++t) acc = fma(-D[i][t], LiT[j][t], acc);
+        LiT[j][i] = acc * dinv[i];
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < nb * nb; t += 256) {
+    const int r = t % nb, cc = t / nb;
+    if (cc <= r) A[r + (int64_t)cc * p] = D[r][cc];
+  }
+  if (tid == 0 && failed) {
+    info[c] = (int)j0 + 1;
+    atomicMin((unsigned long long*)bad, (unsigned long long)c);
+  }
+  // rows below the block:  X = A_panel L_JJ^-T, i.e. X[r][cc] = sum_{t <= cc} A[r][t] Linv[cc][t].  One thread per
+  // row: 64 accumulators in registers (compile-time indices), the row streamed once from global memory (coalesced
+  // over the rows), the inverse read from LDS as wave-wide broadcasts.
+  for (int64_t r = nb + tid; r < m; r += 256) {
+    double acc[CH_NB];
+#pragma unroll
+    for (int cc = 0; cc < CH_NB; ++cc) acc[cc] = 0.0;
+    for (int t = 0; t < nb; ++t) {
+      const double a = A[r + (int64_t)t * p];
+#pragma unroll
+      for (int cc = 0; cc < CH_NB; ++cc) acc[cc] = fma(a, LiT[t][cc], acc[cc]);
+    }
+#pragma unroll
+    for (int cc = 0; cc < CH_NB; ++cc)
+      if (cc < nb) A[r + (int64_t)cc * p] = acc[cc];
+  }
+}
+
+static omc_status potrf_blocked(omc_ctx* ctx, rocblas_handle h, int64_t p, double* Q, int64_t C) {
+  OMC_HIP_CHECK(hipMemsetAsync(ctx->dense_info, 0, (size_t)C * sizeof(int), ctx->stream));
+  const double minus_one = -1.0, one = 1.0;
+  for (int64_t j0 = 0; j0 < p; j0 += CH_NB) {
+    const int nb = (int)((p - j0 < CH_NB) ? p - j0 : CH_NB);
+    if (j0 > 0)
+      OMC_BLAS_CHECK(rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose,
+                                                   (rocblas_int)(p - j0), (rocblas_int)nb, (rocblas_int)j0, &minus_one,
+                                                   Q + j0, (rocblas_int)p, (rocblas_stride)(p * p), Q + j0, (rocblas_int)p,
+                                                   (rocblas_stride)(p * p), &one, Q + j0 + j0 * p, (rocblas_int)p,
+                                                   (rocblas_stride)(p * p), (rocblas_int)C));
+    hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)C), dim3(256), 0, ctx->stream, p, j0, nb, Q, ctx->dense_info,
+                       ctx->d_bad_chain);
+    OMC_HIP_CHECK(hipGetLastError());
+  }
+  return OMC_OK;
+}
+
 static omc_status tri_solve(omc_ctx* ctx, rocblas_handle h, bool trans, int64_t p, const double* Q, double* x, int64_t ld,
                             int64_t C) {
   if (p <= 8192) {
@@ -277,8 +389,13 @@ omc_status omc_dense_sample_canonical(omc_ctx* ctx, int64_t p, const omc_dense_t
   double* Q = ctx->dense_factor;
   hipLaunchKernelGGL(k_dense_assemble, dim3(gx(p * p) > 64 ? 64 : gx(p * p), (unsigned)C), dim3(256), 0, ctx->stream, T, p, C, Q);
   OMC_HIP_CHECK(hipGetLastError());
-  OMC_BLAS_CHECK(rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, (rocblas_int)p, Q, (rocblas_int)p,
-                                                  (rocblas_stride)(p * p), ctx->dense_info, (rocblas_int)C));
+  if (p >= 256 && !ctx->dense_use_rocsolver) {
+    st = potrf_blocked(ctx, h, p, Q, C);
+    if (st != OMC_OK) return st;
+  } else {
+    OMC_BLAS_CHECK(rocsolver_dpotrf_strided_batched(h, rocblas_fill_lower, (rocblas_int)p, Q, (rocblas_int)p,
+                                                    (rocblas_stride)(p * p), ctx->dense_info, (rocblas_int)C));
+  }
   hipLaunchKernelGGL(k_dense_post_factor, dim3((unsigned)C), dim3(256), 0, ctx->stream, p, C, Q, ctx->dense_info,
                      logdet_out, ctx->d_bad_chain);
   OMC_HIP_CHECK(hipGetLastError());
