@@ -227,6 +227,10 @@ __global__ void __launch_bounds__(256) k_tri_solve_batched(int64_t p, const doub
 // rocSOLVER's potrf_strided_batched spent 13 ms on 256 matrices of order 1000 (6.5 TFLOP/s: small-panel kernels
 // and a syr2k-based update); here the flops sit in 15 well-shaped batched GEMMs.
 #define CH_NB 64
+__device__ __forceinline__ void lds_barrier() {  // workgroup barrier that waits for LDS traffic only
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int nb, double* Qall, int* info,
                                                     long long* bad) {
   __shared__ double D[CH_NB][CH_NB + 1];  // diagonal block, then its Cholesky factor (zero outside the live nb x nb)
@@ -244,46 +248,50 @@ __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int n
   if (tid < CH_NB) dinv[tid] = 0.0;
   if (tid == 0) failed = 0;
   __syncthreads();
-  if (tid < 64) {
-    // unblocked right-looking Cholesky of the block by ONE wave (lane = row): no workgroup barriers on the
-    // 64-step serial path, only the wave's own in-order LDS traffic
-    const int r = tid;
+  // unblocked right-looking Cholesky of the block: all 256 threads tile the (r, cc) update square 16 x 16, two
+  // LDS-only barriers per column (lds_barrier: no wait on vector memory)
+  {
+    const int tx = tid & 15, ty = tid >> 4;
     for (int k = 0; k < nb; ++k) {
       const double piv = D[k][k];
       const bool ok = piv > 0.0;
       const double sq = ok ? sqrt(piv) : 1.0;
       const double rinv = 1.0 / sq;
-      double lr = 0.0;
-      if (r > k && r < nb) {
-        lr = D[r][k] * rinv;
-        D[r][k] = lr;
-      }
-      if (r == k) {
+      lds_barrier();  // everybody has read the pivot before it is overwritten
+      if (tid > k && tid < nb) D[tid][k] *= rinv;
+      if (tid == k) {
         D[k][k] = sq;
         dinv[k] = rinv;
         if (!ok) failed = 1;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (r > k && r < nb)
-        for (int cc = k + 1; cc <= r; ++cc) D[r][cc] = fma(-lr, D[cc][k], D[r][cc]);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      lds_barrier();
+      for (int r = k + 1 + ty; r < nb; r += 16) {
+        const double lr = D[r][k];
+        for (int cc = k + 1 + tx; cc <= r; cc += 16) D[r][cc] = fma(-lr, D[cc][k], D[r][cc]);
+      }
+      lds_barrier();
     }
   }
-  // inverse of the diagonal factor, one column per lane (forward substitution on e_j), stored transposed:
+  // inverse of the diagonal factor, one column per group of four adjacent lanes (forward substitution on e_j, the
+  // inner sum split four ways and combined with two shuffles), stored transposed:
   // LiT[t][cc] = (L_JJ^-1)[cc][t], so that the row update below reads 64 consecutive doubles per t
-  if (tid < 64) {
-    const int j = tid;
-    for (int i = 0; i < CH_NB; ++i) LiT[j][i] = 0.0;
-    if (j < nb) {
-      for (int i = j; i < nb; ++i) {
-        double acc = (i == j) ? 1.0 : 0.0;
-        for (int t = j; t < i; ++t) acc = fma(-D[i][t], LiT[j][t], acc);
-        LiT[j][i] = acc * dinv[i];
-      }
+  {
+    const int j = tid >> 2, part = tid & 3;
+    if (part == 0)
+      for (int i = 0; i < CH_NB; ++i) LiT[j][i] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = j; i < nb; ++i) {   // j is uniform within a group of four lanes; i runs in lock-step for the group
+      double acc = 0.0;
+      if (j < nb)
+        for (int t = j + part; t < i; t += 4) acc = fma(-D[i][t], LiT[j][t], acc);
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (part == 0 && j < nb) LiT[j][i] = (acc + ((i == j) ? 1.0 : 0.0)) * dinv[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
   __syncthreads();
@@ -296,16 +304,30 @@ __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int n
     atomicMin((unsigned long long*)bad, (unsigned long long)c);
   }
   // rows below the block:  X = A_panel L_JJ^-T, i.e. X[r][cc] = sum_{t <= cc} A[r][t] Linv[cc][t].  One thread per
-  // row: 64 accumulators in registers (compile-time indices), the row streamed once from global memory (coalesced
-  // over the rows), the inverse read from LDS as wave-wide broadcasts.
+  // row: 64 accumulators in registers (compile-time indices); the row is fetched eight entries at a time, the next
+  // eight while the current ones are used (each fetch is coalesced over the rows); the inverse is read from LDS as
+  // wave-wide broadcasts, and the zero half of the triangle is skipped per chunk.
   for (int64_t r = nb + tid; r < m; r += 256) {
     double acc[CH_NB];
 #pragma unroll
     for (int cc = 0; cc < CH_NB; ++cc) acc[cc] = 0.0;
-    for (int t = 0; t < nb; ++t) {
-      const double a = A[r + (int64_t)t * p];
+    double a_cur[8], a_next[8];
 #pragma unroll
-      for (int cc = 0; cc < CH_NB; ++cc) acc[cc] = fma(a, LiT[t][cc], acc[cc]);
+    for (int q = 0; q < 8; ++q) a_cur[q] = (q < nb) ? A[r + (int64_t)q * p] : 0.0;
+#pragma unroll
+    for (int t0 = 0; t0 < CH_NB; t0 += 8) {
+      if (t0 < nb) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a_next[q] = (t0 + 8 + q < nb) ? A[r + (int64_t)(t0 + 8 + q) * p] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+          for (int cc = t0; cc < CH_NB; ++cc) acc[cc] = fma(a_cur[q], LiT[t0 + q][cc], acc[cc]);
+          __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of later rows of the inverse from piling up
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a_cur[q] = a_next[q];
+      }
     }
 #pragma unroll
     for (int cc = 0; cc < CH_NB; ++cc)
