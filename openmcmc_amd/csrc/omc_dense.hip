@@ -45,7 +45,8 @@ omc_status omc_ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need)
   return OMC_OK;
 }
 
-// Q[c] = sum_k s_k[c] M_k (full matrix; symmetric so the storage order does not matter)
+// Q[c] = sum_k s_k[c] M_k, lower triangle only (column-major: element (row, col) at col*p + row, row >= col): the
+// factorisations read nothing else, and the upper half would be 1 GB of writes per sweep at p = 1000, C = 256
 __global__ void __launch_bounds__(256) k_dense_assemble(DenseTermsDev T, int64_t p, int64_t C, double* Q) {
   const int64_t c = blockIdx.y;
   double sc[OMC_MAX_TERMS];
@@ -55,6 +56,7 @@ __global__ void __launch_bounds__(256) k_dense_assemble(DenseTermsDev T, int64_t
   const int64_t total = p * p;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / p, cl = i - r * p;
+    if (cl < r) continue;
     double v = 0.0;
 #pragma unroll
     for (int k = 0; k < OMC_MAX_TERMS; ++k) {
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int n
                                                     long long* bad) {
   __shared__ double D[CH_NB][CH_NB + 1];  // diagonal block, then its Cholesky factor (zero outside the live nb x nb)
   __shared__ double LiT[CH_NB][CH_NB];    // transposed inverse of the factor (row t: column t of L_JJ^-1)
-  __shared__ double dinv[CH_NB];
+  __shared__ double dinv[CH_NB], dsq[CH_NB];
   __shared__ int failed;
   const int64_t c = blockIdx.x;
   double* A = Qall + c * p * p + j0 + j0 * p;  // panel origin: element (r, cc) at A[r + cc * p]
@@ -253,14 +255,13 @@ __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int n
   {
     const int tx = tid & 15, ty = tid >> 4;
     for (int k = 0; k < nb; ++k) {
-      const double piv = D[k][k];
+      const double piv = D[k][k];  // final since the update of step k - 1; nobody writes it during this step
       const bool ok = piv > 0.0;
       const double sq = ok ? sqrt(piv) : 1.0;
       const double rinv = 1.0 / sq;
-      lds_barrier();  // everybody has read the pivot before it is overwritten
       if (tid > k && tid < nb) D[tid][k] *= rinv;
       if (tid == k) {
-        D[k][k] = sq;
+        dsq[k] = sq;   // the diagonal goes to its own array: D[k][k] is still being read by slower waves
         dinv[k] = rinv;
         if (!ok) failed = 1;
       }
@@ -297,7 +298,7 @@ __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int n
   __syncthreads();
   for (int t = tid; t < nb * nb; t += 256) {
     const int r = t % nb, cc = t / nb;
-    if (cc <= r) A[r + (int64_t)cc * p] = D[r][cc];
+    if (cc <= r) A[r + (int64_t)cc * p] = (cc == r) ? dsq[r] : D[r][cc];
   }
   if (tid == 0 && failed) {
     info[c] = (int)j0 + 1;
