@@ -24,19 +24,6 @@ static unsigned gx(int64_t n) {
   return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
 
-// out[c][i] = a[c][i] - mu[i]   (mu NULL = 0)
-__global__ void k_sub_shared(int64_t d, const double* a, int64_t ld_a, const double* mu, double* out, int64_t ld_o) {
-  const int64_t c = blockIdx.y;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d; i += (int64_t)gridDim.x * blockDim.x)
-    out[c * ld_o + i] = a[c * ld_a + i] - (mu ? mu[i] : 0.0);
-}
-// out = a + alpha * b
-__global__ void k_axpby(int64_t d, const double* a, int64_t ld_a, double alpha, const double* b, int64_t ld_b, double* out,
-                        int64_t ld_o) {
-  const int64_t c = blockIdx.y;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d; i += (int64_t)gridDim.x * blockDim.x)
-    out[c * ld_o + i] = fma(alpha, b[c * ld_b + i], a[c * ld_a + i]);
-}
 // z[c][:] from the injected array or the chain's normal stream
 __global__ void k_draw_normals(int64_t d, int64_t chain_offset, omc_rng_key key, const double* zin, int64_t ld_z,
                                double* z, int64_t ld_o) {
@@ -53,52 +40,6 @@ __global__ void k_draw_normals(int64_t d, int64_t chain_offset, omc_rng_key key,
     z[c * ld_o + 2 * q] = z0;
     if (2 * q + 1 < d) z[c * ld_o + 2 * q + 1] = z1;
   }
-}
-// out[c] = sum_i a[c][i]^2
-__global__ void __launch_bounds__(256) k_colsumsq(int64_t d, const double* a, int64_t ld_a, double* out) {
-  __shared__ double red[4];
-  const int64_t c = blockIdx.x;
-  double acc = 0.0;
-  for (int64_t i = threadIdx.x; i < d; i += blockDim.x) acc = fma(a[c * ld_a + i], a[c * ld_a + i], acc);
-  for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) out[c] = red[0] + red[1] + red[2] + red[3];
-}
-// accept/reject: one lane per chain decides, the flag is broadcast for the copy kernel
-__global__ void k_mh_decide(int64_t C, int64_t chain_offset, omc_rng_key key, const double* u_in, double dnum,
-                            const double* sumlogL, double log_step_term, int mala, const double* ss_fwd,
-                            const double* ss_rev, const double* ss_cur, const double* ss_prop, double lp_scale,
-                            int* flag, long long* acc_cnt, long long* prop_cnt) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double sl = sumlogL[0];
-  // log p (gmrf.py:339-344) with L_Q = step * L:  |L_Q'(x-mu)|^2 = lp_scale * ss
-  const double logdetQ = 2.0 * (sl + log_step_term);
-  const double lp_cur = 0.5 * (logdetQ - dnum * 1.8378770664093453 - lp_scale * ss_cur[c]);
-  const double lp_prop = 0.5 * (logdetQ - dnum * 1.8378770664093453 - lp_scale * ss_prop[c]);
-  double log_alpha = lp_prop - lp_cur;
-  if (mala) {
-    const double lq_fwd = sl - 0.5 * ss_fwd[c], lq_rev = sl - 0.5 * ss_rev[c];  // metropolis_hastings.py:372-373
-    log_alpha = lp_prop + lq_rev - (lp_cur + lq_fwd);                            // :155
-  }
-  double u;
-  if (u_in) {
-    u = u_in[c];
-  } else {
-    const uint4 w = omc_rng_block(key, chain_offset + c, 0u);
-    u = omc_u53(w.x, w.y);
-  }
-  const int ok = log(u) < log_alpha;  // :173
-  flag[c] = ok;
-  if (prop_cnt) prop_cnt[c] += 1;
-  if (acc_cnt && ok) acc_cnt[c] += 1;
-}
-__global__ void k_select_rows(int64_t d, const int* flag, const double* prop, int64_t ld_p, double* x, int64_t ld_x) {
-  const int64_t c = blockIdx.y;
-  if (!flag[c]) return;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d; i += (int64_t)gridDim.x * blockDim.x)
-    x[c * ld_x + i] = prop[c * ld_p + i];
 }
 __global__ void k_sumlogdiag(int64_t d, const double* L, double* out) {
   __shared__ double red[4];
@@ -156,31 +97,124 @@ omc_status omc_dense_cholesky(omc_ctx* ctx, int64_t d, const double* A, double s
   return OMC_OK;
 }
 
-// Shared constant Hessian: the drift matrix A1 = -(L L')^{-1} Q (one potrs) and the explicit L^{-T}
-// (one trsm on the identity) are formed once per (Q, L, step) and cached in the context; every step
-// is then 3 GEMMs + 1 TRMM instead of 2 GEMMs + 5 TRSMs + 4 TRMMs (TRSM with 512 right-hand sides is
-// ~10x slower than the GEMM of the same shape, and the old sequence was launch-bound).
+// Shared constant Hessian: the drift matrix A1 = -(L L')^{-1} Q (one potrs), A1p = I + A1/2 and the explicit
+// L^{-T} (one trsm on the identity) are formed once per (Q, L, step) and cached in the context.  The proposal mean
+// is then m(x) = A1p x + c0, and a step is 3 GEMMs (x' = A1p x + L^{-T} z accumulated in place, m' = A1p x'),
+// one TRMM for the three quadratic forms that need L' (the fourth, |L'(x' - m)|^2, is |z|^2), and three small
+// kernels (draw, build, finish) -- 7 launches instead of the first version's 23 (2 GEMMs + 5 TRSMs + 4 TRMMs;
+// TRSM with 512 right-hand sides is ~10x slower than the GEMM of the same shape).
 __global__ void k_set_identity(int64_t d, double* A) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d * d; i += (int64_t)gridDim.x * blockDim.x)
     A[i] = (i / d == i % d) ? 1.0 : 0.0;
 }
-// T4 columns: [ R | XP - M | R' | X - M' ]  (each d x C), from X, mu, XP, M (current) and M' (proposed)
-__global__ void k_build_t4(int64_t d, int64_t C, const double* x, int64_t ld_x, const double* mu, const double* xp,
-                           const double* m_cur, const double* m_prop, double* t4) {
+// A1p = I + 0.5 * A1  (the proposal mean of a chain is then ONE matrix product: m = A1p x + c0, c0 = -0.5 A1 mu)
+__global__ void k_half_plus_identity(int64_t d, const double* A1, double* out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d * d; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = 0.5 * A1[i] + ((i / d == i % d) ? 1.0 : 0.0);
+}
+// a[c][:] += v
+__global__ void k_add_shared(int64_t d, double* a, int64_t ld_a, const double* v) {
+  const int64_t c = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d; i += (int64_t)gridDim.x * blockDim.x)
+    a[c * ld_a + i] += v[i];
+}
+// T3 columns: [ x - mu | x' - mu | x - m' ]  with m' = mp + c0 (each block d x C)
+__global__ void k_build_t3(int64_t d, int64_t C, const double* x, int64_t ld_x, const double* mu, const double* c0,
+                           const double* xp, const double* mp, double* t3) {
   const int64_t c = blockIdx.y;
   const int64_t blk = C * d;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d; i += (int64_t)gridDim.x * blockDim.x) {
     const double xv = x[c * ld_x + i], pv = xp[c * d + i], mv = mu ? mu[i] : 0.0;
-    t4[c * d + i] = xv - mv;
-    t4[blk + c * d + i] = pv - m_cur[c * d + i];
-    t4[2 * blk + c * d + i] = pv - mv;
-    t4[3 * blk + c * d + i] = xv - m_prop[c * d + i];
+    t3[c * d + i] = xv - mv;
+    t3[blk + c * d + i] = pv - mv;
+    t3[2 * blk + c * d + i] = xv - (mp[c * d + i] + (c0 ? c0[i] : 0.0));
   }
+}
+// random walk: x' = x + step * z (two roundings like numpy's mu + z*step), T2 = [ x - mu | x' - mu ]
+__global__ void k_rw_build(int64_t d, int64_t C, const double* x, int64_t ld_x, const double* mu, double step,
+                           const double* z, double* xp, double* t2) {
+  const int64_t c = blockIdx.y;
+  const int64_t blk = C * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d; i += (int64_t)gridDim.x * blockDim.x) {
+    const double xv = x[c * ld_x + i], mv = mu ? mu[i] : 0.0;
+    double pv;
+    {
+#pragma clang fp contract(off)
+      const double prod = z[c * d + i] * step;
+      pv = xv + prod;
+    }
+    xp[c * d + i] = pv;
+    t2[c * d + i] = xv - mv;
+    t2[blk + c * d + i] = pv - mv;
+  }
+}
+// One workgroup per chain: the squared norms the decision needs, the decision, and the move of the accepted
+// proposal into the state (metropolis_hastings.py:127-173).  n_cur / n_prop / n_rev: columns of L'(.) (n_rev and z
+// NULL for the symmetric random walk); z: the proposal's N(0, I) draw, |z|^2 = |L'(x' - m)|^2.
+__global__ void __launch_bounds__(256) k_mh_finish(int64_t d, int64_t chain_offset, omc_rng_key key, const double* u_in,
+                                                   const double* sumlogL, double log_step_term, double lp_scale,
+                                                   const double* n_cur, const double* n_prop, const double* n_rev,
+                                                   const double* z, const double* xp, double* x, int64_t ld_x,
+                                                   long long* acc_cnt, long long* prop_cnt) {
+  __shared__ double red[4][4];
+  __shared__ int accept;
+  const int64_t c = blockIdx.x;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  for (int64_t i = threadIdx.x; i < d; i += 256) {
+    const double v0 = n_cur[c * d + i], v1 = n_prop[c * d + i];
+    a0 = fma(v0, v0, a0);
+    a1 = fma(v1, v1, a1);
+    if (n_rev) {
+      const double v2 = n_rev[c * d + i], v3 = z[c * d + i];
+      a2 = fma(v2, v2, a2);
+      a3 = fma(v3, v3, a3);
+    }
+  }
+  for (int s = 32; s >= 1; s >>= 1) {
+    a0 += __shfl_xor(a0, s, 64); a1 += __shfl_xor(a1, s, 64);
+    a2 += __shfl_xor(a2, s, 64); a3 += __shfl_xor(a3, s, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    red[0][w] = a0; red[1][w] = a1; red[2][w] = a2; red[3][w] = a3;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double ss_cur = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double ss_prop = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double sl = sumlogL[0];
+    const double logdetQ = 2.0 * (sl + log_step_term);
+    const double dnum = (double)d;
+    // log p (gmrf.py:339-344) with L_Q = step * L:  |L_Q'(x-mu)|^2 = lp_scale * ss
+    const double lp_cur = 0.5 * (logdetQ - dnum * 1.8378770664093453 - lp_scale * ss_cur);
+    const double lp_prop = 0.5 * (logdetQ - dnum * 1.8378770664093453 - lp_scale * ss_prop);
+    double log_alpha = lp_prop - lp_cur;
+    if (n_rev) {
+      const double ss_rev = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+      const double ss_fwd = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
+      const double lq_fwd = sl - 0.5 * ss_fwd, lq_rev = sl - 0.5 * ss_rev;  // metropolis_hastings.py:372-373
+      log_alpha = lp_prop + lq_rev - (lp_cur + lq_fwd);                      // :155
+    }
+    double u;
+    if (u_in) {
+      u = u_in[c];
+    } else {
+      const uint4 w = omc_rng_block(key, chain_offset + c, 0u);
+      u = omc_u53(w.x, w.y);
+    }
+    const int ok = log(u) < log_alpha;  // :173
+    accept = ok;
+    if (prop_cnt) prop_cnt[c] += 1;
+    if (acc_cnt && ok) acc_cnt[c] += 1;
+  }
+  __syncthreads();
+  if (accept)
+    for (int64_t i = threadIdx.x; i < d; i += 256) x[c * ld_x + i] = xp[c * d + i];
 }
 
 static omc_status mala_prepare(omc_ctx* ctx, int64_t d, const double* Q, const double* L, double step) {
   if (ctx->mala_Q == Q && ctx->mala_L == L && ctx->mala_step == step && ctx->mala_d == d && ctx->mala_prep) return OMC_OK;
-  omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->mala_prep, &ctx->mala_prep_bytes, (size_t)3 * d * d * sizeof(double));
+  omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->mala_prep, &ctx->mala_prep_bytes, (size_t)4 * d * d * sizeof(double));
   if (st != OMC_OK) return st;
   rocblas_handle h = (rocblas_handle)ctx->blas;
   const rocblas_int di = (rocblas_int)d;
@@ -194,6 +228,7 @@ static omc_status mala_prepare(omc_ctx* ctx, int64_t d, const double* Q, const d
   const double one = 1.0;
   OMC_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
                                rocblas_diagonal_non_unit, di, di, &one, L, di, LinvT, di));
+  hipLaunchKernelGGL(k_half_plus_identity, dim3(gx(d * d)), dim3(256), 0, ctx->stream, d, A1, ctx->mala_prep + 3 * d * d);
   OMC_HIP_CHECK(hipGetLastError());
   ctx->mala_Q = Q; ctx->mala_L = L; ctx->mala_step = step; ctx->mala_d = d;
   return OMC_OK;
@@ -217,43 +252,41 @@ omc_status omc_mala_step(omc_ctx* ctx, int64_t d, const double* Q, const double*
   if (st != OMC_OK) return st;
   const double* A1 = ctx->mala_prep;
   const double* LinvT = ctx->mala_prep + d * d;
+  const double* A1p = ctx->mala_prep + 3 * d * d;  // I + A1/2
   rocblas_handle h = (rocblas_handle)ctx->blas;
   const rocblas_int di = (rocblas_int)d, Ci = (rocblas_int)C;
-  const double one = 1.0, zero = 0.0;
+  const double one = 1.0, zero = 0.0, minus_half = -0.5;
   const dim3 g2(gx(d) > 8 ? 8 : gx(d), (unsigned)C), b2(256);
   hipStream_t s = ctx->stream;
-  // workspace roles: R (residual), G (drift), M (current mean), V (draws / M'), XP (proposal), T4 (4 d x C)
-  double* T4 = w.T;  // 4 * C * d doubles (mh_workspace sizes T for it)
-  double* N4 = w.T + 4 * C * d;
-  double *ss = w.ss;  // [4][C]: |L'R|^2, |L'(x'-M)|^2, |L'R'|^2, |L'(x-M')|^2
-
-  // current state: M = x + 1/2 A1 (x - mu)
-  hipLaunchKernelGGL(k_sub_shared, g2, b2, 0, s, d, x, ld_x, mu, w.R, d);
-  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, A1, di, w.R, di, &zero,
-                               w.G, di));
-  hipLaunchKernelGGL(k_axpby, g2, b2, 0, s, d, x, ld_x, 0.5, w.G, d, w.M, d);
-  // proposal: x' = M + L^{-T} z
+  // workspace roles: Z (draw), XP (proposal x'), V (A1p x'), T3 = [x-mu | x'-mu | x-m'] and its image under L'
+  double* Z = w.R;
+  double* T3 = w.T;
+  double* N3 = w.T + 3 * C * d;
+  double* c0 = nullptr;
+  if (mu) {  // c0 = -1/2 A1 mu: the constant part of the proposal mean m(x) = A1p x + c0
+    c0 = w.G;
+    OMC_BLAS_CHECK(rocblas_dgemv(h, rocblas_operation_none, di, di, &minus_half, A1, di, mu, 1, &zero, c0, 1));
+  }
+  // proposal: x' = m(x) + L^{-T} z = A1p x + L^{-T} z (+ c0): two GEMMs into the same buffer, no element-wise pass
   hipLaunchKernelGGL(k_draw_normals, dim3(gx((d + 1) / 2) > 8 ? 8 : gx((d + 1) / 2), (unsigned)C), b2, 0, s, d,
-                     ctx->chain_offset, omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), z_inject, ld_z, w.R, d);
-  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, LinvT, di, w.R, di,
-                               &zero, w.V, di));
-  hipLaunchKernelGGL(k_axpby, g2, b2, 0, s, d, w.M, d, 1.0, w.V, d, w.XP, d);
-  // proposed state: M' = x' + 1/2 A1 (x' - mu)
-  hipLaunchKernelGGL(k_sub_shared, g2, b2, 0, s, d, w.XP, d, mu, w.R, d);
-  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, A1, di, w.R, di, &zero,
-                               w.G, di));
-  hipLaunchKernelGGL(k_axpby, g2, b2, 0, s, d, w.XP, d, 0.5, w.G, d, w.V, d);  // V = M'
-  // the four quadratic forms |L'(.)|^2 in one TRMM on [R | x'-M | R' | x-M']
-  hipLaunchKernelGGL(k_build_t4, g2, b2, 0, s, d, C, x, ld_x, mu, w.XP, w.M, w.V, T4);
+                     ctx->chain_offset, omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), z_inject, ld_z, Z, d);
+  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, A1p, di, x,
+                               (rocblas_int)ld_x, &zero, w.XP, di));
+  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, LinvT, di, Z, di, &one,
+                               w.XP, di));
+  if (c0) hipLaunchKernelGGL(k_add_shared, g2, b2, 0, s, d, w.XP, d, c0);
+  // proposed state's mean: m' = A1p x' (+ c0, added when T3 is built)
+  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, A1p, di, w.XP, di, &zero,
+                               w.V, di));
+  // |L'(x - mu)|^2, |L'(x' - mu)|^2, |L'(x - m')|^2 in one TRMM; |L'(x' - m)|^2 = |z|^2 needs none
+  hipLaunchKernelGGL(k_build_t3, g2, b2, 0, s, d, C, x, ld_x, mu, c0, w.XP, w.V, T3);
   OMC_BLAS_CHECK(rocblas_dtrmm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                               rocblas_diagonal_non_unit, di, 4 * Ci, &one, L, di, T4, di, N4, di));
-  hipLaunchKernelGGL(k_colsumsq, dim3((unsigned)(4 * C)), dim3(256), 0, s, d, N4, d, ss);
-  // accept / reject.  L = chol(Q / step^2) => chol(Q) = step * L
-  hipLaunchKernelGGL(k_mh_decide, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, C, ctx->chain_offset,
-                     omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), u_inject, (double)d, sumlogL,
-                     (double)d * log(step), 1, ss + C, ss + 3 * C, ss, ss + 2 * C, step * step, w.flag,
-                     (long long*)accept_count, (long long*)proposal_count);
-  hipLaunchKernelGGL(k_select_rows, g2, b2, 0, s, d, w.flag, w.XP, d, x, ld_x);
+                               rocblas_diagonal_non_unit, di, 3 * Ci, &one, L, di, T3, di, N3, di));
+  // accept / reject and the move of accepted proposals.  L = chol(Q / step^2) => chol(Q) = step * L
+  hipLaunchKernelGGL(k_mh_finish, dim3((unsigned)C), dim3(256), 0, s, d, ctx->chain_offset,
+                     omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), u_inject, sumlogL, (double)d * log(step),
+                     step * step, N3, N3 + C * d, N3 + 2 * C * d, Z, w.XP, x, ld_x, (long long*)accept_count,
+                     (long long*)proposal_count);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }
@@ -276,22 +309,18 @@ omc_status omc_rw_step(omc_ctx* ctx, int64_t d, const double* mu, const double* 
   const double one = 1.0;
   const dim3 g2(gx(d) > 8 ? 8 : gx(d), (unsigned)C), b2(256);
   hipStream_t s = ctx->stream;
-  double *ss_cur = w.ss + 2 * C, *ss_prop = w.ss + 3 * C;
-  hipLaunchKernelGGL(k_sub_shared, g2, b2, 0, s, d, x, ld_x, mu, w.R, d);
-  OMC_BLAS_CHECK(rocblas_dtrmm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                               rocblas_diagonal_non_unit, di, Ci, &one, LQ, di, w.R, di, w.T, di));
-  hipLaunchKernelGGL(k_colsumsq, dim3((unsigned)C), dim3(256), 0, s, d, w.T, d, ss_cur);
+  double* Z = w.V;
+  double* T2 = w.T;
+  double* N2 = w.T + 2 * C * d;
   hipLaunchKernelGGL(k_draw_normals, dim3(gx((d + 1) / 2) > 8 ? 8 : gx((d + 1) / 2), (unsigned)C), b2, 0, s, d,
-                     ctx->chain_offset, omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), z_inject, ld_z, w.V, d);
-  hipLaunchKernelGGL(k_axpby, g2, b2, 0, s, d, x, ld_x, step, w.V, d, w.XP, d);  // :250
-  hipLaunchKernelGGL(k_sub_shared, g2, b2, 0, s, d, w.XP, d, mu, w.R, d);
+                     ctx->chain_offset, omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), z_inject, ld_z, Z, d);
+  hipLaunchKernelGGL(k_rw_build, g2, b2, 0, s, d, C, x, ld_x, mu, step, Z, w.XP, T2);  // :250
   OMC_BLAS_CHECK(rocblas_dtrmm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                               rocblas_diagonal_non_unit, di, Ci, &one, LQ, di, w.R, di, w.T, di));
-  hipLaunchKernelGGL(k_colsumsq, dim3((unsigned)C), dim3(256), 0, s, d, w.T, d, ss_prop);
-  hipLaunchKernelGGL(k_mh_decide, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, C, ctx->chain_offset,
-                     omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), u_inject, (double)d, sumlogLQ, 0.0, 0,
-                     ss_cur, ss_cur, ss_cur, ss_prop, 1.0, w.flag, (long long*)accept_count, (long long*)proposal_count);
-  hipLaunchKernelGGL(k_select_rows, g2, b2, 0, s, d, w.flag, w.XP, d, x, ld_x);
+                               rocblas_diagonal_non_unit, di, 2 * Ci, &one, LQ, di, T2, di, N2, di));
+  hipLaunchKernelGGL(k_mh_finish, dim3((unsigned)C), dim3(256), 0, s, d, ctx->chain_offset,
+                     omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), u_inject, sumlogLQ, 0.0, 1.0, N2, N2 + C * d,
+                     (const double*)nullptr, (const double*)nullptr, w.XP, x, ld_x, (long long*)accept_count,
+                     (long long*)proposal_count);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }
