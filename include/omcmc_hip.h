@@ -324,6 +324,16 @@ omc_status omc_rw_propose(omc_ctx* ctx, int64_t p, const double* x, int64_t x_ch
                           const double* draw_inject, uint64_t draw_index, uint32_t sub, double* z,
                           int64_t z_chain_stride, int64_t z_elem_stride, double* lq_fwd, double* lq_rev);
 
+/* ManifoldMALA.proposal / _proposal_params / _log_proposal_density (metropolis_hastings.py:301-373) when the Hessian
+ * is DIAGONAL per chain (hdiag [C][kmax], e.g. the mixture-Normal prior of a variable-size coefficient vector):
+ *   precision = h/step^2, L_jj = sqrt(h_j)/step, m = x + (1/2) precision^{-1} grad;
+ *   propose != 0: x_other = m + z / L is WRITTEN (zeros beyond count[c]), lq = log q(x_other | x);
+ *   propose == 0: x_other is READ, lq = log q(x_other | x) (the reverse move, with grad / hdiag of the proposed state
+ *   passed as x's); log q = sum_j log L_jj - |L'(x_other - m)|^2 / 2.  z_inject [C][kmax] standard normals.      */
+omc_status omc_mala_diag(omc_ctx* ctx, int64_t kmax, const double* x, const double* grad, const double* hdiag,
+                         const double* count, double step, int32_t propose, const double* z_inject, uint64_t draw_index,
+                         uint32_t sub, double* x_other, double* lq);
+
 /* MetropolisHastings._accept_reject_proposal + accept_proposal (metropolis_hastings.py:127-173):
  *   log_alpha = lp_prop + lq_rev - (lp_cur + lq_fwd); accept[c] = log(u) < log_alpha (NaN rejects);
  *   counters (int64, per chain) incremented for participating chains; lq_* / log_alpha / counters may be NULL. */
@@ -406,6 +416,15 @@ omc_status omc_uniform_draw(omc_ctx* ctx, int64_t p, const double* lower, const 
                             uint64_t draw_index, uint32_t sub, double* out);
 omc_status omc_diag_gauss_logpdf(omc_ctx* ctx, int64_t kmax, const double* x, const double* mean, const double* prec,
                                  const double* count, double* out, int32_t accumulate);
+/* omc_gamma_logpdf_ragged: Gamma.log_p (distribution.py:241-261) of a ragged (1, k) response: the sum over the live
+ *   entries, or with last_only != 0 the density of the LAST live entry (what ReversibleJump reads from
+ *   log_p(..., by_observation=True)[-1], reversible_jump.py:132,143);
+ * omc_diag_gauss_grad: gradient of the diagonal Gaussian log-density w.r.t. its response, -prec (x - mean) on the live
+ *   entries, 0 beyond (location_scale.py:222-226).                                                              */
+omc_status omc_gamma_logpdf_ragged(omc_ctx* ctx, int64_t kmax, const double* x, const double* count, double shape,
+                                   double rate, int32_t last_only, double* out, int32_t accumulate);
+omc_status omc_diag_gauss_grad(omc_ctx* ctx, int64_t kmax, const double* x, const double* mean, const double* prec,
+                               const double* count, double* grad);
 omc_status omc_poisson_logpmf(omc_ctx* ctx, const double* x, double rate, double* out, int32_t accumulate);
 omc_status omc_count_logpdf(omc_ctx* ctx, const double* count, double per_element, double* out, int32_t accumulate);
 omc_status omc_mixture_gather(omc_ctx* ctx, int64_t kmax, int64_t m, const double* param, const double* alloc,

@@ -130,6 +130,7 @@ SIGNATURES = {
         i32,
         [C.c_void_p, i64, c_dp, i64, i64, c_dp, i64, c_dp, c_dp, c_dp, i64, c_dp, u64, u32, c_dp, i64, i64, c_dp, c_dp],
     ),
+    "omc_mala_diag": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, C.c_double, i32, c_dp, u64, u32, c_dp, c_dp]),
     "omc_mh_accept": (i32, [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, i64, c_dp, u64, u32, c_dp, c_dp, c_dp, c_dp]),
     "omc_chain_select": (i32, [C.c_void_p, c_dp, i64, c_dp, c_dp]),
     "omc_ragged_resize": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, i64]),
@@ -144,6 +145,8 @@ SIGNATURES = {
     ),
     "omc_uniform_draw": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, u64, u32, c_dp]),
     "omc_diag_gauss_logpdf": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i32]),
+    "omc_gamma_logpdf_ragged": (i32, [C.c_void_p, i64, c_dp, c_dp, C.c_double, C.c_double, i32, c_dp, i32]),
+    "omc_diag_gauss_grad": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "omc_poisson_logpmf": (i32, [C.c_void_p, c_dp, C.c_double, c_dp, i32]),
     "omc_count_logpdf": (i32, [C.c_void_p, c_dp, C.c_double, c_dp, i32]),
     "omc_mixture_gather": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, C.c_double, c_dp]),

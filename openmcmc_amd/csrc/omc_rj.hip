@@ -61,6 +61,51 @@ __global__ void k_rw_propose(int64_t C, int64_t chain_offset, int64_t p, const d
   lq_rev[c] = r;
 }
 
+// ManifoldMALA with a DIAGONAL Hessian h (metropolis_hastings.py:301-373): precision h/step^2, L_jj = sqrt(h_j)/step,
+// m = x + (1/2) step^2 g / h.  propose != 0: x_other = m + step z / sqrt(h) is written and log q(x_other | x) returned;
+// propose == 0: x_other is read and log q(x_other | x) returned (the reverse move).  log q = sum log L_jj - |L'(.-m)|^2/2.
+__global__ void k_mala_diag(int64_t C, int64_t chain_offset, int64_t kmax, const double* x, const double* grad,
+                            const double* hdiag, const double* count, double step, int propose, const double* z_in,
+                            omc_rng_key key, uint32_t sub, double* x_other, double* lq, long long* bad) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int64_t k = count ? (int64_t)count[c] : kmax;
+  double sum_log = 0.0, ss = 0.0;
+  bool fail = false;
+  for (int64_t j = 0; j < kmax; ++j) {
+    const int64_t t = c * kmax + j;
+    if (j >= k) {
+      if (propose) x_other[t] = 0.0;
+      continue;
+    }
+    const double h = hdiag[t];
+    if (!(h > 0.0)) fail = true;
+    const double prec = h / (step * step);
+    const double L = sqrt(prec);
+    const double m = x[t] + 0.5 * (grad[t] / prec);
+    double xo;
+    if (propose) {
+      double z;
+      if (z_in) {
+        z = z_in[t];
+      } else {
+        double n0, n1;
+        omc_normal_pair(omc_rng_block(key, chain_offset + c, sub + (uint32_t)(j >> 1)), n0, n1);
+        z = (j & 1) ? n1 : n0;
+      }
+      xo = m + z / L;
+      x_other[t] = xo;
+    } else {
+      xo = x_other[t];
+    }
+    const double w = L * (xo - m);
+    sum_log += log(L);
+    ss = fma(w, w, ss);
+  }
+  lq[c] = sum_log - 0.5 * ss;
+  if (fail) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+}
+
 // MetropolisHastings._accept_reject_proposal / accept_proposal (metropolis_hastings.py:127-173)
 __global__ void k_mh_accept(int64_t C, int64_t chain_offset, const double* lp_cur, const double* lp_prop,
                             const double* lq_fwd, const double* lq_rev, const double* count, int64_t index,
@@ -484,6 +529,18 @@ omc_status omc_rw_propose(omc_ctx* ctx, int64_t p, const double* x, int64_t x_ch
                      ctx->chain_offset, p, x, x_chain_stride, x_elem_stride, step, step_elem_stride, lower, upper, count,
                      index, draw_inject, omc_make_key(ctx->seed, draw_index, lower ? OMC_RNG_UNIFORM : OMC_RNG_NORMAL), sub,
                      z, z_chain_stride, z_elem_stride, lq_fwd, lq_rev);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_mala_diag(omc_ctx* ctx, int64_t kmax, const double* x, const double* grad, const double* hdiag,
+                         const double* count, double step, int32_t propose, const double* z_inject, uint64_t draw_index,
+                         uint32_t sub, double* x_other, double* lq) {
+  if (!ctx || kmax < 1 || !x || !grad || !hdiag || !(step > 0.0) || !x_other || !lq) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_mala_diag, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, ctx->chain_offset,
+                     kmax, x, grad, hdiag, count, step, (int)propose, z_inject,
+                     omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), sub, x_other, lq, ctx->d_bad_chain);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

@@ -277,6 +277,35 @@ __global__ void k_mixture_gather(int64_t C, int64_t kmax, int64_t m, const doubl
   out[t] = v;
 }
 
+// Gamma.log_p of a ragged (1, k) response (distribution.py:241-261): sum over the live entries, or (last_only) the
+// density of the LAST live entry -- what ReversibleJump takes from log_p(..., by_observation=True)[-1]
+// (reversible_jump.py:132,143)
+__global__ void k_gamma_logpdf_ragged(int64_t C, int64_t kmax, const double* x, const double* count, double shape,
+                                      double rate, double lnorm, int last_only, double* out, int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int64_t k = count ? (int64_t)count[c] : kmax;
+  double lp = 0.0;
+  for (int64_t j = last_only ? (k > 0 ? k - 1 : 0) : 0; j < k; ++j) {
+    const double v = x[c * kmax + j];
+    double t = (v > 0.0) ? lnorm + (shape - 1.0) * log(v) - rate * v : -INFINITY;
+    if (v == 0.0 && shape == 1.0) t = lnorm;
+    lp += t;
+  }
+  out[c] = accumulate ? out[c] + lp : lp;
+}
+
+// gradient of a diagonal Gaussian log-density w.r.t. its response: g_j = -prec_j (x_j - mean_j) on the live entries
+// (location_scale.py:222-226 with the MixtureParameterMatrix precision of parameter.py:501)
+__global__ void k_diag_gauss_grad(int64_t C, int64_t kmax, const double* x, const double* mean, const double* prec,
+                                  const double* count, double* grad) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= C * kmax) return;
+  const int64_t c = t / kmax, j = t % kmax;
+  const bool live = !count || (double)j < count[c];
+  grad[t] = live ? -prec[t] * (x[t] - (mean ? mean[t] : 0.0)) : 0.0;
+}
+
 // Uniform.rvs (distribution.py:444-458): lower + range * U, product rounded before the sum as numpy does
 __global__ void k_uniform_draw(int64_t C, int64_t chain_offset, int64_t p, const double* lower, const double* range,
                                const double* u_in, omc_rng_key key, uint32_t sub, double* out) {
@@ -306,6 +335,27 @@ omc_status omc_uniform_draw(omc_ctx* ctx, int64_t p, const double* lower, const 
   hipLaunchKernelGGL(k_uniform_draw, dim3(grid1(ctx->n_chains * p, 256)), dim3(256), 0, ctx->stream, ctx->n_chains,
                      ctx->chain_offset, p, lower, range, u_inject, omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), sub,
                      out);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_gamma_logpdf_ragged(omc_ctx* ctx, int64_t kmax, const double* x, const double* count, double shape,
+                                   double rate, int32_t last_only, double* out, int32_t accumulate) {
+  if (!ctx || kmax < 1 || !x || !out || !(shape > 0.0) || !(rate > 0.0)) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  const double lnorm = shape * log(rate) - lgamma(shape);
+  hipLaunchKernelGGL(k_gamma_logpdf_ragged, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, kmax, x,
+                     count, shape, rate, lnorm, (int)last_only, out, (int)accumulate);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_diag_gauss_grad(omc_ctx* ctx, int64_t kmax, const double* x, const double* mean, const double* prec,
+                               const double* count, double* grad) {
+  if (!ctx || kmax < 1 || !x || !prec || !grad) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_diag_gauss_grad, dim3(grid1(ctx->n_chains * kmax, 256)), dim3(256), 0, ctx->stream, ctx->n_chains,
+                     kmax, x, mean, prec, count, grad);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

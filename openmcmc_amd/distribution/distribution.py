@@ -66,22 +66,40 @@ class Gamma(Distribution):
         return float(np.asarray(a).item()), float(np.asarray(b).item())
 
     def log_p(self, state: dict, by_observation: bool = False, engine=None, out=None, accumulate=False):
-        """distribution.py:241-261.  Per-chain response -> (C,) tensor via omc_gamma_logpdf."""
+        """distribution.py:241-261.  Per-chain response -> (C,) tensor via omc_gamma_logpdf; a (1, k) response (ragged or
+        not: e.g. the kernel widths of a reversible-jump basis) sums over its live entries."""
         x = state[self.response]
         a, b = self.host_shape_rate(state)
         if not is_chain(x):
-            from math import lgamma, log
+            from scipy import stats
 
-            v = float(np.asarray(x).item())
-            return a * log(b) - lgamma(a) + (a - 1) * log(v) - b * v
+            return float(np.sum(stats.gamma.logpdf(np.asarray(x, dtype=np.float64), a, scale=1.0 / b)))
+        if by_observation:
+            raise NotImplementedError("by_observation on a per-chain response (use log_p_last)")
         if engine is None:
             raise RuntimeError("Gamma.log_p on a per-chain response needs the engine (use Model.log_p)")
         out = engine.empty(engine.n_chains) if out is None else out
-        engine.gamma_logpdf(x.scalar(), a, b, out, accumulate=accumulate)
+        if x.size == 1 and x.ragged is None:
+            engine.gamma_logpdf(x.scalar(), a, b, out, accumulate=accumulate)
+        else:
+            if x.shape[0] != 1:
+                raise NotImplementedError("vector-valued Gamma response with replicates")
+            engine.gamma_logpdf_ragged(x.data[:, 0, :], a, b, out, count=x.count(state), accumulate=accumulate)
         return out
 
-    def rvs(self, state, n: int = 1, engine=None, draw_index=0):
-        """distribution.py:263-278: prior draw, used by MCMC when the state has no initial value."""
+    def log_p_last(self, state: dict, engine):
+        """log-density of the LAST live replicate of a per-chain (1, k) response: what ReversibleJump reads from
+        log_p(current_state, by_observation=True)[-1] (reversible_jump.py:132,143).  (C,) tensor."""
+        x = state[self.response]
+        a, b = self.host_shape_rate(state)
+        out = engine.empty(engine.n_chains)
+        engine.gamma_logpdf_ragged(x.data[:, 0, :], a, b, out, count=x.count(state), last_only=True)
+        return out
+
+    def rvs(self, state, n: int = 1, engine=None, draw_index=0, sub=0, inject=None):
+        """distribution.py:263-278: one Gamma(shape, rate) draw per chain (prior draw when the state has no initial
+        value, mcmc.py:78-80; new element of an associated parameter in a birth move, reversible_jump.py:130).
+        `inject`: (C,) standard-gamma draws Gamma(shape, 1), as scipy's gamma.rvs(a, scale=s) == standard_gamma(a)*s."""
         if engine is None:
             raise RuntimeError("Gamma.rvs needs the engine")
         if n != 1:
@@ -89,7 +107,9 @@ class Gamma(Distribution):
         a, b = self.host_shape_rate(state)
         out = engine.empty(engine.n_chains)
         # Gamma(a, rate b) = the conjugate update with no data: n_pos = 0, quad = 0
-        engine.normal_gamma_update(a, b, 0, engine.zeros(engine.n_chains), out, draw_index=draw_index)
+        # `sub` separates several Gamma draws made under one draw index (bits 44-47 of the 48-bit stream index)
+        engine.normal_gamma_update(a, b, 0, engine.zeros(engine.n_chains), out, g=inject,
+                                   draw_index=int(draw_index) + ((int(sub) & 0xF) << 44))
         return ChainArray(out.reshape(-1, 1, 1))
 
 
@@ -120,6 +140,10 @@ class Uniform(Distribution):
     def log_p_per_replicate(self, state) -> float:
         """-sum_p log(range): what every replicate contributes (distribution.py:437)."""
         return float(-np.sum(np.log(self.domain_range(state))))
+
+    def log_p_last(self, state: dict, engine=None) -> float:
+        """log_p(state, by_observation=True)[-1] (reversible_jump.py:132,143): the same constant for every replicate."""
+        return self.log_p_per_replicate(state)
 
     def log_p(self, state: dict, by_observation: bool = False, engine=None, out=None, accumulate=False):
         """distribution.py:422-442: n_rep * (-sum log range); per chain n_rep is the live length of a ragged response."""

@@ -290,6 +290,19 @@ class Normal(Distribution):
                                                     "scale": scale}], x, draw_index=draw_index)
         return ChainArray(x)
 
+    def grad_log_p_diag(self, state: dict, param: str, engine):
+        """(grad, hdiag), each (C, kmax), when the Hessian w.r.t. `param` is diagonal per chain: the response of a
+        mixture Normal (grad = -prec (x - mean), Hessian diag(prec); location_scale.py:222-226 with parameter.py:501).
+        None when this distribution does not depend on `param`."""
+        if param != self.response:
+            if param in self.param_list:
+                raise NotImplementedError("diagonal-Hessian gradient w.r.t. a mean / precision parameter")
+            return None
+        if not self.is_mixture:
+            raise NotImplementedError("diagonal-Hessian gradient of a Normal with a matrix precision")
+        x, mean, prec, count = self.mixture_pieces(state, engine)
+        return engine.diag_gauss_grad(x, prec, mean=mean, count=count), prec
+
     def grad_log_p(self, state: dict, param: str, hessian_required: bool = True, engine=None):
         """Gradient of +log p and Hessian of -log p for the case the reference's MH samplers use: `param` is
         the response, the precision is a shared dense matrix (location_scale.py:222-232):
@@ -308,3 +321,26 @@ class Normal(Distribution):
         r = x.vector() - engine.to_device(np.asarray(mu, dtype=np.float64).reshape(1, -1))
         grad = ChainArray(-engine.design_predict(dQ, r))  # Q symmetric: Q r for every chain
         return (grad, Q) if hessian_required else grad
+
+
+@dataclass
+class NullDistribution(Normal):
+    """Null distribution of the reference's reversible-jump prior-recovery tests (location_scale.py:63-124): log-density
+    0, zero gradient and Hessian, no draws.  Mean / precision parameters are kept so that `param_list` and
+    `model.response` predictors behave as for a Normal."""
+
+    def log_p(self, state: dict, by_observation: bool = False, engine=None, out=None, accumulate=False):
+        if out is None:
+            return 0.0
+        if not accumulate:
+            out.zero_()
+        return out
+
+    def grad_log_p_diag(self, state: dict, param: str, engine):
+        return None  # contributes nothing
+
+    def grad_log_p(self, state: dict, param: str, hessian_required: bool = True, engine=None):
+        raise NotImplementedError("NullDistribution.grad_log_p: use grad_log_p_diag (zero contribution)")
+
+    def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):
+        return None

@@ -631,6 +631,30 @@ class Engine:
         check(lib.omc_diag_gauss_logpdf(self._ctx, kmax, self._p(x), self._p(mean), self._p(prec),
                                         self._chain_scalar(count), self._chain_scalar(out), int(accumulate)))
 
+    def gamma_logpdf_ragged(self, x, shape, rate, out, count=None, last_only=False, accumulate=False):
+        Cn, kmax = x.shape
+        check(lib.omc_gamma_logpdf_ragged(self._ctx, kmax, self._p(x), self._chain_scalar(count), float(shape), float(rate),
+                                          int(last_only), self._chain_scalar(out), int(accumulate)))
+        return out
+
+    def diag_gauss_grad(self, x, prec, mean=None, count=None):
+        Cn, kmax = x.shape
+        grad = self.empty(Cn, kmax)
+        check(lib.omc_diag_gauss_grad(self._ctx, kmax, self._p(x), self._p(mean), self._p(prec), self._chain_scalar(count),
+                                      self._p(grad)))
+        return grad
+
+    def mala_diag(self, x, grad, hdiag, step, count=None, x_other=None, z=None, draw_index=0, sub=0):
+        """ManifoldMALA with a diagonal Hessian.  x_other None: propose -> (x_proposed (C, kmax), log q(x'|x));
+        x_other given: -> log q(x_other | x) of the reverse move."""
+        Cn, kmax = x.shape
+        propose = x_other is None
+        out = self.empty(Cn, kmax) if propose else x_other
+        lq = self.empty(Cn)
+        check(lib.omc_mala_diag(self._ctx, kmax, self._p(x), self._p(grad), self._p(hdiag), self._chain_scalar(count),
+                                float(step), int(propose), self._p(z), int(draw_index), int(sub), self._p(out), self._p(lq)))
+        return (out, lq) if propose else lq
+
     def poisson_logpmf(self, x, rate, out, accumulate=False):
         check(lib.omc_poisson_logpmf(self._ctx, self._chain_scalar(x), float(rate), self._chain_scalar(out), int(accumulate)))
 

@@ -37,6 +37,22 @@ class Model(dict):
         return out
 
 
+    def grad_log_p_diag(self, state: dict, param: str, engine):
+        """(grad, hdiag) summed over the members when every contribution has a per-chain DIAGONAL Hessian
+        (model.py:72-112 restricted to that structure; distributions raise NotImplementedError otherwise)."""
+        grad, hdiag = None, None
+        for dst in self.values():
+            part = dst.grad_log_p_diag(state, param, engine) if hasattr(dst, "grad_log_p_diag") else None
+            if part is None:
+                if param in dst.param_list and not hasattr(dst, "grad_log_p_diag"):
+                    raise NotImplementedError(f"{type(dst).__name__}: no diagonal-Hessian gradient")
+                continue
+            g, h = part
+            grad, hdiag = (g, h) if grad is None else (grad + g, hdiag + h)
+        if grad is None:
+            raise ValueError(f"no distribution depends on '{param}'")
+        return grad, hdiag
+
     def _grad_log_p(self, state: dict, param: str, hessian_required: bool = True, engine=None):
         grad, hess = None, None
         for dst in self.values():

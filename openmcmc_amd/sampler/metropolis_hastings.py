@@ -267,8 +267,32 @@ class RandomWalkLoop(RandomWalk):
 class ManifoldMALA(MetropolisHastings):
     """Manifold MALA (Girolami & Calderhead 2011; metropolis_hastings.py:292-373)."""
 
+    def _diag_step(self, current_state: dict) -> dict:
+        """Generic route when the Hessian is diagonal per chain (e.g. the mixture-Normal prior of a variable-size
+        coefficient vector under a null likelihood): metropolis_hastings.py:301-373 with omc_mala_diag for the proposal
+        and its two densities, then the generic accept/reject with the sampler's model."""
+        eng = self.engine
+        x = current_state[self.param]
+        if not is_chain(x) or x.shape[1] != 1:
+            raise NotImplementedError("ManifoldMALA needs a per-chain (d, 1) parameter")
+        step = float(self.step.item())
+        count = x.count(current_state) if (x.ragged is not None and x.ragged[1] == 0) else None
+        grad, h = self.model.grad_log_p_diag(current_state, self.param, eng)
+        z = self.inject(self, self._sweep) if self.inject is not None else None
+        xp, lq_f = eng.mala_diag(x.vector(), grad, h, step, count=count, z=z, draw_index=self._draw_index(), sub=0)
+        prop_state = dict(current_state)
+        prop_state[self.param] = x.like(xp.unsqueeze(2))
+        grad_p, h_p = self.model.grad_log_p_diag(prop_state, self.param, eng)
+        lq_r = eng.mala_diag(xp, grad_p, h_p, step, count=count, x_other=x.vector().contiguous())
+        u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
+        return self._accept_reject_proposal(current_state, prop_state, lq_f, lq_r, u=u, sub=(x.shape[0] + 1) // 2 + 1)
+
     def sample(self, current_state: dict) -> dict:
         eng = self._need_engine()
+        if not self._gaussian_target(current_state):
+            current_state = self._diag_step(current_state)
+            self._sweep += 1
+            return current_state
         Q, mu, d = self._target(current_state)
         step = float(self.step.item())
         if self._plan is None:

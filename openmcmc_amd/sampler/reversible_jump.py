@@ -26,7 +26,7 @@ from typing import Callable, Union
 import numpy as np
 
 from openmcmc_amd.chains import ChainArray, is_chain
-from openmcmc_amd.distribution.distribution import Uniform
+from openmcmc_amd.distribution.distribution import Gamma, Uniform
 from openmcmc_amd.sampler.metropolis_hastings import MetropolisHastings, _add_contribution
 
 # Philox sub-streams within one ReversibleJump.sample call (block numbers; omc_rj_move owns 0..63)
@@ -83,13 +83,15 @@ class ReversibleJump(MetropolisHastings):
             dist, cur = self.model[key], current_state[key]
             if not is_chain(cur) or cur.ragged is None or cur.ragged[0] != self.param:
                 raise NotImplementedError(f"associated parameter '{key}' must be a ragged ChainArray counted by '{self.param}'")
-            if not isinstance(dist, Uniform):
-                raise NotImplementedError("associated parameters with a non-Uniform prior")
+            if not isinstance(dist, (Uniform, Gamma)):
+                raise NotImplementedError("associated parameters need a Uniform or Gamma prior")
             new = dist.rvs(current_state, n=1, engine=eng, draw_index=di, sub=_SUB_ASSOCIATED + 2 * j,
                            inject=inj_assoc.get(key))  # reversible_jump.py:130
             prop_state[key] = cur.like(eng.ragged_resize(cur.data, count, birth, del_index, axis=cur.ragged[1],
                                                          new_vals=new.data.reshape(eng.n_chains, -1)))
-            log_prop_density += dist.log_p_per_replicate(current_state)  # log_p(..., by_observation=True)[-1], :132,143
+            # log_p(current_state, by_observation=True)[-1] (:132, :143): the density of the LAST element of the
+            # CURRENT value -- a constant for a Uniform prior, a per-chain number for a Gamma one
+            log_prop_density = log_prop_density + dist.log_p_last(current_state, eng)
         lq_f, lq_r = eng.zeros(eng.n_chains), eng.zeros(eng.n_chains)
         if callable(self.state_birth_function):
             prop_state, f_extra, r_extra = self.state_birth_function(current_state, prop_state)

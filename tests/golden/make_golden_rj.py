@@ -483,7 +483,179 @@ def gen_band_chain():
     np.savez_compressed(os.path.join(OUT, "band_chain.npz"), **out)
 
 
-GENERATORS = {"band_chain": gen_band_chain, "truncnorm": gen_truncnorm, "rj_gmrf_chain": gen_rj_gmrf_chain, "example2": gen_example2,
+# ----------------------------------------------------------------------------- the reference's own RJ test model
+def gen_rj_prior_chain():
+    """The model of the reference's reversible-jump unit tests (tests/test_reversible_jump.py fixtures: null
+    likelihood, mixture-Normal coefficients, Poisson number of knots, Uniform knot locations, Gamma kernel widths)
+    with its sampler list [ManifoldMALA(beta), RandomWalkLoop(theta), RandomWalkLoop(omega), ReversibleJump(n_basis;
+    theta, omega; matched beta)], 120 sweeps for three chains, every draw recorded per call site."""
+    from openmcmc.distribution.location_scale import NullDistribution
+    from openmcmc.sampler.metropolis_hastings import ManifoldMALA
+
+    n_data, n_max, n_iter = 40, 6, 120
+    rng0 = np.random.default_rng(5)
+    X = np.sort(rng0.uniform(-10, 10, size=(n_data, 1)), axis=0)
+
+    def basis(Xl, knots, scales):
+        B = np.full((Xl.shape[0], knots.shape[1]), np.nan)
+        for k in range(knots.shape[1]):
+            B[:, [k]] = stats.norm.pdf(Xl, loc=knots[:, k], scale=scales[:, k])
+        return B
+
+    def move_fn(state, col):
+        state["B"] = basis(state["X"], state["theta"], state["omega"])
+        return state, 0.0, 0.0
+
+    def birth_fn(cur, prop):
+        prop["B"] = basis(prop["X"], prop["theta"], prop["omega"])
+        prop["alloc_beta"] = np.concatenate((prop["alloc_beta"], np.array([0], ndmin=2)), axis=0)
+        return prop, 0.0, 0.0
+
+    def death_fn(cur, prop, idx):
+        prop["B"] = np.delete(prop["B"], obj=idx, axis=1)
+        prop["alloc_beta"] = np.delete(prop["alloc_beta"], obj=idx, axis=0)
+        return prop, 0.0, 0.0
+
+    mdl = Model([
+        NullDistribution(response="y", mean=parameter.LinearCombination(form={"beta": "B"}),
+                         precision=parameter.ScaledMatrix(matrix="P", scalar="tau_y")),
+        Normal(response="beta", mean=parameter.MixtureParameterVector(param="mu_beta", allocation="alloc_beta"),
+               precision=parameter.MixtureParameterMatrix(param="tau_beta", allocation="alloc_beta")),
+        Poisson(response="n_basis", rate="rho"),
+        Uniform(response="theta", domain_response_lower=np.array([-10.0], ndmin=2), domain_response_upper=np.array([10.0], ndmin=2)),
+        Gamma("omega", shape="a_omega", rate="b_omega"),
+    ])
+    mdl.response = {"y": "mean"}
+    K = n_max
+    fields = {"mala_z": K, "mala_u": 0, "rwt_u": K, "rwt_acc": K, "rwo_u": K, "rwo_acc": K, "rj_move_u": 0, "rj_theta_u": 0,
+              "rj_omega_g": 0, "rj_beta_u": 0, "rj_idx": 0, "rj_acc_u": 0}
+    out = {"n_data": n_data, "n_max": n_max, "n_iter": n_iter, "X": X.ravel(), "rho": 4.0, "tau_beta": 0.25, "a_omega": 3.0, "b_omega": 2.0}
+    per_chain = []
+    for c, k0 in enumerate((4, 1, 6)):
+        rng = np.random.default_rng(7100 + c)
+        rows, ctx = [], {"where": None, "knot": None, "stage": None}
+
+        def cur():
+            return rows[-1]
+
+        def _norm(loc=0, scale=1, size=None, **_):
+            z = rng.standard_normal(size)
+            flat = np.asarray(z, dtype=float).reshape(-1)
+            cur()["mala_z"][: flat.size] = flat
+            return loc + z * scale
+
+        def _uniform(loc=0, scale=1, size=None, **_):
+            u = rng.random(size)
+            w = ctx["where"]
+            if w == "beta":
+                cur()["mala_u"] = float(u)
+            elif w == "theta":
+                cur()["rwt_acc"][ctx["knot"]] = float(u)
+            elif w == "omega":
+                cur()["rwo_acc"][ctx["knot"]] = float(u)
+            elif size is not None:
+                cur()["rj_theta_u"] = float(np.asarray(u).reshape(-1)[0])
+            elif ctx["stage"] == "move":
+                cur()["rj_move_u"] = float(u)
+            else:
+                cur()["rj_acc_u"] = float(u)
+            return loc + u * scale
+
+        def _trunc(a, b, loc=0, scale=1, size=None, **_):
+            u = rng.random(size)
+            v = float(np.asarray(u).reshape(-1)[0])
+            w = ctx["where"]
+            if w == "theta":
+                cur()["rwt_u"][ctx["knot"]] = v
+            elif w == "omega":
+                cur()["rwo_u"][ctx["knot"]] = v
+            else:
+                cur()["rj_beta_u"] = v
+            return stats.truncnorm.ppf(u, a, b) * scale + loc
+
+        def _gamma(a, loc=0, scale=1, size=None, **_):
+            g = rng.standard_gamma(np.asarray(a, dtype=np.float64), size=size)
+            cur()["rj_omega_g"] = float(np.asarray(g).reshape(-1)[0])
+            return loc + g * scale
+
+        def _randint(low, high, size=None, **_):
+            v = int(rng.integers(low, int(np.asarray(high).item())))
+            cur()["rj_idx"] = float(v)
+            return v
+
+        theta0 = rng.uniform(-10, 10, size=(1, k0))
+        omega0 = rng.uniform(0.6, 1.8, size=(1, k0))
+        st = {"y": np.zeros((n_data, 1)), "beta": rng.standard_normal((k0, 1)), "tau_y": 100.0, "P": sparse.eye(n_data),
+              "B": basis(X, theta0, omega0), "n_basis": k0, "X": X, "theta": theta0, "omega": omega0, "mu_beta": np.zeros((1, 1)),
+              "tau_beta": 0.25 * np.ones((1, 1)), "rho": 4.0, "alloc_beta": np.zeros((k0, 1), dtype=int),
+              "a_omega": 3.0 * np.ones((1, 1)), "b_omega": 2.0 * np.ones((1, 1))}
+        init = {"theta": np.full(K, np.nan), "omega": np.full(K, np.nan), "beta": np.full(K, np.nan)}
+        init["theta"][:k0], init["omega"][:k0], init["beta"][:k0] = theta0.ravel(), omega0.ravel(), st["beta"].ravel()
+        samplers = [
+            ManifoldMALA(param="beta", model=mdl, step=np.array(0.5), max_variable_size=n_max),
+            RandomWalkLoop(param="theta", model=mdl, step=np.array(0.1), max_variable_size=n_max,
+                           domain_limits=np.array([[-10.0, 10.0]]), state_update_function=move_fn),
+            RandomWalkLoop(param="omega", model=mdl, step=np.array(0.1), max_variable_size=n_max,
+                           domain_limits=np.array([[0.5, 2.0]]), state_update_function=move_fn),
+            ReversibleJump(param="n_basis", model=mdl, associated_params=["theta", "omega"], n_max=n_max,
+                           state_birth_function=birth_fn, state_death_function=death_fn,
+                           matching_params={"variable": "beta", "matrix": "B", "scale": 1.0, "limits": [-10.0, 10.0]}),
+        ]
+        names = ["beta", "theta", "omega", "n_basis"]
+
+        def wrap(smp, name):
+            inner = smp.sample
+
+            def sample(state):
+                if name == "beta":
+                    rows.append({k: (np.full(v, np.nan) if v else np.nan) for k, v in fields.items()})
+                    rows[-1]["rj_idx"] = -1.0
+                ctx["where"], ctx["stage"] = name, "move"
+                return inner(state)
+
+            smp.sample = sample
+
+        for smp, name in zip(samplers, names):
+            wrap(smp, name)
+        for smp in samplers[1:3]:
+            def make(inner):
+                def prop(state, param_index=None):
+                    ctx["knot"] = param_index
+                    return inner(state, param_index)
+                return prop
+            smp.proposal = make(smp.proposal)
+        rj_inner = samplers[3].proposal
+
+        def rj_prop(state, param_index=None):
+            res = rj_inner(state)
+            ctx["stage"] = "accept"
+            return res
+
+        samplers[3].proposal = rj_prop
+        saved = (stats.norm.rvs, stats.gamma.rvs, stats.uniform.rvs, stats.truncnorm.rvs, stats.randint.rvs)
+        stats.norm.rvs, stats.gamma.rvs, stats.uniform.rvs = _norm, _gamma, _uniform
+        stats.truncnorm.rvs, stats.randint.rvs = _trunc, _randint
+        try:
+            M = MCMC(state=st, samplers=samplers, model=mdl, n_burn=0, n_iter=n_iter)
+            M.run_mcmc()
+        finally:
+            stats.norm.rvs, stats.gamma.rvs, stats.uniform.rvs, stats.truncnorm.rvs, stats.randint.rvs = saved
+        rec = {"init_theta": init["theta"], "init_omega": init["omega"], "init_beta": init["beta"], "init_k": float(k0)}
+        for key in fields:
+            rec["tape_" + key] = np.array([row[key] for row in rows])
+        for key in ("beta", "theta", "omega", "n_basis", "log_post"):
+            rec["store_" + key] = np.asarray(M.store[key])
+        for i, nm in enumerate(("mala", "rwt", "rwo", "rj")):
+            cnt = samplers[i].accept_rate.count
+            rec["accept_" + nm] = np.array([cnt["accept"], cnt["proposal"]], dtype=float)
+        per_chain.append(rec)
+        print("chain", c, "k0", k0, "visited", np.unique(M.store["n_basis"]), [s.accept_rate.get_acceptance_rate() for s in samplers])
+    for key in per_chain[0]:
+        out[key] = np.stack([rec[key] for rec in per_chain])
+    np.savez_compressed(os.path.join(OUT, "rj_prior_chain.npz"), **out)
+
+
+GENERATORS = {"rj_prior_chain": gen_rj_prior_chain, "band_chain": gen_band_chain, "truncnorm": gen_truncnorm, "rj_gmrf_chain": gen_rj_gmrf_chain, "example2": gen_example2,
               "truncated_conditional": gen_truncated_conditional}
 
 if __name__ == "__main__":

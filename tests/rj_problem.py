@@ -108,3 +108,68 @@ def build(y, X, P, n_max, engine, init_theta, init_beta, init_k):
                        matching_params={"variable": "beta", "matrix": "B", "scale": 1.0, "limits": [-10.0, 10.0]}),
     ]
     return mdl, state, samplers
+
+
+def build_prior_model(X, n_max, engine, init_theta, init_omega, init_beta, init_k, rho=4.0):
+    """(model, state, samplers) of the reference's own reversible-jump unit-test fixtures
+    (tests/test_reversible_jump.py: null likelihood, mixture-Normal coefficients, Poisson number of knots, Uniform knot
+    locations, Gamma kernel widths; ManifoldMALA(beta), RandomWalkLoop(theta), RandomWalkLoop(omega),
+    ReversibleJump(n_basis; theta, omega; matched beta)) on the chains of `engine`."""
+    import torch
+
+    from openmcmc_amd.chains import ChainArray, ragged_from_lists
+    from openmcmc_amd.distribution.distribution import Gamma, Poisson, Uniform
+    from openmcmc_amd.distribution.location_scale import Normal, NullDistribution
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import LinearCombination, MixtureParameterMatrix, MixtureParameterVector, ScaledMatrix
+    from openmcmc_amd.sampler.metropolis_hastings import ManifoldMALA, RandomWalkLoop
+    from openmcmc_amd.sampler.reversible_jump import ReversibleJump
+
+    n = np.asarray(X).size
+    dev = engine.device
+    X_dev = torch.as_tensor(np.asarray(X, dtype=np.float64).reshape(-1), device=dev)
+    mdl = Model([
+        NullDistribution("y", mean=LinearCombination({"beta": "B"}), precision=ScaledMatrix("P", "tau_y")),
+        Normal("beta", mean=MixtureParameterVector("mu_beta", "alloc_beta"), precision=MixtureParameterMatrix("tau_beta", "alloc_beta")),
+        Poisson("n_basis", rate="rho"),
+        Uniform("theta", domain_response_lower=np.array([[-10.0]]), domain_response_upper=np.array([[10.0]])),
+        Gamma("omega", shape="a_omega", rate="b_omega"),
+    ])
+    mdl.response = {"y": "mean"}
+
+    def basis(state):
+        theta, omega = state["theta"], state["omega"]
+        C, _, k_max = theta.data.shape
+        out = engine.empty(C, k_max, n)
+        engine.gaussian_basis(X_dev, theta.data[:, 0, :], out, count=theta.count(state), scales=omega.data[:, 0, :].contiguous())
+        return ChainArray(out.transpose(1, 2), ragged=(theta.ragged[0], 1))
+
+    def move_function(state, col):
+        state["B"] = basis(state)
+        return state, 0.0, 0.0
+
+    def birth_function(cur, prop):
+        prop["B"] = basis(prop)
+        return prop, 0.0, 0.0
+
+    state = {
+        "y": np.zeros((n, 1)), "X": np.asarray(X, dtype=np.float64).reshape(n, 1), "P": sparse.eye(n, format="csc"), "tau_y": 100.0,
+        "mu_beta": np.zeros((1, 1)), "tau_beta": 0.25 * np.ones((1, 1)), "rho": float(rho), "a_omega": 3.0 * np.ones((1, 1)),
+        "b_omega": 2.0 * np.ones((1, 1)),
+        "n_basis": ChainArray(torch.as_tensor(np.asarray(init_k, dtype=np.float64), device=dev).reshape(-1, 1, 1)),
+        "theta": ragged_from_lists(init_theta, n_max, 1, "n_basis", dev),
+        "omega": ragged_from_lists(init_omega, n_max, 1, "n_basis", dev),
+        "beta": ragged_from_lists(init_beta, n_max, 0, "n_basis", dev),
+        "alloc_beta": ragged_from_lists([np.zeros(int(k)) for k in init_k], n_max, 0, "n_basis", dev),
+    }  # fmt: skip
+    state["B"] = basis(state)
+    samplers = [
+        ManifoldMALA("beta", mdl, step=np.array(0.5), max_variable_size=n_max),
+        RandomWalkLoop("theta", mdl, step=np.array(0.1), max_variable_size=n_max, domain_limits=np.array([[-10.0, 10.0]]),
+                       state_update_function=move_function),
+        RandomWalkLoop("omega", mdl, step=np.array(0.1), max_variable_size=n_max, domain_limits=np.array([[0.5, 2.0]]),
+                       state_update_function=move_function),
+        ReversibleJump("n_basis", mdl, associated_params=["theta", "omega"], n_max=n_max, state_birth_function=birth_function,
+                       matching_params={"variable": "beta", "matrix": "B", "scale": 1.0, "limits": [-10.0, 10.0]}),
+    ]
+    return mdl, state, samplers
