@@ -224,3 +224,29 @@ def test_samplers_keep_full_model_like_reference():
     assert rj.accept_rate.get_acceptance_rate() == "No proposals"
     with pytest.raises(RuntimeError):
         rj.sample({})  # not bound to an engine: the product path fails loudly
+
+
+def test_null_distribution_and_band_recognition():
+    """NullDistribution's host behaviour (location_scale.py:63-124) and the band-structure recognition that routes a
+    precision wider than tridiagonal to the band kernel (or to the dense route when the band would not pay)."""
+    from scipy import sparse
+
+    from openmcmc_amd.distribution.location_scale import Normal, NullDistribution, band_storage
+    from openmcmc_amd.parameter import LinearCombination, ScaledMatrix
+
+    nd = NullDistribution("y", mean=LinearCombination({"beta": "B"}), precision=ScaledMatrix("P", "tau"))
+    assert nd.log_p({}) == 0.0 and nd.rvs({}) is None and nd.grad_log_p_diag({}, "beta", None) is None
+    assert nd.param_list == ["y", "beta", "B", "tau", "P"]
+    n = 12
+    D = sparse.diags([np.ones(n - 2), -2 * np.ones(n - 2), np.ones(n - 2)], offsets=[0, 1, 2], shape=(n - 2, n))
+    P = (D.T @ D + 1e-3 * sparse.identity(n)).tocsc()
+    band = band_storage(P, n)
+    assert band.shape == (3, n) and np.array_equal(band[0], P.diagonal()) and np.array_equal(band[2, : n - 2], P.diagonal(-2))
+    assert band[2, n - 2:].tolist() == [0.0, 0.0]
+    st = Normal("b", mean="mu", precision=ScaledMatrix("P", "lam")).structure({"P": P, "lam": 1.0})
+    assert st.diag is False and st.band is not None and st.band_rows().shape == (3, n)
+    assert band_storage(np.ones((6, 6)) + 6 * np.eye(6), 6) is None          # dense: the band would not pay
+    tri = Normal("b", mean="mu", precision="Q").structure({"Q": sparse.diags([[-1.0] * 4, [2.0] * 5, [-1.0] * 4], [-1, 0, 1]).tocsc()})
+    assert tri.band is None and tri.band_rows().shape == (2, 5)
+    with pytest.raises(ValueError):
+        band_storage(sparse.csc_matrix(np.triu(np.ones((8, 8)), 0) * (np.abs(np.subtract.outer(np.arange(8), np.arange(8))) <= 2)), 8)
