@@ -410,6 +410,12 @@ omc_status omc_rj_matched_transition(omc_ctx* ctx, int64_t kmax, const double* g
  *     replicate contributes -sum log(upper - lower));
  *   omc_mixture_gather:    MixtureParameterVector.predictor (parameter.py:447): out[c][j] = param[alloc[c][j]]
  *     for live j, `fill` beyond (param [m] shared, alloc holds integer values as float64).               */
+/* out[c] = sum_i (a[c][i] - center_a[i]) * (b[c][i] - center_b[i]).  With b = M x from omc_design_predict (one GEMM over
+ * all chains) and center_b = M m this is the quadratic form (x - m)' M (x - m) of a DENSE shared precision: the
+ * sufficient statistic of NormalGamma.sample (sampler.py:276,284) and of Normal.log_p (gmrf.py:343-344).      */
+omc_status omc_centered_rowdot(omc_ctx* ctx, int64_t n, const double* a, int64_t ld_a, const double* center_a,
+                               const double* b, int64_t ld_b, const double* center_b, double* out);
+
 /* Uniform.rvs (distribution.py:444-458): out[c][e] = lower[e] + range[e] * U(0,1], e < p (lower/range device [p]);
  * u_inject [C][p]; in-kernel uniforms come from Philox blocks sub, sub+1, ... (two per block).               */
 omc_status omc_uniform_draw(omc_ctx* ctx, int64_t p, const double* lower, const double* range, const double* u_inject,

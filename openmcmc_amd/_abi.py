@@ -143,6 +143,7 @@ SIGNATURES = {
         [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_double, i32, C.c_double, C.c_double, c_dp, u64, u32,
          c_dp, c_dp, c_dp],
     ),
+    "omc_centered_rowdot": (i32, [C.c_void_p, i64, c_dp, i64, c_dp, c_dp, i64, c_dp, c_dp]),
     "omc_uniform_draw": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, u64, u32, c_dp]),
     "omc_diag_gauss_logpdf": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i32]),
     "omc_gamma_logpdf_ragged": (i32, [C.c_void_p, i64, c_dp, c_dp, C.c_double, C.c_double, i32, c_dp, i32]),

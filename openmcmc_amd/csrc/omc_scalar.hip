@@ -306,6 +306,21 @@ __global__ void k_diag_gauss_grad(int64_t C, int64_t kmax, const double* x, cons
   grad[t] = live ? -prec[t] * (x[t] - (mean ? mean[t] : 0.0)) : 0.0;
 }
 
+// out[c] = sum_i (a[c][i] - ca[i]) (b[c][i] - cb[i]): the quadratic form (x - m)' M (x - m) of a DENSE shared M from
+// b = M x (one GEMM over all chains) and cb = M m, without forming x - m
+__global__ void __launch_bounds__(256) k_centered_rowdot(int64_t n, const double* a, int64_t ld_a, const double* ca,
+                                                        const double* b, int64_t ld_b, const double* cb, double* out) {
+  __shared__ double red[4];
+  const int64_t c = blockIdx.x;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256)
+    acc = fma(a[c * ld_a + i] - (ca ? ca[i] : 0.0), b[c * ld_b + i] - (cb ? cb[i] : 0.0), acc);
+  for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // Uniform.rvs (distribution.py:444-458): lower + range * U, product rounded before the sum as numpy does
 __global__ void k_uniform_draw(int64_t C, int64_t chain_offset, int64_t p, const double* lower, const double* range,
                                const double* u_in, omc_rng_key key, uint32_t sub, double* out) {
@@ -335,6 +350,16 @@ omc_status omc_uniform_draw(omc_ctx* ctx, int64_t p, const double* lower, const 
   hipLaunchKernelGGL(k_uniform_draw, dim3(grid1(ctx->n_chains * p, 256)), dim3(256), 0, ctx->stream, ctx->n_chains,
                      ctx->chain_offset, p, lower, range, u_inject, omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), sub,
                      out);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_centered_rowdot(omc_ctx* ctx, int64_t n, const double* a, int64_t ld_a, const double* center_a,
+                               const double* b, int64_t ld_b, const double* center_b, double* out) {
+  if (!ctx || n < 1 || !a || !b || ld_a < n || ld_b < n || !out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_centered_rowdot, dim3((unsigned)ctx->n_chains), dim3(256), 0, ctx->stream, n, a, ld_a, center_a, b, ld_b,
+                     center_b, out);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

@@ -191,9 +191,21 @@ class Normal(Distribution):
             quad = engine.empty(engine.n_chains)
             engine.weighted_resid_sq(engine.shared(resp).reshape(-1), fitted, quad, w=w)
             return quad
+        if st.diag is False and st.band is None:
+            # dense shared precision: r'Mr through one GEMM over all chains
+            x, m = self.chain_and_center(state)
+            if m.shape[1] != 1 or x.shape[1] != 1:
+                raise NotImplementedError("replicated responses under a dense precision")
+            memo = self.__dict__.setdefault("_dense_memo", {})
+            key = id(st.matrix)
+            c_host = np.ascontiguousarray(m, dtype=np.float64).reshape(-1)
+            hit = memo.get(key)
+            if hit is None or not np.array_equal(hit[0], c_host):
+                Mm = np.asarray(st.matrix @ c_host).reshape(-1)
+                hit = memo[key] = (c_host, engine.to_device(c_host) if c_host.any() else None,
+                                   engine.to_device(Mm) if c_host.any() else None)
+            return engine.dense_quadform(engine.shared(st.matrix), x.vector(), center=hit[1], M_center=hit[2])
         if st.diag is False:
-            if st.band is None:
-                raise NotImplementedError("quadratic form with a dense precision matrix: later round")
             x, m = self.chain_and_center(state)
             if m.shape[1] != 1 or x.shape[1] != 1:
                 raise NotImplementedError("replicated responses under a banded precision")
@@ -267,7 +279,7 @@ class Normal(Distribution):
         if n != 1:
             raise NotImplementedError("replicated prior draws")
         if self.domain_response_lower is not None or self.domain_response_upper is not None:
-            raise NotImplementedError("truncated prior draws (gmrf.sample_truncated_normal): next round")
+            raise NotImplementedError("truncated prior draws (gmrf.sample_truncated_normal)")
         st = self.structure(state)
         mean = self.mean.predictor(state)
         if is_chain(mean):

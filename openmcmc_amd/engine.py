@@ -320,9 +320,11 @@ class Engine:
         hit = self._logdet_cache.get(id(st.matrix))
         if hit is not None and hit[0] is st.matrix:
             return hit[1]
-        if st.diag is False:
-            if st.band is None:
-                raise NotImplementedError("log det of a dense precision matrix: later round")
+        if st.diag is False and st.band is None:
+            # dense: one Cholesky of M itself (gmrf.py:339: 2 sum log L_ii)
+            _, sumlog = self.dense_cholesky(self.shared(st.matrix), 1.0)
+            ld = sumlog * 2.0
+        elif st.diag is False:
             # banded: one factorisation of M itself on the device (every chain computes the same number)
             x, out = self.empty(self.n_chains, st.n), self.empty(self.n_chains)
             self.band_sample_canonical(st.n, [{"band": self.to_device(st.band)}], x, logdet_out=out)
@@ -616,6 +618,15 @@ class Engine:
                                             self._p(coef_cur, Cn, kmax), float(scale), int(limits is not None), lo, hi,
                                             self._chain_scalar(inject), int(draw_index), int(sub), self._p(out),
                                             self._chain_scalar(lq_fwd), self._chain_scalar(lq_rev)))
+        return out
+
+    def dense_quadform(self, M, x, center=None, M_center=None):
+        """(C,) tensor (x - m)' M (x - m) for a dense shared M (device (n, n)): one GEMM + one reduction kernel."""
+        Cn, n = x.shape
+        y = self.design_predict(M, x)  # M symmetric: rows of x times M
+        out = self.empty(Cn)
+        check(lib.omc_centered_rowdot(self._ctx, n, self._p(x, Cn, n), x.stride(0), self._vec(center, n), self._p(y, Cn, n),
+                                      y.stride(0), self._vec(M_center, n), self._p(out)))
         return out
 
     def uniform_draw(self, lower, rng, inject=None, draw_index=0, sub=0):

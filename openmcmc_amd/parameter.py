@@ -68,7 +68,7 @@ class LinearCombination(Parameter):
             A, v = state[prefactor], state[prm]
             if is_chain(v):
                 if not _is_identity(A, v.shape[0]):
-                    raise NotImplementedError("per-chain term with a non-identity design matrix (dense path: next round)")
+                    raise NotImplementedError("per-chain term with a non-identity design matrix: use predictor_device (needs the engine)")
                 chain_sum = v if chain_sum is None else ChainArray(chain_sum.data + v.data)
             else:
                 host_sum = host_sum + A @ v

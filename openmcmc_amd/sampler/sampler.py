@@ -96,10 +96,13 @@ class NormalNormal(MCMCSampler):
     """Normal-Normal conjugate update (sampler.py:121-207): x ~ N(Q^{-1} b, Q^{-1}),
     Q = P + sum_k A_k' W_k A_k, b = P m + sum_k A_k' W_k (y_k - d_k).
 
-    GPU path (this round): every term must reduce to (per-chain scalar) x (shared tridiagonal
-    matrix) -- ScaledMatrix/Identity precisions, Identity means or LinearCombination means whose
-    design matrix for `param` is an identity -- which covers the GMRF smoother of example 4 in both
-    its as-written and sparse-route forms."""
+    GPU routes, chosen from the structure of the terms (per-chain scalar x shared matrix each):
+      tridiagonal  every matrix tridiagonal (example 4 as written and its sparse route; omc_tridiag_sample_canonical,
+                   fused with the NormalGamma updates by MCMC when the sampler list allows);
+      band         banded but wider (RW2, seasonal, lattice GMRFs; omc_band_sample_canonical);
+      dense        anything else, incl. a regression likelihood through its Gram matrix (example 3; blocked batched Cholesky);
+      ragged       a variable-size parameter with a mixture prior and a per-chain design matrix (reversible jump);
+    a prior with domain limits switches the tridiagonal and dense routes to the truncated single-site scan."""
 
     def __post_init__(self):
         super().__post_init__()

@@ -316,3 +316,46 @@ def test_example2_samplers_replay_reference(golden):
     for c in range(C):
         assert np.max(np.abs(got["h"][c] - G["nn_store_h"]) / np.abs(G["nn_store_h"])) < 1e-10
         assert np.max(np.abs(got["log_post"][c] - G["nn_log_post"]) / np.abs(G["nn_log_post"])) < 1e-10
+
+
+def test_dense_prior_normal_gamma_and_log_p():
+    """A DENSE (not banded) prior precision: NormalGamma's r'Mr through one GEMM + omc_centered_rowdot and the
+    log-determinant of M by one device Cholesky, against the oracle's restatement of sampler.py:276-287 and
+    gmrf.py:321-348."""
+    from scipy import sparse
+
+    from openmcmc_amd.chains import ChainArray
+    from openmcmc_amd.distribution.distribution import Gamma
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.engine import Engine
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import ScaledMatrix
+    from openmcmc_amd.sampler.sampler import NormalGamma
+    from oracle import gmrf_ref, sweep_ref
+
+    p, C = 30, 4
+    rng = np.random.default_rng(21)
+    A = rng.standard_normal((p, 2 * p))
+    Qd = A @ A.T / (2 * p) + 0.3 * np.eye(p)
+    Qd = (Qd + Qd.T) / 2
+    mu = rng.standard_normal((p, 1)) * 0.5
+    mdl = Model([Normal("beta", mean="mu", precision=ScaledMatrix("Q", "lam")), Gamma("lam", shape="a", rate="b")])
+    eng = Engine(C)
+    beta = rng.standard_normal((C, p))
+    lam0 = rng.random(C) + 0.5
+    state = {"beta": ChainArray(eng.to_device(beta)), "mu": mu, "Q": Qd, "a": np.array([[2.0]]), "b": np.array([[1.5]]),
+             "lam": ChainArray(eng.to_device(lam0).reshape(C, 1, 1))}
+    lp = mdl.log_p(state, engine=eng).cpu().numpy()
+    for c in range(C):
+        ref = gmrf_ref.gauss_logpdf(beta[c].reshape(p, 1), mu, lam0[c] * Qd) + sweep_ref.gamma_logpdf(lam0[c], 2.0, 1.5)
+        assert abs(lp[c] - ref) < 1e-10 * max(1.0, abs(ref))
+    g = rng.gamma(2.0 + p / 2, size=C)
+    smp = NormalGamma("lam", mdl).bind(eng)
+    smp.inject = lambda s_, t: eng.to_device(g)
+    state = smp.sample(state)
+    eng.check_status()
+    got = state["lam"].scalar().cpu().numpy()
+    for c in range(C):
+        a_c, b_c = sweep_ref.gamma_conditional(2.0, 1.5, beta[c].reshape(p, 1) - mu, sparse.csc_matrix(Qd))
+        assert abs(got[c] - sweep_ref.gamma_draw_from_standard(a_c, b_c, g[c])) < 1e-10 * got[c]
+    eng.close()
