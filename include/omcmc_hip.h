@@ -169,6 +169,8 @@ typedef struct {
   const double* mat[OMC_MAX_TERMS];     /* [p*p] shared symmetric; NULL = identity           */
   const double* rhs[OMC_MAX_TERMS];     /* [p]   shared; NULL = zeros                        */
   const double* scale[OMC_MAX_TERMS];   /* [C]   per-chain scalar; NULL = 1                  */
+  const double* diag_chain;             /* [C][p] per-chain diagonal added to Q_c (a mixture prior precision
+                                           diag(prec[allocation]), parameter.py:501); NULL = none           */
 } omc_dense_terms;
 
 omc_status omc_dense_sample_canonical(omc_ctx* ctx, int64_t p, const omc_dense_terms* terms,
@@ -409,7 +411,13 @@ omc_status omc_rj_matched_transition(omc_ctx* ctx, int64_t kmax, const double* g
  *   omc_count_logpdf:      out = per_element * count[c]  (Uniform.log_p, distribution.py:422-442: every live
  *     replicate contributes -sum log(upper - lower));
  *   omc_mixture_gather:    MixtureParameterVector.predictor (parameter.py:447): out[c][j] = param[alloc[c][j]]
- *     for live j, `fill` beyond (param [m] shared, alloc holds integer values as float64).               */
+ *     for live j, `fill` beyond (param [m] shared with param_stride 0, or per chain [C][m] with param_stride m;
+ *     alloc holds integer values as float64).                                                              */
+/* LogNormal.log_p (location_scale.py:279-300) = Normal.log_p at log(response) minus sum log(response):
+ *   out[c][i] = log x[c][i], sumlog[c] = sum_i log x[c][i] (sumlog may be NULL).                              */
+omc_status omc_log_transform(omc_ctx* ctx, int64_t n, const double* x, int64_t ld_x, double* out, int64_t ld_o,
+                             double* sumlog);
+
 /* out[c] = sum_i (a[c][i] - center_a[i]) * (b[c][i] - center_b[i]).  With b = M x from omc_design_predict (one GEMM over
  * all chains) and center_b = M m this is the quadratic form (x - m)' M (x - m) of a DENSE shared precision: the
  * sufficient statistic of NormalGamma.sample (sampler.py:276,284) and of Normal.log_p (gmrf.py:343-344).      */
@@ -422,6 +430,28 @@ omc_status omc_uniform_draw(omc_ctx* ctx, int64_t p, const double* lower, const 
                             uint64_t draw_index, uint32_t sub, double* out);
 omc_status omc_diag_gauss_logpdf(omc_ctx* ctx, int64_t kmax, const double* x, const double* mean, const double* prec,
                                  const double* count, double* out, int32_t accumulate);
+/* Mixture models: a parameter vector whose prior mean / precision are picked per element
+ * by a categorical allocation (parameter.py:376-538), the allocation's conditional draw and the per-component
+ * precision update.
+ *   omc_mixture_allocation: MixtureAllocation.sample (sampler.py:321-355): prob_k = prior[i or 0][k] *
+ *     N(y[c][i]; mean[c][k], 1/prec[c][k]), normalised; alloc = #{k : U > cumsum_k}.  prior [prior_rows x K] shared
+ *     (prior_rows 1 or p), mean / prec [C][K] (stride 0 = shared [K]), u_inject [C][p];
+ *   omc_categorical_logpmf: Categorical.log_p (distribution.py:318-352, one trial per element):
+ *     sum_i log prob[i or 0][alloc[c][i]];
+ *   omc_mixture_normal_gamma: NormalGamma.sample for a MixtureParameterMatrix precision (sampler.py:276-287 with
+ *     parameter.py:525-538): a_k = a0[k] + #{alloc == k}/2, b_k = b0[k] + sum_{alloc == k} resid^2 / 2,
+ *     out[c][k] = Gamma(a_k, scale 1/b_k); a0 / b0 device [K], g_inject [C][K] standard gammas;
+ *   omc_gamma_logpdf_vec: Gamma.log_p of a (K, 1) response with per-element shape / rate (device [K]).       */
+omc_status omc_mixture_allocation(omc_ctx* ctx, int64_t p, int64_t K, const double* y, const double* prior,
+                                  int64_t prior_rows, const double* mean, int64_t mean_stride, const double* prec,
+                                  int64_t prec_stride, const double* u_inject, uint64_t draw_index, double* alloc);
+omc_status omc_categorical_logpmf(omc_ctx* ctx, int64_t p, int64_t K, const double* alloc, const double* prob,
+                                  int64_t prob_rows, double* out, int32_t accumulate);
+omc_status omc_mixture_normal_gamma(omc_ctx* ctx, int64_t p, int64_t K, const double* resid, const double* alloc,
+                                    const double* a0, const double* b0, const double* g_inject, uint64_t draw_index,
+                                    double* out);
+omc_status omc_gamma_logpdf_vec(omc_ctx* ctx, int64_t K, const double* x, const double* shape, const double* rate,
+                                double* out, int32_t accumulate);
 /* omc_gamma_logpdf_ragged: Gamma.log_p (distribution.py:241-261) of a ragged (1, k) response: the sum over the live
  *   entries, or with last_only != 0 the density of the LAST live entry (what ReversibleJump reads from
  *   log_p(..., by_observation=True)[-1], reversible_jump.py:132,143);
@@ -433,8 +463,8 @@ omc_status omc_diag_gauss_grad(omc_ctx* ctx, int64_t kmax, const double* x, cons
                                const double* count, double* grad);
 omc_status omc_poisson_logpmf(omc_ctx* ctx, const double* x, double rate, double* out, int32_t accumulate);
 omc_status omc_count_logpdf(omc_ctx* ctx, const double* count, double per_element, double* out, int32_t accumulate);
-omc_status omc_mixture_gather(omc_ctx* ctx, int64_t kmax, int64_t m, const double* param, const double* alloc,
-                              const double* count, double fill, double* out);
+omc_status omc_mixture_gather(omc_ctx* ctx, int64_t kmax, int64_t m, const double* param, int64_t param_stride,
+                              const double* alloc, const double* count, double fill, double* out);
 
 /* ---- on-device posterior summaries of the device-resident store ----
  * store is [n_iter][C][size] (iteration-major, as MCMC writes it: mcmc.py:105-106 per chain).

@@ -41,6 +41,7 @@ class DenseTerms(C.Structure):
         ("mat", c_dp * OMC_MAX_TERMS),
         ("rhs", c_dp * OMC_MAX_TERMS),
         ("scale", c_dp * OMC_MAX_TERMS),
+        ("diag_chain", c_dp),
     ]
 
 
@@ -143,6 +144,7 @@ SIGNATURES = {
         [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_double, i32, C.c_double, C.c_double, c_dp, u64, u32,
          c_dp, c_dp, c_dp],
     ),
+    "omc_log_transform": (i32, [C.c_void_p, i64, c_dp, i64, c_dp, i64, c_dp]),
     "omc_centered_rowdot": (i32, [C.c_void_p, i64, c_dp, i64, c_dp, c_dp, i64, c_dp, c_dp]),
     "omc_uniform_draw": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, u64, u32, c_dp]),
     "omc_diag_gauss_logpdf": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i32]),
@@ -150,7 +152,11 @@ SIGNATURES = {
     "omc_diag_gauss_grad": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "omc_poisson_logpmf": (i32, [C.c_void_p, c_dp, C.c_double, c_dp, i32]),
     "omc_count_logpdf": (i32, [C.c_void_p, c_dp, C.c_double, c_dp, i32]),
-    "omc_mixture_gather": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, C.c_double, c_dp]),
+    "omc_mixture_gather": (i32, [C.c_void_p, i64, i64, c_dp, i64, c_dp, c_dp, C.c_double, c_dp]),
+    "omc_mixture_allocation": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, i64, c_dp, i64, c_dp, i64, c_dp, u64, c_dp]),
+    "omc_categorical_logpmf": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, i64, c_dp, i32]),
+    "omc_mixture_normal_gamma": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, u64, c_dp]),
+    "omc_gamma_logpdf_vec": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, i32]),
     "omc_fill_normal": (i32, [C.c_void_p, i64, u64, c_dp, i64]),
     "omc_fill_philox_u32": (i32, [C.c_void_p, i64, u64, c_dp, i64]),
 }

@@ -12,6 +12,7 @@ struct DenseTermsDev {
   const double* mat[OMC_MAX_TERMS];
   const double* rhs[OMC_MAX_TERMS];
   const double* scale[OMC_MAX_TERMS];
+  const double* diag_chain;  // [C][p] per-chain diagonal, or NULL
 };
 
 #define OMC_BLAS_CHECK(expr)                                   \
@@ -63,6 +64,7 @@ __global__ void __launch_bounds__(256) k_dense_assemble(DenseTermsDev T, int64_t
       if (k >= T.n_terms) continue;
       v = fma(sc[k], T.mat[k] ? T.mat[k][i] : (r == cl ? 1.0 : 0.0), v);
     }
+    if (T.diag_chain && r == cl) v += T.diag_chain[c * p + r];
     q[i] = v;
   }
 }
@@ -408,6 +410,7 @@ omc_status omc_dense_sample_canonical(omc_ctx* ctx, int64_t p, const omc_dense_t
     T.rhs[k] = on ? terms->rhs[k] : nullptr;
     T.scale[k] = on ? terms->scale[k] : nullptr;
   }
+  T.diag_chain = terms->diag_chain;
   rocblas_handle h = (rocblas_handle)ctx->blas;
   double* Q = ctx->dense_factor;
   hipLaunchKernelGGL(k_dense_assemble, dim3(gx(p * p) > 64 ? 64 : gx(p * p), (unsigned)C), dim3(256), 0, ctx->stream, T, p, C, Q);

@@ -263,8 +263,8 @@ __global__ void k_count_logpdf(int64_t C, const double* count, double per_elemen
   out[c] = accumulate ? out[c] + lp : lp;
 }
 
-__global__ void k_mixture_gather(int64_t C, int64_t kmax, int64_t m, const double* param, const double* alloc,
-                                 const double* count, double fill, double* out, long long* bad) {
+__global__ void k_mixture_gather(int64_t C, int64_t kmax, int64_t m, const double* param, int64_t pstride,
+                                 const double* alloc, const double* count, double fill, double* out, long long* bad) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= C * kmax) return;
   const int64_t c = t / kmax, j = t % kmax;
@@ -272,7 +272,7 @@ __global__ void k_mixture_gather(int64_t C, int64_t kmax, int64_t m, const doubl
   if (!count || (double)j < count[c]) {
     const int64_t a = (int64_t)alloc[t];
     if (a < 0 || a >= m) atomicMin((unsigned long long*)bad, (unsigned long long)c);
-    else v = param[a];
+    else v = param[c * pstride + a];
   }
   out[t] = v;
 }
@@ -321,6 +321,114 @@ __global__ void __launch_bounds__(256) k_centered_rowdot(int64_t n, const double
   if (threadIdx.x == 0) out[c] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// MixtureAllocation.sample (sampler.py:340-353): one thread per (chain, element)
+__global__ void k_mixture_allocation(int64_t C, int64_t chain_offset, int64_t p, int64_t K, const double* y,
+                                     const double* prior, int64_t prior_rows, const double* mean, int64_t mstride,
+                                     const double* prec, int64_t pstride, const double* u_in, omc_rng_key key, double* alloc) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= C * p) return;
+  const int64_t c = t / p, i = t % p;
+  const double yi = y[t];
+  const double* pr = prior + (prior_rows > 1 ? i * K : 0);
+  double total = 0.0;
+  for (int64_t k = 0; k < K; ++k) {
+    const double sd = 1.0 / sqrt(prec[c * pstride + k]);  // norm.pdf(y, loc, scale = 1/sqrt(prec))
+    const double z = (yi - mean[c * mstride + k]) / sd;
+    total += pr[k] * (exp(-(z * z) / 2.0) / 2.5066282746310002 / sd);
+  }
+  double u;
+  if (u_in) {
+    u = u_in[t];
+  } else {
+    const uint4 w = omc_rng_block(key, chain_offset + c, (uint32_t)(i >> 1));
+    u = (i & 1) ? omc_u53(w.z, w.w) : omc_u53(w.x, w.y);
+  }
+  double cum = 0.0;
+  int64_t pick = 0;
+  for (int64_t k = 0; k < K; ++k) {  // np.sum(U > np.cumsum(prob / total))
+    const double sd = 1.0 / sqrt(prec[c * pstride + k]);
+    const double z = (yi - mean[c * mstride + k]) / sd;
+    cum += pr[k] * (exp(-(z * z) / 2.0) / 2.5066282746310002 / sd) / total;
+    pick += (u > cum) ? 1 : 0;
+  }
+  alloc[t] = (double)pick;
+}
+
+__global__ void k_categorical_logpmf(int64_t C, int64_t p, int64_t K, const double* alloc, const double* prob,
+                                     int64_t prob_rows, double* out, int accumulate, long long* bad) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double lp = 0.0;
+  for (int64_t i = 0; i < p; ++i) {
+    const int64_t a = (int64_t)alloc[c * p + i];
+    if (a < 0 || a >= K) {
+      atomicMin((unsigned long long*)bad, (unsigned long long)c);
+      continue;
+    }
+    lp += log(prob[(prob_rows > 1 ? i * K : 0) + a]);
+  }
+  out[c] = accumulate ? out[c] + lp : lp;
+}
+
+// NormalGamma.sample for a mixture precision: one thread per (chain, component)
+__global__ void k_mixture_normal_gamma(int64_t C, int64_t chain_offset, int64_t p, int64_t K, const double* resid,
+                                       const double* alloc, const double* a0, const double* b0, const double* g_in,
+                                       omc_rng_key key, double* out, long long* bad) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= C * K) return;
+  const int64_t c = t / K, k = t % K;
+  double cnt = 0.0, ss = 0.0;
+  for (int64_t i = 0; i < p; ++i) {
+    if ((int64_t)alloc[c * p + i] == k) {
+      const double r = resid[c * p + i];
+      cnt += 1.0;
+      ss = fma(r, r, ss);
+    }
+  }
+  const double a = a0[k] + 0.5 * cnt, b = b0[k] + 0.5 * ss;
+  const double scale = (b == 0.0) ? INFINITY : 1.0 / b;
+  bool failed = false;
+  double g;
+  if (g_in) {
+    g = g_in[t];
+  } else {  // component k draws from its own stream: the draw index carries k in bits 32-39 of the 48-bit index
+    omc_rng_key kk = key;
+    kk.c3_base |= ((uint32_t)k & 0xffu) << 8;
+    g = omc_standard_gamma(kk, chain_offset + c, a, &failed);
+  }
+  out[t] = g * scale;
+  if (failed) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+}
+
+__global__ void k_gamma_logpdf_vec(int64_t C, int64_t K, const double* x, const double* shape, const double* rate,
+                                   double* out, int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double lp = 0.0;
+  for (int64_t k = 0; k < K; ++k) {
+    const double v = x[c * K + k], a = shape[k], b = rate[k];
+    lp += (v > 0.0) ? a * log(b) - lgamma(a) + (a - 1.0) * log(v) - b * v : -INFINITY;
+  }
+  out[c] = accumulate ? out[c] + lp : lp;
+}
+
+// LogNormal.log_p (location_scale.py:279-300): out = log x element-wise, sumlog[c] = sum_i log x[c][i]
+__global__ void __launch_bounds__(256) k_log_transform(int64_t n, const double* x, int64_t ld_x, double* out, int64_t ld_o,
+                                                      double* sumlog) {
+  __shared__ double red[4];
+  const int64_t c = blockIdx.x;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const double v = log(x[c * ld_x + i]);
+    out[c * ld_o + i] = v;
+    acc += v;
+  }
+  for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && sumlog) sumlog[c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // Uniform.rvs (distribution.py:444-458): lower + range * U, product rounded before the sum as numpy does
 __global__ void k_uniform_draw(int64_t C, int64_t chain_offset, int64_t p, const double* lower, const double* range,
                                const double* u_in, omc_rng_key key, uint32_t sub, double* out) {
@@ -350,6 +458,60 @@ omc_status omc_uniform_draw(omc_ctx* ctx, int64_t p, const double* lower, const 
   hipLaunchKernelGGL(k_uniform_draw, dim3(grid1(ctx->n_chains * p, 256)), dim3(256), 0, ctx->stream, ctx->n_chains,
                      ctx->chain_offset, p, lower, range, u_inject, omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), sub,
                      out);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_mixture_allocation(omc_ctx* ctx, int64_t p, int64_t K, const double* y, const double* prior,
+                                  int64_t prior_rows, const double* mean, int64_t mean_stride, const double* prec,
+                                  int64_t prec_stride, const double* u_inject, uint64_t draw_index, double* alloc) {
+  if (!ctx || p < 1 || K < 1 || !y || !prior || (prior_rows != 1 && prior_rows != p) || !mean || !prec || !alloc)
+    return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_mixture_allocation, dim3(grid1(ctx->n_chains * p, 256)), dim3(256), 0, ctx->stream, ctx->n_chains,
+                     ctx->chain_offset, p, K, y, prior, prior_rows, mean, mean_stride, prec, prec_stride, u_inject,
+                     omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), alloc);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_categorical_logpmf(omc_ctx* ctx, int64_t p, int64_t K, const double* alloc, const double* prob,
+                                  int64_t prob_rows, double* out, int32_t accumulate) {
+  if (!ctx || p < 1 || K < 1 || !alloc || !prob || (prob_rows != 1 && prob_rows != p) || !out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_categorical_logpmf, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, p, K,
+                     alloc, prob, prob_rows, out, (int)accumulate, ctx->d_bad_chain);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_mixture_normal_gamma(omc_ctx* ctx, int64_t p, int64_t K, const double* resid, const double* alloc,
+                                    const double* a0, const double* b0, const double* g_inject, uint64_t draw_index,
+                                    double* out) {
+  if (!ctx || p < 1 || K < 1 || K > 255 || !resid || !alloc || !a0 || !b0 || !out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_mixture_normal_gamma, dim3(grid1(ctx->n_chains * K, 64)), dim3(64), 0, ctx->stream, ctx->n_chains,
+                     ctx->chain_offset, p, K, resid, alloc, a0, b0, g_inject,
+                     omc_make_key(ctx->seed, draw_index, OMC_RNG_GAMMA), out, ctx->d_bad_chain);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_gamma_logpdf_vec(omc_ctx* ctx, int64_t K, const double* x, const double* shape, const double* rate,
+                                double* out, int32_t accumulate) {
+  if (!ctx || K < 1 || !x || !shape || !rate || !out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_gamma_logpdf_vec, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, K, x, shape,
+                     rate, out, (int)accumulate);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_log_transform(omc_ctx* ctx, int64_t n, const double* x, int64_t ld_x, double* out, int64_t ld_o,
+                             double* sumlog) {
+  if (!ctx || n < 1 || !x || !out || ld_x < n || ld_o < n) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_log_transform, dim3((unsigned)ctx->n_chains), dim3(256), 0, ctx->stream, n, x, ld_x, out, ld_o, sumlog);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }
@@ -413,12 +575,12 @@ omc_status omc_count_logpdf(omc_ctx* ctx, const double* count, double per_elemen
   return OMC_OK;
 }
 
-omc_status omc_mixture_gather(omc_ctx* ctx, int64_t kmax, int64_t m, const double* param, const double* alloc,
-                              const double* count, double fill, double* out) {
+omc_status omc_mixture_gather(omc_ctx* ctx, int64_t kmax, int64_t m, const double* param, int64_t param_stride,
+                              const double* alloc, const double* count, double fill, double* out) {
   if (!ctx || kmax < 1 || m < 1 || !param || !alloc || !out) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(k_mixture_gather, dim3(grid1(ctx->n_chains * kmax, 256)), dim3(256), 0, ctx->stream, ctx->n_chains,
-                     kmax, m, param, alloc, count, fill, out, ctx->d_bad_chain);
+                     kmax, m, param, param_stride, alloc, count, fill, out, ctx->d_bad_chain);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

@@ -177,6 +177,7 @@ omc_status omc_dense_gibbs_truncated(omc_ctx* ctx, int64_t p, const omc_dense_te
   if (!ctx || p < 1 || p > 8192 || !terms || terms->n_terms < 1 || terms->n_terms > OMC_MAX_TERMS || !x || ld_x < p ||
       (rhs_chain && ld_rhs < p) || (u_inject && ld_u < p))
     return OMC_INVALID_ARG;
+  if (terms->diag_chain) return OMC_UNSUPPORTED;  // per-chain diagonal (mixture prior) under a truncated conditional
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   const double *m[4] = {0, 0, 0, 0}, *s[4] = {0, 0, 0, 0}, *r[4] = {0, 0, 0, 0};
   for (int k = 0; k < terms->n_terms; ++k) { m[k] = terms->mat[k]; s[k] = terms->scale[k]; r[k] = terms->rhs[k]; }

@@ -59,11 +59,23 @@ class Gamma(Distribution):
         return self.shape.get_param_list() + self.rate.get_param_list()
 
     def host_shape_rate(self, state):
-        """Scalar prior parameters; they are host constants in every supported model."""
+        """Scalar prior parameters; they are host constants in every supported model.  A vector of identical entries
+        (one per mixture component, e.g. gamma_shape = 1e-3 * ones(n_cat)) counts as that scalar."""
         a, b = self.shape.predictor(state), self.rate.predictor(state)
-        if is_chain(a) or is_chain(b) or np.size(a) != 1 or np.size(b) != 1:
-            raise NotImplementedError("Gamma prior parameters must be shared scalars on the GPU path")
-        return float(np.asarray(a).item()), float(np.asarray(b).item())
+        if is_chain(a) or is_chain(b):
+            raise NotImplementedError("Gamma prior parameters must be shared on the GPU path")
+        a, b = np.asarray(a, dtype=np.float64).reshape(-1), np.asarray(b, dtype=np.float64).reshape(-1)
+        if np.any(a != a[0]) or np.any(b != b[0]):
+            raise NotImplementedError("element-wise different Gamma shape / rate: use host_shape_rate_vec")
+        return float(a[0]), float(b[0])
+
+    def host_shape_rate_vec(self, state, K):
+        """(K,) host vectors of the shape and rate (scalars are broadcast)."""
+        a, b = self.shape.predictor(state), self.rate.predictor(state)
+        if is_chain(a) or is_chain(b):
+            raise NotImplementedError("Gamma prior parameters must be shared on the GPU path")
+        bc = lambda v: np.broadcast_to(np.asarray(v, dtype=np.float64).reshape(-1), (K,)).copy()  # noqa: E731
+        return bc(a), bc(b)
 
     def log_p(self, state: dict, by_observation: bool = False, engine=None, out=None, accumulate=False):
         """distribution.py:241-261.  Per-chain response -> (C,) tensor via omc_gamma_logpdf; a (1, k) response (ragged or
@@ -81,6 +93,10 @@ class Gamma(Distribution):
         out = engine.empty(engine.n_chains) if out is None else out
         if x.size == 1 and x.ragged is None:
             engine.gamma_logpdf(x.scalar(), a, b, out, accumulate=accumulate)
+        elif x.shape[1] == 1 and x.ragged is None:
+            # (K, 1) response, e.g. the per-component precisions of a mixture: the same scalar shape / rate for all
+            K = x.shape[0]
+            engine.gamma_logpdf_vec(x.vector(), engine.full((K,), a), engine.full((K,), b), out, accumulate=accumulate)
         else:
             if x.shape[0] != 1:
                 raise NotImplementedError("vector-valued Gamma response with replicates")
@@ -219,3 +235,58 @@ class Poisson(Distribution):
 
     def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):
         raise NotImplementedError("Poisson prior draws on the device: give the jump parameter an initial value")
+
+
+@dataclass
+class Categorical(Distribution):
+    """Categorical distribution (distribution.py:281-375): the response holds category indices 0..n_cat-1, one trial
+    per element; `prob` is a shared (1 or p, n_cat) array."""
+
+    prob: Union[str, Identity]
+
+    def __post_init__(self):
+        if isinstance(self.prob, str):
+            self.prob = Identity(self.prob)
+        if not isinstance(self.prob, Identity):
+            raise TypeError("prob expected to be Identity")
+
+    @property
+    def _dist_params(self) -> list:
+        return self.prob.get_param_list()
+
+    def _prob(self, state):
+        prob = self.prob.predictor(state)
+        if is_chain(prob):
+            raise NotImplementedError("per-chain allocation probabilities")
+        return np.asarray(prob, dtype=np.float64)
+
+    def log_p(self, state: dict, by_observation: bool = False, engine=None, out=None, accumulate=False):
+        """distribution.py:318-352 for one replicate: sum_i log prob[i, z_i] (multinomial.logpmf with one trial)."""
+        x, prob = state[self.response], self._prob(state)
+        if by_observation:
+            raise NotImplementedError("by_observation")
+        if not is_chain(x):
+            z = np.asarray(x).astype(int).reshape(-1)
+            rows = np.zeros_like(z) if prob.shape[0] == 1 else np.arange(z.size)
+            return float(np.sum(np.log(prob[rows, z])))
+        if x.shape[1] != 1:
+            raise NotImplementedError("replicated categorical response")
+        if engine is None:
+            raise RuntimeError("Categorical.log_p on a per-chain response needs the engine (use Model.log_p)")
+        out = engine.empty(engine.n_chains) if out is None else out
+        engine.categorical_logpmf(x.vector(), engine.shared(prob), out, accumulate=accumulate)
+        return out
+
+    def rvs(self, state, n: int = 1, engine=None, draw_index=0):
+        """One category per element and chain by inverse CDF of a uniform (distribution-equivalent to the reference's
+        multinomial draw, distribution.py:354-375; used for missing initial values only)."""
+        if engine is None:
+            raise RuntimeError("Categorical.rvs needs the engine")
+        if n != 1:
+            raise NotImplementedError("replicated prior draws")
+        prob = self._prob(state)
+        p, K = prob.shape[0], prob.shape[1]
+        flat = engine.zeros(engine.n_chains, p)  # the same likelihood for every component: the draw is from the prior
+        alloc = engine.mixture_allocation(flat, engine.shared(prob), engine.zeros(K), engine.full((K,), 1.0),
+                                          draw_index=draw_index)
+        return ChainArray(alloc.unsqueeze(2))

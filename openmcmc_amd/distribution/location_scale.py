@@ -356,3 +356,45 @@ class NullDistribution(Normal):
 
     def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):
         return None
+
+
+@dataclass
+class LogNormal(Normal):
+    """Multivariate log-normal (location_scale.py:275-418): log(response) ~ Normal(mean, precision).  log_p and rvs are
+    built; the analytic gradient / Hessian (location_scale.py:302-402) are not (random-walk samplers do not need them)."""
+
+    def log_p(self, state: dict, by_observation: bool = False, engine=None, out=None, accumulate=False):
+        """location_scale.py:279-300: the Normal log-density at log(response) minus sum log(response)."""
+        if engine is None:
+            raise RuntimeError("LogNormal.log_p needs the engine (use Model.log_p)")
+        if by_observation:
+            raise NotImplementedError("by_observation")
+        from openmcmc_amd.chains import ChainArray
+
+        resp = state[self.response]
+        logged = dict(state)
+        if is_chain(resp):
+            if resp.shape[1] != 1:
+                raise NotImplementedError("replicated per-chain log-normal response")
+            lx, sumlog = engine.log_transform(resp.vector())
+            logged[self.response] = ChainArray(lx)
+        else:
+            memo = self.__dict__.setdefault("_log_memo", {})
+            hit = memo.get(id(resp))
+            if hit is None or hit[0] is not resp:
+                arr = np.asarray(resp, dtype=np.float64)
+                hit = memo[id(resp)] = (resp, np.log(arr), float(np.sum(np.log(arr))))
+            logged[self.response], sumlog = hit[1], hit[2]
+        out = Normal.log_p(self, logged, engine=engine, out=out, accumulate=accumulate)
+        out -= sumlog
+        return out
+
+    def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):
+        """location_scale.py:404-418: exp of the Normal draw."""
+        from openmcmc_amd.chains import ChainArray
+
+        draw = Normal.rvs(self, state, n=n, engine=engine, draw_index=draw_index)
+        return ChainArray(draw.data.exp())
+
+    def grad_log_p(self, state: dict, param: str, hessian_required: bool = True, engine=None):
+        raise NotImplementedError("LogNormal.grad_log_p (location_scale.py:302-402): use a random-walk sampler")

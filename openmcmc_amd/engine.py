@@ -239,13 +239,16 @@ class Engine:
             T.rhs[k] = self._vec(t.get("rhs"), p)
             T.scale[k] = self._chain_scalar(t.get("scale"))
             keep.append(dict(t))
+        T.diag_chain = None
         T._keep = keep
         return T
 
     def dense_sample_canonical(self, p, terms, x_out, z=None, rhs_chain=None, draw_index=0, mean_out=None,
-                               logdet_out=None):
+                               logdet_out=None, diag_chain=None):
+        """diag_chain: optional (C, p) per-chain diagonal added to Q_c (mixture prior precision)."""
         T = terms if isinstance(terms, _abi.DenseTerms) else self.dense_terms(terms, p)
         Cn = self.n_chains
+        T.diag_chain = self._p(diag_chain, Cn, p)
         ld = lambda t: 0 if t is None else t.stride(0)  # noqa: E731
         check(lib.omc_dense_sample_canonical(
             self._ctx, p, C.byref(T), self._p(rhs_chain, Cn, p), ld(rhs_chain), self._p(z, Cn, p), ld(z),
@@ -620,6 +623,13 @@ class Engine:
                                             self._chain_scalar(lq_fwd), self._chain_scalar(lq_rev)))
         return out
 
+    def log_transform(self, x):
+        """(log x (C, n), sum_i log x (C,)) of a per-chain vector."""
+        Cn, n = x.shape
+        out, sumlog = self.empty(Cn, n), self.empty(Cn)
+        check(lib.omc_log_transform(self._ctx, n, self._p(x, Cn, n), x.stride(0), self._p(out), n, self._p(sumlog)))
+        return out, sumlog
+
     def dense_quadform(self, M, x, center=None, M_center=None):
         """(C,) tensor (x - m)' M (x - m) for a dense shared M (device (n, n)): one GEMM + one reduction kernel."""
         Cn, n = x.shape
@@ -674,10 +684,43 @@ class Engine:
                                    int(accumulate)))
 
     def mixture_gather(self, param, alloc, count=None, fill=0.0):
+        """out[c][j] = param[alloc[c][j]]; param: (m,) shared or (C, m) per chain."""
         Cn, kmax = alloc.shape
         out = self.empty(Cn, kmax)
-        check(lib.omc_mixture_gather(self._ctx, kmax, param.numel(), self._p(param), self._p(alloc),
+        per_chain = param.dim() == 2
+        m = param.shape[-1]
+        check(lib.omc_mixture_gather(self._ctx, kmax, m, self._p(param), m if per_chain else 0, self._p(alloc),
                                      self._chain_scalar(count), float(fill), self._p(out)))
+        return out
+
+    def mixture_allocation(self, y, prior, mean, prec, u=None, draw_index=0):
+        """MixtureAllocation.sample: y (C, p), prior (1 or p, K) shared, mean / prec (K,) shared or (C, K) -> alloc (C, p)."""
+        Cn, p = y.shape
+        K = prior.shape[-1]
+        out = self.empty(Cn, p)
+        stride = lambda t: K if t.dim() == 2 else 0  # noqa: E731
+        check(lib.omc_mixture_allocation(self._ctx, p, K, self._p(y, Cn, p), self._p(prior), prior.shape[0], self._p(mean),
+                                         stride(mean), self._p(prec), stride(prec), self._p(u), int(draw_index), self._p(out)))
+        return out
+
+    def categorical_logpmf(self, alloc, prob, out, accumulate=False):
+        Cn, p = alloc.shape
+        check(lib.omc_categorical_logpmf(self._ctx, p, prob.shape[-1], self._p(alloc, Cn, p), self._p(prob), prob.shape[0],
+                                         self._chain_scalar(out), int(accumulate)))
+        return out
+
+    def mixture_normal_gamma(self, resid, alloc, a0, b0, g=None, draw_index=0):
+        Cn, p = resid.shape
+        K = a0.numel()
+        out = self.empty(Cn, K)
+        check(lib.omc_mixture_normal_gamma(self._ctx, p, K, self._p(resid, Cn, p), self._p(alloc, Cn, p), self._p(a0),
+                                           self._p(b0), self._p(g), int(draw_index), self._p(out)))
+        return out
+
+    def gamma_logpdf_vec(self, x, shape, rate, out, accumulate=False):
+        Cn, K = x.shape
+        check(lib.omc_gamma_logpdf_vec(self._ctx, K, self._p(x, Cn, K), self._p(shape), self._p(rate),
+                                       self._chain_scalar(out), int(accumulate)))
         return out
 
     # ------------------------------------------------------------------ posterior summaries

@@ -210,9 +210,10 @@ class MixtureParameter(Parameter, ABC):
     def gather_device(self, state: dict, engine, fill: float):
         """(C, kmax) tensor param[allocation] with `fill` beyond each chain's live length."""
         alloc, par = state[self.allocation], state[self.param]
-        if not is_chain(alloc) or is_chain(par):
-            raise NotImplementedError("mixture parameters need a per-chain allocation and a shared parameter vector")
-        return engine.mixture_gather(engine.shared(par).reshape(-1), alloc.vector(), count=alloc.count(state), fill=fill)
+        if not is_chain(alloc):
+            raise NotImplementedError("mixture parameters need a per-chain allocation")
+        table = par.vector() if is_chain(par) else engine.shared(par).reshape(-1)  # (C, m) per chain or (m,) shared
+        return engine.mixture_gather(table, alloc.vector(), count=alloc.count(state), fill=fill)
 
 
 @dataclass

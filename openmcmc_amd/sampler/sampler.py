@@ -17,7 +17,8 @@ import numpy as np
 from openmcmc_amd.chains import ChainArray, is_chain
 from openmcmc_amd.distribution.location_scale import Normal
 from openmcmc_amd.model import Model
-from openmcmc_amd.parameter import Identity, LinearCombination, ScaledMatrix, _is_identity
+from openmcmc_amd.parameter import (Identity, LinearCombination, MixtureParameterMatrix, MixtureParameterVector,
+                                     ScaledMatrix, _is_identity)
 
 
 @dataclass
@@ -115,12 +116,18 @@ class NormalNormal(MCMCSampler):
         if not isinstance(prior, Normal):
             raise TypeError("NormalNormal needs a Normal prior on the parameter")
         n = state[self.param].shape[0]
-        if prior.is_mixture:
+        mixture_prior = prior.is_mixture
+        if mixture_prior:
             if prior.domain_response_lower is not None or prior.domain_response_upper is not None:
-                raise NotImplementedError("truncated prior on a variable-size parameter")
-            return self._ragged_plan(state, n)
+                raise NotImplementedError("truncated mixture prior")
+            per_chain_design = any(k != self.param and isinstance(d.mean, LinearCombination)
+                                   and is_chain(state[d.mean.form[self.param]]) for k, d in self.model.items())
+            if per_chain_design or state[self.param].ragged is not None:
+                return self._ragged_plan(state, n)
         pieces = []  # one per distribution: what Q and b receive from it
         for key, dist in self.model.items():
+            if mixture_prior and key == self.param:
+                continue  # its diagonal precision and rhs are per chain: added at sample time (diag_chain, rhs_chain)
             if not isinstance(dist, Normal):
                 raise TypeError("NormalNormal handles Normal distributions only")
             st = dist.structure(state)
@@ -166,7 +173,10 @@ class NormalNormal(MCMCSampler):
         tridiagonal = all(pc["design"] is None and pc["st"].diag is not False and pc["st"].n == n for pc in pieces)
         banded = all(pc["design"] is None and pc["st"].n == n and (pc["st"].diag is not False or pc["st"].band is not None)
                      for pc in pieces)
-        if tridiagonal:
+        if mixture_prior:
+            plan = self._dense_plan(state, n, pieces)
+            plan["mixture_prior"] = prior
+        elif tridiagonal:
             plan = self._tridiag_plan(state, n, pieces)
         elif banded:
             plan = self._band_plan(state, n, pieces)
@@ -326,6 +336,12 @@ class NormalNormal(MCMCSampler):
             eng.tridiag_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
         elif p["kind"] == "band":
             eng.band_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())
+        elif p.get("mixture_prior") is not None:
+            # prior N(mean[alloc], diag(prec[alloc])^-1) (parameter.py:447,501): a per-chain diagonal on Q and
+            # prec * mean on b (sampler.py:181-183), next to the shared likelihood terms
+            _, pmean, pprec, _ = p["mixture_prior"].mixture_pieces(current_state, eng)
+            eng.dense_sample_canonical(n, p["terms"], x, z=z, rhs_chain=pprec * pmean, diag_chain=pprec,
+                                       draw_index=self._draw_index())
         else:
             eng.dense_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())
         current_state[self.param] = ChainArray(x)
@@ -366,7 +382,7 @@ class NormalGamma(MCMCSampler):
         others = [k for k in self.model.keys() if k != self.param]
         self.normal_param = others[0]
         precision = self.model[self.normal_param].precision
-        if not isinstance(precision, (Identity, ScaledMatrix)):
+        if not isinstance(precision, (Identity, ScaledMatrix, MixtureParameterMatrix)):
             raise TypeError("precision must be either Identity, ScaledMatrix or MixtureParameterMatrix")
 
     def prior_shape_rate(self, state):
@@ -376,11 +392,76 @@ class NormalGamma(MCMCSampler):
         """a = a0 + #{diag(P)>0}/2, b = b0 + r'Pr/2, lambda ~ Gamma(a, scale 1/b)  (sampler.py:252-288)."""
         eng = self._need_engine()
         dist = self.model[self.normal_param]
+        if dist.is_mixture:
+            return self._sample_mixture(current_state, dist)
         st = dist.structure(current_state)
         quad = dist.residual_quad(current_state, eng, st)
         a0, b0 = self.prior_shape_rate(current_state)
         target = _as_chain_scalar(eng, current_state, self.param)
         g = self.inject(self, self._sweep) if self.inject is not None else None
         eng.normal_gamma_update(a0, b0, st.n_pos, quad, target.scalar(), g=g, draw_index=self._draw_index())
+        self._sweep += 1
+        return current_state
+
+    def _sample_mixture(self, state, dist):
+        """One precision per mixture component (sampler.py:276-287 with MixtureParameterMatrix.precision_unscaled,
+        parameter.py:525-538): a_k = a0_k + #{alloc == k}/2, b_k = b0_k + sum_{alloc == k} r_i^2 / 2."""
+        eng = self.engine
+        target = state[self.param]
+        if not is_chain(target) or target.shape[1] != 1 or target.ragged is not None:
+            raise NotImplementedError("mixture precision vector must be a per-chain (K, 1) parameter")
+        K = target.shape[0]
+        x, pmean, _, count = dist.mixture_pieces(state, eng)
+        if count is not None:
+            raise NotImplementedError("NormalGamma on a variable-size mixture")
+        alloc = state[dist.precision.allocation].vector()
+        a0, b0 = self.model[self.param].host_shape_rate_vec(state, K)
+        consts = self.__dict__.setdefault("_ab_dev", {})
+        key = (a0.tobytes(), b0.tobytes())
+        if key not in consts:
+            consts[key] = (eng.to_device(a0), eng.to_device(b0))
+        g = self.inject(self, self._sweep) if self.inject is not None else None
+        out = eng.mixture_normal_gamma(x - pmean, alloc, consts[key][0], consts[key][1], g=g, draw_index=self._draw_index())
+        state[self.param] = ChainArray(out.unsqueeze(2))
+        self._sweep += 1
+        return state
+
+
+@dataclass
+class MixtureAllocation(MCMCSampler):
+    """Conditional draw of the allocation of a mixture (sampler.py:291-355): for every element of the response
+    parameter, category k with probability proportional to prior_k * N(y_i; mean_k, 1/prec_k)."""
+
+    response_param: Union[str, None] = None
+
+    def __post_init__(self):
+        self.model = Model([self.model[self.param], self.model[self.response_param]])
+        self._init_runtime()
+        resp = self.model[self.response_param]
+        if not isinstance(resp, Normal):
+            raise TypeError("Mixture model currently only implemented for Normal case")
+        if not isinstance(resp.mean, MixtureParameterVector):
+            raise TypeError("Mean must be of type MixtureParameterVector")
+        if not isinstance(resp.precision, MixtureParameterMatrix):
+            raise TypeError("Mean must be of type MixtureParameterMatrix")
+
+    def sample(self, current_state: dict) -> dict:
+        eng = self._need_engine()
+        resp = self.model[self.response_param]
+        prior = self.model[self.param].prob.predictor(current_state)
+        if is_chain(prior):
+            raise NotImplementedError("per-chain allocation probabilities")
+        y = current_state[self.response_param]
+        if not is_chain(y) or y.shape[1] != 1:
+            raise NotImplementedError("MixtureAllocation needs a per-chain (p, 1) response parameter")
+
+        def table(key):  # component means / precisions: shared (K, 1) host array or per-chain (K, 1)
+            v = current_state[key]
+            return v.vector() if is_chain(v) else eng.shared(v).reshape(-1)
+
+        u = self.inject(self, self._sweep) if self.inject is not None else None
+        alloc = eng.mixture_allocation(y.vector(), eng.shared(prior), table(resp.mean.param),
+                                       table(resp.precision.param), u=u, draw_index=self._draw_index())
+        current_state[self.param] = ChainArray(alloc.unsqueeze(2))
         self._sweep += 1
         return current_state

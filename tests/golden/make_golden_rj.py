@@ -655,7 +655,66 @@ def gen_rj_prior_chain():
     np.savez_compressed(os.path.join(OUT, "rj_prior_chain.npz"), **out)
 
 
-GENERATORS = {"rj_prior_chain": gen_rj_prior_chain, "band_chain": gen_band_chain, "truncnorm": gen_truncnorm, "rj_gmrf_chain": gen_rj_gmrf_chain, "example2": gen_example2,
+# ----------------------------------------------------------------------------- mixture prior
+def gen_mixture_chain():
+    """The mixture-prior model of the reference's sampler tests (tests/test_sampler.py fixtures: regression response,
+    parameter vector with MixtureParameterVector / MixtureParameterMatrix prior, Gamma prior on the per-component
+    precisions, Categorical allocation) with samplers [NormalNormal(parameter), NormalGamma(prior_precision_vector),
+    MixtureAllocation(allocation)], 40 sweeps, recorded draws."""
+    from openmcmc.distribution.distribution import Categorical
+    from openmcmc.sampler.sampler import MixtureAllocation
+
+    rng = np.random.default_rng(4)
+    n, p_, K, n_iter = 40, 7, 3, 40
+    X = rng.standard_normal((n, p_))
+    st = {"response": rng.standard_normal((n, 1)), "prefactor_matrix": X, "parameter": rng.standard_normal((p_, 1)),
+          "prior_mean": np.array([[-1.0], [0.5], [2.0]]), "precision_matrix": np.diag(rng.random(n) + 0.5),
+          "prior_precision_vector": 0.5 + rng.random(K), "gamma_shape": 2.0 * np.ones((K,)), "gamma_rate": 1.0 * np.ones((K,)),
+          "allocation": rng.integers(0, K, size=(p_, 1)), "prior_allocation_prob": np.array([[0.2, 0.5, 0.3]])}
+    out = {"n": n, "p": p_, "K": K, "n_iter": n_iter, "X": X, "y": st["response"].ravel(), "w": np.diag(st["precision_matrix"]).copy(),
+           "parameter0": st["parameter"].ravel(), "prior_mean": st["prior_mean"].ravel(), "prec0": np.asarray(st["prior_precision_vector"]).ravel(),
+           "alloc0": st["allocation"].ravel().astype(float), "prob": st["prior_allocation_prob"]}
+    mdl = Model([
+        Normal("response", mean=parameter.LinearCombination({"parameter": "prefactor_matrix"}), precision=parameter.Identity("precision_matrix")),
+        Normal("parameter", mean=parameter.MixtureParameterVector("prior_mean", "allocation"),
+               precision=parameter.MixtureParameterMatrix("prior_precision_vector", "allocation")),
+        Gamma("prior_precision_vector", shape=parameter.Identity("gamma_shape"), rate=parameter.Identity("gamma_rate")),
+        Categorical("allocation", prob="prior_allocation_prob")])
+    samplers = [NormalNormal("parameter", mdl), NormalGamma("prior_precision_vector", mdl),
+                MixtureAllocation("allocation", mdl, response_param="parameter")]
+    rd = np.random.default_rng(61)
+    zs, gs, us = [], [], []
+
+    def _norm(loc=0, scale=1, size=None, **_):
+        z = rd.standard_normal(size)
+        zs.append(np.asarray(z, dtype=float).reshape(-1))
+        return loc + z * scale
+
+    def _gamma(a, loc=0, scale=1, size=None, **_):
+        g = rd.standard_gamma(np.asarray(a, dtype=np.float64), size=size)
+        gs.append(np.asarray(g, dtype=float).reshape(-1))
+        return loc + g * scale
+
+    def _uniform(loc=0, scale=1, size=None, **_):
+        u = rd.random(size)
+        us.append(np.asarray(u, dtype=float).reshape(-1))
+        return loc + u * scale
+
+    saved = (stats.norm.rvs, stats.gamma.rvs, stats.uniform.rvs)
+    stats.norm.rvs, stats.gamma.rvs, stats.uniform.rvs = _norm, _gamma, _uniform
+    try:
+        M = MCMC(st, samplers, model=mdl, n_burn=0, n_iter=n_iter)
+        M.run_mcmc()
+    finally:
+        stats.norm.rvs, stats.gamma.rvs, stats.uniform.rvs = saved
+    out["z"], out["g"], out["u"] = np.array(zs), np.array(gs), np.array(us)
+    for key in ("parameter", "prior_precision_vector", "allocation", "log_post"):
+        out["store_" + key] = np.asarray(M.store[key], dtype=float)
+    print("allocation counts", np.bincount(M.store["allocation"].astype(int).ravel(), minlength=K))
+    np.savez_compressed(os.path.join(OUT, "mixture_chain.npz"), **out)
+
+
+GENERATORS = {"mixture_chain": gen_mixture_chain, "rj_prior_chain": gen_rj_prior_chain, "band_chain": gen_band_chain, "truncnorm": gen_truncnorm, "rj_gmrf_chain": gen_rj_gmrf_chain, "example2": gen_example2,
               "truncated_conditional": gen_truncated_conditional}
 
 if __name__ == "__main__":

@@ -359,3 +359,98 @@ def test_dense_prior_normal_gamma_and_log_p():
         a_c, b_c = sweep_ref.gamma_conditional(2.0, 1.5, beta[c].reshape(p, 1) - mu, sparse.csc_matrix(Qd))
         assert abs(got[c] - sweep_ref.gamma_draw_from_standard(a_c, b_c, g[c])) < 1e-10 * got[c]
     eng.close()
+
+
+def test_mixture_prior_model_replays_reference(golden):
+    """The mixture-prior model of the reference's sampler tests: NormalNormal on a parameter vector whose prior mean and
+    precision are picked by a categorical allocation (dense route + per-chain diagonal), NormalGamma on the
+    per-component precisions, MixtureAllocation; Categorical / vector-Gamma terms in log_post.  40 sweeps with the
+    reference's draws (tests/golden/mixture_chain.npz); allocations must be identical, the rest to 1e-10."""
+    import torch
+
+    from openmcmc_amd.distribution.distribution import Categorical, Gamma
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import Identity, LinearCombination, MixtureParameterMatrix, MixtureParameterVector
+    from openmcmc_amd.sampler.sampler import MixtureAllocation, NormalGamma, NormalNormal
+
+    G = golden("mixture_chain")
+    n, p, K, n_iter = int(G["n"]), int(G["p"]), int(G["K"]), int(G["n_iter"])
+    st = {"response": G["y"].reshape(n, 1), "prefactor_matrix": G["X"], "parameter": G["parameter0"].reshape(p, 1),
+          "prior_mean": G["prior_mean"].reshape(K, 1), "precision_matrix": np.diag(G["w"]), "prior_precision_vector": G["prec0"],
+          "gamma_shape": 2.0 * np.ones((K,)), "gamma_rate": 1.0 * np.ones((K,)), "allocation": G["alloc0"].reshape(p, 1),
+          "prior_allocation_prob": G["prob"]}
+    mdl = Model([
+        Normal("response", mean=LinearCombination({"parameter": "prefactor_matrix"}), precision=Identity("precision_matrix")),
+        Normal("parameter", mean=MixtureParameterVector("prior_mean", "allocation"),
+               precision=MixtureParameterMatrix("prior_precision_vector", "allocation")),
+        Gamma("prior_precision_vector", shape=Identity("gamma_shape"), rate=Identity("gamma_rate")),
+        Categorical("allocation", prob="prior_allocation_prob")])
+    samplers = [NormalNormal("parameter", mdl), NormalGamma("prior_precision_vector", mdl),
+                MixtureAllocation("allocation", mdl, response_param="parameter")]
+    C = 2
+    dev = torch.device("cuda", 0)
+    tile = lambda a: torch.as_tensor(np.tile(a, (C, 1)), device=dev)  # noqa: E731
+    samplers[0].inject = lambda s, it: tile(G["z"][it])
+    samplers[1].inject = lambda s, it: tile(G["g"][it])
+    samplers[2].inject = lambda s, it: tile(G["u"][it])
+    M = MCMC(st, samplers, model=mdl, n_burn=0, n_iter=n_iter, n_chains=C)
+    M.run_mcmc()
+    got = M.collect()
+    for c in range(C):
+        assert np.array_equal(got["allocation"][c], G["store_allocation"])
+        for key in ("parameter", "prior_precision_vector", "log_post"):
+            ref = G["store_" + key]
+            err = np.max(np.abs(got[key][c] - ref) / np.maximum(1.0, np.abs(ref)))
+            assert err < 1e-10, (key, err)
+
+
+def test_lognormal_and_categorical_log_p():
+    """LogNormal.log_p (location_scale.py:279-300) for a per-chain response and for a shared response with a per-chain
+    mean, against scipy.stats.lognorm; Categorical.log_p (distribution.py:318-352) and rvs frequencies."""
+    from scipy import sparse, stats
+
+    from openmcmc_amd.chains import ChainArray
+    from openmcmc_amd.distribution.distribution import Categorical
+    from openmcmc_amd.distribution.location_scale import LogNormal
+    from openmcmc_amd.engine import Engine
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import ScaledMatrix
+
+    n, C = 9, 5
+    rng = np.random.default_rng(2)
+    eng = Engine(C, seed=3)
+    d = LogNormal("y", mean="m", precision=ScaledMatrix("P", "tau"))
+    tau = rng.random(C) + 0.5
+    y = np.exp(rng.standard_normal((C, n)))
+    m = rng.standard_normal((n, 1))
+    state = {"y": ChainArray(eng.to_device(y)), "m": m, "P": sparse.identity(n, format="csc"),
+             "tau": ChainArray(eng.to_device(tau).reshape(C, 1, 1))}
+    lp = Model([d]).log_p(state, engine=eng).cpu().numpy()
+    for c in range(C):
+        ref = stats.lognorm.logpdf(y[c], s=1 / np.sqrt(tau[c]), scale=np.exp(m.ravel())).sum()
+        assert abs(lp[c] - ref) < 1e-10 * max(1.0, abs(ref))
+    # shared response, per-chain mean
+    ys = np.exp(rng.standard_normal((n, 1)))
+    mc = rng.standard_normal((C, n))
+    state = {"y": ys, "m": ChainArray(eng.to_device(mc)), "P": sparse.identity(n, format="csc"),
+             "tau": ChainArray(eng.to_device(tau).reshape(C, 1, 1))}
+    lp = Model([d]).log_p(state, engine=eng).cpu().numpy()
+    for c in range(C):
+        ref = stats.lognorm.logpdf(ys.ravel(), s=1 / np.sqrt(tau[c]), scale=np.exp(mc[c])).sum()
+        assert abs(lp[c] - ref) < 1e-10 * max(1.0, abs(ref))
+    # Categorical
+    prob = np.array([[0.2, 0.5, 0.3]])
+    cat = Categorical("z", prob="pi")
+    z = rng.integers(0, 3, size=(C, 6)).astype(float)
+    st = {"z": ChainArray(eng.to_device(z)), "pi": prob}
+    lp = Model([cat]).log_p(st, engine=eng).cpu().numpy()
+    assert np.allclose(lp, np.log(prob[0][z.astype(int)]).sum(axis=1), rtol=1e-13)
+    assert cat.log_p({"z": z[0].reshape(6, 1), "pi": prob}) == pytest.approx(lp[0])
+    eng2 = Engine(20000, seed=5)
+    draws = cat.rvs({"z": np.zeros((1, 1)), "pi": prob}, engine=eng2).data.cpu().numpy().ravel()
+    freq = np.bincount(draws.astype(int), minlength=3) / draws.size
+    assert np.all(np.abs(freq - prob[0]) < 0.01)
+    eng.check_status()
+    eng.close(), eng2.close()
