@@ -36,6 +36,53 @@ class Distribution(ABC):
     def param_list(self) -> list:
         return [self.response] + self._dist_params
 
+    # ------------------------------------------------------------------ finite-difference derivatives
+    def grad_log_p(self, state: dict, param: str, hessian_required: bool = True, engine=None):
+        """Default of the base class (distribution.py:90-122): central differences of log_p."""
+        grad = self.grad_log_p_diff(state, param, engine=engine)
+        if hessian_required:
+            return grad, self.hessian_log_p_diff(state, param, engine=engine)
+        return grad
+
+    def _perturbed(self, state, param, k, delta):
+        """state with element k (row-major over (p, n_rep)) of the per-chain parameter shifted by delta on every chain."""
+        x = state[param]
+        data = x.data.clone()
+        data.view(x.n_chains, -1)[:, k] += delta
+        out = dict(state)
+        out[param] = x.like(data)
+        return out
+
+    def grad_log_p_diff(self, state: dict, param: str, step_size: float = 1e-4, engine=None):
+        """distribution.py:124-158 for every chain: (log_p(x + h/2 e_k) - log_p(x - h/2 e_k)) / h, k over the elements of
+        the per-chain parameter.  Each log_p is one batched device evaluation; returns a ChainArray shaped like the
+        parameter."""
+        if engine is None:
+            raise RuntimeError("grad_log_p_diff needs the engine")
+        x = state[param]
+        if not is_chain(x) or x.ragged is not None:
+            raise NotImplementedError("finite differences need a fixed-size per-chain parameter")
+        grad = engine.empty(x.n_chains, x.size)
+        for k in range(x.size):
+            lp_plus = self.log_p(self._perturbed(state, param, k, step_size / 2), engine=engine)
+            lp_minus = self.log_p(self._perturbed(state, param, k, -step_size / 2), engine=engine)
+            grad[:, k] = (lp_plus - lp_minus) / step_size
+        return ChainArray(grad.reshape(x.data.shape))
+
+    def hessian_log_p_diff(self, state: dict, param: str, step_size: float = 1e-4, engine=None):
+        """distribution.py:160-198: column k = (grad(x - h/2 e_k) - grad(x + h/2 e_k)) / h (NEGATIVE second derivatives);
+        (C, d, d) tensor."""
+        if engine is None:
+            raise RuntimeError("hessian_log_p_diff needs the engine")
+        x = state[param]
+        d = x.size
+        hess = engine.empty(x.n_chains, d, d)
+        for k in range(d):
+            g_plus = self.grad_log_p(self._perturbed(state, param, k, step_size / 2), param, hessian_required=False, engine=engine)
+            g_minus = self.grad_log_p(self._perturbed(state, param, k, -step_size / 2), param, hessian_required=False, engine=engine)
+            hess[:, :, k] = (g_minus.data - g_plus.data).reshape(x.n_chains, d) / step_size
+        return hess
+
 
 @dataclass
 class Gamma(Distribution):

@@ -43,6 +43,11 @@ def tridiagonal_bands(M, n):
     return diag, off
 
 
+from collections import namedtuple
+
+# Hessian of branch (ii) of Normal.grad_log_p: scale[c] * matrix, the per-chain scalar kept apart from the shared matrix
+ScaledHessian = namedtuple("ScaledHessian", ["scale", "matrix"])
+
 BAND_MAX = 128  # widest band the band kernel takes (omc_band_sample_canonical)
 
 
@@ -316,23 +321,61 @@ class Normal(Distribution):
         return engine.diag_gauss_grad(x, prec, mean=mean, count=count), prec
 
     def grad_log_p(self, state: dict, param: str, hessian_required: bool = True, engine=None):
-        """Gradient of +log p and Hessian of -log p for the case the reference's MH samplers use: `param` is
-        the response, the precision is a shared dense matrix (location_scale.py:222-232):
-        grad_c = -Q (x_c - mu) as one GEMM over all chains, hessian = Q (shared)."""
+        """Gradient of +log p and Hessian of -log p w.r.t. a per-chain parameter (location_scale.py:190-250), the
+        reference's three branches:
+          (i)   `param` is the response and the precision a shared matrix: grad_c = -Q (x_c - mu) as one GEMM over all
+                chains, Hessian = Q (shared host matrix);
+          (ii)  `param` enters the mean only (Identity, or LinearCombination with a shared design A):
+                grad_c = s_c A' W sum_rep (y - fitted_c) as one GEMM, Hessian = n_rep A' W A times the per-chain scalar
+                s_c, returned as ScaledHessian(scale (C,), matrix);
+          (iii) anything else (e.g. the precision's scalar): central differences of log_p (distribution.py:124-198)."""
         if engine is None:
             raise RuntimeError("Normal.grad_log_p needs the engine")
-        if param != self.response or not isinstance(self.precision, Identity):
-            raise NotImplementedError("grad_log_p is built for the response of a Normal with a shared precision matrix")
-        Q, mu = state[self.precision.form], self.mean.predictor(state)
-        x = state[self.response]
-        if is_chain(Q) or is_chain(mu) or not is_chain(x):
-            raise NotImplementedError("grad_log_p needs a per-chain response and shared mean / precision")
         from openmcmc_amd.chains import ChainArray
 
-        dQ = engine.shared(Q)
-        r = x.vector() - engine.to_device(np.asarray(mu, dtype=np.float64).reshape(1, -1))
-        grad = ChainArray(-engine.design_predict(dQ, r))  # Q symmetric: Q r for every chain
-        return (grad, Q) if hessian_required else grad
+        x = state.get(param)
+        if param == self.response and isinstance(self.precision, Identity) and is_chain(x):
+            Q, mu = state[self.precision.form], self.mean.predictor(state)
+            if is_chain(Q) or is_chain(mu):
+                raise NotImplementedError("grad_log_p of the response needs a shared mean and precision")
+            dQ = engine.shared(Q)
+            r = x.vector() - engine.to_device(np.asarray(mu, dtype=np.float64).reshape(1, -1))
+            grad = ChainArray(-engine.design_predict(dQ, r))  # Q symmetric: Q r for every chain
+            return (grad, Q) if hessian_required else grad
+        in_mean = param in self.mean.get_grad_param_list() and param not in self.precision.get_grad_param_list()
+        if in_mean and param != self.response and is_chain(x) and not self.is_mixture:
+            st = self.structure(state)
+            if st.diag is False or st.off is not None:
+                raise NotImplementedError("gradient through the mean needs a diagonal response precision")
+            resp = state[self.response]
+            if is_chain(resp) or x.shape[1] != 1:
+                raise NotImplementedError("gradient through the mean needs a shared response and a (p, 1) parameter")
+            A = None if isinstance(self.mean, Identity) else state[self.mean.form[param]]
+            if is_chain(A):
+                raise NotImplementedError("gradient through a per-chain design matrix")
+            n_rep = resp.shape[1]
+            w = np.ones(st.n) if st.diag is None else np.asarray(st.diag, dtype=np.float64)
+            fitted = x.vector() if isinstance(self.mean, Identity) else self.mean.predictor_device(state, engine)
+            ysum = engine.to_device(np.asarray(resp, dtype=np.float64).sum(axis=1).reshape(1, -1))
+            r = (ysum - float(n_rep) * fitted) * engine.to_device(w.reshape(1, -1))   # W sum_rep (y - fitted)
+            memo = self.__dict__.setdefault("_grad_memo", {})
+            if A is None:
+                g, H = r, (sparse.diags(w) * float(n_rep)).tocsc()
+            else:
+                hit = memo.get(id(A))
+                if hit is None or hit[0] is not A:
+                    Ad = A.toarray() if sparse.issparse(A) else np.asarray(A, dtype=np.float64)
+                    hit = memo[id(A)] = (A, engine.to_device(np.ascontiguousarray(Ad.T)), float(n_rep) * (Ad.T * w) @ Ad)
+                g = engine.design_predict(hit[1], r.contiguous())  # rows of r times A: (C, p)
+                H = hit[2]
+            scale = state[st.scale_key].scalar() if st.scale_key is not None else None
+            if scale is not None:
+                g = g * scale.unsqueeze(1)
+            grad = ChainArray(g)
+            if not hessian_required:
+                return grad
+            return grad, (H if scale is None else ScaledHessian(scale=scale, matrix=H))
+        return Distribution.grad_log_p(self, state, param, hessian_required=hessian_required, engine=engine)
 
 
 @dataclass
@@ -397,4 +440,5 @@ class LogNormal(Normal):
         return ChainArray(draw.data.exp())
 
     def grad_log_p(self, state: dict, param: str, hessian_required: bool = True, engine=None):
-        raise NotImplementedError("LogNormal.grad_log_p (location_scale.py:302-402): use a random-walk sampler")
+        """The reference's analytic forms (location_scale.py:302-402) are not restated: central differences of log_p."""
+        return Distribution.grad_log_p(self, state, param, hessian_required=hessian_required, engine=engine)

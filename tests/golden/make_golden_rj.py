@@ -714,7 +714,35 @@ def gen_mixture_chain():
     np.savez_compressed(os.path.join(OUT, "mixture_chain.npz"), **out)
 
 
-GENERATORS = {"mixture_chain": gen_mixture_chain, "rj_prior_chain": gen_rj_prior_chain, "band_chain": gen_band_chain, "truncnorm": gen_truncnorm, "rj_gmrf_chain": gen_rj_gmrf_chain, "example2": gen_example2,
+# ----------------------------------------------------------------------------- gradients
+def gen_gradients():
+    """Normal.grad_log_p (location_scale.py:190-250) in its three branches and the finite-difference default of the
+    Distribution base class (distribution.py:90-198) on a small regression model, for three states."""
+    rng = np.random.default_rng(23)
+    n, p_ = 12, 4
+    X = rng.standard_normal((n, p_))
+    w = rng.random(n) + 0.5
+    y = rng.standard_normal((n, 1))
+    lik = Normal("y", mean=parameter.LinearCombination({"beta": "X"}), precision=parameter.ScaledMatrix("P_tau", "tau"))
+    prior_tau = Gamma("tau", shape="a", rate="b")
+    out = {"X": X, "w": w, "y": y.ravel(), "a": 2.5, "b": 1.5}
+    betas, taus = rng.standard_normal((3, p_)), rng.random(3) + 0.5
+    out["beta"], out["tau"] = betas, taus
+    for c in range(3):
+        st = {"y": y, "X": X, "beta": betas[c].reshape(p_, 1), "P_tau": sparse.diags(w, format="csc"), "tau": np.array([[taus[c]]]),
+              "a": np.array([[2.5]]), "b": np.array([[1.5]])}
+        g, h = lik.grad_log_p(st, "beta")                       # branch (ii): parameter in the mean
+        out[f"c{c}_grad_beta"], out[f"c{c}_hess_beta"] = np.asarray(g).ravel(), np.asarray(h)
+        g, h = lik.grad_log_p(st, "tau")                        # branch (iii): finite differences
+        out[f"c{c}_grad_tau_lik"], out[f"c{c}_hess_tau_lik"] = float(np.squeeze(g)), float(np.squeeze(h))
+        g, h = prior_tau.grad_log_p(st, "tau")                  # base-class default
+        out[f"c{c}_grad_tau_prior"], out[f"c{c}_hess_tau_prior"] = float(np.squeeze(g)), float(np.squeeze(h))
+        g = lik.grad_log_p(st, "y", hessian_required=False)     # branch (i): the response
+        out[f"c{c}_grad_y"] = np.asarray(g).ravel()
+    np.savez_compressed(os.path.join(OUT, "gradients.npz"), **out)
+
+
+GENERATORS = {"gradients": gen_gradients, "mixture_chain": gen_mixture_chain, "rj_prior_chain": gen_rj_prior_chain, "band_chain": gen_band_chain, "truncnorm": gen_truncnorm, "rj_gmrf_chain": gen_rj_gmrf_chain, "example2": gen_example2,
               "truncated_conditional": gen_truncated_conditional}
 
 if __name__ == "__main__":

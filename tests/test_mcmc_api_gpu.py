@@ -454,3 +454,43 @@ def test_lognormal_and_categorical_log_p():
     assert np.all(np.abs(freq - prob[0]) < 0.01)
     eng.check_status()
     eng.close(), eng2.close()
+
+
+def test_gradient_branches_match_reference(golden):
+    """Normal.grad_log_p in its three branches and the finite-difference default of the Distribution base class
+    (location_scale.py:190-250, distribution.py:90-198) against the reference (tests/golden/gradients.npz), three chains
+    with different coefficients and precisions evaluated together."""
+    from scipy import sparse
+
+    from openmcmc_amd.chains import ChainArray
+    from openmcmc_amd.distribution.distribution import Gamma
+    from openmcmc_amd.distribution.location_scale import Normal, ScaledHessian
+    from openmcmc_amd.engine import Engine
+    from openmcmc_amd.parameter import LinearCombination, ScaledMatrix
+
+    G = golden("gradients")
+    X, w, y = G["X"], G["w"], G["y"]
+    n, p = X.shape
+    C = 3
+    eng = Engine(C)
+    lik = Normal("y", mean=LinearCombination({"beta": "X"}), precision=ScaledMatrix("P_tau", "tau"))
+    prior = Gamma("tau", shape="a", rate="b")
+    state = {"y": y.reshape(n, 1), "X": X, "beta": ChainArray(eng.to_device(G["beta"])), "P_tau": sparse.diags(w, format="csc"),
+             "tau": ChainArray(eng.to_device(G["tau"]).reshape(C, 1, 1)), "a": np.array([[float(G["a"])]]), "b": np.array([[float(G["b"])]])}
+    grad, hess = lik.grad_log_p(state, "beta", engine=eng)                      # (ii)
+    assert isinstance(hess, ScaledHessian)
+    for c in range(C):
+        ref_g, ref_h = G[f"c{c}_grad_beta"], G[f"c{c}_hess_beta"]
+        assert np.max(np.abs(grad.chain(c).ravel() - ref_g)) < 1e-10 * np.abs(ref_g).max()
+        got_h = hess.scale[c].item() * hess.matrix
+        assert np.max(np.abs(got_h - ref_h)) < 1e-10 * np.abs(ref_h).max()
+    g_tau, h_tau = lik.grad_log_p(state, "tau", engine=eng)                     # (iii) finite differences
+    gp, hp = prior.grad_log_p(state, "tau", engine=eng)                         # base-class default
+    for c in range(C):
+        # differences of log densities of size ~1e2 over a step of 1e-4: rounding of the densities (1e-13 relative)
+        # is amplified by 1e4 / |gradient|, so these are compared at 1e-6 (the reference's own numbers carry the same noise)
+        assert abs(g_tau.chain(c).item() - float(G[f"c{c}_grad_tau_lik"])) < 1e-6 * abs(float(G[f"c{c}_grad_tau_lik"]))
+        assert abs(h_tau[c, 0, 0].item() - float(G[f"c{c}_hess_tau_lik"])) < 1e-4 * abs(float(G[f"c{c}_hess_tau_lik"]))
+        assert abs(gp.chain(c).item() - float(G[f"c{c}_grad_tau_prior"])) < 1e-6 * max(1.0, abs(float(G[f"c{c}_grad_tau_prior"])))
+        assert abs(hp[c, 0, 0].item() - float(G[f"c{c}_hess_tau_prior"])) < 1e-4 * abs(float(G[f"c{c}_hess_tau_prior"]))
+    eng.close()
