@@ -307,6 +307,40 @@ class Normal(Distribution):
                                                     "scale": scale}], x, draw_index=draw_index)
         return ChainArray(x)
 
+    def grad_terms(self, state: dict, param: str, engine):
+        """This distribution's share of the gradient and Hessian w.r.t. a per-chain (p, 1) parameter, in the form the
+        dense route consumes: (grad (C, p) tensor, [{"mat": shared host matrix or None = identity, "scale": (C,) tensor or
+        None}], diag (C, p) per-chain diagonal or None).  None when the distribution does not involve `param`.  Covers
+        branches (i) and (ii) of location_scale.py:190-250 for constant Hessians (Gaussian in `param`)."""
+        if param not in self.param_list:
+            return None
+        x = state[param]
+        if not is_chain(x) or x.shape[1] != 1:
+            raise NotImplementedError("grad_terms needs a per-chain (p, 1) parameter")
+        if param == self.response:
+            if self.is_mixture:
+                xv, mean, prec, count = self.mixture_pieces(state, engine)
+                if count is not None:
+                    raise NotImplementedError("variable-size parameter on the dense route")
+                return engine.diag_gauss_grad(xv, prec, mean=mean), [], prec
+            st = self.structure(state)
+            mu = self.mean.predictor(state)
+            if is_chain(mu):
+                raise NotImplementedError("per-chain prior mean")
+            Md = engine.shared(st.matrix)
+            r = x.vector() - engine.to_device(np.asarray(mu, dtype=np.float64).reshape(1, -1))
+            g = -engine.design_predict(Md, r.contiguous())           # M symmetric: rows of r times M
+            scale = state[st.scale_key].scalar() if st.scale_key is not None else None
+            if scale is not None:
+                g = g * scale.unsqueeze(1)
+            return g, [{"mat": st.matrix, "scale": scale}], None
+        grad, hess = self.grad_log_p(state, param, hessian_required=True, engine=engine)  # branch (ii)
+        if isinstance(hess, ScaledHessian):
+            return grad.vector(), [{"mat": hess.matrix, "scale": hess.scale}], None
+        if hasattr(hess, "shape") and not hasattr(hess, "data_ptr"):
+            return grad.vector(), [{"mat": hess, "scale": None}], None
+        raise NotImplementedError("parameter-dependent Hessian on the dense route")
+
     def grad_log_p_diag(self, state: dict, param: str, engine):
         """(grad, hdiag), each (C, kmax), when the Hessian w.r.t. `param` is diagonal per chain: the response of a
         mixture Normal (grad = -prec (x - mean), Hessian diag(prec); location_scale.py:222-226 with parameter.py:501).
@@ -394,8 +428,11 @@ class NullDistribution(Normal):
     def grad_log_p_diag(self, state: dict, param: str, engine):
         return None  # contributes nothing
 
+    def grad_terms(self, state: dict, param: str, engine):
+        return None
+
     def grad_log_p(self, state: dict, param: str, hessian_required: bool = True, engine=None):
-        raise NotImplementedError("NullDistribution.grad_log_p: use grad_log_p_diag (zero contribution)")
+        raise NotImplementedError("NullDistribution.grad_log_p: use grad_log_p_diag / grad_terms (zero contribution)")
 
     def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):
         return None

@@ -37,6 +37,28 @@ class Model(dict):
         return out
 
 
+    def grad_terms(self, state: dict, param: str, engine):
+        """(grad (C, p), terms, diag): the members' gradients summed and their Hessians collected as per-chain-scalar x
+        shared-matrix terms plus an optional per-chain diagonal (model.py:72-112 for Hessians that are constant in
+        `param`): what the dense ManifoldMALA route factorises per chain."""
+        grad, terms, diag = None, [], None
+        for dst in self.values():
+            if not hasattr(dst, "grad_terms"):
+                if param in dst.param_list:
+                    raise NotImplementedError(f"{type(dst).__name__}: no structured Hessian")
+                continue
+            part = dst.grad_terms(state, param, engine)
+            if part is None:
+                continue
+            g, t, d = part
+            grad = g if grad is None else grad + g
+            terms += t
+            if d is not None:
+                diag = d if diag is None else diag + d
+        if grad is None:
+            raise ValueError(f"no distribution depends on '{param}'")
+        return grad, terms, diag
+
     def grad_log_p_diag(self, state: dict, param: str, engine):
         """(grad, hdiag) summed over the members when every contribution has a per-chain DIAGONAL Hessian
         (model.py:72-112 restricted to that structure; distributions raise NotImplementedError otherwise)."""

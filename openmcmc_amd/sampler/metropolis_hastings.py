@@ -287,10 +287,64 @@ class ManifoldMALA(MetropolisHastings):
         u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
         return self._accept_reject_proposal(current_state, prop_state, lq_f, lq_r, u=u, sub=(x.shape[0] + 1) // 2 + 1)
 
+    def _dense_step(self, current_state: dict) -> dict:
+        """Generic route for a Hessian that is a per-chain combination of shared matrices (+ a per-chain diagonal):
+        regression coefficients under a Gaussian or a mixture prior.  Lambda_c = H_c / step^2 is factorised per chain by
+        the dense route (omc_dense_sample_canonical with b = Lambda x + g/2 gives x' = m + L^-T z and m at once, again
+        with z = 0 for the reverse mean); log q = (1/2) log det Lambda - (1/2)(. - m)' Lambda (. - m)
+        (metropolis_hastings.py:301-373), the quadratic forms term by term as GEMMs."""
+        eng = self.engine
+        x = current_state[self.param]
+        xv = x.vector().contiguous()
+        Cn, p = xv.shape
+        s2 = float(self.step.item()) ** 2
+        grad, terms, diag = self.model.grad_terms(current_state, self.param, eng)
+        dterms = []
+        for t in terms:
+            sc = eng.full((Cn,), 1.0 / s2) if t["scale"] is None else t["scale"] / s2
+            dterms.append({"mat": None if t["mat"] is None else eng.shared(t["mat"]), "scale": sc})
+        if not dterms:
+            dterms.append({"mat": None, "scale": eng.zeros(Cn)})
+        dscaled = None if diag is None else diag / s2
+        T = eng.dense_terms(dterms, p)
+
+        def lam_times(v):   # Lambda_c v_c for every chain
+            out = None if dscaled is None else dscaled * v
+            for t in dterms:
+                part = (v if t["mat"] is None else eng.design_predict(t["mat"], v.contiguous())) * t["scale"].unsqueeze(1)
+                out = part if out is None else out + part
+            return out
+
+        def lam_quad(d):    # d_c' Lambda_c d_c
+            out = None if dscaled is None else (dscaled * d * d).sum(dim=1)
+            for t in dterms:
+                q = (d * d).sum(dim=1) if t["mat"] is None else eng.dense_quadform(t["mat"], d.contiguous())
+                out = q * t["scale"] if out is None else out + q * t["scale"]
+            return out
+
+        z = self.inject(self, self._sweep) if self.inject is not None else None
+        xp, mu, logdet = eng.empty(Cn, p), eng.empty(Cn, p), eng.empty(Cn)
+        eng.dense_sample_canonical(p, T, xp, z=z, rhs_chain=lam_times(xv) + 0.5 * grad, draw_index=self._draw_index(),
+                                   mean_out=mu, logdet_out=logdet, diag_chain=dscaled)
+        lq_f = 0.5 * logdet - 0.5 * lam_quad(xp - mu)
+        prop_state = dict(current_state)
+        prop_state[self.param] = x.like(xp.unsqueeze(2))
+        grad_p, _, _ = self.model.grad_terms(prop_state, self.param, eng)   # the Hessian does not depend on the parameter
+        mu_p, scratch = eng.empty(Cn, p), eng.empty(Cn, p)
+        eng.dense_sample_canonical(p, T, scratch, z=eng.zeros(Cn, p), rhs_chain=lam_times(xp) + 0.5 * grad_p,
+                                   mean_out=mu_p, diag_chain=dscaled)
+        lq_r = 0.5 * logdet - 0.5 * lam_quad(xv - mu_p)
+        u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
+        return self._accept_reject_proposal(current_state, prop_state, lq_f, lq_r, u=u, sub=(p + 1) // 2 + 1)
+
     def sample(self, current_state: dict) -> dict:
         eng = self._need_engine()
         if not self._gaussian_target(current_state):
-            current_state = self._diag_step(current_state)
+            x = current_state[self.param]
+            diag_only = x.ragged is not None or all(
+                getattr(d, "is_mixture", False) and k == self.param or type(d).__name__ == "NullDistribution"
+                for k, d in self.model.items())
+            current_state = self._diag_step(current_state) if diag_only else self._dense_step(current_state)
             self._sweep += 1
             return current_state
         Q, mu, d = self._target(current_state)

@@ -742,7 +742,64 @@ def gen_gradients():
     np.savez_compressed(os.path.join(OUT, "gradients.npz"), **out)
 
 
-GENERATORS = {"gradients": gen_gradients, "mixture_chain": gen_mixture_chain, "rj_prior_chain": gen_rj_prior_chain, "band_chain": gen_band_chain, "truncnorm": gen_truncnorm, "rj_gmrf_chain": gen_rj_gmrf_chain, "example2": gen_example2,
+# ----------------------------------------------------------------------------- mMALA on regression coefficients
+def gen_mala_regression():
+    """ManifoldMALA (metropolis_hastings.py:301-373) on the coefficients of a regression: likelihood through the mean
+    (grad_log_p branch ii), (a) a ScaledMatrix Gaussian prior, (b) a mixture prior; 40 steps each, recorded draws."""
+    from openmcmc.sampler.metropolis_hastings import ManifoldMALA
+
+    rng = np.random.default_rng(29)
+    n, p_ = 30, 6
+    X = rng.standard_normal((n, p_))
+    w = rng.random(n) + 0.5
+    y = X @ rng.standard_normal((p_, 1)) + 0.3 * rng.standard_normal((n, 1))
+    A = rng.standard_normal((p_, 2 * p_))
+    Pm = A @ A.T / (2 * p_) + 0.5 * np.eye(p_)
+    Pm = (Pm + Pm.T) / 2
+    out = {"X": X, "w": w, "y": y.ravel(), "P": Pm, "tau": 2.0, "lam": 0.7, "mu": 0.3, "step": 1.25, "n_steps": 40,
+           "beta0": rng.standard_normal(p_), "prior_mean": np.array([-1.0, 0.5, 2.0]), "prior_prec": np.array([0.4, 1.5, 3.0]),
+           "alloc": rng.integers(0, 3, size=p_).astype(float)}
+    lik = Normal("y", mean=parameter.LinearCombination({"beta": "X"}), precision=parameter.ScaledMatrix("P_tau", "tau"))
+    priors = {"scaled": Normal("beta", mean="mu", precision=parameter.ScaledMatrix("P_lam", "lam")),
+              "mixture": Normal("beta", mean=parameter.MixtureParameterVector("prior_mean", "alloc"),
+                                precision=parameter.MixtureParameterMatrix("prior_prec", "alloc"))}
+    for tag, prior in priors.items():
+        mdl = Model([lik, prior])
+        st = {"y": y, "X": X, "beta": out["beta0"].reshape(p_, 1).copy(), "P_tau": sparse.diags(w, format="csc"),
+              "tau": np.array([[2.0]]), "P_lam": Pm, "lam": np.array([[0.7]]), "mu": np.full((p_, 1), 0.3),
+              "prior_mean": out["prior_mean"].reshape(3, 1), "prior_prec": out["prior_prec"].reshape(3, 1),
+              "alloc": out["alloc"].astype(int).reshape(p_, 1)}
+        smp = ManifoldMALA("beta", mdl, step=np.array(1.25))
+        rd = np.random.default_rng(300)
+        zs, us, xs, acc = [], [], [], []
+
+        def _norm(loc=0, scale=1, size=None, **_):
+            z = rd.standard_normal(size)
+            zs.append(np.asarray(z, dtype=float).reshape(-1))
+            return loc + z * scale
+
+        def _uniform(loc=0, scale=1, size=None, **_):
+            u = rd.random(size)
+            us.append(float(u))
+            return loc + u * scale
+
+        saved = (stats.norm.rvs, stats.uniform.rvs)
+        stats.norm.rvs, stats.uniform.rvs = _norm, _uniform
+        try:
+            for _ in range(40):
+                before = smp.accept_rate.count["accept"]
+                st = smp.sample(st)
+                xs.append(st["beta"].ravel().copy())
+                acc.append(smp.accept_rate.count["accept"] - before)
+        finally:
+            stats.norm.rvs, stats.uniform.rvs = saved
+        out[tag + "_z"], out[tag + "_u"], out[tag + "_x"] = np.array(zs), np.array(us), np.array(xs)
+        out[tag + "_accept"] = np.array(acc, dtype=float)
+        print(tag, "accepted", int(np.sum(acc)), "of 40")
+    np.savez_compressed(os.path.join(OUT, "mala_regression.npz"), **out)
+
+
+GENERATORS = {"mala_regression": gen_mala_regression, "gradients": gen_gradients, "mixture_chain": gen_mixture_chain, "rj_prior_chain": gen_rj_prior_chain, "band_chain": gen_band_chain, "truncnorm": gen_truncnorm, "rj_gmrf_chain": gen_rj_gmrf_chain, "example2": gen_example2,
               "truncated_conditional": gen_truncated_conditional}
 
 if __name__ == "__main__":
