@@ -247,6 +247,221 @@ __global__ void __launch_bounds__(BAND_TX* BAND_TY) k_band_sample(int64_t C, int
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Narrow bands (w <= 8): ONE LANE PER CHAIN.  The (w+1) x (w+1) window of open columns lives in registers (static
+// indices, shifted by one column per step), so a column costs a few dozen register-only instructions instead of two
+// workgroup barriers and a dozen LDS round trips; 64 chains share a wave and every global access is coalesced
+// across them: the factor and the forward-substituted right-hand side go to a workspace laid out [column][entry][chain],
+// the draw is handed back chain-major through a 64 x 64 LDS transpose tile.  The kernel is latency-bound (one
+// dependent chain of n columns per lane), so the loop bodies are kept short: ONE banded term (the prior; the other
+// terms are identities, the usual likelihoods) and running pointers instead of index arithmetic.
+struct BandLaneArgs {
+  const double* band;      // [(bw+1) x n] of the banded term
+  int bw;
+  const double* s_band;    // [C] or NULL
+  const double* s_ident[OMC_MAX_TERMS - 1];  // scales of the identity terms ([C] or NULL = 1); n_ident of them
+  int n_ident;
+  const double* rhs[OMC_MAX_TERMS];          // shared right-hand sides with their scales
+  const double* s_rhs[OMC_MAX_TERMS];
+  int n_rhs;
+};
+
+template <int W>
+__global__ void __launch_bounds__(64) k_band_lane(int64_t C, int64_t chain_offset, int64_t n, BandLaneArgs P,
+                                                  const double* z_in, int64_t ld_z, omc_rng_key key, double* Lws,
+                                                  double* x, int64_t ld_x, double* mean, int64_t ld_mean, double* logdet,
+                                                  long long* bad) {
+  constexpr int W1 = W + 1;
+  __shared__ double tile_x[64][65];
+  __shared__ double tile_m[64][65];
+  const int lane = threadIdx.x;
+  const int64_t c0 = (int64_t)blockIdx.x * 64;
+  const int64_t c = c0 + lane;
+  const bool live = c < C;
+  const int64_t cc = live ? c : C - 1;
+  const double sb = P.s_band ? P.s_band[cc] : 1.0;
+  double sid = 0.0;
+#pragma unroll
+  for (int k = 0; k < OMC_MAX_TERMS - 1; ++k)
+    if (k < P.n_ident) sid += P.s_ident[k] ? P.s_ident[k][cc] : 1.0;
+  double sr[OMC_MAX_TERMS];
+#pragma unroll
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) sr[k] = (k < P.n_rhs && P.s_rhs[k]) ? P.s_rhs[k][cc] : 1.0;
+  // workspace: L[(j*W1 + d)*C + c] (d = 0 holds 1/L_jj), then u[j*C + c]
+  double* Lp = Lws + cc;
+  double* Up = Lws + (int64_t)n * W1 * C + cc;
+  // band rows are zero-padded to n entries, so Q[col + d, col] = sb * band[d][col] (+ sid on the diagonal) for col < n
+  const double* brow[W1];
+#pragma unroll
+  for (int d = 0; d < W1; ++d) brow[d] = (d <= P.bw) ? P.band + (int64_t)d * n : nullptr;
+  auto column = [&](int64_t col, double (&q)[W1], double& r) {
+    if (col < n) {
+#pragma unroll
+      for (int d = 0; d < W1; ++d) q[d] = brow[d] ? sb * brow[d][col] : 0.0;
+      q[0] += sid;
+      double b = 0.0;
+#pragma unroll
+      for (int k = 0; k < OMC_MAX_TERMS; ++k)
+        if (k < P.n_rhs) b = fma(sr[k], P.rhs[k][col], b);
+      r = b;
+    } else {
+#pragma unroll
+      for (int d = 0; d < W1; ++d) q[d] = 0.0;
+      r = 0.0;
+    }
+  };
+  double A[W1][W1];  // A[b][d] = current value of Q[j+b+d, j+b]
+  double R[W1];      // current right-hand side at j+b
+#pragma unroll
+  for (int b = 0; b < W1; ++b) column((int64_t)b, A[b], R[b]);
+  double ld_mant = 1.0;
+  long long ld_exp = 0;
+  bool fail = false;
+  // the column that enters the window at the end of step j is fetched during step j - 1
+  double pre[W1], preR;
+  column((int64_t)W1, pre, preR);
+  for (int64_t j = 0; j < n; ++j) {
+    double pre_next[W1], preR_next;
+    column(j + 1 + W1, pre_next, preR_next);
+    const double pivot = A[0][0];
+    const bool ok = pivot > 0.0;
+    fail |= !ok;
+    double rinv = 1.0;
+    if (ok) {
+      const double g = __builtin_amdgcn_rsq(pivot);
+      const double h = 0.5 * g;
+      double sq = pivot * g;
+      double e = fma(-sq, sq, pivot);
+      sq = fma(e, h, sq);
+      e = fma(-sq, sq, pivot);
+      sq = fma(e, h, sq);
+      rinv = omc_rcp_nr(sq);
+    }
+    double l[W1];
+    l[0] = rinv;
+#pragma unroll
+    for (int d = 1; d < W1; ++d) l[d] = A[0][d] * rinv;
+    const double u = R[0] * rinv;
+#pragma unroll
+    for (int d = 0; d < W1; ++d) Lp[(int64_t)d * C] = l[d];
+    Lp += (int64_t)W1 * C;
+    *Up = u;
+    Up += C;
+    ld_mant *= __builtin_amdgcn_frexp_mant(ok ? pivot : 1.0);
+    ld_exp += __builtin_amdgcn_frexp_exp(ok ? pivot : 1.0);
+    if ((j & 15) == 15) {
+      ld_exp += __builtin_amdgcn_frexp_exp(ld_mant);
+      ld_mant = __builtin_amdgcn_frexp_mant(ld_mant);
+    }
+    // trailing update and shift of the window by one column
+#pragma unroll
+    for (int b = 1; b < W1; ++b) {
+#pragma unroll
+      for (int d = 0; d < W1; ++d) {
+        double v = A[b][d];
+        if (b + d < W1) v = fma(-l[b + d], l[b], v);  // Q[j+a, j+b] -= l_a l_b with a = b + d
+        A[b - 1][d] = v;
+      }
+      R[b - 1] = fma(-l[b], u, R[b]);
+    }
+#pragma unroll
+    for (int d = 0; d < W1; ++d) { A[W][d] = pre[d]; pre[d] = pre_next[d]; }
+    R[W] = preR;
+    preR = preR_next;
+  }
+  if (logdet && live) logdet[c] = log(ld_mant) + (double)ld_exp * 0.69314718055994530942;
+  if (fail && live) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+
+  // backward pass  L' x = u + z (and L' m = u), 64 columns at a time into the transpose tiles; Lp / Up now point
+  // one column past the end and walk back
+  const int64_t gc = chain_offset + cc;
+  const double* zrow = z_in ? z_in + cc * ld_z : nullptr;
+  double z_even = 0.0;
+  double xs[W1], ms[W1];  // xs[d] = x_{j+d} for d = 1..W (xs[0] unused)
+#pragma unroll
+  for (int d = 0; d < W1; ++d) { xs[d] = 0.0; ms[d] = 0.0; }
+  double lnext[W1], unext;
+  Lp -= (int64_t)W1 * C;
+  Up -= C;
+#pragma unroll
+  for (int d = 0; d < W1; ++d) lnext[d] = Lp[(int64_t)d * C];
+  unext = *Up;
+  for (int64_t jb = ((n - 1) / 64) * 64; jb >= 0; jb -= 64) {
+    const int len = (int)((n - jb < 64) ? n - jb : 64);
+    for (int t = len - 1; t >= 0; --t) {
+      const int64_t j = jb + t;
+      double lcol[W1];
+#pragma unroll
+      for (int d = 0; d < W1; ++d) lcol[d] = lnext[d];
+      const double u = unext;
+      if (j > 0) {
+        Lp -= (int64_t)W1 * C;
+        Up -= C;
+#pragma unroll
+        for (int d = 0; d < W1; ++d) lnext[d] = Lp[(int64_t)d * C];
+        unext = *Up;
+      }
+      double z;
+      if (zrow) {
+        z = zrow[j];
+      } else if ((j & 1) || j == n - 1) {  // a Philox block gives the draws of columns 2q and 2q+1: made once, used twice
+        double n0, n1;
+        omc_normal_pair(omc_rng_block(key, gc, (uint32_t)(j >> 1)), n0, n1);
+        z = (j & 1) ? n1 : n0;
+        z_even = n0;
+      } else {
+        z = z_even;
+      }
+      double ax = u + z, am = u;
+#pragma unroll
+      for (int d = 1; d < W1; ++d) {
+        ax = fma(-lcol[d], xs[d], ax);
+        am = fma(-lcol[d], ms[d], am);
+      }
+      const double xv = fail ? NAN : ax * lcol[0], mv = am * lcol[0];
+#pragma unroll
+      for (int d = W; d > 1; --d) { xs[d] = xs[d - 1]; ms[d] = ms[d - 1]; }
+      xs[1] = xv; ms[1] = mv;
+      tile_x[lane][t] = xv;
+      if (mean) tile_m[lane][t] = mv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int r = 0; r < 64; ++r) {
+      if (c0 + r < C && lane < len) {
+        x[(c0 + r) * ld_x + jb + lane] = tile_x[r][lane];
+        if (mean) mean[(c0 + r) * ld_mean + jb + lane] = tile_m[r][lane];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// Does the term list fit k_band_lane (exactly one banded term, the others identities)?
+static bool band_lane_args(const BandTermsDev& T, BandLaneArgs* P) {
+  P->band = nullptr; P->bw = 0; P->s_band = nullptr; P->n_ident = 0; P->n_rhs = 0;
+  for (int k = 0; k < T.n_terms; ++k) {
+    if (T.band[k]) {
+      if (P->band) return false;
+      P->band = T.band[k]; P->bw = T.bw[k]; P->s_band = T.scale[k];
+    } else {
+      P->s_ident[P->n_ident++] = T.scale[k];
+    }
+    if (T.rhs[k]) { P->rhs[P->n_rhs] = T.rhs[k]; P->s_rhs[P->n_rhs] = T.scale[k]; ++P->n_rhs; }
+  }
+  return P->band != nullptr;
+}
+
+template <int W>
+static void launch_band_lane(omc_ctx* ctx, int64_t n, const BandLaneArgs& P, const double* z, int64_t ld_z, omc_rng_key key,
+                             double* x, int64_t ld_x, double* mean, int64_t ld_mean, double* logdet) {
+  hipLaunchKernelGGL((k_band_lane<W>), dim3((unsigned)((ctx->n_chains + 63) / 64)), dim3(64), 0, ctx->stream, ctx->n_chains,
+                     ctx->chain_offset, n, P, z, ld_z, key, ctx->workspace, x, ld_x, mean, ld_mean, logdet, ctx->d_bad_chain);
+}
+
 // quad[c] = (x_c - m)' M (x_c - m) for a shared band matrix (NormalGamma.sample sampler.py:276,284; gmrf.py:343-344)
 __global__ void __launch_bounds__(256) k_band_quadform(int64_t C, int64_t n, int w, const double* band, const double* center,
                                                        const double* x, int64_t ld, double* quad) {
@@ -290,9 +505,26 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
     if (on && (terms->bw[k] < 0 || terms->bw[k] > w)) return OMC_INVALID_ARG;
   }
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  const size_t need = (size_t)ctx->n_chains * n * (w + 1) * sizeof(double);
+  const size_t need = (size_t)ctx->n_chains * n * (w + 2) * sizeof(double);
   omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->workspace, &ctx->workspace_bytes, need);
   if (st != OMC_OK) return st;
+  BandLaneArgs LP;
+  if (w >= 1 && w <= 8 && !rhs_chain && ctx->band_algo != 2 && band_lane_args(T, &LP)) {
+    // narrow band: one lane per chain, window in registers (see k_band_lane)
+    const omc_rng_key lane_key = omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL);
+    switch ((int)w) {
+      case 1: launch_band_lane<1>(ctx, n, LP, z_inject, ld_z, lane_key, x, ld_x, mean, ld_mean, logdet); break;
+      case 2: launch_band_lane<2>(ctx, n, LP, z_inject, ld_z, lane_key, x, ld_x, mean, ld_mean, logdet); break;
+      case 3: launch_band_lane<3>(ctx, n, LP, z_inject, ld_z, lane_key, x, ld_x, mean, ld_mean, logdet); break;
+      case 4: launch_band_lane<4>(ctx, n, LP, z_inject, ld_z, lane_key, x, ld_x, mean, ld_mean, logdet); break;
+      case 5: launch_band_lane<5>(ctx, n, LP, z_inject, ld_z, lane_key, x, ld_x, mean, ld_mean, logdet); break;
+      case 6: launch_band_lane<6>(ctx, n, LP, z_inject, ld_z, lane_key, x, ld_x, mean, ld_mean, logdet); break;
+      case 7: launch_band_lane<7>(ctx, n, LP, z_inject, ld_z, lane_key, x, ld_x, mean, ld_mean, logdet); break;
+      default: launch_band_lane<8>(ctx, n, LP, z_inject, ld_z, lane_key, x, ld_x, mean, ld_mean, logdet); break;
+    }
+    OMC_HIP_CHECK(hipGetLastError());
+    return OMC_OK;
+  }
   const int W1 = (int)w + 1;
   size_t lds = ((size_t)W1 * W1 + 2 * W1 + 2) * sizeof(double);
   const size_t lds_back = (size_t)(2 * W1 + 8) * sizeof(double);

@@ -44,6 +44,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->stamps = nullptr;
   c->debug_zero_z = 0;
   c->dense_use_rocsolver = 0;
+  c->band_algo = 0;
   if (c->own_stream) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { omc_set_error("hipStreamCreate", e); delete c; return OMC_HIP_ERROR; }
@@ -108,6 +109,11 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "tridiag_seg")) {
     if (value != 0 && value != 8 && value != 10 && value != 16 && value != 20 && value != 32) return OMC_INVALID_ARG;
     ctx->tridiag_seg = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "band_algo")) {
+    if (value < 0 || value > 2) return OMC_INVALID_ARG;
+    ctx->band_algo = (int)value;
     return OMC_OK;
   }
   if (!strcmp(name, "dense_use_rocsolver")) {

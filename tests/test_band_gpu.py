@@ -44,7 +44,9 @@ def random_band_spd(n, w, rng):
     return sparse.csc_matrix(A)
 
 
-def check_case(eng, M, w, rng, C):
+def check_case(eng, M, w, rng, C, per_chain_rhs=True):
+    """per_chain_rhs=True exercises the workgroup-per-chain kernel (the only one that takes a per-chain right-hand
+    side); False lets narrow bands (w <= 8) take the lane-per-chain kernel."""
     from oracle import gmrf_ref
 
     n = M.shape[0]
@@ -52,11 +54,12 @@ def check_case(eng, M, w, rng, C):
     m = rng.standard_normal(n)
     y = rng.standard_normal(n)
     z = rng.standard_normal((C, n))
-    extra = rng.standard_normal((C, n)) * 0.3
+    extra = rng.standard_normal((C, n)) * 0.3 if per_chain_rhs else np.zeros((C, n))
     terms = [{"band": eng.to_device(band_of(M, w)), "rhs": eng.to_device(M @ m), "scale": eng.to_device(lam)},
              {"rhs": eng.to_device(y), "scale": eng.to_device(tau)}]
     x, mu, ld = eng.empty(C, n), eng.empty(C, n), eng.empty(C)
-    eng.band_sample_canonical(n, terms, x, z=eng.to_device(z), rhs_chain=eng.to_device(extra), mean_out=mu, logdet_out=ld)
+    eng.band_sample_canonical(n, terms, x, z=eng.to_device(z), rhs_chain=eng.to_device(extra) if per_chain_rhs else None,
+                              mean_out=mu, logdet_out=ld)
     eng.check_status()
     xg, mg, lg = x.cpu().numpy(), mu.cpu().numpy(), ld.cpu().numpy()
     worst = 0.0
@@ -77,12 +80,13 @@ def check_case(eng, M, w, rng, C):
     return worst
 
 
+@pytest.mark.parametrize("per_chain_rhs", [True, False], ids=["workgroup", "lane"])
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 40, 301])
-def test_rw2_precision(n):
+def test_rw2_precision(n, per_chain_rhs):
     rng = np.random.default_rng(n)
     C = 5
     eng = make_engine(C)
-    worst = check_case(eng, rw2_precision(n), 2 if n >= 3 else 0, rng, C)
+    worst = check_case(eng, rw2_precision(n), 2 if n >= 3 else 0, rng, C, per_chain_rhs)
     assert worst < 1e-8, worst  # RW2 + ridge is ill-conditioned (cond ~ n^4): compared at its conditioning
     eng.close()
 
@@ -95,6 +99,29 @@ def test_random_band_matrices(w, n):
     eng = make_engine(C)
     worst = check_case(eng, random_band_spd(n, w, rng), w, rng, C)
     assert worst < RTOL, worst
+    eng.close()
+
+
+@pytest.mark.parametrize("w,n,C", [(1, 9, 3), (2, 200, 70), (3, 3, 64), (4, 65, 65), (5, 129, 130), (6, 64, 7), (7, 130, 4),
+                                    (8, 300, 100), (8, 9, 1)])
+def test_lane_per_chain_kernel(w, n, C):
+    """Narrow bands without a per-chain right-hand side take k_band_lane (window in registers, chains across the lanes):
+    every bandwidth 1..8, chain counts around the wave size, lengths around the 64-column output tile."""
+    rng = np.random.default_rng(1000 * w + n + C)
+    eng = make_engine(C)
+    worst = check_case(eng, random_band_spd(n, w, rng), w, rng, C, per_chain_rhs=False)
+    assert worst < RTOL, worst
+    # the two kernels agree with each other as well
+    M = random_band_spd(n, w, rng)
+    band = eng.to_device(band_of(M, w))
+    z = eng.to_device(rng.standard_normal((C, n)))
+    a, b = eng.empty(C, n), eng.empty(C, n)
+    eng.band_sample_canonical(n, [{"band": band}], a, z=z)
+    eng.set_option("band_algo", 2)
+    eng.band_sample_canonical(n, [{"band": band}], b, z=z)
+    eng.set_option("band_algo", 0)
+    eng.check_status()
+    assert np.max(np.abs(a.cpu().numpy() - b.cpu().numpy())) < 1e-11 * max(1.0, np.abs(b.cpu().numpy()).max())
     eng.close()
 
 
