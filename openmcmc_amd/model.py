@@ -14,14 +14,23 @@ class Model(dict):
         """Distributions that mention `param` (model.py:41-55)."""
         return Model([dst for dst in self.values() if param in dst.param_list])
 
-    def log_p(self, state: dict, engine=None, out=None):
-        """Sum of the members' log densities, one value per chain (model.py:57-70)."""
+    def affected_by(self, changed_keys) -> list:
+        """Responses of the member distributions that read any of the given state entries."""
+        changed = set(changed_keys)
+        return [key for key, dst in self.items() if changed.intersection(dst.param_list)]
+
+    def log_p(self, state: dict, engine=None, out=None, members=None):
+        """Sum of the members' log densities, one value per chain (model.py:57-70).  `members`: restrict the sum to
+        these responses (Metropolis-Hastings needs only the terms a proposal can change: the others are the same
+        number on both sides of the acceptance ratio)."""
         if engine is None:
             raise RuntimeError("Model.log_p needs the engine that holds the chains")
         out = engine.empty(engine.n_chains) if out is None else out
         first = True
         host_sum = 0.0
-        for dst in self.values():
+        for key, dst in self.items():
+            if members is not None and key not in members:
+                continue
             from openmcmc_amd.chains import is_chain
 
             touches_chain = any(is_chain(state.get(k)) for k in dst.param_list)

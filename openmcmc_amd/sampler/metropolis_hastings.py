@@ -108,9 +108,15 @@ class MetropolisHastings(MCMCSampler):
         for every proposal; inside a loop over columns it is the value selected at the previous step); it is
         updated in place to the log-density of the returned state and kept in self._lp_state."""
         eng = self._need_engine()
-        if lp_cur is None:
-            lp_cur = self.model.log_p(current_state, engine=eng)
-        lp_prop = self.model.log_p(prop_state, engine=eng)
+        # Only distributions that read an entry the proposal replaced can differ between the two states; the others
+        # contribute the same number to both log-densities (the reference sums them all and subtracts,
+        # metropolis_hastings.py:150-155).  Proposals and callbacks must REPLACE state entries, never mutate them.
+        changed = [k for k, v in prop_state.items() if v is not current_state.get(k)]
+        members = self.model.affected_by(changed)
+        if lp_cur is None or getattr(self, "_lp_members", None) != members:
+            lp_cur = self.model.log_p(current_state, engine=eng, members=members)
+        self._lp_members = members
+        lp_prop = self.model.log_p(prop_state, engine=eng, members=members)
         log_alpha = eng.empty(eng.n_chains) if trace is not None else None
         acc = eng.mh_accept(lp_cur, lp_prop, _as_chain_tensor(eng, logp_pr_g_cr), _as_chain_tensor(eng, logp_cr_g_pr),
                             count=count, index=index, u=u, draw_index=self._draw_index(), sub=sub,
