@@ -13,10 +13,16 @@ from openmcmc_amd import _abi
 from openmcmc_amd._abi import check, lib
 
 
-def _torch():
-    import torch
+_TORCH = None
 
-    return torch
+
+def _torch():
+    global _TORCH
+    if _TORCH is None:
+        import torch
+
+        _TORCH = torch
+    return _TORCH
 
 
 class Engine:
@@ -59,14 +65,18 @@ class Engine:
         """Device pointer of a float64 tensor (None passes through as NULL)."""
         if t is None:
             return None
-        torch = _torch()
-        if not isinstance(t, torch.Tensor) or t.dtype != torch.float64 or not t.is_cuda:
-            raise TypeError("expected a float64 ROCm tensor")
-        if t.dim() >= 1 and t.stride(-1) != 1 and t.shape[-1] != 1:
+        # hot: ~1000 calls per sweep of a reversible-jump model.  A plain int is a valid c_void_p argument.
+        try:
+            if t.dtype is not _TORCH.float64 or not t.is_cuda:
+                raise TypeError("expected a float64 ROCm tensor")
+        except AttributeError:
+            raise TypeError("expected a float64 ROCm tensor") from None
+        shape = t.shape
+        if len(shape) >= 1 and shape[-1] != 1 and t.stride(-1) != 1:
             raise ValueError("last dimension must be contiguous")
-        if rows is not None and (t.dim() != 2 or t.shape[0] != rows or t.shape[1] < min_cols):
-            raise ValueError(f"expected shape ({rows}, >={min_cols}), got {tuple(t.shape)}")
-        return C.c_void_p(t.data_ptr())
+        if rows is not None and (len(shape) != 2 or shape[0] != rows or shape[1] < min_cols):
+            raise ValueError(f"expected shape ({rows}, >={min_cols}), got {tuple(shape)}")
+        return t.data_ptr()
 
     def _vec(self, t, n):
         if t is None:
