@@ -39,7 +39,7 @@ __device__ inline double omc_ndtri_exp_lower(double y) {
   int iters;
   if (y > -600.0) {
     x = normcdfinv(exp(y));
-    iters = 2;
+    iters = 1;  // normcdfinv is already good to a few ulp; one Newton step removes the rounding of exp(y) for large |y|
   } else {  // Phi(x) ~ phi(x)/|x|:  x^2 = -2y - log(2 pi) - log(x^2)
     const double r = -2.0 * y - 1.8378770664093453;
     x = -sqrt(r - log(r));
@@ -55,9 +55,16 @@ __device__ inline double omc_ndtri_exp_lower(double y) {
 
 __device__ inline double omc_truncnorm_ppf(double u, double a, double b) {
   const double l1 = log1p(-u), l0 = log(u);
+  // log Phi(x); the two tails satisfy exp(yp) + exp(yq) = 1, so "yp is the smaller one" is yp <= log(1/2) and the
+  // upper tail is only worked out when it is the one to invert
   const double yp = omc_logaddexp(l1 + omc_log_ndtr(a), l0 + omc_log_ndtr(b));
-  const double yq = omc_logaddexp(l1 + omc_log_ndtr(-a), l0 + omc_log_ndtr(-b));
-  const double x = (yp <= yq) ? omc_ndtri_exp_lower(yp) : -omc_ndtri_exp_lower(yq);
+  double x;
+  if (yp <= -0.69314718055994530942) {
+    x = omc_ndtri_exp_lower(yp);
+  } else {
+    const double yq = omc_logaddexp(l1 + omc_log_ndtr(-a), l0 + omc_log_ndtr(-b));
+    x = -omc_ndtri_exp_lower(yq);
+  }
   return fmin(fmax(x, a), b);
 }
 
