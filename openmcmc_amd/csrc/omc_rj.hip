@@ -365,8 +365,8 @@ __global__ void __launch_bounds__(64) k_small_sample_canonical(int64_t C, int64_
 // ------------------------------------------------------------------------------------------------
 // LU with partial pivoting of an m x m matrix held row-per-lane in LDS (ld = row stride), with nrhs
 // right-hand-side columns appended at A[:, m .. m+nrhs).  Returns det (sign included); the solution
-// overwrites the rhs columns.  One wave; every lane calls it.
-__device__ double lu_solve_wave(double* A, int ld, int m, int nrhs, double* scratch, int* iscratch) {
+// overwrites the rhs columns.  One wave; every lane calls it (iscratch: one shared int for the pivot row).
+__device__ double lu_solve_wave(double* A, int ld, int m, int nrhs, int* iscratch) {
   const int lane = threadIdx.x;
   double det = 1.0;
   for (int j = 0; j < m; ++j) {
@@ -409,7 +409,6 @@ __device__ double lu_solve_wave(double* A, int ld, int m, int nrhs, double* scra
     }
   }
   __syncthreads();
-  (void)scratch;
   return det;
 }
 
@@ -444,7 +443,7 @@ __global__ void __launch_bounds__(64) k_rj_matched(int64_t C, int64_t chain_offs
     for (int j = 0; j < nr; ++j) A[lane * lda + m + j] = Gm[lane * kmax + (j < idx ? j : j + 1)];
   }
   __syncthreads();
-  lu_solve_wave(A, lda, m, nr, nullptr, isc);  // G = A[:, m..m+nr)  (m x nr)
+  lu_solve_wave(A, lda, m, nr, isc);  // G = A[:, m..m+nr)  (m x nr)
   double la_f = 0.0, la_r = 0.0;
   if (b) {
     // mu* = G beta; beta*[:-1] = mu*[:-1]; last ~ (truncated) Normal(mu*[-1], scale); log|det F| = log det G[:k, :k]
@@ -454,7 +453,7 @@ __global__ void __launch_bounds__(64) k_rj_matched(int64_t C, int64_t chain_offs
     if (lane < nr)
       for (int j = 0; j < nr; ++j) F[lane * ldf + j] = A[lane * lda + m + j];
     __syncthreads();
-    const double det = (nr > 0) ? lu_solve_wave(F, ldf, nr, 0, nullptr, isc) : 1.0;
+    const double det = (nr > 0) ? lu_solve_wave(F, ldf, nr, 0, isc) : 1.0;
     double last = 0.0;
     if (lane == m - 1) {
       double d;
@@ -493,7 +492,7 @@ __global__ void __launch_bounds__(64) k_rj_matched(int64_t C, int64_t chain_offs
       F[lane * ldf + m] = coef_cur[c * kmax + lane];
     }
     __syncthreads();
-    const double det = lu_solve_wave(F, ldf, m, 1, nullptr, isc);
+    const double det = lu_solve_wave(F, ldf, m, 1, isc);
     if (lane == 0) {
       const double del_val = F[idx * ldf + m];
       if (has_limits) {
