@@ -289,13 +289,14 @@ def main():
     if stamps is not None and rank == 0:
         st = stamps.cpu().numpy().reshape(C, 16, 16).astype(np.float64)
         nwv = int((st[0, :, 0] > 0).sum())
-        st = st[:, :nwv, :10]
-        d = np.diff(st, axis=2)
-        names = ["rng", "fill b,a", "moebius+scan", "newton", "l,sqrt", "rhs+fwd", "bwd", "store+quad", "epilogue"]
-        print("phase stamps (100 MHz ticks -> us), mean over chains/waves; wave0 and wave%d shown" % (nwv - 1), file=sys.stderr)
+        d = np.diff(st[:, :nwv, :], axis=2)
+        names = ["gamma draws", "fill b", "fill a", "moebius local", "moebius scan", "newton", "l", "fill rhs",
+                 "fwd map+scan", "fwd pass+rng", "bwd map+scan", "bwd pass", "tile+quad", "quad sum", "epilogue+store"]
+        tot = (st[:, :nwv, 15] - st[:, :nwv, 0]).mean()
+        print("phase stamps, %% of a wave's lifetime, mean over chains and waves; wave 0 and wave %d shown" % (nwv - 1), file=sys.stderr)
         for i, nm in enumerate(names):
-            print(f"  {nm:14s} mean {d[:, :, i].mean() / 100:8.2f} us   wave0 {d[:, 0, i].mean() / 100:8.2f}   last {d[:, -1, i].mean() / 100:8.2f}", file=sys.stderr)
-        print(f"  total/wave     {(st[:, :, 9] - st[:, :, 0]).mean() / 100:8.2f} us; block span {((st[:, :, 9].max(1) - st[:, :, 0].min(1)).mean()) / 100:8.2f} us", file=sys.stderr)
+            print(f"  {nm:16s} mean {100 * d[:, :, i].mean() / tot:6.2f}   wave0 {100 * d[:, 0, i].mean() / tot:6.2f}   last {100 * d[:, -1, i].mean() / tot:6.2f}", file=sys.stderr)
+        print(f"  wave lifetime {tot:.0f} ticks; block span {(st[:, :nwv, 15].max(1) - st[:, :nwv, 0].min(1)).mean():.0f} ticks", file=sys.stderr)
     if rank == 0:
         kern_ms = None
         if use_ev:

@@ -146,18 +146,19 @@ __device__ __forceinline__ double sweep_gamma_draws_wave(const TriArgs& A, int64
   return gd;
 }
 
-__device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c, const double (&quad)[OMC_MAX_TERMS],
+__device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c, double q0, double q1, double q2, double q3,
                                                     double s_old, double ldet, double gd, bool failed, int lane) {
   const int k = lane >> 4, j = lane & 15;
   const bool term_on = k < A.T.n_terms;
   // per-lane copy of this lane's term, selected with compile-time indices (a dynamically indexed
   // kernel-argument array would be spilled to scratch)
   GammaDev g = A.gb[0];
-  double qk = quad[0], s = s_old;  // this lane's term; scalars were loaded before the quad phase
+  double s = s_old;  // this lane's term; scalars were loaded before the quad phase
 #pragma unroll
   for (int t = 1; t < OMC_MAX_TERMS; ++t) {
-    if (k == t) { g = A.gb[t]; qk = quad[t]; }
+    if (k == t) g = A.gb[t];
   }
+  const double qk = (k == 0) ? q0 : ((k == 1) ? q1 : ((k == 2) ? q2 : q3));
   if (!term_on) s = 1.0;
   if (term_on && g.enabled) {
     const double b = g.b0 + 0.5 * qk;
@@ -257,12 +258,15 @@ __device__ __forceinline__ Mob mob_norm(Mob m) {
   double s = ldexp(1.0, -e);  // exact power of two: the map is unchanged
   return Mob{m.a * s, m.b * s, m.c * s, m.d * s};
 }
-// later-after-earlier composition
+// later-after-earlier composition.  The Moebius product is left unscaled: a product of k matrices whose
+// largest entries lie in [1, 2) has entries below 2^(2k-1), so the scans rescale (`renorm`, an exact power
+// of two: the map is unchanged) once per 16-lane row pass and per fold, not once per product.
 __device__ __forceinline__ Mob compose(const Mob& L, const Mob& E) {
-  return mob_norm(Mob{fma(L.a, E.a, L.b * E.c), fma(L.a, E.b, L.b * E.d), fma(L.c, E.a, L.d * E.c),
-                      fma(L.c, E.b, L.d * E.d)});
+  return Mob{fma(L.a, E.a, L.b * E.c), fma(L.a, E.b, L.b * E.d), fma(L.c, E.a, L.d * E.c), fma(L.c, E.b, L.d * E.d)};
 }
 __device__ __forceinline__ Aff compose(const Aff& L, const Aff& E) { return Aff{fma(L.q, E.p, L.p), L.q * E.q}; }
+__device__ __forceinline__ Mob renorm(const Mob& m) { return mob_norm(m); }
+__device__ __forceinline__ Aff renorm(const Aff& f) { return f; }
 
 __device__ __forceinline__ Mob shfl(const Mob& v, int d, int w, bool rev) {
   return rev ? Mob{__shfl_down(v.a, d, w), __shfl_down(v.b, d, w), __shfl_down(v.c, d, w), __shfl_down(v.d, d, w)}
@@ -281,7 +285,9 @@ __device__ __forceinline__ T excl_scan(T v, const T ident, int pos, int Wd, bool
   for (int d = 1; d < Wd; d <<= 1) {
     T o = shfl(v, d, Wd, rev);
     if (p >= d) v = compose(v, o);
+    if (d & 0x2a) v = renorm(v);  // every other doubling step
   }
+  v = renorm(v);
   T e = shfl(v, 1, Wd, rev);
   if (p == 0) e = ident;
   if (MULTI) {
@@ -289,9 +295,9 @@ __device__ __forceinline__ T excl_scan(T v, const T ident, int pos, int Wd, bool
     __syncthreads();
     T pre = ident;
     if (!rev) {
-      for (int w = 0; w < wave; ++w) pre = compose(lds[w], pre);
+      for (int w = 0; w < wave; ++w) pre = renorm(compose(lds[w], pre));
     } else {
-      for (int w = nw - 1; w > wave; --w) pre = compose(lds[w], pre);
+      for (int w = nw - 1; w > wave; --w) pre = renorm(compose(lds[w], pre));
     }
     e = compose(e, pre);
     __syncthreads();
@@ -373,7 +379,7 @@ __device__ __forceinline__ T row_scan(T v, const T& id) {
     v = compose(v, dpp_mov<DPP_ROW_SHL(4)>(v, id));
     v = compose(v, dpp_mov<DPP_ROW_SHL(8)>(v, id));
   }
-  return v;
+  return renorm(v);
 }
 
 // Exclusive scan over all lanes of the workgroup (one chain), in segment order or reversed.
@@ -393,7 +399,7 @@ __device__ __forceinline__ T excl_scan_wg(T v, const T id, T* lds, int lane, int
     const T p1 = compose(t2, t3), p0 = compose(t1, p1);
     pre = row == 2 ? t3 : (row == 1 ? p1 : (row == 0 ? p0 : id));
   }
-  v = compose(v, pre);
+  v = renorm(compose(v, pre));
   T e = REV ? dpp_mov<DPP_WAVE_SHL1>(v, id) : dpp_mov<DPP_WAVE_SHR1>(v, id);
   if (nw > 1) {
     if (lane == (REV ? 0 : 63)) lds[wave] = v;  // wave total
@@ -422,12 +428,13 @@ __device__ __forceinline__ void prev_lane2_wg(double& v0, double& v1, double id0
   v0 = a; v1 = b;
 }
 
-// four sums over the workgroup with a single barrier; lds: [4][16]
-__device__ __forceinline__ void sum4_wg(const double (&v)[OMC_MAX_TERMS], double (&out)[OMC_MAX_TERMS], double* lds, int lane,
-                                        int wave, int nw) {
-  double t[OMC_MAX_TERMS];
+// sums of the first nt accumulators over the workgroup with a single barrier; lds: [4][16]
+__device__ __forceinline__ void sum4_wg(const double (&v)[OMC_MAX_TERMS], double (&out)[OMC_MAX_TERMS], int nt, double* lds,
+                                        int lane, int wave, int nw) {
+  double t[OMC_MAX_TERMS] = {0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+    if (k >= nt) continue;  // wave-uniform
     double x = v[k];
     x += dpp_mov<DPP_ROW_SHR(1)>(x, 0.0);
     x += dpp_mov<DPP_ROW_SHR(2)>(x, 0.0);
@@ -438,15 +445,17 @@ __device__ __forceinline__ void sum4_wg(const double (&v)[OMC_MAX_TERMS], double
   if (nw > 1) {
     if (lane == 0) {
 #pragma unroll
-      for (int k = 0; k < OMC_MAX_TERMS; ++k) lds[k * 16 + wave] = t[k];
+      for (int k = 0; k < OMC_MAX_TERMS; ++k)
+        if (k < nt) lds[k * 16 + wave] = t[k];
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < OMC_MAX_TERMS; ++k) {
-      double u = 0.0;
-      for (int w = 0; w < nw; ++w) u += lds[k * 16 + w];
-      t[k] = u;
-    }
+    // lane 16 k + w holds wave w's partial sum of term k; one row reduction serves all terms
+    double x = ((lane & 15) < nw && (lane >> 4) < nt) ? lds[lane] : 0.0;
+    x += dpp_mov<DPP_ROW_SHR(1)>(x, 0.0);
+    x += dpp_mov<DPP_ROW_SHR(2)>(x, 0.0);
+    x += dpp_mov<DPP_ROW_SHR(4)>(x, 0.0);
+    x += dpp_mov<DPP_ROW_SHR(8)>(x, 0.0);
+    t[0] = read_lane(x, 15); t[1] = read_lane(x, 31); t[2] = read_lane(x, 47); t[3] = read_lane(x, 63);
   }
 #pragma unroll
   for (int k = 0; k < OMC_MAX_TERMS; ++k) out[k] = t[k];
@@ -563,75 +572,131 @@ __device__ __forceinline__ void tile_fill_comb(double* tile, const Geom<M, MULTI
   wave_lds_fence();
 }
 
-// Workgroup-per-chain form of the combined fills: node index is linear in the tile element
-// (node = wave*64*M + e), so all loads of one fill are issued back to back (memory-level
-// parallelism; L2 latency is paid once per fill, not once per element) and only then combined.
-template <int M, int WHICH, bool FULL>
-__device__ __forceinline__ void tile_fill_comb_body(double* tile, int lane, int wave_u, const TriArgs& A,
-                                                    const double (&sc)[OMC_MAX_TERMS], const double* rc) {
-  constexpr int CH = OMC_CH(M);  // loads in flight per lane and term
-  const int nt = A.T.n_terms;
-  // 32-bit node indices (n <= 32768 here) on a wave-uniform base pointer: scalar base + 32-bit
-  // lane offset addressing.  FULL = every node of this wave's tile is inside the vector: no
-  // per-element bounds test (true for all waves but the chain's last one).
-  const int n = (int)A.n;
-  const int lim = (WHICH == COMB_OFF) ? n - 1 : n;
-  const int wbase = wave_u * 64 * M;
-  int e = lane, q = lane / M, r = lane % M;
-#pragma unroll
-  for (int t0 = 0; t0 < M; t0 += CH) {
-    double v[CH];
-#pragma unroll
-    for (int t = 0; t < CH; ++t) v[t] = 0.0;
-#pragma unroll
-    for (int k = 0; k < OMC_MAX_TERMS; ++k) {
-      if (k >= nt) continue;
-      const double* src = (WHICH == COMB_DIAG) ? A.T.diag[k] : (WHICH == COMB_OFF ? A.T.off[k] : A.T.rhs[k]);
-      if (!src) {
-        if (WHICH == COMB_DIAG) {
-#pragma unroll
-          for (int t = 0; t < CH; ++t) v[t] += sc[k];
-        }
-        continue;
-      }
-      const double* ps = src + wbase;
-      double ld[CH];
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        const int off = lane + (t0 + t) * 64;
-        ld[t] = (FULL || wbase + off < lim) ? ps[(unsigned)off] : 0.0;
-      }
-#pragma unroll
-      for (int t = 0; t < CH; ++t) v[t] = fma(sc[k], ld[t], v[t]);
-    }
-    if (WHICH == COMB_RHS && rc) {
-      const double* pr = rc + wbase;
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        const int off = lane + (t0 + t) * 64;
-        if (FULL || wbase + off < n) v[t] += pr[(unsigned)off];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < CH; ++t) {
-      const int off = lane + (t0 + t) * 64;
-      tile[e + q] = (!FULL && WHICH == COMB_DIAG && wbase + off >= n) ? 1.0 : v[t];
-      e += 64; q += 64 / M; r += 64 % M;
-      if (r >= M) { r -= M; ++q; }
-    }
-    __builtin_amdgcn_sched_barrier(0);  // keep the next chunk's loads from being hoisted over this one
+// Workgroup-per-chain form of the tile traffic.  A wave's tile is 64 rows (segments) of M nodes at row
+// stride M+1.  In the coalesced mapping step t moves tile elements e = 64 t + lane (node wbase + e: one
+// aligned 512-byte request per wave and step); element e lives at tile[e + e/M].  With 64 t = M A_t + B_t
+// (compile-time) and lane = M q0 + r0:  e/M = A_t + q0 + (r0 >= M - B_t), so the address is a lane-only
+// base (lane + q0), an immediate (64 t + A_t) and a one-bit carry: a compare and a select per element instead
+// of running index arithmetic on the vector ALU (the kernel is bound by VALU issue).
+template <int M>
+struct TileMap {
+  static constexpr int LU = 64;                 // lanes in use
+  static constexpr int NS = M;                  // steps per tile
+  static constexpr int CH = (M % 5 == 0) ? 5 : 4;  // steps per batch of loads (memory-level parallelism vs registers)
+  __device__ static __forceinline__ int lane_base(int lane) { return lane + lane / M; }
+  __device__ static __forceinline__ int lane_col(int lane) { return lane % M; }
+  __device__ static constexpr int upto(int t) { return 64 * t; }  // elements of steps [0, t)
+  // tile element of step t; tl = tile + lane_base, r0 = lane_col
+  template <class P>
+  __device__ static __forceinline__ P* elem(P* tl, int r0, int t) {
+    const int At = (64 * t) / M, Bt = (64 * t) % M;
+    P* p = tl + (64 * t + At);
+    return (Bt != 0 && r0 >= M - Bt) ? p + 1 : p;
   }
+  // its successor in node order: the next column, or column 0 of the next row
+  template <class P>
+  __device__ static __forceinline__ P* succ(P* p, int r0, int t) {
+    const int Bt = (64 * t) % M;
+    return (r0 == M - 1 - Bt) ? p + 2 : p + 1;
+  }
+};
+
+// number of this wave's tile elements that lie below `lim` (wave-uniform)
+template <int M>
+__device__ __forceinline__ int wave_valid(int wave_u, int lim) {
+  const int v = lim - wave_u * 64 * M;
+  return v < 0 ? 0 : (v > 64 * M ? 64 * M : v);
 }
 
+// Per-chain combination of the shared term vectors, formed while the tile is filled.  All loads of a
+// batch are issued back to back (L2 latency is paid once per batch) and only then combined.  A batch
+// that lies wholly inside the vector takes the test-free path; the chain's last wave takes the
+// predicated one for its boundary batch and only writes fill values beyond it.
 template <int M, int WHICH>
-__device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wave, const TriArgs& A,
+__device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wave, int lbase, const TriArgs& A,
                                                   const double (&sc)[OMC_MAX_TERMS], bool chain_ok, int64_t cc) {
+  using TM = TileMap<M>;
+  constexpr int CH = TM::CH;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int lim = (WHICH == COMB_OFF) ? (int)A.n - 1 : (int)A.n;
-  const double* rc = (WHICH == COMB_RHS && A.rhs_chain && chain_ok) ? A.rhs_chain + cc * A.ld_rhs : nullptr;
+  const int nt = A.T.n_terms;
+  const int n = (int)A.n;
+  const int wbase = wave_u * 64 * M;
+  const int nvalid = wave_valid<M>(wave_u, (WHICH == COMB_OFF) ? n - 1 : n);
+  const double* rc = (WHICH == COMB_RHS && A.rhs_chain && chain_ok) ? A.rhs_chain + cc * A.ld_rhs + wbase : nullptr;
+  const double fillv = (WHICH == COMB_DIAG) ? 1.0 : 0.0;
+  double* tl = tile + lbase;
+  const int r0 = TM::lane_col(lane);
   wave_lds_fence();
-  if ((wave_u + 1) * 64 * M <= lim) tile_fill_comb_body<M, WHICH, true>(tile, lane, wave_u, A, sc, rc);
-  else tile_fill_comb_body<M, WHICH, false>(tile, lane, wave_u, A, sc, rc);
+  {
+#pragma unroll
+    for (int t0 = 0; t0 < TM::NS; t0 += CH) {
+      const int cnt = (TM::NS - t0 < CH) ? TM::NS - t0 : CH;
+      double v[CH];
+#pragma unroll
+      for (int t = 0; t < CH; ++t) v[t] = 0.0;
+      if (TM::upto(t0 + cnt) <= nvalid) {  // wave-uniform: the whole batch is inside
+#pragma unroll
+        for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+          if (k >= nt) continue;
+          const double* src = (WHICH == COMB_DIAG) ? A.T.diag[k] : (WHICH == COMB_OFF ? A.T.off[k] : A.T.rhs[k]);
+          if (!src) {
+            if (WHICH == COMB_DIAG) {
+#pragma unroll
+              for (int t = 0; t < CH; ++t) v[t] += sc[k];
+            }
+            continue;
+          }
+          const double* ps = src + wbase;
+          double ld[CH];
+#pragma unroll
+          for (int t = 0; t < CH; ++t)
+            if (t < cnt) ld[t] = ps[(unsigned)(lane + (t0 + t) * TM::LU)];
+#pragma unroll
+          for (int t = 0; t < CH; ++t)
+            if (t < cnt) v[t] = fma(sc[k], ld[t], v[t]);
+        }
+        if (WHICH == COMB_RHS && rc) {
+          double ld[CH];
+#pragma unroll
+          for (int t = 0; t < CH; ++t)
+            if (t < cnt) ld[t] = rc[(unsigned)(lane + (t0 + t) * TM::LU)];
+#pragma unroll
+          for (int t = 0; t < CH; ++t)
+            if (t < cnt) v[t] += ld[t];
+        }
+#pragma unroll
+        for (int t = 0; t < CH; ++t)
+          if (t < cnt) *TM::elem(tl, r0, t0 + t) = v[t];
+      } else {
+#pragma unroll
+        for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+          if (k >= nt) continue;
+          const double* src = (WHICH == COMB_DIAG) ? A.T.diag[k] : (WHICH == COMB_OFF ? A.T.off[k] : A.T.rhs[k]);
+          if (!src) {
+            if (WHICH == COMB_DIAG) {
+#pragma unroll
+              for (int t = 0; t < CH; ++t) v[t] += sc[k];
+            }
+            continue;
+          }
+          const double* ps = src + wbase;
+#pragma unroll
+          for (int t = 0; t < CH; ++t) {
+            const int idx = lane + (t0 + t) * TM::LU;
+            if (t < cnt && idx < nvalid) v[t] = fma(sc[k], ps[(unsigned)idx], v[t]);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+          const int idx = lane + (t0 + t) * TM::LU;
+          if (t >= cnt) continue;
+          if (WHICH == COMB_RHS && rc && idx < nvalid) v[t] += rc[(unsigned)idx];
+          if (idx < 64 * M) *TM::elem(tl, r0, t0 + t) = (idx < nvalid) ? v[t] : fillv;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the next batch's loads from being hoisted over this one
+    }
+  }
   wave_lds_fence();
 }
 
@@ -654,60 +719,82 @@ __device__ __forceinline__ double fast_sqrt(double r) { return omc_sqrt_nr(r); }
 #define OMC_NEWTON_MAX 4
 
 // Quadratic forms (x - m_k)' M_k (x - m_k) of one wave's 64*M nodes in the coalesced mapping: x comes
-// back from the tile (x_{i+1} = the next tile element; `xfirst_next` for the wave's last node), the
-// shared vectors straight from L2.  FULL: every node i of the wave has i + 1 < n (no bounds tests).
-template <int M, bool FULL>
-__device__ __forceinline__ void quad_chunks(const double* tile, int lane, int wave_u, const TriArgs& A,
-                                            double xfirst_next, double (&acc)[OMC_MAX_TERMS]) {
-  constexpr int CH = OMC_CH(M);
+// back from the tile (x_{i+1} = the next tile element; the slot behind the tile's last row holds the
+// first x of the next wave), the shared vectors straight from L2.
+template <int M>
+__device__ __forceinline__ void quad_wg(const double* tile, int lane, int wave_u, int lbase, const TriArgs& A,
+                                        double (&acc)[OMC_MAX_TERMS]) {
+  using TM = TileMap<M>;
+  constexpr int CH = TM::CH;
   const int nt = A.T.n_terms, n32 = (int)A.n;
   const int wbase = wave_u * 64 * M;
-  int e = lane, q = lane / M, r = lane % M;  // tile element, e / M, e % M
+  const int nrem = n32 - wbase;  // nodes of the chain from this wave's first one on (may exceed the tile)
+  const int nvalid = nrem < 64 * M ? (nrem < 0 ? 0 : nrem) : 64 * M;
+  const double* tl = tile + lbase;
+  const int r0 = TM::lane_col(lane);
+  {
 #pragma unroll
-  for (int t0 = 0; t0 < M; t0 += CH) {
-    double xv[CH], xn[CH];  // x_i and x_{i+1}
+    for (int t0 = 0; t0 < TM::NS; t0 += CH) {
+      const int cnt = (TM::NS - t0 < CH) ? TM::NS - t0 : CH;
+      double xv[CH], xn[CH];  // x_i and x_{i+1}
+      if (TM::upto(t0 + cnt) < nrem) {  // wave-uniform: i + 1 < n for every node of the batch
 #pragma unroll
-    for (int t = 0; t < CH; ++t) {
-      xv[t] = tile[e + q];
-      const int e1 = e + 1, q1 = (r + 1 == M) ? q + 1 : q;
-      xn[t] = (e1 < 64 * M) ? tile[e1 + q1] : xfirst_next;
-      e += 64; q += 64 / M; r += 64 % M;
-      if (r >= M) { r -= M; ++q; }
-    }
+        for (int t = 0; t < CH; ++t)
+          if (t < cnt) {
+            xv[t] = *TM::elem(tl, r0, t0 + t);
+            xn[t] = *TM::succ(TM::elem(tl, r0, t0 + t), r0, t0 + t);
+          }
 #pragma unroll
-    for (int k = 0; k < OMC_MAX_TERMS; ++k) {
-      if (k >= nt) continue;
-      const double *ck = A.T.center[k], *dk = A.T.diag[k], *ok = A.T.off[k];
-      double ri[CH], rn[CH], dv[CH];
+        for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+          if (k >= nt) continue;
+          const double *ck = A.T.center[k], *dk = A.T.diag[k], *ok = A.T.off[k];
+          double ri[CH], rn[CH], dv[CH], ov[CH];
 #pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        const int off = lane + (t0 + t) * 64, i = wbase + off;
-        const bool in = FULL || i < n32, in1 = FULL || i + 1 < n32;
-        ri[t] = (ck && in) ? (ck + wbase)[(unsigned)off] : 0.0;
-        rn[t] = (ck && ok && in1) ? (ck + wbase)[(unsigned)off + 1u] : 0.0;
-        dv[t] = in ? (dk ? (dk + wbase)[(unsigned)off] : 1.0) : 0.0;
+          for (int t = 0; t < CH; ++t) {
+            if (t >= cnt) continue;
+            const unsigned off = (unsigned)(lane + (t0 + t) * TM::LU);
+            ri[t] = ck ? (ck + wbase)[off] : 0.0;
+            rn[t] = (ck && ok) ? (ck + wbase)[off + 1u] : 0.0;
+            dv[t] = dk ? (dk + wbase)[off] : 1.0;
+            ov[t] = ok ? (ok + wbase)[off] : 0.0;
+          }
+          if (ok) {
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+              if (t >= cnt) continue;
+              const double a = xv[t] - ri[t], bnx = xn[t] - rn[t];
+              acc[k] = fma(fma(2.0 * ov[t], bnx, dv[t] * a), a, acc[k]);
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+              if (t >= cnt) continue;
+              const double a = xv[t] - ri[t];
+              acc[k] = fma(dv[t] * a, a, acc[k]);
+            }
+          }
+        }
+      } else if (t0 * TM::LU < nvalid) {  // the chain's boundary batch
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+          if (t >= cnt) continue;
+          const int idx = lane + (t0 + t) * TM::LU;
+          const bool in = idx < nvalid, in1 = in && idx + 1 < nrem;
+          const double x0 = in ? *TM::elem(tl, r0, t0 + t) : 0.0, x1 = in1 ? *TM::succ(TM::elem(tl, r0, t0 + t), r0, t0 + t) : 0.0;
+#pragma unroll
+          for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+            if (k >= nt) continue;
+            const double *ck = A.T.center[k], *dk = A.T.diag[k], *ok = A.T.off[k];
+            const double a = x0 - ((ck && in) ? (ck + wbase)[(unsigned)idx] : 0.0);
+            const double bnx = x1 - ((ck && ok && in1) ? (ck + wbase)[(unsigned)idx + 1u] : 0.0);
+            const double d = in ? (dk ? (dk + wbase)[(unsigned)idx] : 1.0) : 0.0;
+            const double o = (ok && in1) ? (ok + wbase)[(unsigned)idx] : 0.0;
+            acc[k] = fma(fma(2.0 * o, bnx, d * a), a, acc[k]);
+          }
+        }
       }
-      if (ok) {
-        double ov[CH];
-#pragma unroll
-        for (int t = 0; t < CH; ++t) {
-          const int off = lane + (t0 + t) * 64;
-          ov[t] = (FULL || wbase + off + 1 < n32) ? (ok + wbase)[(unsigned)off] : 0.0;
-        }
-#pragma unroll
-        for (int t = 0; t < CH; ++t) {
-          const double a = xv[t] - ri[t], bnx = xn[t] - rn[t];
-          acc[k] = fma(fma(2.0 * ov[t], bnx, dv[t] * a), a, acc[k]);
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < CH; ++t) {
-          const double a = xv[t] - ri[t];
-          acc[k] = fma(dv[t] * a, a, acc[k]);
-        }
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -716,7 +803,7 @@ __device__ __forceinline__ void quad_chunks(const double* tile, int lane, int wa
 template <int M, bool MULTI, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   constexpr int NWMAX = MAXT / 64;
-  __shared__ double lds_tile[NWMAX][64 * (M + 1)];
+  __shared__ double lds_tile[NWMAX][64 * (M + 1) + 2];  // + the successor slot of the last row (quad_wg)
   __shared__ Mob lds_mob[16];
   __shared__ Aff lds_aff[4][16];   // scans alternate buffers instead of paying a trailing barrier
   __shared__ double lds_x[2][32];  // neighbour exchange of the Newton passes (alternating)
@@ -740,6 +827,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   double* tile = lds_tile[wave];
   const double* trow = tile + (MULTI ? lane : s) * (M + 1);  // shared vectors: every group reads rows 0..G-1
   double* crow = tile + lane * (M + 1);                      // per-chain data: one row per lane
+  const int lbase = TileMap<M>::lane_base(lane);             // this lane's element of step 0 (coalesced mapping)
   const int pos = MULTI ? lane : s;
   const bool chain_ok = c < A.C;
   const int64_t cc = chain_ok ? c : 0;
@@ -753,15 +841,17 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 
   double Y[M], W[M];
   OMC_STAMP(0);
-  // Normal-Gamma standard draws, made up front on wave 0 (see sweep_gamma_draws_wave)
+  // Normal-Gamma standard draws, made up front (see sweep_gamma_draws_wave) by the chain's last wave: its
+  // tile is the one that may be partly empty, so it has the least other work
+  const bool epi_wave = MULTI && A.fused && wave == 0;
   double early_gamma = 0.0;
   bool early_failed = false;
-  if (MULTI && A.fused && wave == 0 && chain_ok) early_gamma = sweep_gamma_draws_wave(A, c, lane, &early_failed);
+  if (epi_wave && chain_ok) early_gamma = sweep_gamma_draws_wave(A, c, lane, &early_failed);
 
   OMC_STAMP(1);
 
   // ---- conditional precision: b -> Y (registers), a -> LDS tile ----
-  if (MULTI) tile_fill_comb_wg<M, COMB_OFF>(tile, lane, wave, A, sc, chain_ok, cc);
+  if (MULTI) tile_fill_comb_wg<M, COMB_OFF>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
   else tile_fill_comb<M, MULTI, COMB_OFF>(tile, geo, A, sc);
 #pragma unroll
   for (int j = 0; j < M; ++j) Y[j] = crow[j];
@@ -769,11 +859,12 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   if (i0 > 0 && i0 < n)
     _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt)
       if (A.T.off[k]) bm1 = fma(sc[k], A.T.off[k][i0 - 1], bm1);
-  if (MULTI) tile_fill_comb_wg<M, COMB_DIAG>(tile, lane, wave, A, sc, chain_ok, cc);
+  OMC_STAMP(2);
+  if (MULTI) tile_fill_comb_wg<M, COMB_DIAG>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
   else tile_fill_comb<M, MULTI, COMB_DIAG>(tile, geo, A, sc);
   const double* arow = crow;
 
-  OMC_STAMP(2);
+  OMC_STAMP(3);
   // ---- Moebius product of the segment, scan -> incoming pivot ----
   double Dst;
   {
@@ -788,13 +879,14 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       if ((j & 7) == 7) m = mob_norm(m);
     }
     m = mob_norm(m);
+    OMC_STAMP(4);
     const Mob idm{1.0, 0.0, 0.0, 1.0};
     const Mob E = MULTI ? excl_scan_wg<Mob, false>(m, idm, lds_mob, lane, wave, nw)
                         : excl_scan<Mob, false>(m, idm, pos, Wd, false, lds_mob, wave, nw);
     Dst = (E.a + E.b) / (E.c + E.d);
   }
 
-  OMC_STAMP(3);
+  OMC_STAMP(5);
   // ---- true pivot recurrence, Newton multiple shooting on the segment joins ----
   bool bad = false;
   double lin = 0.0;  // l_{i0-1}
@@ -830,7 +922,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
                           : excl_scan<Aff, false>(own, Aff{0.0, 1.0}, pos, Wd, false, lds_aff[0], wave, nw);
     Dst += fma(Jp, ex.p, e);  // delta_s = e_s + J_{s-1} delta_{s-1}
   }
-  OMC_STAMP(4);
+  OMC_STAMP(6);
   double logdet = 0.0;
 #pragma unroll
   for (int j = 0; j < M; ++j) {
@@ -839,10 +931,11 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     if (A.logdet && i0 + j < n) logdet -= log(rD);
   }
 
-  OMC_STAMP(5);
+  OMC_STAMP(7);
   // ---- right-hand side -> tile; forward substitution (local affine map, scan, true pass) ----
-  if (MULTI) tile_fill_comb_wg<M, COMB_RHS>(tile, lane, wave, A, sc, chain_ok, cc);
+  if (MULTI) tile_fill_comb_wg<M, COMB_RHS>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
   else tile_fill_comb<M, MULTI, COMB_RHS>(tile, geo, A, sc);
+  OMC_STAMP(8);
   {
     Aff f{0.0, 1.0};
     double lp = lin;
@@ -855,6 +948,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     double u = (MULTI ? excl_scan_wg<Aff, false>(f, Aff{0.0, 1.0}, lds_aff[2], lane, wave, nw)
                       : excl_scan<Aff, false>(f, Aff{0.0, 1.0}, pos, Wd, false, lds_aff[0], wave, nw)).p;
     lp = lin;
+    OMC_STAMP(9);
     // g_j = u_j/D_j + z_j/sqrt(D_j); the draws are produced here, pair by pair, so that no array of
     // z ever has to be kept in registers next to l and 1/D (Philox + Box-Muller interleave with the
     // serial u recurrence; the scheduling barrier keeps the five bodies from being overlapped)
@@ -881,7 +975,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     }
   }
 
-  OMC_STAMP(6);
+  OMC_STAMP(10);
   // ---- backward substitution: local affine map, reverse scan, true pass ----
   double xnext;
   {
@@ -894,13 +988,14 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     xnext = (MULTI ? excl_scan_wg<Aff, true>(f, Aff{0.0, 1.0}, lds_aff[3], lane, wave, nw)
                    : excl_scan<Aff, false>(f, Aff{0.0, 1.0}, pos, Wd, true, lds_aff[0], wave, nw)).p;
     double x = xnext;
+    OMC_STAMP(11);
 #pragma unroll
     for (int j = M - 1; j >= 0; --j) {
       x = fma(-Y[j], x, W[j]);
       W[j] = x;
     }
   }
-  OMC_STAMP(7);
+  OMC_STAMP(12);
   const bool want_quad = A.quad || A.fused;
   double qsum[OMC_MAX_TERMS] = {0, 0, 0, 0};
   double my_scale = 1.0, my_logdet = 0.0;  // epilogue scalars of this lane's term (wave 0)
@@ -910,26 +1005,24 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     wave_lds_fence();
 #pragma unroll
     for (int j = 0; j < M; ++j) crow[j] = W[j];
-    wave_lds_fence();  // wave-private tile: no workgroup barrier needed (see xfirst_next below)
-    const int n32 = (int)n;
+    // x at the first node of the NEXT wave's tile = what the reverse scan handed this wave's last segment as
+    // its successor value; it goes behind the last row so that every node finds x_{i+1} one element on
+    if (lane == 63) tile[64 * (M + 1)] = xnext;
+    wave_lds_fence();  // wave-private tile: no workgroup barrier needed
     double acc[OMC_MAX_TERMS] = {0, 0, 0, 0};
     // scalars of the epilogue: issue their loads now so the latency hides behind the quad phase
-    if (A.fused && wave == 0) {  // lane group k = lane >> 4 serves term k
+    if (epi_wave) {  // lane group k = lane >> 4 serves term k
       _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt && (lane >> 4) == k) {
         if (A.T.scale[k]) my_scale = A.T.scale[k][cc];
         if (A.log_post && A.gb[k].logdet_unscaled) my_logdet = A.gb[k].logdet_unscaled[0];
       }
     }
     if (want_quad) {
-      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-      // x at the first node of the NEXT wave's tile = what the reverse scan handed this wave's last
-      // segment as its successor value
-      const double xfirst_next = read_lane_d(xnext, 63);
-      if ((wave_u + 1) * 64 * M < n32) quad_chunks<M, true>(tile, lane, wave_u, A, xfirst_next, acc);
-      else quad_chunks<M, false>(tile, lane, wave_u, A, xfirst_next, acc);
+      quad_wg<M>(tile, lane, __builtin_amdgcn_readfirstlane(wave), lbase, A, acc);
     }
+    OMC_STAMP(13);
     if (want_quad) {
-      sum4_wg(acc, qsum, &lds_d[0][0], lane, wave, nw);  // all terms behind one barrier
+      sum4_wg(acc, qsum, nt, &lds_d[0][0], lane, wave, nw);  // all terms behind one barrier
       _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt) {
         if (A.quad && s == 0 && chain_ok) A.quad[k * A.C + c] = qsum[k];
       }
@@ -978,32 +1071,41 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     }
   }
   }
-  OMC_STAMP(8);
+  OMC_STAMP(14);
   if (A.logdet) {
     const double t = MULTI ? sum_wg(logdet, lds_d[4], lane, wave, nw) : group_sum<false>(logdet, Wd, lds_d[0], wave, nw);
     if (s == 0 && chain_ok) A.logdet[c] = t;
   }
   if (bad && chain_ok) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
   if (MULTI) {
-    if (A.fused && wave == 0 && chain_ok) sweep_epilogue_wave(A, c, qsum, my_scale, my_logdet, early_gamma, early_failed, lane);
+    if (epi_wave && chain_ok) sweep_epilogue_wave(A, c, qsum[0], qsum[1], qsum[2], qsum[3], my_scale, my_logdet, early_gamma, early_failed, lane);
     // x leaves last: a load issued behind a store would have to wait for the store to be
     // acknowledged (vmcnt retires in order); this way nothing ever waits on the x stream.
     if (A.x && chain_ok) {
-      double* xo = A.x + cc * A.ld_x;
-      const int wb = wave * 64 * M + lane, n32 = (int)n;
-      int e = lane, q = lane / M, r = lane % M;
+      using TM = TileMap<M>;
+      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+      double* xo = A.x + cc * A.ld_x + wave_u * 64 * M;
+      const int nvalid = wave_valid<M>(wave_u, (int)n);
+      const double* tl = tile + lbase;
+      const int r0 = TM::lane_col(lane);
+      {
+        if (nvalid == 64 * M) {
 #pragma unroll
-      for (int t = 0; t < M; ++t) {
-        const int i = wb + t * 64;
-        if (i < n32) xo[(unsigned)i] = tile[e + q];
-        e += 64; q += 64 / M; r += 64 % M;
-        if (r >= M) { r -= M; ++q; }
+          for (int t = 0; t < TM::NS; ++t)
+            xo[(unsigned)(lane + t * TM::LU)] = *TM::elem(tl, r0, t);
+        } else {
+#pragma unroll
+          for (int t = 0; t < TM::NS; ++t) {
+            const int idx = lane + t * TM::LU;
+            if (idx < nvalid) xo[(unsigned)idx] = *TM::elem(tl, r0, t);
+          }
+        }
       }
     }
   } else if (A.fused && s == 0 && chain_ok) {
     sweep_epilogue(A, c, qsum);
   }
-  OMC_STAMP(9);
+  OMC_STAMP(15);
 }
 
 // ------------------------------------------------------------------------------------------
