@@ -717,6 +717,12 @@ __device__ __forceinline__ double fast_sqrt(double r) { return omc_sqrt_nr(r); }
 // meets it for well-conditioned chains, weakly coupled ones take one or two Newton corrections
 #define OMC_NEWTON_TOL 1.6e-14
 #define OMC_NEWTON_MAX 4
+#ifndef OMC_RPRE
+#define OMC_RPRE 0  // SIG 1: right-hand side vector fetched before the pivot phases
+#endif
+#ifndef OMC_QPRE
+#define OMC_QPRE 0  // SIG 1: quad vectors fetched under the reverse scan (0..2), 3 = also the rest before the back pass
+#endif
 
 // Quadratic forms (x - m_k)' M_k (x - m_k) of one wave's 64*M nodes in the coalesced mapping: x comes
 // back from the tile (x_{i+1} = the next tile element; the slot behind the tile's last row holds the
@@ -798,10 +804,47 @@ __device__ __forceinline__ void quad_wg(const double* tile, int lane, int wave_u
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Structure-specialised form of the workgroup-per-chain kernel (template parameter SIG).
+//   SIG 0: any term structure (every pointer tested at run time).
+//   SIG 1: the GMRF smoother of examples/4 and BASELINE configs[2]: two terms in either order,
+//            term I = scaled identity precision (diag, off absent) with rhs and center,
+//            term P = tridiagonal precision (diag, off present) without rhs and center,
+//          so  a = sI + sP diagP,  b = sP offP,  r = sI rhsI (+ rhs_chain),
+//              qI = |x - centerI|^2,  qP = x' M_P x.
+// Knowing the structure at compile time removes the pointer tests, and, more to the point, lets the
+// kernel issue the shared-vector loads of a later phase *before* the compute of the current one and keep
+// them in registers: with one workgroup per CU all waves are in the same phase, so a phase that only
+// waits for L2 (80 KB per vector and workgroup at ~30 B/clk per CU) is otherwise dead time.
+template <int M, bool FULLW>
+__device__ __forceinline__ void coal_load(double (&v)[M], const double* base, int lane, int nvalid) {
+#pragma unroll
+  for (int t = 0; t < M; ++t) {
+    const int idx = lane + 64 * t;
+    v[t] = (FULLW || idx < nvalid) ? base[(unsigned)idx] : 0.0;
+  }
+}
+template <int M>
+__device__ __forceinline__ void coal_load(double (&v)[M], const double* base, int lane, int nvalid) {
+  if (nvalid == 64 * M) coal_load<M, true>(v, base, lane, nvalid);
+  else coal_load<M, false>(v, base, lane, nvalid);
+}
+// is_smoother: host-side test of the SIG 1 structure
+static bool is_smoother(const TermsDev& T) {
+  if (T.n_terms != 2) return false;
+  for (int i = 0; i < 2; ++i) {  // i: the identity term
+    const int p = 1 - i;
+    if (!T.diag[i] && !T.off[i] && T.rhs[i] && T.center[i] && T.diag[p] && T.off[p] && !T.rhs[p] && !T.center[p]) return true;
+  }
+  return false;
+}
+
 // Register plan per lane (M nodes): Y = b -> l ; W = 1/D -> g -> x (draws are consumed as they are made).
 // The combined diagonal a (then the right-hand side r) lives in the wave's LDS tile.
-template <int M, bool MULTI, int MAXT>
+template <int M, bool MULTI, int MAXT, int SIG = 0>
 __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
+  static_assert(SIG == 0 || MULTI, "specialised structures exist for the workgroup-per-chain form only");
+  using TM = TileMap<M>;
   constexpr int NWMAX = MAXT / 64;
   __shared__ double lds_tile[NWMAX][64 * (M + 1) + 2];  // + the successor slot of the last row (quad_wg)
   __shared__ Mob lds_mob[16];
@@ -833,11 +876,21 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   const int64_t cc = chain_ok ? c : 0;
   const int64_t n = A.n;
   const int64_t i0 = (int64_t)s * M;
-  const int nt = A.T.n_terms;
+  const int nt = (SIG == 1) ? 2 : A.T.n_terms;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int r0 = TM::lane_col(lane);
+  double* tl = tile + lbase;
 
   double sc[OMC_MAX_TERMS];
 #pragma unroll
   for (int k = 0; k < OMC_MAX_TERMS; ++k) sc[k] = (k < nt && A.T.scale[k]) ? A.T.scale[k][cc] : 1.0;
+  // SIG 1: which of the two terms is the tridiagonal one (wave-uniform; selects, not indexed kernel arguments)
+  const bool p_first = SIG == 1 && A.T.diag[0] != nullptr;
+  const double sP = p_first ? sc[0] : sc[1], sI = p_first ? sc[1] : sc[0];
+  const double* const vPd = p_first ? A.T.diag[0] : A.T.diag[1];
+  const double* const vPo = p_first ? A.T.off[0] : A.T.off[1];
+  const double* const vIr = p_first ? A.T.rhs[1] : A.T.rhs[0];
+  const double* const vIc = p_first ? A.T.center[1] : A.T.center[0];
 
   double Y[M], W[M];
   OMC_STAMP(0);
@@ -851,17 +904,45 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   OMC_STAMP(1);
 
   // ---- conditional precision: b -> Y (registers), a -> LDS tile ----
-  if (MULTI) tile_fill_comb_wg<M, COMB_OFF>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
-  else tile_fill_comb<M, MULTI, COMB_OFF>(tile, geo, A, sc);
-#pragma unroll
-  for (int j = 0; j < M; ++j) Y[j] = crow[j];
   double bm1 = 0.0;  // coupling b_{i0-1} into the segment
-  if (i0 > 0 && i0 < n)
-    _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt)
-      if (A.T.off[k]) bm1 = fma(sc[k], A.T.off[k][i0 - 1], bm1);
-  OMC_STAMP(2);
-  if (MULTI) tile_fill_comb_wg<M, COMB_DIAG>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
-  else tile_fill_comb<M, MULTI, COMB_DIAG>(tile, geo, A, sc);
+  double pre[M];  // SIG 1: the right-hand side vector, fetched under the pivot phases
+  if constexpr (SIG == 1) {
+    const int wbase = wave_u * 64 * M;
+    const int nv = wave_valid<M>(wave_u, (int)n), nvo = wave_valid<M>(wave_u, (int)n - 1);
+    double po[M], pd[M];  // both vectors in flight at once: one exposed L2 round trip for the two
+    coal_load<M>(po, vPo + wbase, lane, nvo);
+    coal_load<M>(pd, vPd + wbase, lane, nv);
+    if (i0 > 0 && i0 < n) bm1 = sP * vPo[i0 - 1];
+    wave_lds_fence();
+#pragma unroll
+    for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = sP * po[t];
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < M; ++j) Y[j] = crow[j];
+    OMC_STAMP(2);
+    wave_lds_fence();
+    if (nv == 64 * M) {
+#pragma unroll
+      for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = fma(sP, pd[t], sI);
+    } else {
+#pragma unroll
+      for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = (lane + 64 * t < nv) ? fma(sP, pd[t], sI) : 1.0;
+    }
+    wave_lds_fence();
+    if (OMC_RPRE && !(A.rhs_chain && chain_ok)) coal_load<M>(pre, vIr + wbase, lane, nv);
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+    if (MULTI) tile_fill_comb_wg<M, COMB_OFF>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
+    else tile_fill_comb<M, MULTI, COMB_OFF>(tile, geo, A, sc);
+#pragma unroll
+    for (int j = 0; j < M; ++j) Y[j] = crow[j];
+    if (i0 > 0 && i0 < n)
+      _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt)
+        if (A.T.off[k]) bm1 = fma(sc[k], A.T.off[k][i0 - 1], bm1);
+    OMC_STAMP(2);
+    if (MULTI) tile_fill_comb_wg<M, COMB_DIAG>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
+    else tile_fill_comb<M, MULTI, COMB_DIAG>(tile, geo, A, sc);
+  }
   const double* arow = crow;
 
   OMC_STAMP(3);
@@ -933,8 +1014,23 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 
   OMC_STAMP(7);
   // ---- right-hand side -> tile; forward substitution (local affine map, scan, true pass) ----
-  if (MULTI) tile_fill_comb_wg<M, COMB_RHS>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
-  else tile_fill_comb<M, MULTI, COMB_RHS>(tile, geo, A, sc);
+  bool rhs_done = false;
+  if constexpr (SIG == 1) {
+    if (!(A.rhs_chain && chain_ok)) {
+      if (!OMC_RPRE) coal_load<M>(pre, vIr + wave_u * 64 * M, lane, wave_valid<M>(wave_u, (int)n));
+      wave_lds_fence();
+#pragma unroll
+      for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = sI * pre[t];
+      wave_lds_fence();
+      rhs_done = true;
+    }
+  }
+  if (rhs_done) {
+  } else if (MULTI) {
+    tile_fill_comb_wg<M, COMB_RHS>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
+  } else {
+    tile_fill_comb<M, MULTI, COMB_RHS>(tile, geo, A, sc);
+  }
   OMC_STAMP(8);
   {
     Aff f{0.0, 1.0};
@@ -976,6 +1072,17 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   }
 
   OMC_STAMP(10);
+  const bool want_quad = A.quad || A.fused;
+  // SIG 1: the three shared vectors of the quadratic forms, fetched under the reverse scan
+  double qc[M], qd[M], qo[M];
+  constexpr int QPRE = OMC_QPRE;
+  if constexpr (SIG == 1) {
+    const int wbase = wave_u * 64 * M;
+    const int nv = want_quad ? wave_valid<M>(wave_u, (int)n) : 0, nvo = want_quad ? wave_valid<M>(wave_u, (int)n - 1) : 0;
+    if (QPRE >= 1) coal_load<M>(qo, vPo + wbase, lane, nvo);
+    if (QPRE >= 2) coal_load<M>(qd, vPd + wbase, lane, nv);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   // ---- backward substitution: local affine map, reverse scan, true pass ----
   double xnext;
   {
@@ -989,6 +1096,16 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
                    : excl_scan<Aff, false>(f, Aff{0.0, 1.0}, pos, Wd, true, lds_aff[0], wave, nw)).p;
     double x = xnext;
     OMC_STAMP(11);
+    if constexpr (SIG == 1) {  // the remaining vectors: registers for them are free only now
+      const int wbase = wave_u * 64 * M;
+      const int nv = want_quad ? wave_valid<M>(wave_u, (int)n) : 0, nvo = want_quad ? wave_valid<M>(wave_u, (int)n - 1) : 0;
+      if (QPRE >= 3) {
+        if (QPRE < 1) coal_load<M>(qo, vPo + wbase, lane, nvo);
+        if (QPRE < 2) coal_load<M>(qd, vPd + wbase, lane, nv);
+        coal_load<M>(qc, vIc + wbase, lane, nv);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
 #pragma unroll
     for (int j = M - 1; j >= 0; --j) {
       x = fma(-Y[j], x, W[j]);
@@ -996,7 +1113,6 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     }
   }
   OMC_STAMP(12);
-  const bool want_quad = A.quad || A.fused;
   double qsum[OMC_MAX_TERMS] = {0, 0, 0, 0};
   double my_scale = 1.0, my_logdet = 0.0;  // epilogue scalars of this lane's term (wave 0)
   if (MULTI) {
@@ -1017,8 +1133,38 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         if (A.log_post && A.gb[k].logdet_unscaled) my_logdet = A.gb[k].logdet_unscaled[0];
       }
     }
-    if (want_quad) {
-      quad_wg<M>(tile, lane, __builtin_amdgcn_readfirstlane(wave), lbase, A, acc);
+    if constexpr (SIG == 1) {
+      const int nv = wave_valid<M>(wave_u, (int)n);
+      if (QPRE < 3) {
+        const int wbase = wave_u * 64 * M;
+        const int nvq = want_quad ? nv : 0, nvo = want_quad ? wave_valid<M>(wave_u, (int)n - 1) : 0;
+        if (QPRE < 1) coal_load<M>(qo, vPo + wbase, lane, nvo);
+        if (QPRE < 2) coal_load<M>(qd, vPd + wbase, lane, nvq);
+        coal_load<M>(qc, vIc + wbase, lane, nvq);
+      }
+      double aI = 0.0, aP = 0.0;
+      if (!want_quad) {
+      } else if (nv == 64 * M) {
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+          const double* pe = TM::elem(tl, r0, t);
+          const double xv = *pe, xn = *TM::succ(pe, r0, t), a = xv - qc[t];
+          aI = fma(a, a, aI);
+          aP = fma(fma(2.0 * qo[t], xn, qd[t] * xv), xv, aP);
+        }
+      } else {  // the chain's last wave: nodes beyond n hold finite fill values, their vectors were loaded as 0
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+          const double* pe = TM::elem(tl, r0, t);
+          const double xv = *pe, xn = *TM::succ(pe, r0, t), a = (lane + 64 * t < nv) ? xv - qc[t] : 0.0;
+          aI = fma(a, a, aI);
+          aP = fma(fma(2.0 * qo[t], xn, qd[t] * xv), xv, aP);
+        }
+      }
+      acc[0] = p_first ? aP : aI;
+      acc[1] = p_first ? aI : aP;
+    } else {
+      if (want_quad) quad_wg<M>(tile, lane, wave_u, lbase, A, acc);
     }
     OMC_STAMP(13);
     if (want_quad) {
@@ -1082,12 +1228,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     // x leaves last: a load issued behind a store would have to wait for the store to be
     // acknowledged (vmcnt retires in order); this way nothing ever waits on the x stream.
     if (A.x && chain_ok) {
-      using TM = TileMap<M>;
-      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
       double* xo = A.x + cc * A.ld_x + wave_u * 64 * M;
       const int nvalid = wave_valid<M>(wave_u, (int)n);
-      const double* tl = tile + lbase;
-      const int r0 = TM::lane_col(lane);
       {
         if (nvalid == 64 * M) {
 #pragma unroll
@@ -1187,11 +1329,12 @@ static int pow2_ceil(int v) {
 
 // nodes-per-lane variants: M -> (largest n, launch bound of the one-chain-per-workgroup form)
 template <int M> struct SegCfg;
-template <> struct SegCfg<8>  { static constexpr int MAXT = 1024; };
-template <> struct SegCfg<10> { static constexpr int MAXT = 1024; };
-template <> struct SegCfg<16> { static constexpr int MAXT = 640; };
-template <> struct SegCfg<20> { static constexpr int MAXT = 512; };
-template <> struct SegCfg<32> { static constexpr int MAXT = 512; };
+// SMOOTHER: 1 where the structure-specialised instantiation (SIG 1) exists -- the variants auto_seg picks
+template <> struct SegCfg<8>  { static constexpr int MAXT = 1024; static constexpr int SMOOTHER = 1; };
+template <> struct SegCfg<10> { static constexpr int MAXT = 1024; static constexpr int SMOOTHER = 1; };
+template <> struct SegCfg<16> { static constexpr int MAXT = 640; static constexpr int SMOOTHER = 0; };
+template <> struct SegCfg<20> { static constexpr int MAXT = 512; static constexpr int SMOOTHER = 0; };
+template <> struct SegCfg<32> { static constexpr int MAXT = 512; static constexpr int SMOOTHER = 0; };
 static int64_t seg_max_n(int seg) {
   switch (seg) {
     case 8: return 8 * 1024;
@@ -1213,8 +1356,12 @@ static void launch_seg(omc_ctx* ctx, const TriArgs& A) {
     hipLaunchKernelGGL((k_tridiag_seg<M, false, 256>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, G);
   } else {
     const int threads = 64 * ((S + 63) / 64);
-    hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT>), dim3((unsigned)A.C), dim3(threads), 0, ctx->stream,
-                       A, threads);
+    if (SegCfg<M>::SMOOTHER && is_smoother(A.T) && A.n >= 2)
+      hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT, SegCfg<M>::SMOOTHER>), dim3((unsigned)A.C), dim3(threads), 0,
+                         ctx->stream, A, threads);
+    else
+      hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT>), dim3((unsigned)A.C), dim3(threads), 0, ctx->stream,
+                         A, threads);
   }
 }
 
