@@ -130,7 +130,14 @@ __device__ __forceinline__ double sweep_gamma_draws_wave(const TriArgs& A, int64
   } else if (draw) {
     const omc_gamma_prep p = omc_gamma_prepare(g.key, A.chain_offset + c, g.a0 + g.half_npos);
     double v = 0.0;
-    bool ok = omc_gamma_attempt(g.key, A.chain_offset + c, p, (uint32_t)j, v);
+    // Attempt 0 alone first: it is accepted with probability > 0.95 (-> 1 for large shapes), mostly by the
+    // log-free squeeze test, and with one lane per term active the wave rarely has to walk the log branch
+    // that some lane of a full 16-attempt evaluation nearly always needs.
+    bool ok = (j == 0) && omc_gamma_attempt(g.key, A.chain_offset + c, p, 0u, v);
+    const unsigned long long first = __ballot(ok), want = __ballot(j == 0);
+    if (first != want) {  // wave-uniform: some term's first attempt was rejected -> evaluate the other 15 as well
+      if (j != 0) ok = omc_gamma_attempt(g.key, A.chain_offset + c, p, (uint32_t)j, v);
+    }
     const unsigned long long m = (__ballot(ok) >> (16 * k)) & 0xffffull;  // accepted attempts of this group
     if (m == 0ull) {  // astronomically rare: continue serially on the group's first lane
       if (j == 0) {
