@@ -69,18 +69,22 @@ __host__ __device__ inline omc_rng_key omc_make_key(uint64_t seed, uint64_t draw
   return k;
 }
 
+// one round, key schedule included
+__device__ __forceinline__ void omc_philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t& k0,
+                                                 uint32_t& k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+  const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+  const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+  const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+  c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+  k0 += W0; k1 += W1;
+}
+
 __device__ __forceinline__ uint4 omc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                    uint32_t k0, uint32_t k1) {
-  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
-    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
-    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-    k0 += W0; k1 += W1;
-  }
+  for (int r = 0; r < 10; ++r) omc_philox_round(c0, c1, c2, c3, k0, k1);
   return make_uint4(c0, c1, c2, c3);
 }
 

@@ -724,9 +724,6 @@ __device__ __forceinline__ double fast_sqrt(double r) { return omc_sqrt_nr(r); }
 // meets it for well-conditioned chains, weakly coupled ones take one or two Newton corrections
 #define OMC_NEWTON_TOL 1.6e-14
 #define OMC_NEWTON_MAX 4
-#ifndef OMC_RPRE
-#define OMC_RPRE 0  // SIG 1: right-hand side vector fetched before the pivot phases
-#endif
 #ifndef OMC_QPRE
 #define OMC_QPRE 0  // SIG 1: quad vectors fetched under the reverse scan (0..2), 3 = also the rest before the back pass
 #endif
@@ -819,10 +816,15 @@ __device__ __forceinline__ void quad_wg(const double* tile, int lane, int wave_u
 //            term P = tridiagonal precision (diag, off present) without rhs and center,
 //          so  a = sI + sP diagP,  b = sP offP,  r = sI rhsI (+ rhs_chain),
 //              qI = |x - centerI|^2,  qP = x' M_P x.
-// Knowing the structure at compile time removes the pointer tests, and, more to the point, lets the
-// kernel issue the shared-vector loads of a later phase *before* the compute of the current one and keep
-// them in registers: with one workgroup per CU all waves are in the same phase, so a phase that only
-// waits for L2 (80 KB per vector and workgroup at ~30 B/clk per CU) is otherwise dead time.
+// Knowing the structure at compile time removes the pointer tests and makes the load phases explicit, so
+// that work which depends on nothing can be placed in their shadow: with one workgroup per CU all waves are
+// in the same phase, and a phase that only waits for L2 (80 KB per vector and workgroup at ~30 B/clk per
+// CU, 1.3 us) is otherwise dead time for the vector ALU.  The standard-normal draws are such work (pure
+// functions of the Philox counter, 1.45 us per pair and workgroup): all but the last pair of a segment are
+// generated while the precision and right-hand-side vectors are in flight and parked in LDS (`lds_z`,
+// lane-private slots).  benchmarks/micro/overlap.hip measures the effect in isolation.  (Holding
+// prefetched vectors of a later phase in registers instead was tried: at 128 VGPRs it spills, and the spill
+// traffic costs more than the overlap gains.)
 template <int M, bool FULLW>
 __device__ __forceinline__ void coal_load(double (&v)[M], const double* base, int lane, int nvalid) {
 #pragma unroll
@@ -836,6 +838,29 @@ __device__ __forceinline__ void coal_load(double (&v)[M], const double* base, in
   if (nvalid == 64 * M) coal_load<M, true>(v, base, lane, nvalid);
   else coal_load<M, false>(v, base, lane, nvalid);
 }
+// One pair of draws (Philox block `block` of the chain, Box-Muller) with the M loads of a coalesced vector
+// issued one per Philox round: the loads drain while the wave computes (issued back to back in front of
+// the arithmetic they also overlap, but less: a wave blocks at issue once the CU's vector-memory queue is
+// full).
+template <int M, bool FULLW>
+__device__ __forceinline__ void draws_over_load(const omc_rng_key& key, int64_t gc, uint32_t block, double& z0, double& z1,
+                                                double (&v)[M], const double* base, int lane, int nvalid) {
+  static_assert(M <= 10, "one load per Philox round");
+  uint32_t c0 = block, c1 = key.c1, c2 = (uint32_t)gc;
+  uint32_t c3 = key.c3_base | ((uint32_t)((uint64_t)gc >> 32) & 0xffu) << 16;
+  uint32_t k0 = key.k0, k1 = key.k1;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    if (r < M) {
+      const int idx = lane + 64 * r;
+      v[r] = (FULLW || idx < nvalid) ? base[(unsigned)idx] : 0.0;
+    }
+    omc_philox_round(c0, c1, c2, c3, k0, k1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  omc_normal_pair(make_uint4(c0, c1, c2, c3), z0, z1);
+}
+
 // is_smoother: host-side test of the SIG 1 structure
 static bool is_smoother(const TermsDev& T) {
   if (T.n_terms != 2) return false;
@@ -858,6 +883,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   __shared__ Aff lds_aff[4][16];   // scans alternate buffers instead of paying a trailing barrier
   __shared__ double lds_x[2][32];  // neighbour exchange of the Newton passes (alternating)
   __shared__ double lds_d[6][16];  // reductions: one slot per call site
+  constexpr int NZB = (SIG == 1) ? M / 2 - 1 : 0;  // SIG 1: pairs of draws per lane made ahead of the forward pass
+  __shared__ double lds_z[SIG == 1 ? NWMAX : 1][NZB > 0 ? 2 * NZB : 1][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int Wd = MULTI ? 64 : G;
   int64_t c;
@@ -909,35 +936,57 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   if (epi_wave && chain_ok) early_gamma = sweep_gamma_draws_wave(A, c, lane, &early_failed);
 
   OMC_STAMP(1);
+  // draws: stream position of this segment; SIG 1 makes all but the last pair ahead of the forward pass
+  const int64_t gc = A.chain_offset + cc;
+  const uint32_t blk0 = (uint32_t)(i0 >> 1);
+  const bool gen_z = !A.z && !A.zero_z;
 
   // ---- conditional precision: b -> Y (registers), a -> LDS tile ----
   double bm1 = 0.0;  // coupling b_{i0-1} into the segment
-  double pre[M];  // SIG 1: the right-hand side vector, fetched under the pivot phases
+  double pre[M];  // SIG 1: the right-hand side vector
   if constexpr (SIG == 1) {
     const int wbase = wave_u * 64 * M;
     const int nv = wave_valid<M>(wave_u, (int)n), nvo = wave_valid<M>(wave_u, (int)n - 1);
-    double po[M], pd[M];  // both vectors in flight at once: one exposed L2 round trip for the two
-    coal_load<M>(po, vPo + wbase, lane, nvo);
-    coal_load<M>(pd, vPd + wbase, lane, nv);
-    if (i0 > 0 && i0 < n) bm1 = sP * vPo[i0 - 1];
-    wave_lds_fence();
+    // one vector (20 registers) in flight beside the generation of one pair of draws: more than that spills
+    auto vec_and_draws = [&](double (&v)[M], const double* base, int nvalid, int jb) {
+      if (gen_z && jb < NZB) {
+        double z0, z1;
+        if (nvalid == 64 * M) draws_over_load<M, true>(A.key, gc, blk0 + (uint32_t)jb, z0, z1, v, base, lane, nvalid);
+        else draws_over_load<M, false>(A.key, gc, blk0 + (uint32_t)jb, z0, z1, v, base, lane, nvalid);
+        lds_z[wave][2 * jb][lane] = z0;
+        lds_z[wave][2 * jb + 1][lane] = z1;
+      } else {
+        coal_load<M>(v, base, lane, nvalid);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+      double po[M];
+      // b_{i0-1}: only loaded here; any arithmetic on it would put a wait for all loads in front of the draws
+      const double bm1_raw = vPo[(i0 > 0 && i0 < n) ? i0 - 1 : 0];
+      vec_and_draws(po, vPo + wbase, nvo, 0);
+      wave_lds_fence();
 #pragma unroll
-    for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = sP * po[t];
-    wave_lds_fence();
-#pragma unroll
-    for (int j = 0; j < M; ++j) Y[j] = crow[j];
-    OMC_STAMP(2);
-    wave_lds_fence();
-    if (nv == 64 * M) {
-#pragma unroll
-      for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = fma(sP, pd[t], sI);
-    } else {
-#pragma unroll
-      for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = (lane + 64 * t < nv) ? fma(sP, pd[t], sI) : 1.0;
+      for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = sP * po[t];
+      wave_lds_fence();
+      bm1 = (i0 > 0 && i0 < n) ? sP * bm1_raw : 0.0;
     }
-    wave_lds_fence();
-    if (OMC_RPRE && !(A.rhs_chain && chain_ok)) coal_load<M>(pre, vIr + wbase, lane, nv);
-    __builtin_amdgcn_sched_barrier(0);
+    {
+      double pd[M];
+      vec_and_draws(pd, vPd + wbase, nv, 1);
+#pragma unroll
+      for (int j = 0; j < M; ++j) Y[j] = crow[j];
+      OMC_STAMP(2);
+      wave_lds_fence();
+      if (nv == 64 * M) {
+#pragma unroll
+        for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = fma(sP, pd[t], sI);
+      } else {
+#pragma unroll
+        for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = (lane + 64 * t < nv) ? fma(sP, pd[t], sI) : 1.0;
+      }
+      wave_lds_fence();
+    }
   } else {
     if (MULTI) tile_fill_comb_wg<M, COMB_OFF>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
     else tile_fill_comb<M, MULTI, COMB_OFF>(tile, geo, A, sc);
@@ -1024,7 +1073,29 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   bool rhs_done = false;
   if constexpr (SIG == 1) {
     if (!(A.rhs_chain && chain_ok)) {
-      if (!OMC_RPRE) coal_load<M>(pre, vIr + wave_u * 64 * M, lane, wave_valid<M>(wave_u, (int)n));
+      {
+        const int nvr = wave_valid<M>(wave_u, (int)n);
+        const double* base = vIr + wave_u * 64 * M;
+        if (gen_z && NZB > 2) {
+          double z0, z1;
+          if (nvr == 64 * M) draws_over_load<M, true>(A.key, gc, blk0 + 2u, z0, z1, pre, base, lane, nvr);
+          else draws_over_load<M, false>(A.key, gc, blk0 + 2u, z0, z1, pre, base, lane, nvr);
+          lds_z[wave][4][lane] = z0;
+          lds_z[wave][5][lane] = z1;
+        } else {
+          coal_load<M>(pre, base, lane, nvr);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (gen_z) {
+#pragma unroll
+        for (int jb = 3; jb < NZB; ++jb) {
+          double z0, z1;
+          omc_normal_pair(omc_rng_block(A.key, gc, blk0 + (uint32_t)jb), z0, z1);
+          lds_z[wave][2 * jb][lane] = z0;
+          lds_z[wave][2 * jb + 1][lane] = z1;
+        }
+      }
       wave_lds_fence();
 #pragma unroll
       for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = sI * pre[t];
@@ -1055,8 +1126,6 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     // g_j = u_j/D_j + z_j/sqrt(D_j); the draws are produced here, pair by pair, so that no array of
     // z ever has to be kept in registers next to l and 1/D (Philox + Box-Muller interleave with the
     // serial u recurrence; the scheduling barrier keeps the five bodies from being overlapped)
-    const int64_t gc = A.chain_offset + cc;
-    const uint32_t blk0 = (uint32_t)(i0 >> 1);
     const double* zin = A.z ? A.z + cc * A.ld_z + i0 : nullptr;
 #pragma unroll
     for (int j = 0; j < M; j += 2) {
@@ -1064,6 +1133,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       if (zin) {
         if (i0 + j < n) z0 = zin[j];
         if (i0 + j + 1 < n) z1 = zin[j + 1];
+      } else if (SIG == 1 && (j >> 1) < NZB) {
+        if (gen_z) { z0 = lds_z[wave][j][lane]; z1 = lds_z[wave][j + 1][lane]; }
       } else if (!A.zero_z) {
         omc_normal_pair(omc_rng_block(A.key, gc, blk0 + (uint32_t)(j >> 1)), z0, z1);
       }
@@ -1074,7 +1145,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       u = fma(-lp, u, crow[j + 1]);
       W[j + 1] = fma(u, W[j + 1], z1 * fast_sqrt(bad_guard1));
       lp = Y[j + 1];
-      __builtin_amdgcn_sched_barrier(0);
+      if (!(SIG == 1 && (j >> 1) < NZB - 1)) __builtin_amdgcn_sched_barrier(0);  // parked draws: let the pairs pipeline
     }
   }
 
