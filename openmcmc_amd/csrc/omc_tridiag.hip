@@ -391,8 +391,11 @@ __device__ __forceinline__ T row_scan(T v, const T& id) {
 
 // Exclusive scan over all lanes of the workgroup (one chain), in segment order or reversed.
 // `lds` holds one entry per wave.  Every lane of the block must call it.
-template <class T, bool REV>
-__device__ __forceinline__ T excl_scan_wg(T v, const T id, T* lds, int lane, int wave, int nw) {
+// ONE_WAVE: the scan over the wave totals is done by wave 0 alone and handed out through `lds2` behind a second
+// barrier, instead of redundantly by every wave -- worth it for the Moebius elements, whose 16-lane row scan
+// is ~140 vector-ALU instructions per wave (x 16 waves on 4 SIMDs) against a few hundred cycles of one wave.
+template <class T, bool REV, bool ONE_WAVE = false>
+__device__ __forceinline__ T excl_scan_wg(T v, const T id, T* lds, int lane, int wave, int nw, T* lds2 = nullptr) {
   v = row_scan<T, REV>(v, id);
   // row totals sit in the last (first) lane of each row; fold the preceding rows in
   const int row = lane >> 4;
@@ -411,11 +414,21 @@ __device__ __forceinline__ T excl_scan_wg(T v, const T id, T* lds, int lane, int
   if (nw > 1) {
     if (lane == (REV ? 0 : 63)) lds[wave] = v;  // wave total
     __syncthreads();
-    T t = (lane < nw) ? lds[lane] : id;        // nw <= 16: one row
-    t = row_scan<T, REV>(t, id);
     const int w = __builtin_amdgcn_readfirstlane(wave);
     const int src = REV ? w + 1 : w - 1;
-    if (src >= 0 && src < nw) e = compose(e, read_lane(t, src));
+    if (ONE_WAVE) {
+      if (w == 0) {
+        T t = (lane < nw) ? lds[lane] : id;
+        t = row_scan<T, REV>(t, id);
+        if (lane < nw) lds2[lane] = t;
+      }
+      __syncthreads();
+      if (src >= 0 && src < nw) e = compose(e, lds2[src]);
+    } else {
+      T t = (lane < nw) ? lds[lane] : id;        // nw <= 16: one row
+      t = row_scan<T, REV>(t, id);
+      if (src >= 0 && src < nw) e = compose(e, read_lane(t, src));
+    }
     // no trailing barrier: consecutive calls must use different `lds` buffers (the barrier of
     // the next call then orders this call's reads before the buffer is written again)
   }
@@ -879,7 +892,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   using TM = TileMap<M>;
   constexpr int NWMAX = MAXT / 64;
   __shared__ double lds_tile[NWMAX][64 * (M + 1) + 2];  // + the successor slot of the last row (quad_wg)
-  __shared__ Mob lds_mob[16];
+  __shared__ Mob lds_mob[16], lds_mob2[16];
   __shared__ Aff lds_aff[4][16];   // scans alternate buffers instead of paying a trailing barrier
   __shared__ double lds_x[2][32];  // neighbour exchange of the Newton passes (alternating)
   __shared__ double lds_d[6][16];  // reductions: one slot per call site
@@ -1018,7 +1031,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     m = mob_norm(m);
     OMC_STAMP(4);
     const Mob idm{1.0, 0.0, 0.0, 1.0};
-    const Mob E = MULTI ? excl_scan_wg<Mob, false>(m, idm, lds_mob, lane, wave, nw)
+    const Mob E = MULTI ? excl_scan_wg<Mob, false, true>(m, idm, lds_mob, lane, wave, nw, lds_mob2)
                         : excl_scan<Mob, false>(m, idm, pos, Wd, false, lds_mob, wave, nw);
     Dst = (E.a + E.b) / (E.c + E.d);
   }
