@@ -893,6 +893,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   constexpr int NWMAX = MAXT / 64;
   __shared__ double lds_tile[NWMAX][64 * (M + 1) + 2];  // + the successor slot of the last row (quad_wg)
   __shared__ Mob lds_mob[16], lds_mob2[16];
+  __shared__ double lds_g[64];     // wave 0's Normal-Gamma standard draws, start of kernel -> epilogue
   __shared__ Aff lds_aff[4][16];   // scans alternate buffers instead of paying a trailing barrier
   __shared__ double lds_x[2][32];  // neighbour exchange of the Newton passes (alternating)
   __shared__ double lds_d[6][16];  // reductions: one slot per call site
@@ -944,9 +945,14 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // Normal-Gamma standard draws, made up front (see sweep_gamma_draws_wave) by the chain's last wave: its
   // tile is the one that may be partly empty, so it has the least other work
   const bool epi_wave = MULTI && A.fused && wave == 0;
-  double early_gamma = 0.0;
-  bool early_failed = false;
-  if (epi_wave && chain_ok) early_gamma = sweep_gamma_draws_wave(A, c, lane, &early_failed);
+  // the draws are parked in LDS until the epilogue: two registers that would otherwise be live (or, as the
+  // compiler prefers, spilled to scratch by every wave) across the whole kernel.  SIG 1 makes them later, where
+  // wave 0's SIMD has issue slots to spare (the opening phase is bound by the vector ALU there).
+  if (SIG != 1 && epi_wave && chain_ok) {
+    bool f = false;
+    const double g = sweep_gamma_draws_wave(A, c, lane, &f);
+    lds_g[lane] = f ? -g : g;  // a Gamma draw is positive; the sign flags a draw that did not terminate
+  }
 
   OMC_STAMP(1);
   // draws: stream position of this segment; SIG 1 makes all but the last pair ahead of the forward pass
@@ -1225,6 +1231,13 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       }
     }
     if constexpr (SIG == 1) {
+      // Normal-Gamma standard draws (functions of the priors only): here, in front of the load-bound phase of
+      // the quadratic forms, wave 0's delay costs nothing -- the other waves' loads keep the L2 path busy
+      if (epi_wave && chain_ok) {
+        bool f = false;
+        const double g = sweep_gamma_draws_wave(A, c, lane, &f);
+        lds_g[lane] = f ? -g : g;
+      }
       const int nv = wave_valid<M>(wave_u, (int)n);
       if (QPRE < 3) {
         const int wbase = wave_u * 64 * M;
@@ -1315,7 +1328,10 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   }
   if (bad && chain_ok) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
   if (MULTI) {
-    if (epi_wave && chain_ok) sweep_epilogue_wave(A, c, qsum[0], qsum[1], qsum[2], qsum[3], my_scale, my_logdet, early_gamma, early_failed, lane);
+    if (epi_wave && chain_ok) {
+      const double g = lds_g[lane];
+      sweep_epilogue_wave(A, c, qsum[0], qsum[1], qsum[2], qsum[3], my_scale, my_logdet, fabs(g), g < 0.0, lane);
+    }
     // x leaves last: a load issued behind a store would have to wait for the store to be
     // acknowledged (vmcnt retires in order); this way nothing ever waits on the x stream.
     if (A.x && chain_ok) {
