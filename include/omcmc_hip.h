@@ -78,7 +78,9 @@ omc_status omc_ctx_destroy(omc_ctx* ctx);
 omc_status omc_ctx_status(omc_ctx* ctx, int64_t* first_bad_chain);
 omc_status omc_ctx_synchronize(omc_ctx* ctx);
 /* Tuning knobs, by name: "tridiag_algo" (0 auto, 1 serial lane-per-chain, 2 segmented),
- * "tridiag_seg" (nodes per lane: 0 auto, 8, 10, 16, 20, 32).  Unknown name -> OMC_INVALID_ARG.       */
+ * "tridiag_seg" (nodes per lane: 0 auto, 8, 10, 16, 20, 32), "tridiag_generic" (1: never use the
+ * instantiation specialised for the two-term smoother structure; for cross-checks).
+ * Unknown name -> OMC_INVALID_ARG.                                                            */
 omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value);
 const char* omc_last_error(void);          /* [host] text of the last HIP failure, thread-local */
 int32_t omc_abi_version(void);

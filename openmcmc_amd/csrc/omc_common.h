@@ -26,6 +26,7 @@ struct omc_ctx {
   int tridiag_algo;  // 0 auto, 1 serial, 2 segmented
   int tridiag_seg;   // 0 auto, else nodes per lane
   int debug_zero_z;  // diagnostic: skip the draw generation (timing what-if only)
+  int tridiag_generic;  // 1: never take the structure-specialised instantiation of the segmented kernel (tests)
   int band_algo;  // 0 auto, 1 lane-per-chain (narrow bands), 2 workgroup-per-chain
   int dense_use_rocsolver;  // 1: factor dense precisions with rocSOLVER's batched potrf instead of the blocked route
   unsigned long long* stamps;  // diagnostic phase stamps of the segmented kernel (NULL = off)

@@ -41,6 +41,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->mala_prep = nullptr; c->mala_prep_bytes = 0; c->mala_Q = nullptr; c->mala_L = nullptr; c->mala_step = 0.0; c->mala_d = 0;
   c->tridiag_algo = 0;
   c->tridiag_seg = 0;
+  c->tridiag_generic = 0;
   c->stamps = nullptr;
   c->debug_zero_z = 0;
   c->dense_use_rocsolver = 0;
@@ -109,6 +110,10 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "tridiag_seg")) {
     if (value != 0 && value != 8 && value != 10 && value != 16 && value != 20 && value != 32) return OMC_INVALID_ARG;
     ctx->tridiag_seg = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "tridiag_generic")) {
+    ctx->tridiag_generic = value != 0;
     return OMC_OK;
   }
   if (!strcmp(name, "band_algo")) {

@@ -1463,7 +1463,7 @@ static void launch_seg(omc_ctx* ctx, const TriArgs& A) {
     hipLaunchKernelGGL((k_tridiag_seg<M, false, 256>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, G);
   } else {
     const int threads = 64 * ((S + 63) / 64);
-    if (SegCfg<M>::SMOOTHER && is_smoother(A.T) && A.n >= 2)
+    if (SegCfg<M>::SMOOTHER && !ctx->tridiag_generic && is_smoother(A.T) && A.n >= 2)
       hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT, SegCfg<M>::SMOOTHER>), dim3((unsigned)A.C), dim3(threads), 0,
                          ctx->stream, A, threads);
     else

@@ -385,3 +385,62 @@ def test_fused_equals_unfused(torch, n, C, seg):
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
     assert relerr(out[1][3], out[0][3]) < 1e-13  # log_post: summation order of the four terms differs
+
+
+# ---------------------------------------------------------------------------------------------------
+# The structure-specialised instantiation (two-term smoother: scaled identity around y + zero-mean
+# tridiagonal prior, BASELINE configs[2]) against the oracle and against the generic instantiation.
+def _smoother_terms(eng, n, rng, C, p_first):
+    pd, po = rw1(n)
+    pd = pd * (1 + 0.1 * rng.random(n))
+    y = rng.standard_normal(n) + 2
+    lam, tau = 50 + 100 * rng.random(C), 0.5 + rng.random(C)
+    d_pd, d_po, d_y = eng.to_device(pd), eng.to_device(po), eng.to_device(y)
+    tp = {"diag": d_pd, "off": d_po, "scale": eng.to_device(lam)}
+    ti = {"rhs": d_y, "center": d_y, "scale": eng.to_device(tau)}
+    return (pd, po, y, lam, tau), ([tp, ti] if p_first else [ti, tp])
+
+
+@pytest.mark.parametrize("p_first", [True, False])
+@pytest.mark.parametrize("n", [513, 641, 5000, 8192, 8193, 9601, 10000, 10240])
+def test_smoother_specialisation_vs_oracle(torch, n, p_first):
+    """Injected draws: x, mean and both quadratic forms of the specialised kernel equal the oracle's; sizes
+    cover both segment widths, a last wave with one node, and a chain that fills its workgroup exactly."""
+    rng = np.random.default_rng(n + int(p_first))
+    C = 3
+    eng = make_engine(C)
+    (pd, po, y, lam, tau), terms = _smoother_terms(eng, n, rng, C, p_first)
+    z = rng.standard_normal((C, n))
+    extra = rng.standard_normal((C, n))
+    for with_extra in (False, True):
+        x, mean, quad = eng.empty(C, n), eng.empty(C, n), eng.empty(2, C)
+        eng.tridiag_sample_canonical(n, terms, x, z=eng.to_device(z), rhs_chain=eng.to_device(extra) if with_extra else None,
+                                     mean_out=mean, quad_out=quad)
+        eng.check_status()
+        x, mean, quad = x.cpu().numpy(), mean.cpu().numpy(), quad.cpu().numpy()
+        for c in range(C):
+            xo, mo, qo, _ = oracle_draw(n, pd, po, lam[c], tau[c], y, np.zeros(n), z[c], extra[c] if with_extra else None)
+            q = qo if p_first else qo[::-1]
+            assert relerr(x[c], xo) < TOL and relerr(mean[c], mo) < TOL
+            assert relerr(quad[:, c], q) < TOL
+    eng.close()
+
+
+@pytest.mark.parametrize("n,C", [(1000, 5), (8191, 4), (10000, 6)])
+def test_smoother_specialisation_equals_generic(torch, n, C):
+    """In-kernel draws: the specialised instantiation makes its draws ahead of the forward pass (parked in
+    LDS) -- the stream positions must be the ones the generic instantiation uses, so x agrees to rounding."""
+    rng = np.random.default_rng(7 * n)
+    out = []
+    for generic in (0, 1):
+        eng = make_engine(C, seed=99)
+        eng.set_option("tridiag_generic", generic)
+        rs = np.random.default_rng(n)
+        _, terms = _smoother_terms(eng, n, rs, C, True)
+        x, quad = eng.empty(C, n), eng.empty(2, C)
+        eng.tridiag_sample_canonical(n, terms, x, z=None, draw_index=5, quad_out=quad)
+        eng.check_status()
+        out.append((x.cpu().numpy(), quad.cpu().numpy()))
+        eng.close()
+    assert relerr(out[0][0], out[1][0]) < 1e-12
+    assert relerr(out[0][1], out[1][1]) < 1e-12
