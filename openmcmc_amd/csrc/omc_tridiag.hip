@@ -959,6 +959,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   const int64_t gc = A.chain_offset + cc;
   const uint32_t blk0 = (uint32_t)(i0 >> 1);
   const bool gen_z = !A.z && !A.zero_z;
+  // SIG 1: may this wave's off-diagonal slice be parked in the draws' LDS slots (see the forward pass)?
+  const bool park_off = SIG == 1 && gen_z && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n - 1) == 64 * M &&
+                        (reinterpret_cast<uintptr_t>(vPo) & 15u) == 0;
 
   // ---- conditional precision: b -> Y (registers), a -> LDS tile ----
   double bm1 = 0.0;  // coupling b_{i0-1} into the segment
@@ -1155,6 +1158,18 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       } else if (SIG == 1 && (j >> 1) < NZB) {
         if (gen_z) { z0 = lds_z[wave][j][lane]; z1 = lds_z[wave][j + 1][lane]; }
       } else if (!A.zero_z) {
+        if constexpr (SIG == 1) {
+          // The parked draws have all been read: their LDS slots now take the first 128 NZB entries of this
+          // wave's slice of the off-diagonal vector for the quadratic forms (LDS-DMA, no registers), under the
+          // generation of the segment's last pair of draws.
+          if (j == 2 * NZB && park_off) {
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < NZB; ++k)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vPo + wave_u * 64 * M + 128 * k + 2 * lane),
+                                               (__attribute__((address_space(3))) void*)&lds_z[wave][2 * k][0], 16, 0, 0);
+          }
+        }
         omc_normal_pair(omc_rng_block(A.key, gc, blk0 + (uint32_t)(j >> 1)), z0, z1);
       }
       const double bad_guard0 = bad ? 1.0 : W[j], bad_guard1 = bad ? 1.0 : W[j + 1];
@@ -1242,7 +1257,23 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       if (QPRE < 3) {
         const int wbase = wave_u * 64 * M;
         const int nvq = want_quad ? nv : 0, nvo = want_quad ? wave_valid<M>(wave_u, (int)n - 1) : 0;
-        if (QPRE < 1) coal_load<M>(qo, vPo + wbase, lane, nvo);
+        if (QPRE < 1) {
+          if (park_off) {
+            const double* zf = &lds_z[wave][0][0];
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA has landed (the reverse scan's barrier drained it already)
+            wave_lds_fence();
+#pragma unroll
+            for (int t = 0; t < M; ++t)
+              if (t < 2 * NZB) qo[t] = zf[64 * t + lane];
+#pragma unroll
+            for (int t = 0; t < M; ++t) {
+              if (t < 2 * NZB) continue;
+              qo[t] = (vPo + wbase)[(unsigned)(lane + 64 * t)];
+            }
+          } else {
+            coal_load<M>(qo, vPo + wbase, lane, nvo);
+          }
+        }
         if (QPRE < 2) coal_load<M>(qd, vPd + wbase, lane, nvq);
         coal_load<M>(qc, vIc + wbase, lane, nvq);
       }
