@@ -858,15 +858,19 @@ __device__ __forceinline__ void coal_load(double (&v)[M], const double* base, in
 template <int M, bool FULLW>
 __device__ __forceinline__ void draws_over_load(const omc_rng_key& key, int64_t gc, uint32_t block, double& z0, double& z1,
                                                 double (&v)[M], const double* base, int lane, int nvalid) {
-  static_assert(M <= 10, "one load per Philox round");
+  constexpr int LPR = (M + 9) / 10;  // loads per round
   uint32_t c0 = block, c1 = key.c1, c2 = (uint32_t)gc;
   uint32_t c3 = key.c3_base | ((uint32_t)((uint64_t)gc >> 32) & 0xffu) << 16;
   uint32_t k0 = key.k0, k1 = key.k1;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    if (r < M) {
-      const int idx = lane + 64 * r;
-      v[r] = (FULLW || idx < nvalid) ? base[(unsigned)idx] : 0.0;
+#pragma unroll
+    for (int q = 0; q < LPR; ++q) {
+      const int t = r * LPR + q;
+      if (t < M) {
+        const int idx = lane + 64 * t;
+        v[t] = (FULLW || idx < nvalid) ? base[(unsigned)idx] : 0.0;
+      }
     }
     omc_philox_round(c0, c1, c2, c3, k0, k1);
     __builtin_amdgcn_sched_barrier(0);
@@ -897,7 +901,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   __shared__ Aff lds_aff[4][16];   // scans alternate buffers instead of paying a trailing barrier
   __shared__ double lds_x[2][32];  // neighbour exchange of the Newton passes (alternating)
   __shared__ double lds_d[6][16];  // reductions: one slot per call site
-  constexpr int NZB = (SIG == 1) ? M / 2 - 1 : 0;  // SIG 1: pairs of draws per lane made ahead of the forward pass
+  // SIG 1: pairs of draws per lane made ahead of the forward pass (all but the last; at most 8: LDS)
+  constexpr int NZB = (SIG == 1) ? (M / 2 - 1 > 8 ? 8 : M / 2 - 1) : 0;
   __shared__ double lds_z[SIG == 1 ? NWMAX : 1][NZB > 0 ? 2 * NZB : 1][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int Wd = MULTI ? 64 : G;
@@ -1470,8 +1475,8 @@ template <int M> struct SegCfg;
 // SMOOTHER: 1 where the structure-specialised instantiation (SIG 1) exists -- the variants auto_seg picks
 template <> struct SegCfg<8>  { static constexpr int MAXT = 1024; static constexpr int SMOOTHER = 1; };
 template <> struct SegCfg<10> { static constexpr int MAXT = 1024; static constexpr int SMOOTHER = 1; };
-template <> struct SegCfg<16> { static constexpr int MAXT = 640; static constexpr int SMOOTHER = 0; };
-template <> struct SegCfg<20> { static constexpr int MAXT = 512; static constexpr int SMOOTHER = 0; };
+template <> struct SegCfg<16> { static constexpr int MAXT = 640; static constexpr int SMOOTHER = 0; };  // measured at cfg3 with SIG 1:
+template <> struct SegCfg<20> { static constexpr int MAXT = 512; static constexpr int SMOOTHER = 0; };  // 125 and 112 us against 102 for M = 10
 template <> struct SegCfg<32> { static constexpr int MAXT = 512; static constexpr int SMOOTHER = 0; };
 static int64_t seg_max_n(int seg) {
   switch (seg) {
