@@ -352,10 +352,16 @@ __device__ __forceinline__ double group_sum(double v, int Wd, double* lds, int w
 #define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138
 
+// `fill` is always a compile-time identity element (0.0 or 1.0) at the call sites: a word of it that is zero
+// is produced by the instruction's own bound_ctrl zero fill instead of a preloaded destination register
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v, double fill) {
-  int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), CTRL, 0xf, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), CTRL, 0xf, 0xf, false);
+  const int flo = __double2loint(fill), fhi = __double2hiint(fill);
+  int lo, hi;
+  if (__builtin_constant_p(flo) && flo == 0) lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  else lo = __builtin_amdgcn_update_dpp(flo, __double2loint(v), CTRL, 0xf, 0xf, false);
+  if (__builtin_constant_p(fhi) && fhi == 0) hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  else hi = __builtin_amdgcn_update_dpp(fhi, __double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 template <int CTRL> __device__ __forceinline__ Mob dpp_mov(const Mob& v, const Mob& f) {
@@ -1088,11 +1094,16 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   }
   OMC_STAMP(6);
   double logdet = 0.0;
+  // a chain with a non-positive pivot is reported through `bad`; its lanes continue on 1/D = 1 so that nothing
+  // downstream sees the square root of a negative number (wave-uniform branch: no per-node selects)
+  if (__ballot(bad) != 0ull) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) W[j] = bad ? 1.0 : W[j];
+  }
 #pragma unroll
   for (int j = 0; j < M; ++j) {
-    const double rD = bad ? 1.0 : W[j];
     Y[j] *= W[j];               // l_j = b_j / D_j
-    if (A.logdet && i0 + j < n) logdet -= log(rD);
+    if (A.logdet && i0 + j < n) logdet -= log(W[j]);
   }
 
   OMC_STAMP(7);
@@ -1177,12 +1188,11 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         }
         omc_normal_pair(omc_rng_block(A.key, gc, blk0 + (uint32_t)(j >> 1)), z0, z1);
       }
-      const double bad_guard0 = bad ? 1.0 : W[j], bad_guard1 = bad ? 1.0 : W[j + 1];
       u = fma(-lp, u, crow[j]);
-      W[j] = fma(u, W[j], z0 * fast_sqrt(bad_guard0));
+      W[j] = fma(u, W[j], z0 * fast_sqrt(W[j]));
       lp = Y[j];
       u = fma(-lp, u, crow[j + 1]);
-      W[j + 1] = fma(u, W[j + 1], z1 * fast_sqrt(bad_guard1));
+      W[j + 1] = fma(u, W[j + 1], z1 * fast_sqrt(W[j + 1]));
       lp = Y[j + 1];
       if (!(SIG == 1 && (j >> 1) < NZB - 1)) __builtin_amdgcn_sched_barrier(0);  // parked draws: let the pairs pipeline
     }
