@@ -743,9 +743,6 @@ __device__ __forceinline__ double fast_sqrt(double r) { return omc_sqrt_nr(r); }
 // meets it for well-conditioned chains, weakly coupled ones take one or two Newton corrections
 #define OMC_NEWTON_TOL 1.6e-14
 #define OMC_NEWTON_MAX 4
-#ifndef OMC_QPRE
-#define OMC_QPRE 0  // SIG 1: quad vectors fetched under the reverse scan (0..2), 3 = also the rest before the back pass
-#endif
 
 // Quadratic forms (x - m_k)' M_k (x - m_k) of one wave's 64*M nodes in the coalesced mapping: x comes
 // back from the tile (x_{i+1} = the next tile element; the slot behind the tile's last row holds the
@@ -973,6 +970,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // SIG 1: may this wave's off-diagonal slice be parked in the draws' LDS slots (see the forward pass)?
   const bool park_off = SIG == 1 && gen_z && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n - 1) == 64 * M &&
                         (reinterpret_cast<uintptr_t>(vPo) & 15u) == 0;
+  const bool park_diag = SIG == 1 && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n) == 64 * M &&
+                         (reinterpret_cast<uintptr_t>(vPd) & 15u) == 0;
 
   // ---- conditional precision: b -> Y (registers), a -> LDS tile ----
   double bm1 = 0.0;  // coupling b_{i0-1} into the segment
@@ -1200,15 +1199,18 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 
   OMC_STAMP(10);
   const bool want_quad = A.quad || A.fused;
-  // SIG 1: the three shared vectors of the quadratic forms, fetched under the reverse scan
-  double qc[M], qd[M], qo[M];
-  constexpr int QPRE = OMC_QPRE;
+  // SIG 1: the tile's right-hand side is dead now; until x is written into it, it takes this wave's slice of
+  // the tridiagonal term's diagonal (LDS-DMA, contiguous image), which the back pass below reads in the row
+  // mapping for the x' diag x part of the quadratic form -- one vector less to wait for afterwards
+  double aPd = 0.0;
   if constexpr (SIG == 1) {
-    const int wbase = wave_u * 64 * M;
-    const int nv = want_quad ? wave_valid<M>(wave_u, (int)n) : 0, nvo = want_quad ? wave_valid<M>(wave_u, (int)n - 1) : 0;
-    if (QPRE >= 1) coal_load<M>(qo, vPo + wbase, lane, nvo);
-    if (QPRE >= 2) coal_load<M>(qd, vPd + wbase, lane, nv);
-    __builtin_amdgcn_sched_barrier(0);
+    if (park_diag) {
+      wave_lds_fence();
+#pragma unroll
+      for (int k = 0; k < (64 * M) / 128; ++k)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vPd + wave_u * 64 * M + 128 * k + 2 * lane),
+                                         (__attribute__((address_space(3))) void*)(tile + 128 * k), 16, 0, 0);
+    }
   }
   // ---- backward substitution: local affine map, reverse scan, true pass ----
   double xnext;
@@ -1223,20 +1225,22 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
                    : excl_scan<Aff, false>(f, Aff{0.0, 1.0}, pos, Wd, true, lds_aff[0], wave, nw)).p;
     double x = xnext;
     OMC_STAMP(11);
-    if constexpr (SIG == 1) {  // the remaining vectors: registers for them are free only now
-      const int wbase = wave_u * 64 * M;
-      const int nv = want_quad ? wave_valid<M>(wave_u, (int)n) : 0, nvo = want_quad ? wave_valid<M>(wave_u, (int)n - 1) : 0;
-      if (QPRE >= 3) {
-        if (QPRE < 1) coal_load<M>(qo, vPo + wbase, lane, nvo);
-        if (QPRE < 2) coal_load<M>(qd, vPd + wbase, lane, nv);
-        coal_load<M>(qc, vIc + wbase, lane, nv);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
+    if (SIG == 1 && park_diag) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA has landed (the scan's barrier drained it already)
+      wave_lds_fence();
+      const double* drow = tile + lane * M;  // contiguous image: no row padding
 #pragma unroll
-    for (int j = M - 1; j >= 0; --j) {
-      x = fma(-Y[j], x, W[j]);
-      W[j] = x;
+      for (int j = M - 1; j >= 0; --j) {
+        x = fma(-Y[j], x, W[j]);
+        W[j] = x;
+        aPd = fma(drow[j] * x, x, aPd);
+      }
+    } else {
+#pragma unroll
+      for (int j = M - 1; j >= 0; --j) {
+        x = fma(-Y[j], x, W[j]);
+        W[j] = x;
+      }
     }
   }
   OMC_STAMP(12);
@@ -1269,10 +1273,11 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         lds_g[lane] = f ? -g : g;
       }
       const int nv = wave_valid<M>(wave_u, (int)n);
-      if (QPRE < 3) {
+      double qc[M], qd[M], qo[M];
+      {
         const int wbase = wave_u * 64 * M;
         const int nvq = want_quad ? nv : 0, nvo = want_quad ? wave_valid<M>(wave_u, (int)n - 1) : 0;
-        if (QPRE < 1) {
+        {
           if (park_off) {
             const double* zf = &lds_z[wave][0][0];
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA has landed (the reverse scan's barrier drained it already)
@@ -1289,10 +1294,15 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
             coal_load<M>(qo, vPo + wbase, lane, nvo);
           }
         }
-        if (QPRE < 2) coal_load<M>(qd, vPd + wbase, lane, nvq);
+        if (park_diag) {
+#pragma unroll
+          for (int t = 0; t < M; ++t) qd[t] = 0.0;  // that part is in aPd already
+        } else {
+          coal_load<M>(qd, vPd + wbase, lane, nvq);
+        }
         coal_load<M>(qc, vIc + wbase, lane, nvq);
       }
-      double aI = 0.0, aP = 0.0;
+      double aI = 0.0, aP = aPd;
       if (!want_quad) {
       } else if (nv == 64 * M) {
 #pragma unroll
