@@ -527,6 +527,16 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// In front of an LDS-DMA (global_load_lds) into a region this wave has been reading: the DMA's write reaches
+// LDS through the vector-memory path, not the DS queue, so "DS operations execute in order" does not cover
+// it -- a ds_read that has been issued but not yet served could see the new bytes.  Wait until every DS
+// operation of the wave has returned (lgkmcnt(0); vmcnt and expcnt left alone).
+__device__ __forceinline__ void lds_reads_done() {
+  wave_lds_fence();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  wave_lds_fence();
+}
+
 // shared vector v[0..lim) -> tile (fill beyond lim); every sub-wave group then reads rows 0..G-1
 template <int M, bool MULTI>
 __device__ __forceinline__ void tile_fill_shared(double* tile, const Geom<M, MULTI>& g, const double* v, int64_t lim,
@@ -743,6 +753,12 @@ __device__ __forceinline__ double fast_sqrt(double r) { return omc_sqrt_nr(r); }
 // meets it for well-conditioned chains, weakly coupled ones take one or two Newton corrections
 #define OMC_NEWTON_TOL 1.6e-14
 #define OMC_NEWTON_MAX 4
+#ifndef OMC_PARK_OFF
+#define OMC_PARK_OFF 1
+#endif
+#ifndef OMC_PARK_DIAG
+#define OMC_PARK_DIAG 1
+#endif
 
 // Quadratic forms (x - m_k)' M_k (x - m_k) of one wave's 64*M nodes in the coalesced mapping: x comes
 // back from the tile (x_{i+1} = the next tile element; the slot behind the tile's last row holds the
@@ -942,7 +958,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   for (int k = 0; k < OMC_MAX_TERMS; ++k) sc[k] = (k < nt && A.T.scale[k]) ? A.T.scale[k][cc] : 1.0;
   // SIG 1: which of the two terms is the tridiagonal one (wave-uniform; selects, not indexed kernel arguments)
   const bool p_first = SIG == 1 && A.T.diag[0] != nullptr;
-  const double sP = p_first ? sc[0] : sc[1], sI = p_first ? sc[1] : sc[0];
+  double sP = 1.0, sI = 1.0;  // the two scales by role; selected where first needed (a use up here would put the wait for
+                              // the scalar loads in front of the first vector loads and draws)
   const double* const vPd = p_first ? A.T.diag[0] : A.T.diag[1];
   const double* const vPo = p_first ? A.T.off[0] : A.T.off[1];
   const double* const vIr = p_first ? A.T.rhs[1] : A.T.rhs[0];
@@ -968,9 +985,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   const uint32_t blk0 = (uint32_t)(i0 >> 1);
   const bool gen_z = !A.z && !A.zero_z;
   // SIG 1: may this wave's off-diagonal slice be parked in the draws' LDS slots (see the forward pass)?
-  const bool park_off = SIG == 1 && gen_z && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n - 1) == 64 * M &&
+  const bool park_off = OMC_PARK_OFF && SIG == 1 && gen_z && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n - 1) == 64 * M &&
                         (reinterpret_cast<uintptr_t>(vPo) & 15u) == 0;
-  const bool park_diag = SIG == 1 && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n) == 64 * M &&
+  const bool park_diag = OMC_PARK_DIAG && SIG == 1 && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n) == 64 * M &&
                          (reinterpret_cast<uintptr_t>(vPd) & 15u) == 0;
 
   // ---- conditional precision: b -> Y (registers), a -> LDS tile ----
@@ -997,6 +1014,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       // b_{i0-1}: only loaded here; any arithmetic on it would put a wait for all loads in front of the draws
       const double bm1_raw = vPo[(i0 > 0 && i0 < n) ? i0 - 1 : 0];
       vec_and_draws(po, vPo + wbase, nvo, 0);
+      sP = p_first ? sc[0] : sc[1];
+      sI = p_first ? sc[1] : sc[0];
       wave_lds_fence();
 #pragma unroll
       for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = sP * po[t];
@@ -1178,7 +1197,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           // wave's slice of the off-diagonal vector for the quadratic forms (LDS-DMA, no registers), under the
           // generation of the segment's last pair of draws.
           if (j == 2 * NZB && park_off) {
-            wave_lds_fence();
+            lds_reads_done();
 #pragma unroll
             for (int k = 0; k < NZB; ++k)
               __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vPo + wave_u * 64 * M + 128 * k + 2 * lane),
@@ -1205,7 +1224,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   double aPd = 0.0;
   if constexpr (SIG == 1) {
     if (park_diag) {
-      wave_lds_fence();
+      lds_reads_done();
 #pragma unroll
       for (int k = 0; k < (64 * M) / 128; ++k)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vPd + wave_u * 64 * M + 128 * k + 2 * lane),
