@@ -1322,7 +1322,15 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         coal_load<M>(qc, vIc + wbase, lane, nvq);
       }
       double aI = 0.0, aP = aPd;
+      // x leaves from the same pass, behind the loads issued above (vmcnt retires in order: nothing waits on the
+      // x stream, and the 80 KB of stores drain under the reduction and the epilogue instead of after them)
+      double* xo = (A.x && chain_ok) ? A.x + cc * A.ld_x + wave_u * 64 * M : nullptr;
       if (!want_quad) {
+        if (xo) {
+#pragma unroll
+          for (int t = 0; t < M; ++t)
+            if (lane + 64 * t < nv) xo[(unsigned)(lane + 64 * t)] = *TM::elem(tl, r0, t);
+        }
       } else if (nv == 64 * M) {
 #pragma unroll
         for (int t = 0; t < M; ++t) {
@@ -1330,6 +1338,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           const double xv = *pe, xn = *TM::succ(pe, r0, t), a = xv - qc[t];
           aI = fma(a, a, aI);
           aP = fma(fma(2.0 * qo[t], xn, qd[t] * xv), xv, aP);
+          if (xo) xo[(unsigned)(lane + 64 * t)] = xv;
         }
       } else {  // the chain's last wave: nodes beyond n hold finite fill values, their vectors were loaded as 0
 #pragma unroll
@@ -1338,6 +1347,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           const double xv = *pe, xn = *TM::succ(pe, r0, t), a = (lane + 64 * t < nv) ? xv - qc[t] : 0.0;
           aI = fma(a, a, aI);
           aP = fma(fma(2.0 * qo[t], xn, qd[t] * xv), xv, aP);
+          if (xo && lane + 64 * t < nv) xo[(unsigned)(lane + 64 * t)] = xv;
         }
       }
       acc[0] = p_first ? aP : aI;
@@ -1409,7 +1419,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     }
     // x leaves last: a load issued behind a store would have to wait for the store to be
     // acknowledged (vmcnt retires in order); this way nothing ever waits on the x stream.
-    if (A.x && chain_ok) {
+    // (SIG 1 has stored it from its quadratic-form pass already.)
+    if (SIG != 1 && A.x && chain_ok) {
       double* xo = A.x + cc * A.ld_x + wave_u * 64 * M;
       const int nvalid = wave_valid<M>(wave_u, (int)n);
       {
