@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--python-loop", action="store_true", help="issue every sweep from Python instead of omc_gmrf_run")
     ap.add_argument("--unfused", action="store_true", help="one launch per sampler instead of the fused sweep kernel")
     ap.add_argument("--zero-z", action="store_true", help="diagnostic what-if: no draw generation (results are not samples)")
+    ap.add_argument("--generic", action="store_true", help="diagnostic: never use the structure-specialised kernel instantiation")
     ap.add_argument("--stamps", action="store_true", help="diagnostic: print in-kernel phase stamps (not a timing run)")
     ap.add_argument("--seg", type=int, default=0, help="nodes per lane of the segmented kernel (0 = auto)")
     args = ap.parse_args()
@@ -208,6 +209,8 @@ def main():
                       fused=not args.unfused, seg=args.seg)
     if args.zero_z:
         sweep.eng.set_option("debug_zero_z", 1)
+    if args.generic:
+        sweep.eng.set_option("tridiag_generic", 1)
     stamps = None
     if args.stamps:
         stamps = torch.zeros(C * 16 * 16, dtype=torch.int64, device="cuda")

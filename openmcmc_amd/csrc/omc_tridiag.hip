@@ -1549,7 +1549,9 @@ static void launch_seg(omc_ctx* ctx, const TriArgs& A) {
     hipLaunchKernelGGL((k_tridiag_seg<M, false, 256>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, G);
   } else {
     const int threads = 64 * ((S + 63) / 64);
-    if (SegCfg<M>::SMOOTHER && !ctx->tridiag_generic && is_smoother(A.T) && A.n >= 2)
+    // the specialised instantiation owns the CU (its LDS image is sized for a full workgroup); a short chain
+    // leaves room for a second workgroup of the generic one, which then wins (n = 2000: 38 against 53 us)
+    if (SegCfg<M>::SMOOTHER && !ctx->tridiag_generic && is_smoother(A.T) && A.n >= 2 && 2 * threads > SegCfg<M>::MAXT)
       hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT, SegCfg<M>::SMOOTHER>), dim3((unsigned)A.C), dim3(threads), 0,
                          ctx->stream, A, threads);
     else
