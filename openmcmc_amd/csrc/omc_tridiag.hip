@@ -1055,6 +1055,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   OMC_STAMP(3);
   // ---- Moebius product of the segment, scan -> incoming pivot ----
   double Dst;
+  double Dnext0 = 0.0;  // the start value the NEXT segment derives from the same scan (up to rounding)
   {
     Mob m{1.0, 0.0, 0.0, 1.0};
     double bp = bm1;
@@ -1072,17 +1073,22 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     const Mob E = MULTI ? excl_scan_wg<Mob, false, true>(m, idm, lds_mob, lane, wave, nw, lds_mob2)
                         : excl_scan<Mob, false>(m, idm, pos, Wd, false, lds_mob, wave, nw);
     Dst = (E.a + E.b) / (E.c + E.d);
+    if (MULTI) {
+      const Mob inc = compose(m, E);
+      Dnext0 = (inc.a + inc.b) * fast_rcp(inc.c + inc.d);
+    }
   }
 
   OMC_STAMP(5);
   // ---- true pivot recurrence, Newton multiple shooting on the segment joins ----
   bool bad = false;
   double lin = 0.0;  // l_{i0-1}
-  for (int it = 0;; ++it) {
+  // one pass of the true recurrence over the segment from Dst: W = 1/D, returns the last pivot
+  auto pivot_pass = [&]() -> double {
     wave_lds_fence();  // re-read a from LDS every pass instead of keeping a register copy
     const double rst = fast_rcp(Dst);
     lin = bm1 * rst;
-    double lp = lin, bprev = bm1, J = 1.0, Dend = Dst;
+    double lp = lin, bprev = bm1, Dend = Dst;
     bool badp = false;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
@@ -1090,12 +1096,31 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       badp |= !(D > 0.0);
       const double r = fast_rcp(D);
       W[j] = r;
-      J *= lp * lp;
       bprev = Y[j];
       lp = bprev * r;
       Dend = D;
     }
     bad = badp;
+    return Dend;
+  };
+  double Dend = pivot_pass();
+  // Join test.  Workgroup form: every segment tests the join at its END against the start value its successor
+  // took from the Moebius scan, which it can compute itself (Dnext0): no neighbour exchange, one barrier.  97 %
+  // of the cfg3 chains stop here.  Otherwise (and in the sub-wave form) the joins are tested at the segment
+  // starts with an exchange, and corrected: Newton on the joins with Jacobian prod l^2, one affine scan each.
+  bool settled = false;
+  if (MULTI) {
+    const bool has_next = i0 + M < n;
+    const int need = (has_next && fabs(Dend - Dnext0) > OMC_NEWTON_TOL * fabs(Dnext0)) ? 1 : 0;  // false for NaN: -> `bad`
+    settled = !__syncthreads_or(need);
+  }
+  for (int it = 0; !settled; ++it) {
+    double J = lin * lin;  // d(last pivot)/d(start pivot) of this segment = prod of l^2 over it
+#pragma unroll
+    for (int j = 0; j + 1 < M; ++j) {
+      const double l = Y[j] * W[j];
+      J *= l * l;
+    }
     double Dp = Dend, Jp = J;
     if (MULTI) prev_lane2_wg(Dp, Jp, Dst, 0.0, lds_x[it & 1], lane, wave, nw);
     else prev_lane2<false>(Dp, Jp, Dst, 0.0, pos, Wd, lds_x[0], wave);
@@ -1109,6 +1134,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     const Aff ex = MULTI ? excl_scan_wg<Aff, false>(own, Aff{0.0, 1.0}, lds_aff[it & 1], lane, wave, nw)
                           : excl_scan<Aff, false>(own, Aff{0.0, 1.0}, pos, Wd, false, lds_aff[0], wave, nw);
     Dst += fma(Jp, ex.p, e);  // delta_s = e_s + J_{s-1} delta_{s-1}
+    Dend = pivot_pass();
   }
   OMC_STAMP(6);
   double logdet = 0.0;
