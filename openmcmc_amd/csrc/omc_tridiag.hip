@@ -370,6 +370,21 @@ template <int CTRL> __device__ __forceinline__ Mob dpp_mov(const Mob& v, const M
 template <int CTRL> __device__ __forceinline__ Aff dpp_mov(const Aff& v, const Aff& f) {
   return Aff{dpp_mov<CTRL>(v.p, f.p), dpp_mov<CTRL>(v.q, f.q)};
 }
+// row_bcast15 / row_bcast31 (GFX9 DPP): the last lane of a row -> every lane of the next row / lane 31 -> rows 2
+// and 3.  Rows not selected by ROW_MASK keep `fill` (the identity), so composing with the result is a no-op there.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_bcast(double v, double fill) {
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ Mob dpp_bcast(const Mob& v, const Mob& f) {
+  return Mob{dpp_bcast<CTRL, ROW_MASK>(v.a, f.a), dpp_bcast<CTRL, ROW_MASK>(v.b, f.b), dpp_bcast<CTRL, ROW_MASK>(v.c, f.c),
+             dpp_bcast<CTRL, ROW_MASK>(v.d, f.d)};
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ Aff dpp_bcast(const Aff& v, const Aff& f) {
+  return Aff{dpp_bcast<CTRL, ROW_MASK>(v.p, f.p), dpp_bcast<CTRL, ROW_MASK>(v.q, f.q)};
+}
 __device__ __forceinline__ double read_lane(double v, int l) {  // l must be wave-uniform
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
@@ -405,17 +420,16 @@ __device__ __forceinline__ T excl_scan_wg(T v, const T id, T* lds, int lane, int
   v = row_scan<T, REV>(v, id);
   // row totals sit in the last (first) lane of each row; fold the preceding rows in
   const int row = lane >> 4;
-  T pre = id;
   if (!REV) {
-    const T t0 = read_lane(v, 15), t1 = read_lane(v, 31), t2 = read_lane(v, 47);
-    const T p2 = compose(t1, t0), p3 = compose(t2, p2);
-    pre = row == 1 ? t0 : (row == 2 ? p2 : (row == 3 ? p3 : id));
-  } else {
+    // the classic wave64 pattern: lane 15 -> row 1 and lane 47 -> row 3, then lane 31 -> rows 2 and 3
+    v = compose(v, dpp_bcast<0x142, 0xA>(v, id));
+    v = compose(v, dpp_bcast<0x143, 0xC>(v, id));
+  } else {  // no mirrored broadcast exists: fold through readlanes
     const T t3 = read_lane(v, 48), t2 = read_lane(v, 32), t1 = read_lane(v, 16);
     const T p1 = compose(t2, t3), p0 = compose(t1, p1);
-    pre = row == 2 ? t3 : (row == 1 ? p1 : (row == 0 ? p0 : id));
+    const T pre = row == 2 ? t3 : (row == 1 ? p1 : (row == 0 ? p0 : id));
+    v = compose(v, pre);
   }
-  v = renorm(compose(v, pre));
   T e = REV ? dpp_mov<DPP_WAVE_SHL1>(v, id) : dpp_mov<DPP_WAVE_SHR1>(v, id);
   if (nw > 1) {
     if (lane == (REV ? 0 : 63)) lds[wave] = v;  // wave total
@@ -1065,7 +1079,10 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       const double na = fma(aj, m.a, -b2 * m.c), nb = fma(aj, m.b, -b2 * m.d);
       m.c = m.a; m.d = m.b; m.a = na; m.b = nb;
       bp = Y[j];
-      if ((j & 7) == 7) m = mob_norm(m);
+      if ((j & 7) == 7) {  // cheap guard against overflow inside long segments: scale by the exponent of the leading entry
+        const int ex = -__builtin_amdgcn_frexp_exp(m.a);
+        m = Mob{ldexp(m.a, ex), ldexp(m.b, ex), ldexp(m.c, ex), ldexp(m.d, ex)};
+      }
     }
     m = mob_norm(m);
     OMC_STAMP(4);
