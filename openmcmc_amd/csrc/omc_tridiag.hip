@@ -410,6 +410,15 @@ __device__ __forceinline__ T row_scan(T v, const T& id) {
   return renorm(v);
 }
 
+// Workgroup barrier that orders LDS traffic only.  `__syncthreads()` is a fence as well: it waits for every
+// outstanding vector-memory operation of the wave (vmcnt(0)) -- here that would be the 80 KB of x stores and the
+// LDS-DMA transfers, which no other wave ever reads; the hand-overs of the scans and reductions go through LDS.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Exclusive scan over all lanes of the workgroup (one chain), in segment order or reversed.
 // `lds` holds one entry per wave.  Every lane of the block must call it.
 // ONE_WAVE: the scan over the wave totals is done by wave 0 alone and handed out through `lds2` behind a second
@@ -433,7 +442,7 @@ __device__ __forceinline__ T excl_scan_wg(T v, const T id, T* lds, int lane, int
   T e = REV ? dpp_mov<DPP_WAVE_SHL1>(v, id) : dpp_mov<DPP_WAVE_SHR1>(v, id);
   if (nw > 1) {
     if (lane == (REV ? 0 : 63)) lds[wave] = v;  // wave total
-    __syncthreads();
+    lds_barrier();
     const int w = __builtin_amdgcn_readfirstlane(wave);
     const int src = REV ? w + 1 : w - 1;
     if (ONE_WAVE) {
@@ -442,7 +451,7 @@ __device__ __forceinline__ T excl_scan_wg(T v, const T id, T* lds, int lane, int
         t = row_scan<T, REV>(t, id);
         if (lane < nw) lds2[lane] = t;
       }
-      __syncthreads();
+      lds_barrier();
       if (src >= 0 && src < nw) e = compose(e, lds2[src]);
     } else {
       T t = (lane < nw) ? lds[lane] : id;        // nw <= 16: one row
@@ -461,7 +470,7 @@ __device__ __forceinline__ void prev_lane2_wg(double& v0, double& v1, double id0
   double a = dpp_mov<DPP_WAVE_SHR1>(v0, id0), b = dpp_mov<DPP_WAVE_SHR1>(v1, id1);
   if (nw > 1) {
     if (lane == 63) { lds[2 * wave] = v0; lds[2 * wave + 1] = v1; }
-    __syncthreads();
+    lds_barrier();
     if (lane == 0 && wave > 0) { a = lds[2 * (wave - 1)]; b = lds[2 * (wave - 1) + 1]; }
     // no trailing barrier: see excl_scan_wg
   }
@@ -488,7 +497,7 @@ __device__ __forceinline__ void sum4_wg(const double (&v)[OMC_MAX_TERMS], double
       for (int k = 0; k < OMC_MAX_TERMS; ++k)
         if (k < nt) lds[k * 16 + wave] = t[k];
     }
-    __syncthreads();
+    lds_barrier();
     // lane 16 k + w holds wave w's partial sum of term k; one row reduction serves all terms
     double x = ((lane & 15) < nw && (lane >> 4) < nt) ? lds[lane] : 0.0;
     x += dpp_mov<DPP_ROW_SHR(1)>(x, 0.0);
@@ -509,7 +518,7 @@ __device__ __forceinline__ double sum_wg(double v, double* lds, int lane, int wa
   double t = (read_lane(v, 15) + read_lane(v, 31)) + (read_lane(v, 47) + read_lane(v, 63));
   if (nw > 1) {
     if (lane == 0) lds[wave] = t;
-    __syncthreads();
+    lds_barrier();
     double u = 0.0;
     for (int w = 0; w < nw; ++w) u += lds[w];
     t = u;  // no trailing barrier: every call site owns its 16-entry slot of `lds`
