@@ -208,8 +208,10 @@ omc_status omc_weighted_resid_sq(omc_ctx* ctx, int64_t n, const double* y, const
  *   reverse (350-373); log alpha = lp' + q_rev - lp - q_fwd (155); accept iff log u < log alpha (173).
  *   As level-3 BLAS on the d x C state matrix.  Because H is constant, the drift matrix
  *   -(H/step^2)^{-1} Q and L^{-T} are formed once per (Q, L, step) (cached in the context, so Q and L
- *   must stay unchanged while they are in use); a step is then 3 GEMM + 1 TRMM.
+ *   must stay unchanged while they are in use); a step is then 4 GEMMs (the product with L' runs on a copy
+ *   of L with an explicitly zero upper triangle).
  * omc_rw_step: one untruncated RandomWalk.sample (metropolis_hastings.py:212-269): x' = x + step z.
+ *   The zero-padded copy of LQ is cached in the context the same way (LQ must stay unchanged while in use).
  *   z_inject [C][ld_z] / u_inject [C]: injected N(0,1) / U(0,1) draws (NULL = generate);
  *   accept_count / proposal_count [C] int64 (NULL = not kept): the AcceptRate counters
  *   (metropolis_hastings.py:25-66), INT path: bit-exact.                                        */

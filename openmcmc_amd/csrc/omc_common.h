@@ -23,6 +23,7 @@ struct omc_ctx {
   double* mh_work; size_t mh_work_bytes;  // omc_mala.hip
   double* mala_prep; size_t mala_prep_bytes;  // cached drift matrix and L^{-T} of the current (Q, L, step)
   const double* mala_Q; const double* mala_L; double mala_step; int64_t mala_d;
+  double* rw_prep; size_t rw_prep_bytes; const double* rw_LQ; int64_t rw_d;  // omc_rw_step: LQ with a zero upper triangle
   int tridiag_algo;  // 0 auto, 1 serial, 2 segmented
   int tridiag_seg;   // 0 auto, else nodes per lane
   int debug_zero_z;  // diagnostic: skip the draw generation (timing what-if only)

@@ -38,6 +38,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->dense_info = nullptr; c->dense_info_bytes = 0;
   c->dense_tmp = nullptr; c->dense_tmp_bytes = 0;
   c->mh_work = nullptr; c->mh_work_bytes = 0;
+  c->rw_prep = nullptr; c->rw_prep_bytes = 0; c->rw_LQ = nullptr; c->rw_d = 0;
   c->mala_prep = nullptr; c->mala_prep_bytes = 0; c->mala_Q = nullptr; c->mala_L = nullptr; c->mala_step = 0.0; c->mala_d = 0;
   c->tridiag_algo = 0;
   c->tridiag_seg = 0;
@@ -71,6 +72,7 @@ omc_status omc_ctx_destroy(omc_ctx* ctx) {
   if (ctx->dense_tmp) hipFree(ctx->dense_tmp);
   if (ctx->mh_work) hipFree(ctx->mh_work);
   if (ctx->mala_prep) hipFree(ctx->mala_prep);
+  if (ctx->rw_prep) hipFree(ctx->rw_prep);
   omc_dense_release(ctx);
   hipFree(ctx->d_bad_chain);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);

@@ -212,6 +212,15 @@ __global__ void __launch_bounds__(256) k_mh_finish(int64_t d, int64_t chain_offs
     for (int64_t i = threadIdx.x; i < d; i += 256) x[c * ld_x + i] = xp[c * d + i];
 }
 
+// lower triangle of a column-major d x d matrix, zeros above the diagonal: the triangular products below run as
+// plain GEMMs on this image (rocBLAS's out-of-place TRMM reached 5.6 TFLOP/s at d = 500, its DGEMM 37)
+__global__ void k_lower_copy(int64_t d, const double* L, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d * d) return;
+  const int64_t col = i / d, row = i - col * d;
+  out[i] = row >= col ? L[i] : 0.0;
+}
+
 static omc_status mala_prepare(omc_ctx* ctx, int64_t d, const double* Q, const double* L, double step) {
   if (ctx->mala_Q == Q && ctx->mala_L == L && ctx->mala_step == step && ctx->mala_d == d && ctx->mala_prep) return OMC_OK;
   omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->mala_prep, &ctx->mala_prep_bytes, (size_t)4 * d * d * sizeof(double));
@@ -220,9 +229,9 @@ static omc_status mala_prepare(omc_ctx* ctx, int64_t d, const double* Q, const d
   const rocblas_int di = (rocblas_int)d;
   double* A1 = ctx->mala_prep;            // -(L L')^{-1} Q
   double* LinvT = ctx->mala_prep + d * d; // L^{-T}
-  double* Lc = ctx->mala_prep + 2 * d * d; // scratch copy of L (potrs may not alias its factor argument)
+  double* Lc = ctx->mala_prep + 2 * d * d; // copy of L with an explicitly zero upper triangle (potrs; the GEMM form of L'T)
   hipLaunchKernelGGL(k_scale_copy, dim3(gx(d * d)), dim3(256), 0, ctx->stream, d * d, Q, -1.0, A1);
-  hipLaunchKernelGGL(k_scale_copy, dim3(gx(d * d)), dim3(256), 0, ctx->stream, d * d, L, 1.0, Lc);
+  hipLaunchKernelGGL(k_lower_copy, dim3(gx(d * d)), dim3(256), 0, ctx->stream, d, L, Lc);
   OMC_BLAS_CHECK(rocsolver_dpotrs(h, rocblas_fill_lower, di, di, Lc, di, A1, di));
   hipLaunchKernelGGL(k_set_identity, dim3(gx(d * d)), dim3(256), 0, ctx->stream, d, LinvT);
   const double one = 1.0;
@@ -253,6 +262,7 @@ omc_status omc_mala_step(omc_ctx* ctx, int64_t d, const double* Q, const double*
   const double* A1 = ctx->mala_prep;
   const double* LinvT = ctx->mala_prep + d * d;
   const double* A1p = ctx->mala_prep + 3 * d * d;  // I + A1/2
+  const double* Lz = ctx->mala_prep + 2 * d * d;   // L, zeros above the diagonal
   rocblas_handle h = (rocblas_handle)ctx->blas;
   const rocblas_int di = (rocblas_int)d, Ci = (rocblas_int)C;
   const double one = 1.0, zero = 0.0, minus_half = -0.5;
@@ -278,10 +288,10 @@ omc_status omc_mala_step(omc_ctx* ctx, int64_t d, const double* Q, const double*
   // proposed state's mean: m' = A1p x' (+ c0, added when T3 is built)
   OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, A1p, di, w.XP, di, &zero,
                                w.V, di));
-  // |L'(x - mu)|^2, |L'(x' - mu)|^2, |L'(x - m')|^2 in one TRMM; |L'(x' - m)|^2 = |z|^2 needs none
+  // |L'(x - mu)|^2, |L'(x' - mu)|^2, |L'(x - m')|^2 in one product; |L'(x' - m)|^2 = |z|^2 needs none
   hipLaunchKernelGGL(k_build_t3, g2, b2, 0, s, d, C, x, ld_x, mu, c0, w.XP, w.V, T3);
-  OMC_BLAS_CHECK(rocblas_dtrmm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                               rocblas_diagonal_non_unit, di, 3 * Ci, &one, L, di, T3, di, N3, di));
+  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, di, 3 * Ci, di, &one, Lz, di, T3, di,
+                               &zero, N3, di));
   // accept / reject and the move of accepted proposals.  L = chol(Q / step^2) => chol(Q) = step * L
   hipLaunchKernelGGL(k_mh_finish, dim3((unsigned)C), dim3(256), 0, s, d, ctx->chain_offset,
                      omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), u_inject, sumlogL, (double)d * log(step),
@@ -315,8 +325,15 @@ omc_status omc_rw_step(omc_ctx* ctx, int64_t d, const double* mu, const double* 
   hipLaunchKernelGGL(k_draw_normals, dim3(gx((d + 1) / 2) > 8 ? 8 : gx((d + 1) / 2), (unsigned)C), b2, 0, s, d,
                      ctx->chain_offset, omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), z_inject, ld_z, Z, d);
   hipLaunchKernelGGL(k_rw_build, g2, b2, 0, s, d, C, x, ld_x, mu, step, Z, w.XP, T2);  // :250
-  OMC_BLAS_CHECK(rocblas_dtrmm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                               rocblas_diagonal_non_unit, di, 2 * Ci, &one, LQ, di, T2, di, N2, di));
+  if (ctx->rw_LQ != LQ || ctx->rw_d != d || !ctx->rw_prep) {
+    st = omc_ensure_bytes(ctx, (void**)&ctx->rw_prep, &ctx->rw_prep_bytes, (size_t)d * d * sizeof(double));
+    if (st != OMC_OK) return st;
+    hipLaunchKernelGGL(k_lower_copy, dim3(gx(d * d)), dim3(256), 0, s, d, LQ, ctx->rw_prep);
+    ctx->rw_LQ = LQ; ctx->rw_d = d;
+  }
+  const double zero = 0.0;
+  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, di, 2 * Ci, di, &one, ctx->rw_prep, di,
+                               T2, di, &zero, N2, di));
   hipLaunchKernelGGL(k_mh_finish, dim3((unsigned)C), dim3(256), 0, s, d, ctx->chain_offset,
                      omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), u_inject, sumlogLQ, 0.0, 1.0, N2, N2 + C * d,
                      (const double*)nullptr, (const double*)nullptr, w.XP, x, ld_x, (long long*)accept_count,
