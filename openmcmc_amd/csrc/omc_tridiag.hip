@@ -1180,30 +1180,33 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // ---- right-hand side -> tile; forward substitution (local affine map, scan, true pass) ----
   bool rhs_done = false;
   if constexpr (SIG == 1) {
-    if (!(A.rhs_chain && chain_ok)) {
-      {
-        const int nvr = wave_valid<M>(wave_u, (int)n);
-        const double* base = vIr + wave_u * 64 * M;
-        if (gen_z && NZB > 2) {
-          double z0, z1;
-          if (nvr == 64 * M) draws_over_load<M, true>(A.key, gc, blk0 + 2u, z0, z1, pre, base, lane, nvr);
-          else draws_over_load<M, false>(A.key, gc, blk0 + 2u, z0, z1, pre, base, lane, nvr);
-          lds_z[wave][4][lane] = z0;
-          lds_z[wave][5][lane] = z1;
-        } else {
-          coal_load<M>(pre, base, lane, nvr);
-        }
+    // per-chain offsets (rhs_chain) go through the general fill below; the draws are made ahead in either case
+    const bool with_offsets = A.rhs_chain && chain_ok;
+    if (!with_offsets) {
+      const int nvr = wave_valid<M>(wave_u, (int)n);
+      const double* base = vIr + wave_u * 64 * M;
+      if (gen_z && NZB > 2) {
+        double z0, z1;
+        if (nvr == 64 * M) draws_over_load<M, true>(A.key, gc, blk0 + 2u, z0, z1, pre, base, lane, nvr);
+        else draws_over_load<M, false>(A.key, gc, blk0 + 2u, z0, z1, pre, base, lane, nvr);
+        lds_z[wave][4][lane] = z0;
+        lds_z[wave][5][lane] = z1;
+      } else {
+        coal_load<M>(pre, base, lane, nvr);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (gen_z) {
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (gen_z) {
 #pragma unroll
-        for (int jb = 3; jb < NZB; ++jb) {
-          double z0, z1;
-          omc_normal_pair(omc_rng_block(A.key, gc, blk0 + (uint32_t)jb), z0, z1);
-          lds_z[wave][2 * jb][lane] = z0;
-          lds_z[wave][2 * jb + 1][lane] = z1;
-        }
+      for (int jb = 2; jb < NZB; ++jb) {
+        if (jb == 2 && !with_offsets) continue;  // made under the load above
+        double z0, z1;
+        omc_normal_pair(omc_rng_block(A.key, gc, blk0 + (uint32_t)jb), z0, z1);
+        lds_z[wave][2 * jb][lane] = z0;
+        lds_z[wave][2 * jb + 1][lane] = z1;
       }
+    }
+    if (!with_offsets) {
       wave_lds_fence();
 #pragma unroll
       for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = sI * pre[t];

@@ -426,11 +426,15 @@ def test_smoother_specialisation_vs_oracle(torch, n, p_first):
     eng.close()
 
 
+@pytest.mark.parametrize("with_offsets", [False, True])
 @pytest.mark.parametrize("n,C", [(4104, 5), (8191, 4), (10000, 6)])
-def test_smoother_specialisation_equals_generic(torch, n, C):
+def test_smoother_specialisation_equals_generic(torch, n, C, with_offsets):
     """In-kernel draws: the specialised instantiation makes its draws ahead of the forward pass (parked in
-    LDS) -- the stream positions must be the ones the generic instantiation uses, so x agrees to rounding."""
+    LDS) -- the stream positions must be the ones the generic instantiation uses, so x agrees to rounding.
+    With per-chain offsets the right-hand side takes the general fill; the draws must be made ahead all the same
+    (an earlier version left the later pairs ungenerated on that path)."""
     rng = np.random.default_rng(7 * n)
+    extra = rng.standard_normal((C, n))
     out = []
     for generic in (0, 1):
         eng = make_engine(C, seed=99)
@@ -438,7 +442,8 @@ def test_smoother_specialisation_equals_generic(torch, n, C):
         rs = np.random.default_rng(n)
         _, terms = _smoother_terms(eng, n, rs, C, True)
         x, quad = eng.empty(C, n), eng.empty(2, C)
-        eng.tridiag_sample_canonical(n, terms, x, z=None, draw_index=5, quad_out=quad)
+        eng.tridiag_sample_canonical(n, terms, x, z=None, draw_index=5, quad_out=quad,
+                                     rhs_chain=eng.to_device(extra) if with_offsets else None)
         eng.check_status()
         out.append((x.cpu().numpy(), quad.cpu().numpy()))
         eng.close()
@@ -468,3 +473,44 @@ def test_fused_smoother_sweeps_are_deterministic(torch):
         else:
             for a, b in zip(out, ref):
                 assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("misaligned", [False, True])
+@pytest.mark.parametrize("with_offsets", [False, True])
+@pytest.mark.parametrize("n", [4104, 10000])
+def test_smoother_fused_specialised_equals_generic(torch, n, with_offsets, misaligned):
+    """Three fused sweeps (in-kernel Normal and Gamma draws, log_post) through the specialised and the generic
+    instantiation: per-chain offsets take the general right-hand-side fill, vectors that are only 8-byte aligned
+    cannot be parked by LDS-DMA -- every such variant must leave the same chain."""
+    C = 6
+    rng = np.random.default_rng(n + 2 * int(with_offsets) + int(misaligned))
+    pd, po = rw1(n)
+    pd = pd * (1 + 0.1 * rng.random(n))
+    y = rng.standard_normal(n) + 2
+    extra = 0.3 * rng.standard_normal((C, n))
+    out = []
+    for generic in (0, 1):
+        eng = make_engine(C, seed=21)
+        eng.set_option("tridiag_generic", generic)
+
+        def dev(v):
+            if not misaligned:
+                return eng.to_device(v)
+            return eng.to_device(np.concatenate([[0.0], v]))[1:]  # data pointer = base + 8 bytes
+
+        d_pd, d_po, d_y = dev(pd), dev(po), dev(y)
+        lam, tau = eng.to_device(80 + np.arange(C) * 0.5), eng.full((C,), 1.25)
+        terms = eng.tridiag_terms([{"rhs": d_y, "center": d_y, "scale": tau}, {"diag": d_pd, "off": d_po, "scale": lam}], n)
+        logdetP, logdetI = eng.tridiag_logdet(n, d_pd, d_po), eng.zeros(1)
+        x, lp = eng.empty(C, n), eng.empty(C)
+        d_extra = eng.to_device(extra) if with_offsets else None
+        for it in range(3):
+            blocks = [{"a0": 1.0, "b0": 1.0, "n_pos": n, "logdet": logdetI},
+                      {"a0": 10.0, "b0": 1.0, "n_pos": n, "logdet": logdetP}]
+            eng.gmrf_sweep(n, terms, blocks, x, rhs_chain=d_extra, draw_index=3 * it, log_post_out=lp, gamma_draw_base=3 * it + 1)
+        eng.check_status()
+        out.append([t.cpu().numpy().copy() for t in (x, lam, tau, lp)])
+        eng.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.all(np.isfinite(a))
+        assert relerr(a, b) < 1e-10
