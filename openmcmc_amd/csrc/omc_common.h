@@ -122,6 +122,28 @@ __device__ __forceinline__ double omc_sqrt_nr(double r) {  // r > 0, normal rang
   e = fma(-s, s, r);
   return fma(e, h, s);
 }
+// fma with a constant addend (or factor) taken from a scalar register pair.  A VOP3 fp64 instruction cannot
+// carry a 64-bit literal, and for a constant addend the compiler's choice is v_fmac with the constant first
+// copied into the destination: two v_mov_b32 per polynomial coefficient (36 of the 188 vector instructions of
+// one pair of draws), i.e. vector-ALU issue slots -- what the sampling kernels are bound by -- for something
+// two s_mov_b32 on the scalar unit do beside them.
+__device__ __forceinline__ double omc_fma_vvs(double a, double b, double c_scalar) {  // a*b + c
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_scalar));
+  return d;
+}
+__device__ __forceinline__ double omc_fma_vsv(double a, double b_scalar, double c) {  // a*b + c
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_scalar), "v"(c));
+  return d;
+}
+
+__device__ __forceinline__ double omc_mul_vs(double a, double b_scalar) {  // a*b
+  double d;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(b_scalar));
+  return d;
+}
+
 // log(u), 2^-53 <= u <= 1
 __device__ __forceinline__ double omc_log_unit(double u) {
   int k = __builtin_amdgcn_frexp_exp(u);        // u = m * 2^k, m in [0.5, 1)
@@ -130,24 +152,28 @@ __device__ __forceinline__ double omc_log_unit(double u) {
   const double f = m - 1.0;
   const double s = f * omc_rcp_nr(2.0 + f);
   const double z = s * s, w = z * z;
-  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
-                                   2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double t1 = w * omc_fma_vvs(w, omc_fma_vsv(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
+                                    3.999999999940941908e-01);
+  const double t2 = z * omc_fma_vvs(w, omc_fma_vvs(w, omc_fma_vsv(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                                   2.857142874366239149e-01), 6.666666666666735130e-01);
   const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
-  return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+  return omc_mul_vs(dk, 6.93147180369123816490e-01) - ((hfsq - fma(s, hfsq + R, omc_mul_vs(dk, 1.90821492927058770002e-10))) - f);
 }
 // sin(pi a), cos(pi a) for 0 < a <= 2
 __device__ __forceinline__ void omc_sincospi02(double a, double& sn, double& cs) {
   const double n = rint(2.0 * a);               // 0..4 quarter turns
-  const double t = fma(-0.5, n, a) * 3.14159265358979311600e+00;  // |t| <= pi/4, reduction exact
+  const double t = omc_mul_vs(fma(-0.5, n, a), 3.14159265358979311600e+00);  // |t| <= pi/4, reduction exact
   const double z = t * t;
-  const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
-                                      2.75573137070700676789e-06), -1.98412698298579493134e-04),
-                        8.33333333332248946124e-03);
-  const double s0 = fma(z * t, fma(z, ps, -1.66666666666666324348e-01), t);
-  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
-                                             -2.75573143513906633035e-07), 2.48015872894767294178e-05),
-                               -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double ps = omc_fma_vvs(z, omc_fma_vvs(z, omc_fma_vvs(z, omc_fma_vsv(z, 1.58969099521155010221e-10,
+                                                                           -2.50507602534068634195e-08),
+                                                          2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                                8.33333333332248946124e-03);
+  const double s0 = fma(z * t, omc_fma_vvs(z, ps, -1.66666666666666324348e-01), t);
+  const double pc = omc_fma_vvs(z, omc_fma_vvs(z, omc_fma_vvs(z, omc_fma_vvs(z, omc_fma_vsv(z, -1.13596475577881948265e-11,
+                                                                                         2.08757232129817482790e-09),
+                                                                        -2.75573143513906633035e-07),
+                                                          2.48015872894767294178e-05), -1.38888888888741095749e-03),
+                                4.16666666666666019037e-02);
   const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
   const int q = (int)n & 3;
   const double sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;
