@@ -10,6 +10,8 @@
 #include "omc_common.h"
 #include "omc_truncnorm.h"
 
+omc_status omc_ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need);  // omc_dense.hip
+
 static inline unsigned grid1(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
 // a*b + c with the product rounded first (no FMA contraction): what numpy's `mu + z * step` computes
@@ -174,9 +176,17 @@ __global__ void k_design_predict_batched(int64_t C, int64_t n, int64_t kmax, con
   const double* Bc = B + c * kmax * n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double s = 0.0;
-    for (int64_t j = 0; j < kmax; ++j) {
-      const double bj = coef[c * kmax + j];  // wave-uniform
-      if (bj != 0.0) s = fma(Bc[j * n + i], bj, s);
+    // eight columns at a time: the coefficients first (wave-uniform), then the loads of the live columns issued
+    // together, then the sums in column order (a test-and-load per column serialises the memory latencies)
+    for (int64_t j0 = 0; j0 < kmax; j0 += 8) {
+      double cf[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cf[u] = (j0 + u < kmax) ? coef[c * kmax + j0 + u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bv[u] = (cf[u] != 0.0) ? Bc[(j0 + u) * n + i] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (cf[u] != 0.0) s = fma(bv[u], cf[u], s);
     }
     double v = alpha * s + (add_chain ? add_chain[c * n + i] : 0.0) + (add_shared ? add_shared[i] : 0.0);
     if (chain_scale) v *= chain_scale[c];
@@ -209,11 +219,20 @@ __global__ void k_gaussian_basis(int64_t C, int64_t n, int64_t kmax, const doubl
 // (pair (a <= b), row slice): with few live columns the 256 threads split the rows of a tile between them
 // and the slices are summed in a fixed order at the end, so the result does not depend on scheduling.
 #define GRAM_TR 128
+// With blockIdx.y > 1 the rows are cut into gridDim.y contiguous parts, one workgroup each (one workgroup per chain
+// walks 40 tiles of 128 rows behind two barriers each and hides no memory latency: 258 us at cfg5); a part writes
+// its sums to gram[(c * parts + part) * kmax^2 ...] / rhs[(c * parts + part) * kmax ...] and k_gram_reduce adds the
+// parts in order.
 __global__ void __launch_bounds__(256) k_design_gram_batched(int64_t n, int64_t kmax, const double* B, const double* w,
                                                              const double* resid_shared, const double* resid_chain,
                                                              const double* count, double* gram, double* rhs) {
   extern __shared__ double tile[];  // (kmax + 1) x (GRAM_TR + 1) columns + residual, then weights[GRAM_TR]
   const int64_t c = blockIdx.x;
+  const int64_t parts = gridDim.y, part = blockIdx.y;
+  const int64_t rows_per = ((n + parts - 1) / parts + GRAM_TR - 1) / GRAM_TR * GRAM_TR;  // whole tiles
+  const int64_t row_lo = part * rows_per, row_hi = (row_lo + rows_per < n) ? row_lo + rows_per : n;
+  gram += (c * parts + part) * kmax * kmax - c * kmax * kmax;  // the indexing below adds c * kmax^2
+  if (rhs) rhs += (c * parts + part) * kmax - c * kmax;
   const double* Bc = B + c * kmax * n;
   const int k = count ? (int)count[c] : (int)kmax;   // live columns
   const int K1 = k + 1;                              // + residual
@@ -235,8 +254,8 @@ __global__ void __launch_bounds__(256) k_design_gram_batched(int64_t n, int64_t 
   }
   for (int t = threadIdx.x; t < kmax * kmax; t += 256) gram[c * kmax * kmax + t] = 0.0;
   if (rhs) for (int t = threadIdx.x; t < kmax; t += 256) rhs[c * kmax + t] = 0.0;
-  for (int64_t i0 = 0; i0 < n; i0 += GRAM_TR) {
-    const int len = (int)((n - i0 < GRAM_TR) ? n - i0 : GRAM_TR);
+  for (int64_t i0 = row_lo; i0 < row_hi; i0 += GRAM_TR) {
+    const int len = (int)((row_hi - i0 < GRAM_TR) ? row_hi - i0 : GRAM_TR);
     for (int t = threadIdx.x; t < K1 * GRAM_TR; t += 256) {
       const int col = t / GRAM_TR, i = t % GRAM_TR;
       double v = 0.0;
@@ -279,6 +298,16 @@ __global__ void __launch_bounds__(256) k_design_gram_batched(int64_t n, int64_t 
       rhs[c * kmax + a] = acc[q];
     }
   }
+}
+
+// out[c][t] = sum over the parts, in order (deterministic)
+__global__ void k_gram_reduce(int64_t C, int64_t len, int parts, const double* in, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * len) return;
+  const int64_t c = i / len, t = i - c * len;
+  double s = 0.0;
+  for (int p = 0; p < parts; ++p) s += in[(c * parts + p) * len + t];
+  out[i] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -616,8 +645,30 @@ omc_status omc_design_gram_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const 
   if (!ctx || n < 1 || kmax < 1 || kmax > 36 || !B || !gram) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   const size_t lds = (size_t)((kmax + 1) * (GRAM_TR + 1) + GRAM_TR) * sizeof(double);
-  hipLaunchKernelGGL(k_design_gram_batched, dim3((unsigned)ctx->n_chains), dim3(256), lds, ctx->stream, n, kmax, B, w,
-                     resid_shared, resid_chain, count, gram, rhs);
+  const int64_t C = ctx->n_chains;
+  // rows in parts of >= 4 tiles, enough parts to put ~8 workgroups on every CU, at most 16
+  int64_t parts = (n / (4 * GRAM_TR));
+  const int64_t want = (8 * 256 + C - 1) / C;
+  if (parts > want) parts = want;
+  if (parts > 16) parts = 16;
+  if (parts < 2) {
+    hipLaunchKernelGGL(k_design_gram_batched, dim3((unsigned)C), dim3(256), lds, ctx->stream, n, kmax, B, w, resid_shared,
+                       resid_chain, count, gram, rhs);
+  } else {
+    const size_t per = (size_t)(kmax * kmax + kmax);
+    omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->mh_work, &ctx->mh_work_bytes, (size_t)C * parts * per * sizeof(double));
+    if (st != OMC_OK) return st;
+    double* gp = ctx->mh_work;
+    double* rp = rhs ? gp + (size_t)C * parts * kmax * kmax : nullptr;
+    hipLaunchKernelGGL(k_design_gram_batched, dim3((unsigned)C, (unsigned)parts), dim3(256), lds, ctx->stream, n, kmax, B, w,
+                       resid_shared, resid_chain, count, gp, rp);
+    const int64_t lg = kmax * kmax;
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((C * lg + 255) / 256)), dim3(256), 0, ctx->stream, C, lg, (int)parts, gp,
+                       gram);
+    if (rhs)
+      hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((C * kmax + 255) / 256)), dim3(256), 0, ctx->stream, C, kmax, (int)parts,
+                         rp, rhs);
+  }
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }
