@@ -759,7 +759,13 @@ __device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wa
   wave_lds_fence();
 }
 
-__device__ __forceinline__ double fast_sqrt(double r) { return omc_sqrt_nr(r); }
+// sqrt(1/D) that scales a standard-normal draw: one Newton step on v_rsq_f64 (4e-15 relative, measured in
+// benchmarks/micro/rcp_acc.hip) -- the draw's own scale, nothing downstream amplifies it
+__device__ __forceinline__ double fast_sqrt(double r) {
+  const double g = __builtin_amdgcn_rsq(r);
+  const double s = r * g;
+  return fma(fma(-s, s, r), 0.5 * g, s);
+}
 
 // diagnostic phase stamps (guide section 7, in-kernel stamps): lane 0 of every wave, only when enabled
 #define OMC_STAMP(k)                                                                                  \
