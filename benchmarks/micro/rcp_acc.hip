@@ -11,6 +11,7 @@ __global__ void k(const double* x, double* out, int n) {
   double r1 = fma(r, e, r);
   e = fma(-d, r1, 1.0);
   double r2 = fma(r1, e, r1);
+  { double e0 = fma(-d, r, 1.0); r2 = fma(r, fma(e0, e0, e0), r); }  // the three-operation form the library uses
   double g = __builtin_amdgcn_rsq(d);
   double s = d * g, h = 0.5 * g;
   double ee = fma(-s, s, d);

@@ -107,11 +107,11 @@ __device__ __forceinline__ double omc_u53(uint32_t lo, uint32_t hi) {
 // (u in (0,1], angle in (0,2]); these restate the classic fdlibm kernels (e_log.c, k_sin.c,
 // k_cos.c: argument reduction + minimax polynomial, < 1 ulp) for exactly those domains.
 __device__ __forceinline__ double omc_rcp_nr(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  double e = fma(-d, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-d, r, 1.0);
-  return fma(r, e, r);
+  // v_rcp_f64 is good to 4.6e-8; r (1 + e + e^2) with e = 1 - d r leaves e^3 ~ 1e-22 and one rounding (three
+  // operations where two Newton steps take four)
+  const double r = __builtin_amdgcn_rcp(d);
+  const double e = fma(-d, r, 1.0);
+  return fma(r, fma(e, e, e), r);
 }
 __device__ __forceinline__ double omc_sqrt_nr(double r) {  // r > 0, normal range
   const double g = __builtin_amdgcn_rsq(r);
