@@ -376,10 +376,17 @@ omc_status omc_gaussian_basis(omc_ctx* ctx, int64_t n, int64_t kmax, const doubl
  *   omc_design_gram_batched:    gram[c] = B_c' diag(w) B_c (kmax x kmax, row-major),
  *     rhs[c] = B_c' diag(w) (resid_shared - resid_chain[c])   (location_scale.py:238-241, sampler.py:192);
  *     w [n] shared or NULL = ones; resid_* / rhs may be NULL; count [C] (NULL = kmax): only the leading count[c]
- *     columns are live, the rest of gram / rhs is written as 0.  kmax <= 36.                                 */
+ *     columns are live, the rest of gram / rhs is written as 0.  kmax <= 36.
+ *   omc_design_resid_sq_batched: out[c] = sum_i w[i] (y[i] - (B_c coef_c + add_chain[c] + add_shared)[i])^2, the
+ *     quadratic form of Normal.log_p for a regression on a per-chain basis (gmrf.py:343-344 on the residual of
+ *     parameter.py:162-197) without materialising the fitted values; y [n] shared; w, add_chain, add_shared may be
+ *     NULL.  Rows are summed in a fixed order (parts, then an ordered sum of the parts).                        */
 omc_status omc_design_predict_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* coef,
                                       const double* add_chain, const double* add_shared, double alpha,
                                       const double* chain_scale, double* out);
+omc_status omc_design_resid_sq_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* coef,
+                                       const double* add_chain, const double* add_shared, const double* y,
+                                       const double* w, double* out);
 omc_status omc_design_gram_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* w,
                                    const double* resid_shared, const double* resid_chain, const double* count,
                                    double* gram, double* rhs);

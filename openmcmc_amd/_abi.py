@@ -137,6 +137,7 @@ SIGNATURES = {
     "omc_ragged_resize": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, i64]),
     "omc_gaussian_basis": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, C.c_double, c_dp, i64, c_dp]),
     "omc_design_predict_batched": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, C.c_double, c_dp, c_dp]),
+    "omc_design_resid_sq_batched": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "omc_design_gram_batched": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "omc_small_sample_canonical": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, u64, c_dp, c_dp]),
     "omc_rj_matched_transition": (

@@ -224,6 +224,57 @@ __global__ void k_design_predict_batched2(int64_t C, int64_t n, int64_t kmax, co
   }
 }
 
+// part[c][blockIdx.x] = sum over this workgroup's rows of w (y - B coef - add_chain - add_shared)^2: the quadratic form
+// of the regression likelihood straight from the basis (the fitted values are neither written nor read back).  A
+// workgroup owns rows blockIdx.x * 256 * RS_ROWS ...; the 256 partial sums are folded in a fixed tree.
+#define RS_ROWS 4
+__global__ void __launch_bounds__(256) k_design_resid_sq(int64_t n, int64_t kmax, const double* B, const double* coef,
+                                                         const double* add_chain, const double* add_shared, const double* y,
+                                                         const double* w, double* part) {
+  __shared__ double red[256];
+  const int64_t c = blockIdx.y;
+  const double* Bc = B + c * kmax * n;
+  const int64_t base = (int64_t)blockIdx.x * 256 * RS_ROWS + threadIdx.x;
+  double s[RS_ROWS];
+#pragma unroll
+  for (int q = 0; q < RS_ROWS; ++q) s[q] = 0.0;
+  for (int64_t j0 = 0; j0 < kmax; j0 += 4) {
+    double cf[4], bv[4][RS_ROWS];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cf[u] = (j0 + u < kmax) ? coef[c * kmax + j0 + u] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < RS_ROWS; ++q) {
+        const int64_t i = base + q * 256;
+        bv[u][q] = (cf[u] != 0.0 && i < n) ? Bc[(j0 + u) * n + i] : 0.0;
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (cf[u] != 0.0) {
+#pragma unroll
+        for (int q = 0; q < RS_ROWS; ++q) s[q] = fma(bv[u][q], cf[u], s[q]);
+      }
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int q = 0; q < RS_ROWS; ++q) {
+    const int64_t i = base + q * 256;
+    if (i < n) {
+      const double f = s[q] + (add_chain ? add_chain[c * n + i] : 0.0) + (add_shared ? add_shared[i] : 0.0);
+      const double r = y[i] - f;
+      acc = fma((w ? w[i] : 1.0) * r, r, acc);
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[c * gridDim.x + blockIdx.x] = red[0];
+}
+
 // Gaussian-kernel basis B[c][j][i] = phi((X_i - knot_cj) / scale_cj) / scale_cj for the live knots, zero beyond;
 // column >= 0 rewrites only that column (a random-walk move of one knot)
 __global__ void k_gaussian_basis(int64_t C, int64_t n, int64_t kmax, const double* X, const double* knots,
@@ -673,6 +724,24 @@ omc_status omc_design_predict_batched(omc_ctx* ctx, int64_t n, int64_t kmax, con
     hipLaunchKernelGGL(k_design_predict_batched, dim3(gx, (unsigned)ctx->n_chains), dim3(256), 0, ctx->stream,
                        ctx->n_chains, n, kmax, B, coef, add_chain, add_shared, alpha, chain_scale, out);
   }
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_design_resid_sq_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* coef,
+                                       const double* add_chain, const double* add_shared, const double* y,
+                                       const double* w, double* out) {
+  if (!ctx || n < 1 || kmax < 1 || !B || !coef || !y || !out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  const int64_t C = ctx->n_chains;
+  const int64_t parts = (n + 256 * RS_ROWS - 1) / (256 * RS_ROWS);
+  if (parts > 65535) return OMC_UNSUPPORTED;
+  omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->mh_work, &ctx->mh_work_bytes, (size_t)C * parts * sizeof(double));
+  if (st != OMC_OK) return st;
+  hipLaunchKernelGGL(k_design_resid_sq, dim3((unsigned)parts, (unsigned)C), dim3(256), 0, ctx->stream, n, kmax, B, coef,
+                     add_chain, add_shared, y, w, ctx->mh_work);
+  hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, ctx->stream, C, (int64_t)1, (int)parts,
+                     ctx->mh_work, out);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

@@ -191,8 +191,11 @@ class Normal(Distribution):
                 raise NotImplementedError("regression residual needs a diagonal response precision")
             if resp.shape[1] != 1:
                 raise NotImplementedError("replicated responses")
-            fitted = self.mean.predictor_device(state, engine)
             w = None if st.diag is None else engine.shared(st.diag)
+            quad = self.mean.resid_sq_device(state, engine, engine.shared(resp).reshape(-1), w)
+            if quad is not None:
+                return quad
+            fitted = self.mean.predictor_device(state, engine)
             quad = engine.empty(engine.n_chains)
             engine.weighted_resid_sq(engine.shared(resp).reshape(-1), fitted, quad, w=w)
             return quad

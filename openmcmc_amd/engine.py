@@ -596,6 +596,17 @@ class Engine:
                                              self._chain_scalar(chain_scale), self._p(out)))
         return out
 
+    def design_resid_sq_batched(self, B, coef, y, add_chain=None, add_shared=None, w=None, out=None):
+        """out[c] = sum_i w_i (y_i - (B_c coef_c + add_chain[c] + add_shared)_i)^2 without the fitted values in memory."""
+        Cn, kmax, n = B.shape
+        if not B.is_contiguous():
+            raise ValueError("B must be a contiguous (C, kmax, n) tensor")
+        out = self.empty(Cn) if out is None else out
+        check(lib.omc_design_resid_sq_batched(self._ctx, n, kmax, self._p(B.view(Cn, -1)), self._p(coef, Cn, kmax),
+                                              self._p(add_chain), self._vec(add_shared, n), self._vec(y, n),
+                                              self._vec(w, n), self._chain_scalar(out)))
+        return out
+
     def design_gram_batched(self, B, w=None, resid_shared=None, resid_chain=None, count=None):
         """(gram (C, kmax, kmax), rhs (C, kmax) or None) = (B_c' W B_c, B_c' W (resid_shared - resid_chain[c]));
         count (C,): only the leading count[c] columns of chain c are live (the rest of the outputs is 0)."""

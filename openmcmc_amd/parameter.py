@@ -129,6 +129,31 @@ class LinearCombination(Parameter):
             fitted = out
         return fitted
 
+    def resid_sq_device(self, state: dict, engine, y, w=None):
+        """(C,) tensor sum_i w_i (y_i - f_i)^2 for f = predictor, in one pass over the basis without the fitted
+        values in memory -- what the acceptance ratio of a knot move needs of a regression likelihood.  Only for the
+        form predictor_device evaluates in one launch (one per-chain design matrix, at most one per-chain offset,
+        shared terms); None otherwise."""
+        host_sum, ident, batched = 0, [], []
+        for prm, prefactor in self.form.items():
+            A, v = state[prefactor], state[prm]
+            if is_chain(A):
+                if not is_chain(v) or v.shape[1] != 1:
+                    return None
+                batched.append((A, v))
+            elif not is_chain(v):
+                host_sum = host_sum + A @ v
+            elif v.shape[1] == 1 and _is_identity(A, v.shape[0]):
+                ident.append(v.vector())
+            else:
+                return None
+        if len(batched) != 1 or len(ident) > 1:
+            return None
+        shared = None if isinstance(host_sum, int) else engine.to_device(np.asarray(host_sum, dtype=np.float64).reshape(-1))
+        B, v = batched[0]
+        return engine.design_resid_sq_batched(B.columns(), v.vector(), y, add_chain=ident[0] if ident else None,
+                                              add_shared=shared, w=w)
+
     def has_chain_terms(self, state: dict, exclude=None) -> bool:
         """Is any term other than `exclude` per chain (a per-chain offset in the response mean)?"""
         skip = [] if exclude is None else ([exclude] if isinstance(exclude, str) else list(exclude))

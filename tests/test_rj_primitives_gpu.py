@@ -432,3 +432,29 @@ def test_ragged_log_densities():
     assert np.array_equal(got, exp)
     eng.check_status()
     eng.close()
+
+
+def test_design_resid_sq_matches_predict_then_residual():
+    """omc_design_resid_sq_batched = the regression quadratic form without the fitted values in memory: against
+    omc_design_predict_batched + omc_weighted_resid_sq and against numpy, ragged live columns, optional terms."""
+    from openmcmc_amd.engine import Engine
+
+    rng = np.random.default_rng(5)
+    C, kmax, n = 7, 9, 2500
+    eng = Engine(C, seed=1)
+    B = rng.standard_normal((C, kmax, n))
+    coef = rng.standard_normal((C, kmax))
+    for c in range(C):
+        coef[c, rng.integers(1, kmax + 1):] = 0.0  # dead columns carry zero coefficients
+    y, off, sh, w = rng.standard_normal(n), rng.standard_normal((C, n)), rng.standard_normal(n), 0.5 + rng.random(n)
+    dB, dc, dy, doff, dsh, dw = (eng.to_device(v) for v in (B, coef, y, off, sh, w))
+    for add_chain, add_shared, ww in ((None, None, None), (doff, None, dw), (doff, dsh, dw), (None, dsh, None)):
+        got = eng.design_resid_sq_batched(dB, dc, dy, add_chain=add_chain, add_shared=add_shared, w=ww).cpu().numpy()
+        fitted = eng.design_predict_batched(dB, dc, add_chain=add_chain, add_shared=add_shared)
+        two_step = eng.empty(C)
+        eng.weighted_resid_sq(dy, fitted, two_step, w=ww)
+        f = np.einsum("ckn,ck->cn", B, coef) + (off if add_chain is not None else 0.0) + (sh if add_shared is not None else 0.0)
+        ref = (((y - f) ** 2) * (w if ww is not None else 1.0)).sum(axis=1)
+        assert np.max(np.abs(got - ref) / ref) < 1e-12
+        assert np.max(np.abs(got - two_step.cpu().numpy()) / ref) < 1e-12
+    eng.close()
