@@ -234,7 +234,13 @@ __global__ void __launch_bounds__(256) k_design_resid_sq(int64_t n, int64_t kmax
   __shared__ double red[256];
   const int64_t c = blockIdx.y;
   const double* Bc = B + c * kmax * n;
-  const int64_t base = (int64_t)blockIdx.x * 256 * RS_ROWS + threadIdx.x;
+  // gridDim.x == 1: this workgroup walks all row blocks itself and writes the chain's sum (no second launch: with
+  // many chains there are enough workgroups anyway, and the sweeps that use this are bound by the launch rate)
+  const int64_t n_blocks = (n + 256 * RS_ROWS - 1) / (256 * RS_ROWS);
+  const int64_t blk_lo = gridDim.x == 1 ? 0 : blockIdx.x, blk_hi = gridDim.x == 1 ? n_blocks : blockIdx.x + 1;
+  double acc = 0.0;
+  for (int64_t blk = blk_lo; blk < blk_hi; ++blk) {
+  const int64_t base = blk * 256 * RS_ROWS + threadIdx.x;
   double s[RS_ROWS];
 #pragma unroll
   for (int q = 0; q < RS_ROWS; ++q) s[q] = 0.0;
@@ -256,7 +262,6 @@ __global__ void __launch_bounds__(256) k_design_resid_sq(int64_t n, int64_t kmax
         for (int q = 0; q < RS_ROWS; ++q) s[q] = fma(bv[u][q], cf[u], s[q]);
       }
   }
-  double acc = 0.0;
 #pragma unroll
   for (int q = 0; q < RS_ROWS; ++q) {
     const int64_t i = base + q * 256;
@@ -266,6 +271,7 @@ __global__ void __launch_bounds__(256) k_design_resid_sq(int64_t n, int64_t kmax
       acc = fma((w ? w[i] : 1.0) * r, r, acc);
     }
   }
+  }  // row blocks
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int d = 128; d >= 1; d >>= 1) {
@@ -736,6 +742,12 @@ omc_status omc_design_resid_sq_batched(omc_ctx* ctx, int64_t n, int64_t kmax, co
   const int64_t C = ctx->n_chains;
   const int64_t parts = (n + 256 * RS_ROWS - 1) / (256 * RS_ROWS);
   if (parts > 65535) return OMC_UNSUPPORTED;
+  if (parts == 1 || C >= 512) {  // one workgroup per chain, straight into out[c]
+    hipLaunchKernelGGL(k_design_resid_sq, dim3(1u, (unsigned)C), dim3(256), 0, ctx->stream, n, kmax, B, coef, add_chain,
+                       add_shared, y, w, out);
+    OMC_HIP_CHECK(hipGetLastError());
+    return OMC_OK;
+  }
   omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->mh_work, &ctx->mh_work_bytes, (size_t)C * parts * sizeof(double));
   if (st != OMC_OK) return st;
   hipLaunchKernelGGL(k_design_resid_sq, dim3((unsigned)parts, (unsigned)C), dim3(256), 0, ctx->stream, n, kmax, B, coef,

@@ -434,13 +434,14 @@ def test_ragged_log_densities():
     eng.close()
 
 
-def test_design_resid_sq_matches_predict_then_residual():
+@pytest.mark.parametrize("n", [700, 2500])  # one row block (single launch) and several (parts + ordered sum)
+def test_design_resid_sq_matches_predict_then_residual(n):
     """omc_design_resid_sq_batched = the regression quadratic form without the fitted values in memory: against
     omc_design_predict_batched + omc_weighted_resid_sq and against numpy, ragged live columns, optional terms."""
     from openmcmc_amd.engine import Engine
 
     rng = np.random.default_rng(5)
-    C, kmax, n = 7, 9, 2500
+    C, kmax = 7, 9
     eng = Engine(C, seed=1)
     B = rng.standard_normal((C, kmax, n))
     coef = rng.standard_normal((C, kmax))
