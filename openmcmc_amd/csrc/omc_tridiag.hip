@@ -1392,6 +1392,15 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           for (int t = 0; t < M; ++t)
             if (lane + 64 * t < nv) xo[(unsigned)(lane + 64 * t)] = *TM::elem(tl, r0, t);
         }
+      } else if (nv == 64 * M && park_diag) {  // the diagonal part is in aPd already
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+          const double* pe = TM::elem(tl, r0, t);
+          const double xv = *pe, xn = *TM::succ(pe, r0, t), a = xv - qc[t];
+          aI = fma(a, a, aI);
+          aP = fma(2.0 * qo[t] * xn, xv, aP);
+          if (xo) xo[(unsigned)(lane + 64 * t)] = xv;
+        }
       } else if (nv == 64 * M) {
 #pragma unroll
         for (int t = 0; t < M; ++t) {
