@@ -1,6 +1,10 @@
 """Headline benchmark: chain-updates/sec on the GMRF smoother (BASELINE.json configs[2]).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 the ranks are one process per GPU under torch.distributed.run (RCCL); started directly with
+--gpus N > 1 (no WORLD_SIZE in the environment) the script launches that itself as a child process, before
+anything has touched the GPU, and exits with the child's code.
 
 Workload: 10 000 latent nodes, RW1 prior precision lambda*P, Gaussian
 likelihood tau*I, samplers [NormalNormal(b), NormalGamma(lambda), NormalGamma(tau)], 1024 chains
@@ -8,9 +12,11 @@ per GPU.  One step = one full sweep of all samplers for every chain plus the per
 bookkeeping of MCMC.run_mcmc (store of b/lambda/tau and log_post, mcmc.py:105-108); draws come
 from the in-kernel Philox stream; all inputs are resident in HBM before the timed region.
 
-Chains are independent, so ranks share nothing during sampling ("weak" scaling: every GPU runs
-1024 chains); the only collective is the gather of the small per-chain traces at the end,
-outside the timed region.
+Chains are independent, so ranks share nothing during sampling; the only collective is the gather of
+the per-chain traces and stores at the end, outside the timed region.  --scaling weak (default, the
+headline `value`): every GPU runs 1024 chains.  --scaling strong: 1024 chains in all, sharded evenly
+(BASELINE.md section 3).  For N > 1 the default run measures the other mode as well, after the headline,
+and reports it in the same JSON line (`other_scaling`).
 """
 
 import argparse
@@ -168,7 +174,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU (weak) / in all (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --chains per GPU; strong: --chains in all, sharded evenly over the GPUs")
+    ap.add_argument("--one-mode", action="store_true", help="N > 1: do not measure the other scaling mode as well")
+    ap.add_argument("--repeat-ms", type=float, default=250.0,
+                    help="after the headline, repeat the K-step run until this much time has been measured (spread report)")
     ap.add_argument("--nodes", type=int, default=N_NODES)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -180,13 +191,26 @@ def main():
     ap.add_argument("--seg", type=int, default=0, help="nodes per lane of the segmented kernel (0 = auto)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started directly: become the launcher.  Nothing has touched the GPU yet (torch is not even imported), and
+        # the ranks are CHILD processes -- never an exec from a process that holds the GPU.
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("OMC_BENCH_BACKEND", "nccl") != "nccl":
         local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
@@ -203,89 +227,128 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    n, C = args.nodes, args.chains
-    n_store = max(1, min(args.steps, STORE_SLABS_MAX))
-    sweep = GmrfSweep(n, C, seed=2025, chain_offset=rank * C, device=local, n_store=n_store,
-                      fused=not args.unfused, seg=args.seg)
-    if args.zero_z:
-        sweep.eng.set_option("debug_zero_z", 1)
-    if args.generic:
-        sweep.eng.set_option("tridiag_generic", 1)
-    stamps = None
-    if args.stamps:
-        stamps = torch.zeros(C * 16 * 16, dtype=torch.int64, device="cuda")
-        sweep.eng.set_option("stamps_ptr", stamps.data_ptr())
-
-    c_loop = not (args.python_loop or args.unfused)
-    if c_loop:
-        sweep.run_fused(args.warmup)
-    else:
-        for _ in range(args.warmup):
-            sweep.step()
-    sweep.eng.check_status()
-
-    use_ev = not args.no_kernel_events
-    n_ev = 1 if c_loop else args.steps
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)] if use_ev else None
+    n = args.nodes
+    on_gpu = dist is None or dist.get_backend() == "nccl"
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if c_loop:  # one library call issues all K launches; the events bracket them on the launch stream
-        if use_ev:
-            events[0][0].record()
-        sweep.run_fused(args.steps)
-        if use_ev:
-            events[0][1].record()
-    else:
-        for i in range(args.steps):
-            sweep.step(events[i] if use_ev else None)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    sweep.eng.check_status()
+    def shard(mode):
+        """(chains of this rank, global id of its first chain) -- contiguous blocks; strong: as even as it goes"""
+        if mode == "weak":
+            return args.chains, rank * args.chains
+        base, extra = divmod(args.chains, world)
+        return base + (1 if rank < extra else 0), rank * base + min(rank, extra)
 
-    on_gpu = dist is None or dist.get_backend() == "nccl"
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+    def measure(mode, diagnostics=False):
+        """One measurement in the driver's contract: W untimed warm-up steps, then exactly K steps between
+        barrier + synchronize on both sides, MAX over ranks; then the same K-step run repeated (untimed in the
+        headline) for the spread."""
+        C, offset = shard(mode)
+        n_store = max(1, min(args.steps, STORE_SLABS_MAX))
+        sweep = GmrfSweep(n, C, seed=2025, chain_offset=offset, device=local, n_store=n_store,
+                          fused=not args.unfused, seg=args.seg)
+        if args.zero_z:
+            sweep.eng.set_option("debug_zero_z", 1)
+        if args.generic:
+            sweep.eng.set_option("tridiag_generic", 1)
+        stamps = None
+        if diagnostics and args.stamps:
+            stamps = torch.zeros(C * 16 * 16, dtype=torch.int64, device="cuda")
+            sweep.eng.set_option("stamps_ptr", stamps.data_ptr())
+        c_loop = not (args.python_loop or args.unfused)
+
+        def run_k(events):
+            if c_loop:  # one library call issues all K launches; the events bracket them on the launch stream
+                if events:
+                    events[0][0].record()
+                sweep.run_fused(args.steps)
+                if events:
+                    events[0][1].record()
+            else:
+                for i in range(args.steps):
+                    sweep.step(events[i] if events else None)
+
+        if c_loop:
+            sweep.run_fused(args.warmup)
+        else:
+            for _ in range(args.warmup):
+                sweep.step()
+        sweep.eng.check_status()
+
+        use_ev = not args.no_kernel_events
+        n_ev = 1 if c_loop else args.steps
+
+        def new_events():
+            return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)] if use_ev else None
+
+        def timed():
+            ev = new_events()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_k(ev)
+            torch.cuda.synchronize()
+            barrier()
+            dt = time.perf_counter() - t0
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+            if dist is not None:
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            kern = float(np.sum([a.elapsed_time(b) for a, b in ev])) / args.steps if use_ev else None
+            return tmax.item(), kern
+
+        dt, kern_ms = timed()
+        sweep.eng.check_status()
+        # spread: the same K-step run again (every rank the same count: the loop bound comes from rank-agreed dt)
+        reps = int(min(20, max(0, np.ceil(args.repeat_ms * 1e-3 / max(dt, 1e-6)) - 1))) if not (diagnostics and args.stamps) else 0
+        rep_ms, rep_kern = [1e3 * dt / args.steps], [kern_ms]
+        for _ in range(reps):
+            d, k = timed()
+            rep_ms.append(1e3 * d / args.steps)
+            rep_kern.append(k)
+        sweep.eng.check_status()
+        spread = {"runs": len(rep_ms), "ms_per_step_min": min(rep_ms), "ms_per_step_median": float(np.median(rep_ms)),
+                  "ms_per_step_max": max(rep_ms)}
+        if use_ev:
+            spread.update(kernel_ms_min=min(rep_kern), kernel_ms_median=float(np.median(rep_kern)), kernel_ms_max=max(rep_kern))
+        return {"mode": mode, "C": C, "dt": dt, "kern_ms": kern_ms, "sweep": sweep, "stamps": stamps, "spread": spread,
+                "n_store": n_store}
+
+    m = measure(args.scaling, diagnostics=True)
+    sweep, C, dt, n_store, stamps = m["sweep"], m["C"], m["dt"], m["n_store"], m["stamps"]
 
     # the one collective of the path: gather of the per-chain traces (outside the timed region)
     trace = torch.stack([sweep.store_lam[: min(args.steps, n_store)], sweep.store_tau[: min(args.steps, n_store)]])
     if not on_gpu:
         trace = trace.cpu()
     if dist is not None:
-        gathered = [torch.empty_like(trace) for _ in range(world)] if rank == 0 else None
-        dist.gather(trace, gathered, dst=0)
-        if rank == 0:
-            trace = torch.cat(gathered, dim=2)
-    lam_mean = trace[0].mean().item()
+        from openmcmc_amd.parallel import gather_chains
+
+        trace = gather_chains(trace, chain_dim=2, dst=0)
+    lam_mean = trace[0].mean().item() if rank == 0 else None
 
     # ... and of the sample store itself: timed on a bounded part (the last <= 8 stored iterations of b,
-    # 82 MB each per rank) so the run stays short; reported next to the headline, never inside it
+    # 82 MB each per rank at 1024 chains) so the run stays short; reported next to the headline, never inside it
     gather_info = None
     if dist is not None:
         try:
+            from openmcmc_amd.parallel import gather_chains
+
             k_it = min(8, n_store)
             part = sweep.store_b[:k_it].contiguous()
             if not on_gpu:
                 part = part.cpu()
-            bucket = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
             barrier()
             torch.cuda.synchronize()
             tg = time.perf_counter()
-            dist.gather(part, bucket, dst=0)
+            full = gather_chains(part, chain_dim=1, dst=0)
             torch.cuda.synchronize()
             tg = time.perf_counter() - tg
-            nbytes = part.numel() * 8 * (world - 1)
+            nbytes = (full.numel() - part.numel()) * 8 if rank == 0 else 0
             gather_info = {"iterations": k_it, "bytes_into_root": nbytes, "ms": 1e3 * tg,
                            "GBps_into_root": nbytes / tg / 1e9}
-            del bucket
+            del full
         except Exception as exc:  # the headline must survive a collective problem
             gather_info = {"error": repr(exc)}
 
@@ -300,22 +363,36 @@ def main():
         for i, nm in enumerate(names):
             print(f"  {nm:16s} mean {100 * d[:, :, i].mean() / tot:6.2f}   wave0 {100 * d[:, 0, i].mean() / tot:6.2f}   last {100 * d[:, -1, i].mean() / tot:6.2f}", file=sys.stderr)
         print(f"  wave lifetime {tot:.0f} ticks; block span {(st[:, :nwv, 15].max(1) - st[:, :nwv, 0].min(1)).mean():.0f} ticks", file=sys.stderr)
+
+    # N > 1: the other scaling mode as well (a second, separate measurement after the headline)
+    other = None
+    if world > 1 and not args.one_mode and not args.stamps:
+        del sweep
+        m["sweep"] = None
+        torch.cuda.empty_cache()
+        o = measure("strong" if args.scaling == "weak" else "weak")
+        tot_o = args.chains * world if o["mode"] == "weak" else args.chains
+        other = {"scaling": o["mode"], "chains_total": tot_o, "chains_this_rank": o["C"],
+                 "value": tot_o * args.steps / o["dt"], "unit": "chain-updates/s", "ms_per_step": 1e3 * o["dt"] / args.steps,
+                 "kernel_ms": o["kern_ms"], "repeats": o["spread"]}
+        o["sweep"] = None
+
     if rank == 0:
-        kern_ms = None
-        if use_ev:
-            kern_ms = float(np.sum([a.elapsed_time(b) for a, b in events])) / args.steps
-        total_chains = C * world
+        kern_ms = m["kern_ms"]
+        total_chains = args.chains * world if args.scaling == "weak" else args.chains
         value = total_chains * args.steps / dt
         out = {
             "metric": "chain-updates/sec (1024 chains, 10k-node GMRF) at 1/2/4/8 GPUs vs CPU ref",
             "value": value, "unit": "chain-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"GMRF smoother (examples/4): {n} nodes, RW1 precision, {C} chains per GPU, "
-                                   "NormalNormal + 2x NormalGamma + store + log_post per step"
+            "config": {"workload": f"GMRF smoother (examples/4): {n} nodes, RW1 precision, "
+                                   + (f"{args.chains} chains per GPU, " if args.scaling == "weak" else f"{args.chains} chains in all, sharded evenly, ")
+                                   + "NormalNormal + 2x NormalGamma + store + log_post per step"
                                    + (" (one fused launch)" if not args.unfused else " (one launch per sampler)"),
-                       "chains_total": total_chains, "nodes": n, "parallelism": f"chains sharded x{world}",
-                       "check": {"mean_lambda": lam_mean}, "store_gather": gather_info},
+                       "chains_total": total_chains, "chains_rank0": C, "nodes": n, "parallelism": f"chains sharded x{world}",
+                       "check": {"mean_lambda": lam_mean}, "store_gather": gather_info,
+                       "repeats": m["spread"], "other_scaling": other},
         }
         if kern_ms is not None:
             achieved = ALG_BYTES_PER_CHAIN_UPDATE * (n / N_NODES) * C / (kern_ms * 1e-3) / 1e9

@@ -486,6 +486,28 @@ omc_status omc_mixture_gather(omc_ctx* ctx, int64_t kmax, int64_t m, const doubl
 omc_status omc_store_moments(omc_ctx* ctx, int64_t n_iter, int64_t size, const double* store,
                              int32_t pooled, double* mean_out, double* var_out);
 
+/* ---- the one collective of the path: gather of the per-rank stores on a root (RCCL over xGMI) ----
+ * Nothing in the reference to replace (it has one chain and no collective; SURVEY section 2.2 COLL row, section 8b
+ * export list, section 8e): with the chains of MCMC.run_mcmc (mcmc.py:97-115) sharded over GPUs, this is what puts
+ * MCMC.store back together.  One process per GPU; the communicator is RCCL's, bootstrapped from a unique id that the
+ * caller ships to every rank by whatever channel it has (the Python mirror uses torch.distributed's object
+ * broadcast; a non-Python caller its own).
+ *   omc_comm_unique_id     [host] on ONE rank: fills id_out (omc_comm_unique_id_bytes() bytes, 128);
+ *   omc_comm_create        on every rank, collectively: ncclCommInitRank on ctx's device;
+ *   omc_gather_samples     on every rank, collectively, on ctx's stream (returns without synchronising):
+ *       send   [n_outer][counts[rank]][row]  this rank's block (device), chains in local order
+ *       recv   [n_outer][sum counts][row]    on `root` (device; ignored elsewhere): chains in rank order
+ *       counts [world]                       (host) chains held by every rank; shards may be uneven, also 0
+ *     All peers send at once, point to point into the root (xGMI gives every peer its own link); the root stages at
+ *     most staging_limit_bytes (0 = 1 GiB) per round and interleaves on the device.                              */
+typedef struct omc_comm omc_comm;
+int64_t omc_comm_unique_id_bytes(void);
+omc_status omc_comm_unique_id(char* id_out, int64_t id_bytes);
+omc_status omc_comm_create(omc_ctx* ctx, int32_t world, int32_t rank, const char* id, int64_t id_bytes, omc_comm** out);
+omc_status omc_comm_destroy(omc_comm* comm);
+omc_status omc_gather_samples(omc_ctx* ctx, omc_comm* comm, const double* send, int64_t n_outer, int64_t row,
+                              const int64_t* counts, double* recv, int32_t root, int64_t staging_limit_bytes);
+
 /* ---- raw random streams (tests, prior draws for missing state: mcmc.py:78-80) -------------- */
 omc_status omc_fill_normal(omc_ctx* ctx, int64_t n, uint64_t draw_index, double* out, int64_t ld);
 omc_status omc_fill_philox_u32(omc_ctx* ctx, int64_t n_words, uint64_t draw_index, uint32_t* out,

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libomcmc_hip.so")
+# OMC_HIP_LIB selects another build of the same library (A/B timing of kernel variants, benchmarks/ab_headline.py)
+LIB_PATH = os.environ.get("OMC_HIP_LIB") or os.path.join(_HERE, "libomcmc_hip.so")
 
 OMC_MAX_TERMS = 4
 OK, INVALID_ARG, NOT_POSDEF, HIP_ERROR, UNSUPPORTED = range(5)
@@ -158,6 +159,11 @@ SIGNATURES = {
     "omc_categorical_logpmf": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, i64, c_dp, i32]),
     "omc_mixture_normal_gamma": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, u64, c_dp]),
     "omc_gamma_logpdf_vec": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, i32]),
+    "omc_comm_unique_id_bytes": (i64, []),
+    "omc_comm_unique_id": (i32, [C.c_char_p, i64]),
+    "omc_comm_create": (i32, [C.c_void_p, i32, i32, C.c_char_p, i64, C.POINTER(C.c_void_p)]),
+    "omc_comm_destroy": (i32, [C.c_void_p]),
+    "omc_gather_samples": (i32, [C.c_void_p, C.c_void_p, c_dp, i64, i64, C.POINTER(i64), c_dp, i32, i64]),
     "omc_fill_normal": (i32, [C.c_void_p, i64, u64, c_dp, i64]),
     "omc_fill_philox_u32": (i32, [C.c_void_p, i64, u64, c_dp, i64]),
 }

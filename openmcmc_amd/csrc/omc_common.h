@@ -34,6 +34,7 @@ struct omc_ctx {
 };
 
 void omc_set_error(const char* what, hipError_t e);
+void omc_set_error_text(const char* text);  // any other library failure (RCCL) for omc_last_error()
 void omc_dense_release(omc_ctx* ctx);  // destroys the rocBLAS handle if one was created
 
 #define OMC_HIP_CHECK(expr)                  \
@@ -106,12 +107,16 @@ __device__ __forceinline__ double omc_u53(uint32_t lo, uint32_t hi) {
 // The generic libm entry points carry range/special-case handling the transform never needs
 // (u in (0,1], angle in (0,2]); these restate the classic fdlibm kernels (e_log.c, k_sin.c,
 // k_cos.c: argument reduction + minimax polynomial, < 1 ulp) for exactly those domains.
-__device__ __forceinline__ double omc_rcp_nr(double d) {
+__host__ __device__ inline double omc_rcp_nr(double d) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return 1.0 / d;
+#else
   // v_rcp_f64 is good to 4.6e-8; r (1 + e + e^2) with e = 1 - d r leaves e^3 ~ 1e-22 and one rounding (three
   // operations where two Newton steps take four)
   const double r = __builtin_amdgcn_rcp(d);
   const double e = fma(-d, r, 1.0);
   return fma(r, fma(e, e, e), r);
+#endif
 }
 __device__ __forceinline__ double omc_sqrt_nr(double r) {  // r > 0, normal range
   const double g = __builtin_amdgcn_rsq(r);
@@ -141,6 +146,11 @@ __device__ __forceinline__ double omc_fma_vsv(double a, double b_scalar, double 
 __device__ __forceinline__ double omc_mul_vs(double a, double b_scalar) {  // a*b
   double d;
   asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(b_scalar));
+  return d;
+}
+__device__ __forceinline__ double omc_add_vs(double a, double b_scalar) {  // a+b
+  double d;
+  asm("v_add_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(b_scalar));
   return d;
 }
 
@@ -181,17 +191,122 @@ __device__ __forceinline__ void omc_sincospi02(double a, double& sn, double& cs)
   cs = (q == 1 || q == 2) ? -ca : ca;
 }
 
-// One Philox block -> two independent N(0,1) (Box-Muller, fp64; same word->uniform mapping as
-// rocRAND's box_muller_double).
-__device__ __forceinline__ void omc_normal_pair(uint4 w, double& n0, double& n1) {
-  const double u = omc_u53(w.x, w.y);
-  const unsigned long long v2 = (unsigned long long)w.z ^ ((unsigned long long)w.w << 21);
-  const double ang = 0x1.0p-52 + (double)v2 * 0x1.0p-52;  // (0, 2]
-  const double s = omc_sqrt_nr(fmax(-2.0 * omc_log_unit(u), 1e-300));  // u == 1 -> radius 0, not NaN
-  double sn, cs;
-  omc_sincospi02(ang, sn, cs);
-  n0 = sn * s;
-  n1 = cs * s;
+// ---- host/device shims: the Box-Muller map below also compiles for the host, where tests/ checks it against
+// the NumPy model (tests/philox_model.py) without a GPU ----
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OMC_ON_DEVICE 1
+#else
+#define OMC_ON_DEVICE 0
+#endif
+__host__ __device__ inline double omc_bits_to_double(uint32_t hi, uint32_t lo) {
+#if OMC_ON_DEVICE
+  return __hiloint2double((int)hi, (int)lo);
+#else
+  const uint64_t b = ((uint64_t)hi << 32) | lo;
+  double d;
+  __builtin_memcpy(&d, &b, 8);
+  return d;
+#endif
+}
+// double in [1, 2) whose 52 mantissa bits are the top 20 bits of `hi20src` and all of `lo`
+__host__ __device__ inline double omc_unit_mantissa(uint32_t lo, uint32_t hi20src) {
+#if OMC_ON_DEVICE
+  return omc_bits_to_double(__builtin_amdgcn_alignbit(0x3FFu, hi20src, 12), lo);  // one v_alignbit_b32
+#else
+  return omc_bits_to_double(0x3FF00000u | (hi20src >> 12), lo);
+#endif
+}
+// v with the sign bit of `signsrc` (bit 31)
+__host__ __device__ inline double omc_with_sign_of(double v, uint32_t signsrc) {
+#if OMC_ON_DEVICE
+  const uint32_t hi = (uint32_t)__double2hiint(v);
+  return omc_bits_to_double((hi & 0x7fffffffu) | (signsrc & 0x80000000u), (uint32_t)__double2loint(v));  // one v_bfi_b32
+#else
+  uint64_t b;
+  __builtin_memcpy(&b, &v, 8);
+  b = (b & 0x7fffffffffffffffull) | ((uint64_t)(signsrc & 0x80000000u) << 32);
+  __builtin_memcpy(&v, &b, 8);
+  return v;
+#endif
+}
+#if OMC_ON_DEVICE
+#define OMC_FMA_VVS(a, b, c) omc_fma_vvs(a, b, c)
+#define OMC_MUL_VS(a, b) omc_mul_vs(a, b)
+#define OMC_ADD_VS(a, b) omc_add_vs(a, b)
+#else
+#define OMC_FMA_VVS(a, b, c) fma(a, b, c)
+#define OMC_MUL_VS(a, b) ((a) * (b))
+#define OMC_ADD_VS(a, b) ((a) + (b))
+#endif
+
+// One Philox block -> two independent N(0,1): Box-Muller in fp64, 128 random bits per pair (the budget of
+// rocRAND's box_muller_double), arranged for the vector ALU the sampling kernels are bound by:
+//  * both uniforms are spliced straight into mantissas (one v_alignbit_b32 each) instead of being converted
+//    from 64-bit integers (13 instructions each, two of them quarter-rate multiplies):
+//        radius   u = 2 - m,  m in [1,2) from w.x and the top 20 bits of w.y      -> u in (0,1] on a 2^-52 grid
+//        angle    t = (m' - 3/2) pi/2,  m' from w.z and the top 20 bits of w.w    -> t in [-pi/4, pi/4)
+//  * the point (cos t, sin t) on the arc around +x is carried to the whole circle by a random reflection
+//    x -> -x (bit 11 of w.w) and a random swap of the coordinates (bit 10): one v_bfi_b32 and four
+//    v_cndmask_b32 in place of a quadrant reduction;
+//  * -2 log u comes out of the fdlibm log kernel directly (doubled coefficients, one constant for ln 2: u
+//    never needs the hi/lo split, |k ln2| and |log1p f| do not cancel on (0,1]), and its square root takes
+//    one Newton step on v_rsq_f64 (4e-15 relative: the draw's own scale).
+// 70 vector instructions per pair where the integer-conversion form took 111; tests/philox_model.py is the
+// host model of exactly this map.
+__host__ __device__ inline void omc_normal_pair(uint4 w, double& n0, double& n1) {
+  // ---- radius: V = -2 log u ----
+  const double u = 2.0 - omc_unit_mantissa(w.x, w.y);
+#if OMC_ON_DEVICE
+  int k = __builtin_amdgcn_frexp_exp(u);  // u = g 2^k, g in [0.5, 1)
+  double g = __builtin_amdgcn_frexp_mant(u);
+#else
+  int k;
+  double g = frexp(u, &k);
+#endif
+  if (g < 0.70710678118654752440) { g += g; k -= 1; }
+  const double f = g - 1.0;
+  const double s = f * omc_rcp_nr(2.0 + f);
+  const double z = s * s;
+  // 2 R(z) = 2 z (Lg1 + z (Lg2 + ... + z Lg7)), e_log.c coefficients doubled
+  double p = OMC_ADD_VS(OMC_MUL_VS(z, 2.959639721023317182e-01), 3.062767539841874664e-01);
+  p = OMC_FMA_VVS(z, p, 3.636714432323610024e-01);
+  p = OMC_FMA_VVS(z, p, 4.444439686429956792e-01);
+  p = OMC_FMA_VVS(z, p, 5.714285748732478298e-01);
+  p = OMC_FMA_VVS(z, p, 7.999999999881883816e-01);
+  p = OMC_FMA_VVS(z, p, 1.333333333333347026e+00);
+  const double ff = f * f;
+  // -2 log u = -2 k ln2 - 2 f + f^2 - s (f^2 + 2R)
+  double V = fma(-s, fma(z, p, ff), ff);
+  V = fma(f, -2.0, V);
+  V = fma((double)k, -1.38629436111989061883e+00, V);
+  V = fmax(V, 1e-300);  // u == 1 -> radius 0, not NaN
+#if OMC_ON_DEVICE
+  const double rs = __builtin_amdgcn_rsq(V);
+  const double r0 = V * rs;
+  const double r = fma(fma(-r0, r0, V), 0.5 * rs, r0);
+#else
+  const double r = sqrt(V);
+#endif
+  // ---- angle ----
+  const double t = OMC_MUL_VS(OMC_ADD_VS(omc_unit_mantissa(w.z, w.w), -1.5), 1.57079632679489655800e+00);
+  const double q = t * t;
+  // k_sin.c / k_cos.c kernels in plain Horner form (|t| <= pi/4)
+  double ps = OMC_ADD_VS(OMC_MUL_VS(q, 1.58969099521155010221e-10), -2.50507602534068634195e-08);
+  ps = OMC_FMA_VVS(q, ps, 2.75573137070700676789e-06);
+  ps = OMC_FMA_VVS(q, ps, -1.98412698298579493134e-04);
+  ps = OMC_FMA_VVS(q, ps, 8.33333333332248946124e-03);
+  ps = OMC_FMA_VVS(q, ps, -1.66666666666666324348e-01);
+  const double sn = fma(t * q, ps, t);
+  double pc = OMC_ADD_VS(OMC_MUL_VS(q, -1.13596475577881948265e-11), 2.08757232129817482790e-09);
+  pc = OMC_FMA_VVS(q, pc, -2.75573143513906633035e-07);
+  pc = OMC_FMA_VVS(q, pc, 2.48015872894767294178e-05);
+  pc = OMC_FMA_VVS(q, pc, -1.38888888888741095749e-03);
+  pc = OMC_FMA_VVS(q, pc, 4.16666666666666019037e-02);
+  pc = fma(q, pc, -0.5);
+  const double cs = omc_with_sign_of(fma(q, pc, 1.0), w.w << 20);  // random reflection x -> -x (bit 11)
+  const bool swap = (int32_t)(w.w << 21) < 0;                          // random swap (bit 10)
+  n0 = (swap ? cs : sn) * r;
+  n1 = (swap ? sn : cs) * r;
 }
 
 // Marsaglia & Tsang (2000) Gamma(a,1), a > 0, from the chain's Philox stream.

@@ -11,6 +11,8 @@ void omc_set_error(const char* what, hipError_t e) {
   g_last_error = std::string(what) + ": " + hipGetErrorString(e);
 }
 
+void omc_set_error_text(const char* text) { g_last_error = text; }
+
 extern "C" {
 
 const char* omc_last_error(void) { return g_last_error.c_str(); }

@@ -755,6 +755,12 @@ class Engine:
         check(lib.omc_store_moments(self._ctx, n_iter, size, self._p(store), int(pooled), self._p(mean), self._p(var)))
         return mean, var
 
+    # ------------------------------------------------------------------ the gather of the stores (RCCL)
+    def communicator(self, world, rank, unique_id):
+        """RCCL communicator of this rank (omc_comm_create); collective over all ranks.  `unique_id` is the bytes
+        object one rank obtained from `new_unique_id()` and shipped to the others."""
+        return Communicator(self, world, rank, unique_id)
+
     # ------------------------------------------------------------------ random fills
     def fill_normal(self, n, draw_index=0):
         out = self.empty(self.n_chains, n)
@@ -766,3 +772,52 @@ class Engine:
         out = torch.empty(self.n_chains, n_words, dtype=torch.int32, device=self.device)
         check(lib.omc_fill_philox_u32(self._ctx, n_words, int(draw_index), C.c_void_p(out.data_ptr()), n_words))
         return out
+
+
+def new_unique_id():
+    """Bootstrap id of an RCCL communicator (omc_comm_unique_id); call on ONE rank and ship the bytes to the others."""
+    n = int(lib.omc_comm_unique_id_bytes())
+    buf = C.create_string_buffer(n)
+    check(lib.omc_comm_unique_id(buf, n))
+    return buf.raw
+
+
+class Communicator:
+    """omc_comm of one rank: the library's own RCCL communicator, used by exactly one collective of the path, the
+    gather of the per-rank stores on a root (omc_gather_samples)."""
+
+    def __init__(self, engine, world, rank, unique_id):
+        self.engine, self.world, self.rank = engine, int(world), int(rank)
+        comm = C.c_void_p()
+        check(lib.omc_comm_create(engine._ctx, self.world, self.rank, unique_id, len(unique_id), C.byref(comm)))
+        self._comm = comm
+
+    def gather(self, block, counts, root=0, staging_limit_bytes=0):
+        """block (n_outer, counts[rank], ...) float64 device tensor of this rank -> on `root` the tensor
+        (n_outer, sum(counts), ...) with the chains in rank order; None on the other ranks.  Asynchronous on the
+        engine's stream, like every other call."""
+        eng = self.engine
+        counts = [int(c) for c in counts]
+        if len(counts) != self.world:
+            raise ValueError("counts must have one entry per rank")
+        if block.dim() < 2 or block.shape[1] != counts[self.rank]:
+            raise ValueError("block must be (n_outer, counts[rank], ...)")
+        block = block.contiguous()
+        n_outer = int(block.shape[0])
+        row = int(np.prod(block.shape[2:])) if block.dim() > 2 else 1
+        out = eng.empty(n_outer, sum(counts), *block.shape[2:]) if self.rank == root else None
+        arr = (C.c_int64 * self.world)(*counts)
+        check(lib.omc_gather_samples(eng._ctx, self._comm, eng._p(block) if block.numel() else None, n_outer, row, arr,
+                                     eng._p(out) if out is not None and out.numel() else None, int(root), int(staging_limit_bytes)))
+        return out
+
+    def close(self):
+        if self._comm is not None:
+            lib.omc_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -216,9 +216,17 @@ class MCMC:
 
         return {key: store_to_reference_layout(key, t.detach().cpu().numpy()) for key, t in self.store.items()}
 
-    def gather(self, dst=0):
+    def gather(self, dst=0, comm=None, group=None):
         """The one collective of the path: gather every rank's store on rank `dst` over RCCL (xGMI).
-        Returns the host dict of `collect()` for all chains on dst, None elsewhere."""
-        from openmcmc_amd.parallel import gather_store
+        Returns the host dict of `collect()` for all chains on dst, None elsewhere.  `comm`: the library's own
+        communicator (parallel.make_communicator(self.engine)) -> omc_gather_samples; "auto" makes one when the
+        process group runs on RCCL; None -> torch.distributed's gather on the group's backend."""
+        import torch.distributed as dist
 
-        return gather_store(self.store, dst=dst)
+        from openmcmc_amd.parallel import gather_store, make_communicator
+
+        if comm == "auto":
+            comm = None
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and dist.get_backend(group) == "nccl":
+                comm = make_communicator(self.engine, group)
+        return gather_store(self.store, dst=dst, group=group, comm=comm)

@@ -38,15 +38,31 @@ def u53(lo, hi):
     return 2.0**-53 + v.astype(np.float64) * 2.0**-53
 
 
+def unit_mantissa(lo, hi20src):
+    """float64 in [1, 2): mantissa = top 20 bits of hi20src, then all of lo (omc_unit_mantissa)."""
+    bits = (np.uint64(0x3FF) << np.uint64(52)) | ((hi20src.astype(np.uint64) >> np.uint64(12)) << np.uint64(32)) \
+        | lo.astype(np.uint64)
+    return bits.view(np.float64)
+
+
+def normal_pairs(x, y, z, w):
+    """Words of one Philox block -> two N(0,1) (omc_normal_pair): Box-Muller with the radius uniform
+    u = 2 - m(x, y) in (0, 1], the angle t = (m(z, w) - 3/2) pi/2 in [-pi/4, pi/4), a reflection x -> -x on
+    bit 11 of w and a swap of the two coordinates on bit 10."""
+    x, y, z, w = (np.asarray(v, dtype=np.uint32) for v in (x, y, z, w))
+    u = 2.0 - unit_mantissa(x, y)
+    r = np.sqrt(np.maximum(-2.0 * np.log(u), 0.0))
+    t = (unit_mantissa(z, w) - 1.5) * (np.pi / 2)
+    sn, cs = np.sin(t), np.cos(t)
+    cs = np.where((w >> np.uint32(11)) & np.uint32(1), -cs, cs)
+    swap = ((w >> np.uint32(10)) & np.uint32(1)).astype(bool)
+    return np.where(swap, cs, sn) * r, np.where(swap, sn, cs) * r
+
+
 def normals(seed, draw_index, global_chain, n):
-    """First n N(0,1) of the chain's 'normal' stream (Box-Muller as omc_normal_pair)."""
+    """First n N(0,1) of the chain's 'normal' stream."""
     nb = (n + 1) // 2
     x, y, z, w = rng_blocks(seed, draw_index, "normal", global_chain, np.arange(nb))
-    u = u53(x, y)
-    v2 = z.astype(np.uint64) ^ (w.astype(np.uint64) << np.uint64(21))
-    ang = 2.0**-52 + v2.astype(np.float64) * 2.0**-52
-    s = np.sqrt(-2.0 * np.log(u))
     out = np.empty(2 * nb)
-    out[0::2] = np.sin(np.pi * ang) * s
-    out[1::2] = np.cos(np.pi * ang) * s
+    out[0::2], out[1::2] = normal_pairs(x, y, z, w)
     return out[:n]
