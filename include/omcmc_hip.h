@@ -79,9 +79,14 @@ omc_status omc_ctx_status(omc_ctx* ctx, int64_t* first_bad_chain);
 omc_status omc_ctx_synchronize(omc_ctx* ctx);
 /* Tuning knobs, by name: "tridiag_algo" (0 auto, 1 serial lane-per-chain, 2 segmented),
  * "tridiag_seg" (nodes per lane: 0 auto, 8, 10, 16, 20, 32), "tridiag_generic" (1: never use the
- * instantiation specialised for the two-term smoother structure; for cross-checks).
+ * instantiation specialised for the two-term smoother structure; for cross-checks), "tridiag_newton_max" (0..64,
+ * default 4: Newton corrections of the segment joins before the sequential fallback takes over; 0 forces it).
  * Unknown name -> OMC_INVALID_ARG.                                                            */
 omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value);
+/* Diagnostic counters, by name (synchronises): "tridiag_join_fallbacks" = chain-updates of the segmented
+ * tridiagonal kernel whose pivot joins did not meet the Newton tolerance within its iteration limit and were
+ * made consistent by the sequential recurrence instead (same pivots as the serial kernel; slow, rare).       */
+omc_status omc_ctx_counter(omc_ctx* ctx, const char* name, int64_t* value);
 const char* omc_last_error(void);          /* [host] text of the last HIP failure, thread-local */
 int32_t omc_abi_version(void);
 

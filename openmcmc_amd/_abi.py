@@ -80,6 +80,7 @@ SIGNATURES = {
     "omc_ctx_status": (i32, [C.c_void_p, C.POINTER(i64)]),
     "omc_ctx_synchronize": (i32, [C.c_void_p]),
     "omc_ctx_set_option": (i32, [C.c_void_p, C.c_char_p, i64]),
+    "omc_ctx_counter": (i32, [C.c_void_p, C.c_char_p, C.POINTER(i64)]),
     "omc_last_error": (C.c_char_p, []),
     "omc_abi_version": (i32, []),
     "omc_tridiag_sample_canonical": (

@@ -13,6 +13,7 @@ struct omc_ctx {
   hipStream_t stream;
   bool own_stream;
   long long* d_bad_chain;  // device word: min local chain index with a non-positive pivot, or LLONG_MAX
+  unsigned long long* d_fallbacks;  // device word behind d_bad_chain: chain-updates that took the sequential join fallback
   double* workspace;       // scratch for the serial kernel (l vectors), grown on demand
   size_t workspace_bytes;
   // dense path (omc_dense.hip): rocBLAS handle and workspaces, created on first use
@@ -27,6 +28,7 @@ struct omc_ctx {
   int tridiag_algo;  // 0 auto, 1 serial, 2 segmented
   int tridiag_seg;   // 0 auto, else nodes per lane
   int debug_zero_z;  // diagnostic: skip the draw generation (timing what-if only)
+  int tridiag_newton_max;  // Newton join corrections before the sequential fallback (default OMC_NEWTON_MAX = 4; 0 forces the fallback: tests)
   int tridiag_generic;  // 1: never take the structure-specialised instantiation of the segmented kernel (tests)
   int band_algo;  // 0 auto, 1 lane-per-chain (narrow bands), 2 workgroup-per-chain
   int dense_use_rocsolver;  // 1: factor dense precisions with rocSOLVER's batched potrf instead of the blocked route

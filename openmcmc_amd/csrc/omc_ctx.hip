@@ -45,6 +45,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->tridiag_algo = 0;
   c->tridiag_seg = 0;
   c->tridiag_generic = 0;
+  c->tridiag_newton_max = 4;
   c->stamps = nullptr;
   c->debug_zero_z = 0;
   c->dense_use_rocsolver = 0;
@@ -55,10 +56,11 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   } else {
     c->stream = (hipStream_t)stream;
   }
-  hipError_t e = hipMalloc(&c->d_bad_chain, sizeof(long long));
+  hipError_t e = hipMalloc(&c->d_bad_chain, 2 * sizeof(long long));
   if (e != hipSuccess) { omc_set_error("hipMalloc", e); delete c; return OMC_HIP_ERROR; }
-  long long init = OMC_NO_BAD_CHAIN;
-  e = hipMemcpy(c->d_bad_chain, &init, sizeof(init), hipMemcpyHostToDevice);
+  c->d_fallbacks = (unsigned long long*)(c->d_bad_chain + 1);
+  long long init[2] = {OMC_NO_BAD_CHAIN, 0};
+  e = hipMemcpy(c->d_bad_chain, init, sizeof(init), hipMemcpyHostToDevice);
   if (e != hipSuccess) { omc_set_error("hipMemcpy", e); hipFree(c->d_bad_chain); delete c; return OMC_HIP_ERROR; }
   *out = c;
   return OMC_OK;
@@ -104,6 +106,18 @@ omc_status omc_ctx_status(omc_ctx* ctx, int64_t* first_bad_chain) {
   return OMC_NOT_POSDEF;
 }
 
+omc_status omc_ctx_counter(omc_ctx* ctx, const char* name, int64_t* value) {
+  if (!ctx || !name || !value) return OMC_INVALID_ARG;
+  if (!strcmp(name, "tridiag_join_fallbacks")) {
+    unsigned long long v = 0;
+    OMC_HIP_CHECK(hipMemcpyAsync(&v, ctx->d_fallbacks, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *value = (int64_t)v;
+    return OMC_OK;
+  }
+  return OMC_INVALID_ARG;
+}
+
 omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   if (!ctx || !name) return OMC_INVALID_ARG;
   if (!strcmp(name, "tridiag_algo")) {
@@ -114,6 +128,11 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "tridiag_seg")) {
     if (value != 0 && value != 8 && value != 10 && value != 16 && value != 20 && value != 32) return OMC_INVALID_ARG;
     ctx->tridiag_seg = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "tridiag_newton_max")) {
+    if (value < 0 || value > 64) return OMC_INVALID_ARG;
+    ctx->tridiag_newton_max = (int)value;
     return OMC_OK;
   }
   if (!strcmp(name, "tridiag_generic")) {

@@ -63,6 +63,8 @@ struct TriArgs {
   double* quad;
   double* logdet;
   long long* bad;
+  int newton_max;                 // Newton corrections of the segment joins before the sequential fallback takes over
+  unsigned long long* fallbacks;  // diagnostic counter: chains whose pivot joins went through the sequential fallback
   double* work;
   // fused sweep (omc_gmrf_sweep)
   unsigned long long* stamps;  // diagnostic: [chain][wave][16] s_memtime at phase boundaries, or NULL
@@ -788,6 +790,13 @@ __device__ __forceinline__ double fast_sqrt(double r) {
 #ifndef OMC_PARK_DIAG
 #define OMC_PARK_DIAG 1
 #endif
+// timing what-ifs (benchmarks/ab_headline.py builds variants with these; results are wrong by construction)
+#ifndef OMC_WHATIF_NOSTORE
+#define OMC_WHATIF_NOSTORE 0
+#endif
+#ifndef OMC_WHATIF_NOQLOAD
+#define OMC_WHATIF_NOQLOAD 0
+#endif
 
 // Quadratic forms (x - m_k)' M_k (x - m_k) of one wave's 64*M nodes in the coalesced mapping: x comes
 // back from the tile (x_{i+1} = the next tile element; the slot behind the tile's last row holds the
@@ -1161,7 +1170,28 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     if (!joined) Jp = 0.0;
     const int need = (fabs(e) > OMC_NEWTON_TOL * fabs(Dst)) ? 1 : 0;  // false for NaN: falls through to `bad`
     const int any = MULTI ? __syncthreads_or(need) : (__ballot(need) != 0ull);
-    if (!any || it >= OMC_NEWTON_MAX) break;
+    if (!any) break;
+    if (it >= A.newton_max) {
+      // Newton has not brought every join below the tolerance (a recurrence that is not contractive over a
+      // segment: weak coupling, or |l| > 1 on a stretch).  Nothing is left to chance from here: the joins are
+      // made consistent by the sequential recurrence itself.  Every pass starts each segment from the TRUE end
+      // value of its predecessor's last pass, so after pass k the first k+1 segments carry exactly the pivots of
+      // the serial kernel; the loop stops when no start value changes any more (bit for bit), at the latest
+      // after one pass per segment.  Slow (a few hundred cycles per pass) and rare; counted in `fallbacks`.
+      if (A.fallbacks && chain_ok && s == 0) atomicAdd(A.fallbacks, 1ull);
+      const int S = MULTI ? (int)blockDim.x : Wd;
+      for (int pass = 0; pass < S; ++pass) {
+        double Dq = Dend, Jq = 0.0;
+        if (MULTI) prev_lane2_wg(Dq, Jq, Dst, 0.0, lds_x[pass & 1], lane, wave, nw);
+        else prev_lane2<false>(Dq, Jq, Dst, 0.0, pos, Wd, lds_x[0], wave);
+        const int moved = (joined && Dq != Dst && Dq == Dq) ? 1 : 0;  // a NaN pivot is `bad`, not a reason to go on
+        const int some = MULTI ? __syncthreads_or(moved) : (__ballot(moved) != 0ull);
+        if (!some) break;
+        if (joined) Dst = Dq;
+        Dend = pivot_pass();
+      }
+      break;
+    }
     const Aff own{e, Jp};
     const Aff ex = MULTI ? excl_scan_wg<Aff, false>(own, Aff{0.0, 1.0}, lds_aff[it & 1], lane, wave, nw)
                           : excl_scan<Aff, false>(own, Aff{0.0, 1.0}, pos, Wd, false, lds_aff[0], wave, nw);
@@ -1368,7 +1398,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 #pragma unroll
             for (int t = 0; t < M; ++t) {
               if (t < 2 * NZB) continue;
-              qo[t] = (vPo + wbase)[(unsigned)(lane + 64 * t)];
+              qo[t] = OMC_WHATIF_NOQLOAD ? 0.25 : (vPo + wbase)[(unsigned)(lane + 64 * t)];
             }
           } else {
             coal_load<M>(qo, vPo + wbase, lane, nvo);
@@ -1380,7 +1410,12 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         } else {
           coal_load<M>(qd, vPd + wbase, lane, nvq);
         }
-        coal_load<M>(qc, vIc + wbase, lane, nvq);
+        if (OMC_WHATIF_NOQLOAD) {
+#pragma unroll
+          for (int t = 0; t < M; ++t) qc[t] = 1.0;
+        } else {
+          coal_load<M>(qc, vIc + wbase, lane, nvq);
+        }
       }
       double aI = 0.0, aP = aPd;
       // x leaves from the same pass, behind the loads issued above (vmcnt retires in order: nothing waits on the
@@ -1399,7 +1434,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           const double xv = *pe, xn = *TM::succ(pe, r0, t), a = xv - qc[t];
           aI = fma(a, a, aI);
           aP = fma(2.0 * qo[t] * xn, xv, aP);
-          if (xo) xo[(unsigned)(lane + 64 * t)] = xv;
+          if (xo && !OMC_WHATIF_NOSTORE) xo[(unsigned)(lane + 64 * t)] = xv;
         }
       } else if (nv == 64 * M) {
 #pragma unroll
@@ -1408,7 +1443,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           const double xv = *pe, xn = *TM::succ(pe, r0, t), a = xv - qc[t];
           aI = fma(a, a, aI);
           aP = fma(fma(2.0 * qo[t], xn, qd[t] * xv), xv, aP);
-          if (xo) xo[(unsigned)(lane + 64 * t)] = xv;
+          if (xo && !OMC_WHATIF_NOSTORE) xo[(unsigned)(lane + 64 * t)] = xv;
         }
       } else {  // the chain's last wave: nodes beyond n hold finite fill values, their vectors were loaded as 0
 #pragma unroll
@@ -1573,6 +1608,8 @@ static void args_defaults(omc_ctx* ctx, TriArgs* A, int64_t n) {
   A->key = omc_make_key(ctx->seed, 0, OMC_RNG_NORMAL);
   A->x = nullptr; A->ld_x = 0; A->quad = nullptr; A->logdet = nullptr;
   A->bad = ctx->d_bad_chain;
+  A->fallbacks = ctx->d_fallbacks;
+  A->newton_max = ctx->tridiag_newton_max;
   A->work = nullptr;
   A->fused = 0;
   A->stamps = ctx->stamps;

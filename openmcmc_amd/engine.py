@@ -116,6 +116,12 @@ class Engine:
             raise np.linalg.LinAlgError(f"Matrix is not positive definite (chain {bad.value})")
         check(st)
 
+    def counter(self, name):
+        """Diagnostic counter of the context (omc_ctx_counter), e.g. "tridiag_join_fallbacks"."""
+        v = C.c_int64(0)
+        check(lib.omc_ctx_counter(self._ctx, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def set_option(self, name, value):
         check(lib.omc_ctx_set_option(self._ctx, name.encode(), int(value)))
 
