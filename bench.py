@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--generic", action="store_true", help="diagnostic: never use the structure-specialised kernel instantiation")
     ap.add_argument("--stamps", action="store_true", help="diagnostic: print in-kernel phase stamps (not a timing run)")
     ap.add_argument("--seg", type=int, default=0, help="nodes per lane of the segmented kernel (0 = auto)")
+    ap.add_argument("--sweeps-per-launch", type=int, default=0, help="omc_gmrf_run: sweeps per launch (0 = library default, 16)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -273,6 +274,8 @@ def main():
             sweep.eng.set_option("debug_zero_z", 1)
         if args.generic:
             sweep.eng.set_option("tridiag_generic", 1)
+        if args.sweeps_per_launch:
+            sweep.eng.set_option("run_sweeps_per_launch", args.sweeps_per_launch)
         stamps = None
         if diagnostics and args.stamps:
             stamps = torch.zeros(C * 16 * 16, dtype=torch.int64, device="cuda")

@@ -80,7 +80,9 @@ omc_status omc_ctx_synchronize(omc_ctx* ctx);
 /* Tuning knobs, by name: "tridiag_algo" (0 auto, 1 serial lane-per-chain, 2 segmented),
  * "tridiag_seg" (nodes per lane: 0 auto, 8, 10, 16, 20, 32), "tridiag_generic" (1: never use the
  * instantiation specialised for the two-term smoother structure; for cross-checks), "tridiag_newton_max" (0..64,
- * default 4: Newton corrections of the segment joins before the sequential fallback takes over; 0 forces it).
+ * default 4: Newton corrections of the segment joins before the sequential fallback takes over; 0 forces it),
+ * "tridiag_perturb_ppb" (tests: relative error, in 1e-9, put on the segments' start pivots so that the join test must
+ * reject them), "run_sweeps_per_launch" (1..16, default 16: sweeps omc_gmrf_run issues per launch).
  * Unknown name -> OMC_INVALID_ARG.                                                            */
 omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value);
 /* Diagnostic counters, by name (synchronises): "tridiag_join_fallbacks" = chain-updates of the segmented

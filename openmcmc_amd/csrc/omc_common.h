@@ -14,6 +14,10 @@ struct omc_ctx {
   bool own_stream;
   long long* d_bad_chain;  // device word: min local chain index with a non-positive pivot, or LLONG_MAX
   unsigned long long* d_fallbacks;  // device word behind d_bad_chain: chain-updates that took the sequential join fallback
+                                    // (d_fallbacks + 1: hand-overs of a several-sweeps launch that never arrived)
+  unsigned long long* d_handoff;    // omc_gmrf_run: [n_chains][16] hand-over lines, allocated on first use
+  uint32_t run_epoch;               // tag counter of the hand-over lines
+  int run_sweeps_per_launch;        // omc_gmrf_run: sweeps per launch (1 = one launch per sweep)
   double* workspace;       // scratch for the serial kernel (l vectors), grown on demand
   size_t workspace_bytes;
   // dense path (omc_dense.hip): rocBLAS handle and workspaces, created on first use
@@ -29,6 +33,7 @@ struct omc_ctx {
   int tridiag_seg;   // 0 auto, else nodes per lane
   int debug_zero_z;  // diagnostic: skip the draw generation (timing what-if only)
   int tridiag_newton_max;  // Newton join corrections before the sequential fallback (default OMC_NEWTON_MAX = 4; 0 forces the fallback: tests)
+  int tridiag_perturb_ppb;  // tests only: relative error (parts per billion) put on the Moebius start values of the segment joins
   int tridiag_generic;  // 1: never take the structure-specialised instantiation of the segmented kernel (tests)
   int band_algo;  // 0 auto, 1 lane-per-chain (narrow bands), 2 workgroup-per-chain
   int dense_use_rocsolver;  // 1: factor dense precisions with rocSOLVER's batched potrf instead of the blocked route

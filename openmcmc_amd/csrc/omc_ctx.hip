@@ -46,6 +46,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->tridiag_seg = 0;
   c->tridiag_generic = 0;
   c->tridiag_newton_max = 4;
+  c->tridiag_perturb_ppb = 0;
   c->stamps = nullptr;
   c->debug_zero_z = 0;
   c->dense_use_rocsolver = 0;
@@ -56,10 +57,11 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   } else {
     c->stream = (hipStream_t)stream;
   }
-  hipError_t e = hipMalloc(&c->d_bad_chain, 2 * sizeof(long long));
+  c->d_handoff = nullptr; c->run_epoch = 1; c->run_sweeps_per_launch = 16;
+  hipError_t e = hipMalloc(&c->d_bad_chain, 4 * sizeof(long long));
   if (e != hipSuccess) { omc_set_error("hipMalloc", e); delete c; return OMC_HIP_ERROR; }
   c->d_fallbacks = (unsigned long long*)(c->d_bad_chain + 1);
-  long long init[2] = {OMC_NO_BAD_CHAIN, 0};
+  long long init[4] = {OMC_NO_BAD_CHAIN, 0, 0, 0};
   e = hipMemcpy(c->d_bad_chain, init, sizeof(init), hipMemcpyHostToDevice);
   if (e != hipSuccess) { omc_set_error("hipMemcpy", e); hipFree(c->d_bad_chain); delete c; return OMC_HIP_ERROR; }
   *out = c;
@@ -71,6 +73,7 @@ omc_status omc_ctx_destroy(omc_ctx* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (ctx->workspace) hipFree(ctx->workspace);
+  if (ctx->d_handoff) hipFree(ctx->d_handoff);
   if (ctx->dense_factor) hipFree(ctx->dense_factor);
   if (ctx->dense_info) hipFree(ctx->dense_info);
   if (ctx->dense_tmp) hipFree(ctx->dense_tmp);
@@ -92,9 +95,18 @@ omc_status omc_ctx_synchronize(omc_ctx* ctx) {
 
 omc_status omc_ctx_status(omc_ctx* ctx, int64_t* first_bad_chain) {
   if (!ctx || !first_bad_chain) return OMC_INVALID_ARG;
-  long long v = OMC_NO_BAD_CHAIN;
-  OMC_HIP_CHECK(hipMemcpyAsync(&v, ctx->d_bad_chain, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+  long long w[3] = {OMC_NO_BAD_CHAIN, 0, 0};
+  OMC_HIP_CHECK(hipMemcpyAsync(w, ctx->d_bad_chain, sizeof(w), hipMemcpyDeviceToHost, ctx->stream));
   OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  const long long v = w[0];
+  if (w[2] != 0) {  // a several-sweeps launch whose hand-over never arrived: the results of that run are not to be used
+    long long zero = 0;
+    OMC_HIP_CHECK(hipMemcpyAsync(ctx->d_bad_chain + 2, &zero, sizeof(zero), hipMemcpyHostToDevice, ctx->stream));
+    OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    omc_set_error_text("omc_gmrf_run: a sweep's hand-over to the next sweep of its chain did not arrive (set run_sweeps_per_launch = 1)");
+    *first_bad_chain = -1;
+    return OMC_HIP_ERROR;
+  }
   if (v == OMC_NO_BAD_CHAIN) {
     *first_bad_chain = -1;
     return OMC_OK;
@@ -108,6 +120,13 @@ omc_status omc_ctx_status(omc_ctx* ctx, int64_t* first_bad_chain) {
 
 omc_status omc_ctx_counter(omc_ctx* ctx, const char* name, int64_t* value) {
   if (!ctx || !name || !value) return OMC_INVALID_ARG;
+  if (!strcmp(name, "run_handoff_timeouts")) {
+    unsigned long long v = 0;
+    OMC_HIP_CHECK(hipMemcpyAsync(&v, ctx->d_fallbacks + 1, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *value = (int64_t)v;
+    return OMC_OK;
+  }
   if (!strcmp(name, "tridiag_join_fallbacks")) {
     unsigned long long v = 0;
     OMC_HIP_CHECK(hipMemcpyAsync(&v, ctx->d_fallbacks, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
@@ -128,6 +147,16 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "tridiag_seg")) {
     if (value != 0 && value != 8 && value != 10 && value != 16 && value != 20 && value != 32) return OMC_INVALID_ARG;
     ctx->tridiag_seg = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "run_sweeps_per_launch")) {
+    if (value < 1 || value > 16) return OMC_INVALID_ARG;
+    ctx->run_sweeps_per_launch = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "tridiag_perturb_ppb")) {
+    if (value < 0 || value > 1000000000) return OMC_INVALID_ARG;
+    ctx->tridiag_perturb_ppb = (int)value;
     return OMC_OK;
   }
   if (!strcmp(name, "tridiag_newton_max")) {

@@ -52,6 +52,21 @@ struct GammaDev {
   omc_rng_key key;
 };
 
+// omc_gmrf_run: several sweeps of the same chains in ONE launch (blockIdx = sweep * C + chain).  What differs from
+// sweep to sweep is small and wave-uniform; it sits in the kernel arguments, indexed by the sweep.
+#define OMC_RUN_MAX 16
+struct SweepRec {
+  uint64_t draw;      // draw index of the sweep's standard-normal stream; the Gamma streams are draw + gdraw[k]
+  double* x;          // where the draw goes: the sweep's store slab, or the scratch slab
+  double* log_post;   // or NULL
+  int64_t slot_off;   // offset (in doubles) of the sweep's slot in the per-chain scalar stores; < 0: not stored
+};
+// hand-over of a chain's freshly drawn scales from the workgroup of sweep s to the one of sweep s+1, which may sit on
+// another XCD: data-tagged 8-byte granules {32 bits of the double, 32-bit tag}, written and read with agent-scope
+// (sc1) accesses -- no flag, no fence, no ordering between granules needed (MI355X_MICROARCH.md, hand-off forms).
+// One 128-byte line per chain: [term k][half] at word 2 k + half.
+#define OMC_HANDOFF_WORDS 16
+
 struct TriArgs {
   TermsDev T;
   int64_t n, C, chain_offset;
@@ -63,6 +78,7 @@ struct TriArgs {
   double* quad;
   double* logdet;
   long long* bad;
+  double perturb_start;           // tests only: relative error put on every segment's Moebius start value
   int newton_max;                 // Newton corrections of the segment joins before the sequential fallback takes over
   unsigned long long* fallbacks;  // diagnostic counter: chains whose pivot joins went through the sequential fallback
   double* work;
@@ -71,7 +87,26 @@ struct TriArgs {
   int fused;
   GammaDev gb[OMC_MAX_TERMS];
   double* log_post;
+  // several sweeps per launch (n_sweeps > 0; workgroup-per-chain form only)
+  int n_sweeps;
+  uint32_t epoch;                  // tag of sweep 0's inputs + 1 = tag its outputs carry; unique per context over launches
+  uint64_t seed;
+  uint64_t gdraw[OMC_MAX_TERMS];   // Gamma stream of term k = sweep's draw index + gdraw[k]
+  unsigned long long* handoff;     // [C][OMC_HANDOFF_WORDS]
+  unsigned long long* timeouts;    // counter: hand-overs that did not arrive (dispatch-order assumption broken)
+  SweepRec rec[OMC_RUN_MAX];
 };
+
+__device__ __forceinline__ bool run_mode(const TriArgs& A) { return A.n_sweeps > 0; }
+__device__ __forceinline__ omc_rng_key sweep_gamma_key(const TriArgs& A, int sw, const GammaDev& g, uint64_t gd) {
+  return run_mode(A) ? omc_make_key(A.seed, A.rec[sw].draw + gd, OMC_RNG_GAMMA) : g.key;
+}
+__device__ __forceinline__ double* sweep_gamma_store(const TriArgs& A, int sw, const GammaDev& g) {
+  if (!run_mode(A)) return g.store;
+  const int64_t off = A.rec[sw].slot_off;
+  return (g.store && off >= 0) ? g.store + off : nullptr;
+}
+__device__ __forceinline__ double* sweep_log_post(const TriArgs& A, int sw) { return run_mode(A) ? A.rec[sw].log_post : A.log_post; }
 
 __device__ __forceinline__ double fast_rcp(double d) { return omc_rcp_nr(d); }
 
@@ -117,13 +152,15 @@ __device__ __forceinline__ double read_lane_d(double v, int l) {  // l wave-unif
 // shadow of the first global loads; each lane evaluates one Marsaglia-Tsang attempt, the lowest
 // accepted attempt is the serial answer.  Part 2, `sweep_epilogue_wave`: scale by 1/b once the
 // quadratic forms are known, store, log_post.
-__device__ __forceinline__ double sweep_gamma_draws_wave(const TriArgs& A, int64_t c, int lane, bool* failed) {
+__device__ __forceinline__ double sweep_gamma_draws_wave(const TriArgs& A, int64_t c, int lane, bool* failed, int sw = 0) {
   const int k = lane >> 4, j = lane & 15;
   const bool term_on = k < A.T.n_terms;
   GammaDev g = A.gb[0];
+  uint64_t gdr = A.gdraw[0];
 #pragma unroll
   for (int t = 1; t < OMC_MAX_TERMS; ++t)
-    if (k == t) g = A.gb[t];
+    if (k == t) { g = A.gb[t]; gdr = A.gdraw[t]; }
+  g.key = sweep_gamma_key(A, sw, g, gdr);
   const bool draw = term_on && g.enabled;
   double gd = 0.0;
   if (__ballot(draw) == 0ull) return gd;
@@ -156,7 +193,7 @@ __device__ __forceinline__ double sweep_gamma_draws_wave(const TriArgs& A, int64
 }
 
 __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c, double q0, double q1, double q2, double q3,
-                                                    double s_old, double ldet, double gd, bool failed, int lane) {
+                                                    double s_old, double ldet, double gd, bool failed, int lane, int sw = 0) {
   const int k = lane >> 4, j = lane & 15;
   const bool term_on = k < A.T.n_terms;
   // per-lane copy of this lane's term, selected with compile-time indices (a dynamically indexed
@@ -169,15 +206,27 @@ __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c,
   }
   const double qk = (k == 0) ? q0 : ((k == 1) ? q1 : ((k == 2) ? q2 : q3));
   if (!term_on) s = 1.0;
+  double* const lp_out = sweep_log_post(A, sw);
   if (term_on && g.enabled) {
     const double b = g.b0 + 0.5 * qk;
     s = gd * ((b == 0.0) ? INFINITY : omc_rcp_nr(b));  // sampler.py:285-287
     if (j == 0) {
-      g.scale_out[c] = s;
-      if (g.store) g.store[c] = s;
+      // the caller's scale array: written by the launch's last sweep only (two XCDs' write-through stores to one
+      // address within a launch have no defined order)
+      if (!run_mode(A) || sw == A.n_sweeps - 1) g.scale_out[c] = s;
+      double* const st = sweep_gamma_store(A, sw, g);
+      if (st) st[c] = s;
+      if (run_mode(A)) {  // hand the new scale to the workgroup of the chain's next sweep (same launch)
+        const uint32_t tag = A.epoch + (uint32_t)sw + 1u;
+        unsigned long long* h = A.handoff + c * OMC_HANDOFF_WORDS + 2 * k;
+        const unsigned long long lo = ((unsigned long long)tag << 32) | (uint32_t)__double2loint(s);
+        const unsigned long long hi = ((unsigned long long)tag << 32) | (uint32_t)__double2hiint(s);
+        __hip_atomic_store(h, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(h + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
-  if (A.log_post) {
+  if (lp_out) {
     double lp = 0.0;
     if (term_on && j == 0) {
       const double nd = (double)A.n;
@@ -186,7 +235,7 @@ __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c,
     }
     // terms are summed in order 0,1,2,3 as the serial epilogue does
     const double t0 = read_lane_d(lp, 0), t1 = read_lane_d(lp, 16), t2 = read_lane_d(lp, 32), t3 = read_lane_d(lp, 48);
-    if (lane == 0) A.log_post[c] = ((t0 + t1) + t2) + t3;
+    if (lane == 0) lp_out[c] = ((t0 + t1) + t2) + t3;
   }
   if (failed) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
 }
@@ -794,6 +843,10 @@ __device__ __forceinline__ double fast_sqrt(double r) {
 #ifndef OMC_WHATIF_NOSTORE
 #define OMC_WHATIF_NOSTORE 0
 #endif
+// the draw is written once and never read back by this kernel: streaming (nt) stores measured 0.6 % faster
+#ifndef OMC_STORE_NT
+#define OMC_STORE_NT 1
+#endif
 #ifndef OMC_WHATIF_NOQLOAD
 #define OMC_WHATIF_NOQLOAD 0
 #endif
@@ -967,8 +1020,14 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   int s;
   Geom<M, MULTI> geo;
   geo.lane = lane; geo.wave = wave; geo.G = G;
+  int sw = 0;  // sweep of this workgroup inside the launch (omc_gmrf_run: blockIdx = sweep * C + chain)
   if (MULTI) {
-    c = blockIdx.x;
+    unsigned blk = blockIdx.x;
+    if (A.n_sweeps > 1) {
+      sw = (int)(blk / (unsigned)A.C);
+      blk -= (unsigned)sw * (unsigned)A.C;
+    }
+    c = blk;
     s = threadIdx.x;
     geo.chain0 = c;
   } else {
@@ -992,8 +1051,57 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   double* tl = tile + lbase;
 
   double sc[OMC_MAX_TERMS];
+  // Sweeps after the first of a launch take the scales their Normal-Gamma blocks redraw from the hand-over line of
+  // the chain (written by the workgroup of the previous sweep, possibly on another XCD); the loads are issued here
+  // and examined where the scales are first needed (`take_scales`), behind the first pair of draws.
+  const bool handed = MULTI && sw > 0;
+  unsigned long long hw[2 * OMC_MAX_TERMS];
 #pragma unroll
-  for (int k = 0; k < OMC_MAX_TERMS; ++k) sc[k] = (k < nt && A.T.scale[k]) ? A.T.scale[k][cc] : 1.0;
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+    sc[k] = 1.0;
+    hw[2 * k] = hw[2 * k + 1] = 0ull;
+    if (k < nt && A.T.scale[k]) {
+      if (handed && A.gb[k].enabled) {
+        const unsigned long long* h = A.handoff + cc * OMC_HANDOFF_WORDS + 2 * k;
+        hw[2 * k] = __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hw[2 * k + 1] = __hip_atomic_load(h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        sc[k] = A.T.scale[k][cc];
+      }
+    }
+  }
+  auto take_scales = [&]() {
+    if (!handed) return;
+    const uint32_t want = A.epoch + (uint32_t)sw;
+    // In-order dispatch puts the producer (a lower block index) on the chip first, so this loop normally never
+    // turns; it is bounded all the same (about a second), and a hand-over that never comes is reported.
+    for (int spin = 0;; ++spin) {
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < OMC_MAX_TERMS; ++k)
+        if (k < nt && A.T.scale[k] && A.gb[k].enabled)
+          ok = ok && (uint32_t)(hw[2 * k] >> 32) == want && (uint32_t)(hw[2 * k + 1] >> 32) == want;
+      if (__builtin_amdgcn_readfirstlane((int)ok)) break;  // every lane loaded the same words
+      if (spin >= (1 << 19)) {
+        if (threadIdx.x == 0 && chain_ok) atomicAdd(A.timeouts, 1ull);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(64);
+#pragma unroll
+      for (int k = 0; k < OMC_MAX_TERMS; ++k)
+        if (k < nt && A.T.scale[k] && A.gb[k].enabled) {
+          const unsigned long long* h = A.handoff + cc * OMC_HANDOFF_WORDS + 2 * k;
+          hw[2 * k] = __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hw[2 * k + 1] = __hip_atomic_load(h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < OMC_MAX_TERMS; ++k)
+      if (k < nt && A.T.scale[k] && A.gb[k].enabled) sc[k] = __hiloint2double((int)(uint32_t)hw[2 * k + 1], (int)(uint32_t)hw[2 * k]);
+  };
+  // per-sweep arguments (draw stream, output slab)
+  auto nkey_f = [&]() -> omc_rng_key { return (MULTI && run_mode(A)) ? omc_make_key(A.seed, A.rec[sw].draw, OMC_RNG_NORMAL) : A.key; };
+  auto x_out = [&]() -> double* { return (MULTI && run_mode(A)) ? A.rec[sw].x : A.x; };
   // SIG 1: which of the two terms is the tridiagonal one (wave-uniform; selects, not indexed kernel arguments)
   const bool p_first = SIG == 1 && A.T.diag[0] != nullptr;
   double sP = 1.0, sI = 1.0;  // the two scales by role; selected where first needed (a use up here would put the wait for
@@ -1013,7 +1121,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // wave 0's SIMD has issue slots to spare (the opening phase is bound by the vector ALU there).
   if (SIG != 1 && epi_wave && chain_ok) {
     bool f = false;
-    const double g = sweep_gamma_draws_wave(A, c, lane, &f);
+    const double g = sweep_gamma_draws_wave(A, c, lane, &f, sw);
     lds_g[lane] = f ? -g : g;  // a Gamma draw is positive; the sign flags a draw that did not terminate
   }
 
@@ -1038,8 +1146,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     auto vec_and_draws = [&](double (&v)[M], const double* base, int nvalid, int jb) {
       if (gen_z && jb < NZB) {
         double z0, z1;
-        if (nvalid == 64 * M) draws_over_load<M, true>(A.key, gc, blk0 + (uint32_t)jb, z0, z1, v, base, lane, nvalid);
-        else draws_over_load<M, false>(A.key, gc, blk0 + (uint32_t)jb, z0, z1, v, base, lane, nvalid);
+        if (nvalid == 64 * M) draws_over_load<M, true>(nkey_f(), gc, blk0 + (uint32_t)jb, z0, z1, v, base, lane, nvalid);
+        else draws_over_load<M, false>(nkey_f(), gc, blk0 + (uint32_t)jb, z0, z1, v, base, lane, nvalid);
         lds_z[wave][2 * jb][lane] = z0;
         lds_z[wave][2 * jb + 1][lane] = z1;
       } else {
@@ -1052,6 +1160,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       // b_{i0-1}: only loaded here; any arithmetic on it would put a wait for all loads in front of the draws
       const double bm1_raw = vPo[(i0 > 0 && i0 < n) ? i0 - 1 : 0];
       vec_and_draws(po, vPo + wbase, nvo, 0);
+      take_scales();
       sP = p_first ? sc[0] : sc[1];
       sI = p_first ? sc[1] : sc[0];
       wave_lds_fence();
@@ -1077,6 +1186,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       wave_lds_fence();
     }
   } else {
+    take_scales();
     if (MULTI) tile_fill_comb_wg<M, COMB_OFF>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
     else tile_fill_comb<M, MULTI, COMB_OFF>(tile, geo, A, sc);
 #pragma unroll
@@ -1114,6 +1224,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     const Mob E = MULTI ? excl_scan_wg<Mob, false, true>(m, idm, lds_mob, lane, wave, nw, lds_mob2)
                         : excl_scan<Mob, false>(m, idm, pos, Wd, false, lds_mob, wave, nw);
     Dst = (E.a + E.b) / (E.c + E.d);
+    if (A.perturb_start != 0.0 && s > 0) Dst *= 1.0 + A.perturb_start;  // tests: a start the join test must reject
     if (MULTI) {
       const Mob inc = compose(m, E);
       Dnext0 = (inc.a + inc.b) * fast_rcp(inc.c + inc.d);
@@ -1223,8 +1334,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       const double* base = vIr + wave_u * 64 * M;
       if (gen_z && NZB > 2) {
         double z0, z1;
-        if (nvr == 64 * M) draws_over_load<M, true>(A.key, gc, blk0 + 2u, z0, z1, pre, base, lane, nvr);
-        else draws_over_load<M, false>(A.key, gc, blk0 + 2u, z0, z1, pre, base, lane, nvr);
+        if (nvr == 64 * M) draws_over_load<M, true>(nkey_f(), gc, blk0 + 2u, z0, z1, pre, base, lane, nvr);
+        else draws_over_load<M, false>(nkey_f(), gc, blk0 + 2u, z0, z1, pre, base, lane, nvr);
         lds_z[wave][4][lane] = z0;
         lds_z[wave][5][lane] = z1;
       } else {
@@ -1237,7 +1348,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       for (int jb = 2; jb < NZB; ++jb) {
         if (jb == 2 && !with_offsets) continue;  // made under the load above
         double z0, z1;
-        omc_normal_pair(omc_rng_block(A.key, gc, blk0 + (uint32_t)jb), z0, z1);
+        omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + (uint32_t)jb), z0, z1);
         lds_z[wave][2 * jb][lane] = z0;
         lds_z[wave][2 * jb + 1][lane] = z1;
       }
@@ -1295,7 +1406,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
                                                (__attribute__((address_space(3))) void*)&lds_z[wave][2 * k][0], 16, 0, 0);
           }
         }
-        omc_normal_pair(omc_rng_block(A.key, gc, blk0 + (uint32_t)(j >> 1)), z0, z1);
+        omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + (uint32_t)(j >> 1)), z0, z1);
       }
       u = fma(-lp, u, crow[j]);
       W[j] = fma(u, W[j], z0 * fast_sqrt(W[j]));
@@ -1370,8 +1481,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     // scalars of the epilogue: issue their loads now so the latency hides behind the quad phase
     if (epi_wave) {  // lane group k = lane >> 4 serves term k
       _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt && (lane >> 4) == k) {
-        if (A.T.scale[k]) my_scale = A.T.scale[k][cc];
-        if (A.log_post && A.gb[k].logdet_unscaled) my_logdet = A.gb[k].logdet_unscaled[0];
+        if (A.T.scale[k]) my_scale = handed ? sc[k] : A.T.scale[k][cc];
+        if (sweep_log_post(A, sw) && A.gb[k].logdet_unscaled) my_logdet = A.gb[k].logdet_unscaled[0];
       }
     }
     if constexpr (SIG == 1) {
@@ -1379,7 +1490,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       // the quadratic forms, wave 0's delay costs nothing -- the other waves' loads keep the L2 path busy
       if (epi_wave && chain_ok) {
         bool f = false;
-        const double g = sweep_gamma_draws_wave(A, c, lane, &f);
+        const double g = sweep_gamma_draws_wave(A, c, lane, &f, sw);
         lds_g[lane] = f ? -g : g;
       }
       const int nv = wave_valid<M>(wave_u, (int)n);
@@ -1420,7 +1531,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       double aI = 0.0, aP = aPd;
       // x leaves from the same pass, behind the loads issued above (vmcnt retires in order: nothing waits on the
       // x stream, and the 80 KB of stores drain under the reduction and the epilogue instead of after them)
-      double* xo = (A.x && chain_ok) ? A.x + cc * A.ld_x + wave_u * 64 * M : nullptr;
+      double* const xb = x_out();
+      double* xo = (xb && chain_ok) ? xb + cc * A.ld_x + wave_u * 64 * M : nullptr;
       if (!want_quad) {
         if (xo) {
 #pragma unroll
@@ -1434,7 +1546,10 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           const double xv = *pe, xn = *TM::succ(pe, r0, t), a = xv - qc[t];
           aI = fma(a, a, aI);
           aP = fma(2.0 * qo[t] * xn, xv, aP);
-          if (xo && !OMC_WHATIF_NOSTORE) xo[(unsigned)(lane + 64 * t)] = xv;
+          if (xo && !OMC_WHATIF_NOSTORE) {
+            if (OMC_STORE_NT) __builtin_nontemporal_store(xv, &xo[(unsigned)(lane + 64 * t)]);
+            else xo[(unsigned)(lane + 64 * t)] = xv;
+          }
         }
       } else if (nv == 64 * M) {
 #pragma unroll
@@ -1443,7 +1558,10 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           const double xv = *pe, xn = *TM::succ(pe, r0, t), a = xv - qc[t];
           aI = fma(a, a, aI);
           aP = fma(fma(2.0 * qo[t], xn, qd[t] * xv), xv, aP);
-          if (xo && !OMC_WHATIF_NOSTORE) xo[(unsigned)(lane + 64 * t)] = xv;
+          if (xo && !OMC_WHATIF_NOSTORE) {
+            if (OMC_STORE_NT) __builtin_nontemporal_store(xv, &xo[(unsigned)(lane + 64 * t)]);
+            else xo[(unsigned)(lane + 64 * t)] = xv;
+          }
         }
       } else {  // the chain's last wave: nodes beyond n hold finite fill values, their vectors were loaded as 0
 #pragma unroll
@@ -1520,13 +1638,14 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   if (MULTI) {
     if (epi_wave && chain_ok) {
       const double g = lds_g[lane];
-      sweep_epilogue_wave(A, c, qsum[0], qsum[1], qsum[2], qsum[3], my_scale, my_logdet, fabs(g), g < 0.0, lane);
+      sweep_epilogue_wave(A, c, qsum[0], qsum[1], qsum[2], qsum[3], my_scale, my_logdet, fabs(g), g < 0.0, lane, sw);
     }
     // x leaves last: a load issued behind a store would have to wait for the store to be
     // acknowledged (vmcnt retires in order); this way nothing ever waits on the x stream.
     // (SIG 1 has stored it from its quadratic-form pass already.)
-    if (SIG != 1 && A.x && chain_ok) {
-      double* xo = A.x + cc * A.ld_x + wave_u * 64 * M;
+    double* const xb = (SIG != 1) ? x_out() : nullptr;
+    if (SIG != 1 && xb && chain_ok) {
+      double* xo = xb + cc * A.ld_x + wave_u * 64 * M;
       const int nvalid = wave_valid<M>(wave_u, (int)n);
       {
         if (nvalid == 64 * M) {
@@ -1610,10 +1729,14 @@ static void args_defaults(omc_ctx* ctx, TriArgs* A, int64_t n) {
   A->bad = ctx->d_bad_chain;
   A->fallbacks = ctx->d_fallbacks;
   A->newton_max = ctx->tridiag_newton_max;
+  A->perturb_start = ctx->tridiag_perturb_ppb * 1e-9;
   A->work = nullptr;
   A->fused = 0;
   A->stamps = ctx->stamps;
   A->log_post = nullptr;
+  A->n_sweeps = 0; A->epoch = 0; A->seed = ctx->seed; A->handoff = nullptr; A->timeouts = ctx->d_fallbacks + 1;
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) A->gdraw[k] = 0;
+  for (int i = 0; i < OMC_RUN_MAX; ++i) { A->rec[i].draw = 0; A->rec[i].x = nullptr; A->rec[i].log_post = nullptr; A->rec[i].slot_off = -1; }
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
     A->gb[k].enabled = 0; A->gb[k].a0 = A->gb[k].b0 = A->gb[k].half_npos = A->gb[k].lnorm = 0.0;
     A->gb[k].g_inject = nullptr; A->gb[k].store = nullptr; A->gb[k].scale_out = nullptr;
@@ -1649,6 +1772,7 @@ static int64_t seg_max_n(int seg) {
 template <int M>
 static void launch_seg(omc_ctx* ctx, const TriArgs& A) {
   const int S = (int)((A.n + M - 1) / M);
+  const unsigned wg_grid = (unsigned)(A.C * (A.n_sweeps > 0 ? A.n_sweeps : 1));  // workgroup-per-chain form
   if (S <= 64) {
     const int G = pow2_ceil(S);
     const int64_t chains_per_block = 4 * (64 / G);
@@ -1659,10 +1783,10 @@ static void launch_seg(omc_ctx* ctx, const TriArgs& A) {
     // the specialised instantiation owns the CU (its LDS image is sized for a full workgroup); a short chain
     // leaves room for a second workgroup of the generic one, which then wins (n = 2000: 38 against 53 us)
     if (SegCfg<M>::SMOOTHER && !ctx->tridiag_generic && is_smoother(A.T) && A.n >= 2 && 2 * threads > SegCfg<M>::MAXT)
-      hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT, SegCfg<M>::SMOOTHER>), dim3((unsigned)A.C), dim3(threads), 0,
+      hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT, SegCfg<M>::SMOOTHER>), dim3(wg_grid), dim3(threads), 0,
                          ctx->stream, A, threads);
     else
-      hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT>), dim3((unsigned)A.C), dim3(threads), 0, ctx->stream,
+      hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT>), dim3(wg_grid), dim3(threads), 0, ctx->stream,
                          A, threads);
   }
 }
@@ -1683,6 +1807,15 @@ static int auto_seg(int64_t n) {
   if (n <= seg_max_n(8)) return 8;
   if (n <= seg_max_n(10)) return 10;
   return 32;
+}
+
+// true if launch_tridiag would run the workgroup-per-chain form of the segmented kernel for n nodes (the only form
+// that takes several sweeps per launch)
+static bool takes_wg_per_chain(const omc_ctx* ctx, int64_t n) {
+  if (ctx->tridiag_algo == 1) return false;
+  const int seg = ctx->tridiag_seg ? ctx->tridiag_seg : auto_seg(n);
+  if (n > seg_max_n(seg)) return false;
+  return (n + seg - 1) / seg > 64;
 }
 
 static omc_status launch_tridiag(omc_ctx* ctx, TriArgs& A) {
@@ -1789,6 +1922,69 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
   omc_gamma_block b[OMC_MAX_TERMS];
   // mcmc.py:97-98: every iteration, burn-in included, is n_thin sweeps
   const int64_t burn = n_burn * n_thin, total = burn + n_iter * n_thin;
+  if (n < 1 || ld_x < n) return OMC_INVALID_ARG;
+  if (ctx->run_sweeps_per_launch > 1 && takes_wg_per_chain(ctx, n) && C * (int64_t)OMC_RUN_MAX < (int64_t)1 << 31) {
+    // Several sweeps per launch: workgroup (sweep, chain) = block sweep * C + chain.  A chain's sweep s+1 needs only the
+    // scales its sweep s drew; they travel through the chain's hand-over line (see OMC_HANDOFF_WORDS).  Blocks are
+    // dispatched in index order, so a producer is always on the chip before its consumer; the consumer's wait is
+    // bounded anyway and a hand-over that never came is reported by omc_ctx_status.  What this buys: the ramp, tail
+    // and boundary of a launch (7.4 us against 21 us per round of workgroups) are paid once per OMC_RUN_MAX sweeps.
+    TriArgs A;
+    args_defaults(ctx, &A, n);
+    if (!terms_to_dev(terms, &A.T)) return OMC_INVALID_ARG;
+    for (int k = 0; k < A.T.n_terms; ++k) {
+      const omc_gamma_block& bk = blocks[k];
+      GammaDev& g = A.gb[k];
+      g.enabled = bk.enabled ? 1 : 0;
+      if (g.enabled) {
+        if (!terms->scale[k] || bk.n_pos < 0 || !(bk.a0 + 0.5 * (double)bk.n_pos > 0.0)) return OMC_INVALID_ARG;
+        if (log_post_store && !(bk.a0 > 0.0 && bk.b0 > 0.0)) return OMC_INVALID_ARG;
+        if (bk.g_inject) return OMC_INVALID_ARG;
+      }
+      if (log_post_store && !bk.logdet_unscaled) return OMC_INVALID_ARG;
+      g.a0 = bk.a0; g.b0 = bk.b0; g.half_npos = 0.5 * (double)bk.n_pos;
+      g.lnorm = (g.enabled && log_post_store) ? bk.a0 * log(bk.b0) - lgamma(bk.a0) : 0.0;
+      g.g_inject = nullptr; g.store = bk.store;
+      g.scale_out = const_cast<double*>(terms->scale[k]);
+      g.logdet_unscaled = bk.logdet_unscaled;
+      A.gdraw[k] = bk.draw_index;
+    }
+    OMC_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->d_handoff) {
+      const size_t bytes = (size_t)C * OMC_HANDOFF_WORDS * sizeof(unsigned long long);
+      OMC_HIP_CHECK(hipMalloc(&ctx->d_handoff, bytes));
+      OMC_HIP_CHECK(hipMemsetAsync(ctx->d_handoff, 0, bytes, ctx->stream));
+      ctx->run_epoch = 1;
+    }
+    A.handoff = ctx->d_handoff;
+    A.ld_x = ld_x;
+    A.zero_z = ctx->debug_zero_z;
+    A.fused = 1;
+    const int per = ctx->run_sweeps_per_launch < OMC_RUN_MAX ? ctx->run_sweeps_per_launch : OMC_RUN_MAX;
+    for (int64_t t0 = 0; t0 < total; t0 += per) {
+      const int k_sw = (int)(total - t0 < per ? total - t0 : per);
+      for (int i = 0; i < k_sw; ++i) {
+        const int64_t t = t0 + i;
+        const bool stored = t >= burn && ((t - burn + 1) % n_thin == 0);
+        const int64_t it = stored ? (t - burn + 1) / n_thin - 1 : 0;
+        const int64_t slot = (first_slot + it) % n_slots;
+        A.rec[i].draw = draw_index0 + (uint64_t)t * draws_per_sweep;
+        A.rec[i].x = stored ? x_store + slot * x_slot_stride : scratch_x;
+        A.rec[i].log_post = (stored && log_post_store) ? log_post_store + slot * C : nullptr;
+        A.rec[i].slot_off = stored ? slot * C : -1;
+      }
+      A.n_sweeps = k_sw;
+      A.epoch = ctx->run_epoch;
+      ctx->run_epoch += (uint32_t)k_sw;
+      // the non-specialised paths still read these
+      A.key = omc_make_key(ctx->seed, A.rec[0].draw, OMC_RNG_NORMAL);
+      A.x = A.rec[0].x;
+      A.log_post = A.rec[0].log_post;
+      omc_status st = launch_tridiag(ctx, A);
+      if (st != OMC_OK) return st;
+    }
+    return OMC_OK;
+  }
   for (int64_t t = 0; t < total; ++t) {
     const bool stored = t >= burn && ((t - burn + 1) % n_thin == 0);
     const int64_t i = stored ? (t - burn + 1) / n_thin - 1 : 0;
