@@ -36,3 +36,11 @@ go(10000, 3e7, 1.0, 10, 0, 1000, 0)
 go(10000, 3e7, 1.0, 32, None, 0, 0)
 go(10000, 3e7, 1.0, 16, None, 0, 0)
 go(10000, 3e7, 1.0, 10, None, 0, 0, algo=1)
+print("---- extremes")
+for lam in (1e9, 1e12, 1e15):
+    go(10000, lam, 1.0, 10, None, 0, 0)
+    go(10000, lam, 1.0, 10, None, 0, 0, irregular=False)
+go(10000, 1e-9, 1.0, 10, None, 0, 0)
+go(10000, 3e7, 1e-6, 10, None, 0, 0)
+go(10000, 3e7, 1.0, 10, None, 1000, 0)
+go(10000, 3e7, 1.0, 10, 1, 1000000, 0)

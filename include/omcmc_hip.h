@@ -232,6 +232,10 @@ omc_status omc_rw_step(omc_ctx* ctx, int64_t d, const double* mu, const double* 
                        double step, const double* z_inject, int64_t ld_z, const double* u_inject,
                        uint64_t draw_index, double* x, int64_t ld_x, int64_t* accept_count,
                        int64_t* proposal_count);
+/* omc_mh_invalidate: drops the matrices cached for the last (Q, L, step) / LQ.  The cache is keyed by device
+ * addresses; call this whenever Q, L or LQ were rewritten in place or re-created (a new buffer may land on a recycled
+ * address).  The reference has nothing to invalidate: it refactorises every step (metropolis_hastings.py:345-346). */
+omc_status omc_mh_invalidate(omc_ctx* ctx);
 
 /* ---- Normal-Gamma conjugate update ---------------------------------------------------------
  * NormalGamma.sample (sampler.py:252-288) for a scalar precision per chain:

@@ -243,6 +243,13 @@ static omc_status mala_prepare(omc_ctx* ctx, int64_t d, const double* Q, const d
   return OMC_OK;
 }
 
+omc_status omc_mh_invalidate(omc_ctx* ctx) {
+  if (!ctx) return OMC_INVALID_ARG;
+  ctx->mala_Q = nullptr; ctx->mala_L = nullptr; ctx->mala_step = 0.0; ctx->mala_d = 0;
+  ctx->rw_LQ = nullptr; ctx->rw_d = 0;
+  return OMC_OK;
+}
+
 omc_status omc_mala_step(omc_ctx* ctx, int64_t d, const double* Q, const double* mu, const double* L,
                          const double* sumlogL, double step, const double* z_inject, int64_t ld_z,
                          const double* u_inject, uint64_t draw_index, double* x, int64_t ld_x, int64_t* accept_count,

@@ -498,7 +498,11 @@ __device__ __forceinline__ T excl_scan_wg(T v, const T id, T* lds, int lane, int
     const int src = REV ? w + 1 : w - 1;
     if (ONE_WAVE) {
       if (w == 0) {
-        T t = (lane < nw) ? lds[lane] : id;
+        // The wave totals arrive unscaled from two folds; products of Moebius matrices of a precision of magnitude
+        // lambda shrink by ~1/lambda per factor, so sixteen of them in a row underflowed for lambda >= 1e6 on chains of
+        // twelve and more waves (0/0 start values).  Rescaled here, the row pass sees factors in [1, 2) like the one
+        // inside a wave.
+        T t = (lane < nw) ? renorm(lds[lane]) : id;
         t = row_scan<T, REV>(t, id);
         if (lane < nw) lds2[lane] = t;
       }
@@ -1228,6 +1232,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     if (MULTI) {
       const Mob inc = compose(m, E);
       Dnext0 = (inc.a + inc.b) * fast_rcp(inc.c + inc.d);
+      if (A.perturb_start != 0.0) Dnext0 *= 1.0 + A.perturb_start;  // tests: the successor's start is spoiled the same way
     }
   }
 
@@ -1704,6 +1709,23 @@ __global__ void __launch_bounds__(256) k_tridiag_quadform(TermsDev T, int64_t n,
   }
 }
 
+// log det of one shared tridiagonal matrix of any length: D_i = a_i - b_{i-1}^2 / D_{i-1}, sum log D_i (gmrf.py:489-520)
+__global__ void __launch_bounds__(64) k_tridiag_logdet_serial(int64_t n, const double* diag, const double* off, double* logdet,
+                                                              long long* bad) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double D = diag ? diag[0] : 1.0, acc = 0.0;
+  bool neg = !(D > 0.0);
+  acc = log(D);
+  for (int64_t i = 1; i < n; ++i) {
+    const double b = off ? off[i - 1] : 0.0;
+    D = fma(-b * omc_rcp_nr(D), b, diag ? diag[i] : 1.0);
+    neg |= !(D > 0.0);
+    acc += log(D);
+  }
+  logdet[0] = acc;
+  if (neg) atomicMin((unsigned long long*)bad, 0ull);
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 static bool terms_to_dev(const omc_tridiag_terms* t, TermsDev* d) {
@@ -2028,8 +2050,12 @@ omc_status omc_tridiag_matvec(omc_ctx* ctx, int64_t n, const double* diag, const
 
 omc_status omc_tridiag_logdet(omc_ctx* ctx, int64_t n, const double* diag, const double* off, double* logdet) {
   if (!ctx || n < 1 || !logdet) return OMC_INVALID_ARG;
-  if (n > seg_max_n(32)) return OMC_UNSUPPORTED;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  if (n > seg_max_n(32)) {  // beyond one workgroup: the plain recurrence on one lane (set-up time only, once per model)
+    hipLaunchKernelGGL(k_tridiag_logdet_serial, dim3(1), dim3(64), 0, ctx->stream, n, diag, off, logdet, ctx->d_bad_chain);
+    OMC_HIP_CHECK(hipGetLastError());
+    return OMC_OK;
+  }
   TriArgs A;
   args_defaults(ctx, &A, n);
   for (int k = 0; k < OMC_MAX_TERMS; ++k)

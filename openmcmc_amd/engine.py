@@ -315,6 +315,10 @@ class Engine:
         check(lib.omc_dense_cholesky(self._ctx, d, self._p(A), float(scale), self._p(L), self._p(sl)))
         return L, sl
 
+    def mh_invalidate(self):
+        """Drop what the library derived from the last (Q, L, step) of the fused Metropolis-Hastings routes."""
+        check(lib.omc_mh_invalidate(self._ctx))
+
     def mala_step(self, Q, mu, L, sumlogL, step, x, z=None, u=None, draw_index=0, accept_count=None,
                   proposal_count=None):
         d = Q.shape[0]
@@ -395,7 +399,8 @@ class Engine:
         key = (id(dist), id(st.matrix))
         hit = self._model_cache.get(key)
         c_host = np.ascontiguousarray(center, dtype=np.float64).reshape(-1)
-        if hit is not None and np.array_equal(hit["center_host"], c_host):
+        # ids can be recycled after garbage collection: the entry keeps the objects and is checked by identity
+        if hit is not None and hit["dist"] is dist and hit["matrix"] is st.matrix and np.array_equal(hit["center_host"], c_host):
             return hit
         n = st.n
         diag = None if st.diag is None else self.to_device(st.diag)
@@ -408,7 +413,8 @@ class Engine:
         else:
             rhs = self.tridiag_matvec(n, diag, off, cvec)
         logdet = self.zeros(1) if (diag is None and off is None) else self.tridiag_logdet(n, diag, off)
-        entry = {"diag": diag, "off": off, "center": cvec, "rhs": rhs, "logdet": logdet, "center_host": c_host,
+        entry = {"dist": dist, "matrix": st.matrix, "diag": diag, "off": off, "center": cvec, "rhs": rhs, "logdet": logdet,
+                 "center_host": c_host,
                  "terms_unit": self.tridiag_terms([{"diag": diag, "off": off, "center": cvec}], n)}
         self._model_cache[key] = entry
         return entry

@@ -92,6 +92,18 @@ class MetropolisHastings(MCMCSampler):
         mu = np.asarray(mu, dtype=np.float64).reshape(-1)
         return eng.shared(Q), (eng.shared(mu) if mu.any() else None), Q.shape[0]
 
+    def _factor_plan(self, eng, state, Q, scale):
+        """chol(scale * Q) of the fused routes, kept from step to step (the reference refactorises every step,
+        metropolis_hastings.py:345-346) but rebuilt whenever what it was made from changes: another precision array in
+        the state, or another step size.  The library keeps matrices derived from the factor (drift matrix, L^-T) keyed
+        by device addresses; a rebuilt factor may land on a recycled address, so that cache is dropped as well."""
+        key = (float(scale), id(state[self.model[self.param].precision.form]), int(Q.data_ptr()), int(Q._version))
+        if self._plan is None or getattr(self, "_plan_key", None) != key:
+            eng.mh_invalidate()
+            self._plan = eng.dense_cholesky(Q, scale)
+            self._plan_key = key
+        return self._plan
+
     def _x(self, state):
         v = state[self.param]
         if not is_chain(v) or v.shape[1] != 1:
@@ -237,9 +249,7 @@ class RandomWalk(MetropolisHastings):
         eng = self._need_engine()
         if self.domain_limits is None and self.state_update_function is None and self._gaussian_target(current_state):
             Q, mu, d = self._target(current_state)
-            if self._plan is None:
-                self._plan = eng.dense_cholesky(Q, 1.0)  # chol(Q) for log p (gmrf.py:339)
-            LQ, sl = self._plan
+            LQ, sl = self._factor_plan(eng, current_state, Q, 1.0)  # chol(Q) for log p (gmrf.py:339)
             z = self.inject(self, self._sweep) if self.inject is not None else None
             u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
             eng.rw_step(mu, LQ, sl, float(self.step.item()), self._x(current_state), z=z, u=u,
@@ -355,9 +365,7 @@ class ManifoldMALA(MetropolisHastings):
             return current_state
         Q, mu, d = self._target(current_state)
         step = float(self.step.item())
-        if self._plan is None:
-            self._plan = eng.dense_cholesky(Q, 1.0 / step**2)  # chol(H/step^2), H = Q (metropolis_hastings.py:345-346)
-        L, sl = self._plan
+        L, sl = self._factor_plan(eng, current_state, Q, 1.0 / step**2)  # chol(H/step^2), H = Q (metropolis_hastings.py:345-346)
         z = self.inject(self, self._sweep) if self.inject is not None else None
         u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
         eng.mala_step(Q, mu, L, sl, step, self._x(current_state), z=z, u=u, draw_index=self._draw_index(),
