@@ -428,17 +428,26 @@ def main():
                        "repeats": m["spread"], "other_scaling": other},
         }
         if kern_ms is not None:
-            achieved = ALG_BYTES_PER_CHAIN_UPDATE * (n / N_NODES) * C / (kern_ms * 1e-3) / 1e9
+            # One launch of omc_gmrf_run carries up to 16 sweeps (blocks = sweeps x chains): per launch the kernel
+            # processes spl x C chain-updates.  `kernel_ms` stays the time per SWEEP (events around all launches of the
+            # timed region / K); the launch figures are those of a full launch.
+            spl = args.sweeps_per_launch or 16
+            spl = 1 if (args.python_loop or args.unfused) else min(spl, args.steps)
+            alg_sweep = ALG_BYTES_PER_CHAIN_UPDATE * (n / N_NODES) * C
+            achieved = alg_sweep / (kern_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 rec = json.load(open(tpath))
                 if rec.get("nodes") == n and rec.get("chains") == C:
-                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic = rec.get("hbm_bytes_per_sweep") * spl
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "kernel": "k_tridiag_seg", "kernel_ms": kern_ms,
-                               "alg_bytes_per_launch": ALG_BYTES_PER_CHAIN_UPDATE * (n / N_NODES) * C}
+                               "sweeps_per_launch": spl, "launch_ms": kern_ms * spl,
+                               "alg_bytes_per_launch": alg_sweep * spl,
+                               "note": "achieved = alg_bytes_per_launch / launch_ms; traffic = PMC HBM bytes per launch "
+                                       "(profiles/traffic.json, per sweep x sweeps_per_launch)"}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(out))

@@ -144,12 +144,12 @@ def test_long_chains(torch, algo, seg, n):
     assert run_case(torch, n, 3, algo, seg, rng, with_extra=True) < TOL
 
 
-@pytest.mark.parametrize("lam_tau,tol", [((1e4, 1.0), 1e-10), ((1e6, 1.0), 1e-8), ((1.0, 1e3), 1e-10), ((1e-3, 1.0), 1e-10)])
+@pytest.mark.parametrize("lam_tau,tol", [((1e4, 1.0), 1e-10), ((1e6, 1.0), 1e-10), ((1e9, 1.0), 1e-10), ((1.0, 1e3), 1e-10), ((1e-3, 1.0), 1e-10)])
 @pytest.mark.parametrize("seg", [8, 10, 16, 20, 32])
 def test_weak_and_strong_coupling(torch, seg, lam_tau, tol):
-    """lam/tau large = weakly contractive pivot recurrence: forces the Newton join-correction
-    branch of the segmented kernel.  Tolerance widens with cond(Q) ~ 4 lam/tau (the oracle itself
-    is only accurate to eps*cond)."""
+    """lam/tau large = weakly coupled pivot recurrence, precisions of large magnitude.  The tolerance is the
+    north-star 1e-10 throughout: tests/test_tridiag_joins_gpu.py holds oracle and kernel against a longdouble solve
+    (both are good to ~1e-15 here; an earlier 1e-8 at lam/tau = 1e6 rested on a guess about the oracle)."""
     rng = np.random.default_rng(5)
     assert run_case(torch, 3000, 2, 2, seg, rng, lam_tau=lam_tau) < tol
 
