@@ -161,7 +161,7 @@ __device__ __forceinline__ double omc_add_vs(double a, double b_scalar) {  // a+
   return d;
 }
 
-// log(u), 2^-53 <= u <= 1
+// log(u) for a positive normal u (written for 2^-53 <= u <= 1, the uniforms; nothing in it depends on that range)
 __device__ __forceinline__ double omc_log_unit(double u) {
   int k = __builtin_amdgcn_frexp_exp(u);        // u = m * 2^k, m in [0.5, 1)
   double m = __builtin_amdgcn_frexp_mant(u);

@@ -54,7 +54,7 @@ struct GammaDev {
 
 // omc_gmrf_run: several sweeps of the same chains in ONE launch (blockIdx = sweep * C + chain).  What differs from
 // sweep to sweep is small and wave-uniform; it sits in the kernel arguments, indexed by the sweep.
-#define OMC_RUN_MAX 16
+#define OMC_RUN_MAX 32
 struct SweepRec {
   uint64_t draw;      // draw index of the sweep's standard-normal stream; the Gamma streams are draw + gdraw[k]
   double* x;          // where the draw goes: the sweep's store slab, or the scratch slab
@@ -230,8 +230,11 @@ __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c,
     double lp = 0.0;
     if (term_on && j == 0) {
       const double nd = (double)A.n;
-      lp = 0.5 * (nd * log(s) + ldet - nd * 1.8378770664093453 - s * qk);
-      if (g.enabled) lp += g.lnorm + (g.a0 - 1.0) * log(s) - g.b0 * s;
+      // this is the serial tail of the workgroup (fifteen waves are done): the lean fdlibm log kernel (< 1 ulp) for
+      // finite positive scales, the library's log for the rest (zero-rate guard: scale = inf)
+      const double ls = (s > 0.0 && s < INFINITY) ? omc_log_unit(s) : log(s);
+      lp = 0.5 * (nd * ls + ldet - nd * 1.8378770664093453 - s * qk);
+      if (g.enabled) lp += g.lnorm + (g.a0 - 1.0) * ls - g.b0 * s;
     }
     // terms are summed in order 0,1,2,3 as the serial epilogue does
     const double t0 = read_lane_d(lp, 0), t1 = read_lane_d(lp, 16), t2 = read_lane_d(lp, 32), t3 = read_lane_d(lp, 48);
@@ -851,6 +854,9 @@ __device__ __forceinline__ double fast_sqrt(double r) {
 #ifndef OMC_STORE_NT
 #define OMC_STORE_NT 1
 #endif
+#ifndef OMC_PREFETCH_QUAD
+#define OMC_PREFETCH_QUAD 1
+#endif
 #ifndef OMC_WHATIF_NOQLOAD
 #define OMC_WHATIF_NOQLOAD 0
 #endif
@@ -1438,6 +1444,28 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
                                          (__attribute__((address_space(3))) void*)(tile + 128 * k), 16, 0, 0);
     }
   }
+  // SIG 1: the rest of what the quadratic forms read from L2 -- the centre vector and the part of the off-diagonal
+  // slice that did not fit beside the parked draws -- is fetched here into registers: the reverse scan and the back
+  // pass (a tenth of the wave's lifetime, light on registers) cover its latency, the quadratic-form phase then reads
+  // nothing from memory and its x stores start a load round trip earlier (OMC_PREFETCH_QUAD; measured on
+  // benchmarks/ab_headline.py).
+  constexpr bool PFQ = SIG == 1 && OMC_PREFETCH_QUAD;
+  double qcp[PFQ ? M : 1], qop[PFQ ? M : 1];
+  bool pfq = false;
+  if constexpr (PFQ) {
+    pfq = want_quad && park_off && wave_valid<M>(wave_u, (int)n) == 64 * M;  // wave-uniform; other waves load in the phase itself
+    __builtin_amdgcn_sched_barrier(0);  // not into the forward pass: its registers are all taken
+    if (pfq) {
+      const int wbase = wave_u * 64 * M;
+#pragma unroll
+      for (int t = 0; t < M; ++t) qcp[t] = (vIc + wbase)[(unsigned)(lane + 64 * t)];
+      if (OMC_PREFETCH_QUAD > 1) {
+#pragma unroll
+        for (int t = 2 * NZB; t < M; ++t) qop[t] = (vPo + wbase)[(unsigned)(lane + 64 * t)];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   // ---- backward substitution: local affine map, reverse scan, true pass ----
   double xnext;
   {
@@ -1514,7 +1542,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 #pragma unroll
             for (int t = 0; t < M; ++t) {
               if (t < 2 * NZB) continue;
-              qo[t] = OMC_WHATIF_NOQLOAD ? 0.25 : (vPo + wbase)[(unsigned)(lane + 64 * t)];
+              if constexpr (PFQ && OMC_PREFETCH_QUAD > 1) qo[t] = pfq ? qop[t] : (vPo + wbase)[(unsigned)(lane + 64 * t)];
+              else qo[t] = OMC_WHATIF_NOQLOAD ? 0.25 : (vPo + wbase)[(unsigned)(lane + 64 * t)];
             }
           } else {
             coal_load<M>(qo, vPo + wbase, lane, nvo);
@@ -1529,6 +1558,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         if (OMC_WHATIF_NOQLOAD) {
 #pragma unroll
           for (int t = 0; t < M; ++t) qc[t] = 1.0;
+        } else if (PFQ && pfq) {
+#pragma unroll
+          for (int t = 0; t < M; ++t) qc[t] = qcp[t];
         } else {
           coal_load<M>(qc, vIc + wbase, lane, nvq);
         }
