@@ -36,13 +36,16 @@ struct omc_ctx {
   int tridiag_perturb_ppb;  // tests only: relative error (parts per billion) put on the Moebius start values of the segment joins
   int tridiag_generic;  // 1: never take the structure-specialised instantiation of the segmented kernel (tests)
   int band_algo;  // 0 auto, 1 lane-per-chain (narrow bands), 2 workgroup-per-chain
+  int gram_use_rocblas;  // 1: X' diag(w) X through rocBLAS (scaled copy of X + DGEMM) instead of the own MFMA kernel (cross-checks)
   int dense_use_rocsolver;  // 1: factor dense precisions with rocSOLVER's batched potrf instead of the blocked route
   unsigned long long* stamps;  // diagnostic phase stamps of the segmented kernel (NULL = off)
 };
 
 void omc_set_error(const char* what, hipError_t e);
 void omc_set_error_text(const char* text);  // any other library failure (RCCL) for omc_last_error()
-void omc_dense_release(omc_ctx* ctx);  // destroys the rocBLAS handle if one was created
+void omc_dense_release(omc_ctx* ctx);
+omc_status omc_ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need);  // grow-on-demand workspace (omc_dense.hip)
+extern "C" omc_status omc_gram_mfma_launch(omc_ctx* ctx, int64_t n, int64_t p, const double* X, const double* w, double* G_out);  // omc_gram.hip  // destroys the rocBLAS handle if one was created
 
 #define OMC_HIP_CHECK(expr)                  \
   do {                                       \

@@ -449,6 +449,7 @@ omc_status omc_dense_sample_canonical(omc_ctx* ctx, int64_t p, const omc_dense_t
 omc_status omc_gram(omc_ctx* ctx, int64_t n, int64_t p, const double* X, const double* w, double* G_out) {
   if (!ctx || n < 1 || p < 1 || !X || !G_out) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  if (!ctx->gram_use_rocblas && p <= 46340) return omc_gram_mfma_launch(ctx, n, p, X, w, G_out);  // own fp64 MFMA kernel (omc_gram.hip)
   omc_status st = omc_ensure_blas(ctx);
   if (st != OMC_OK) return st;
   const double* B = X;
