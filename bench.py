@@ -191,7 +191,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU (weak) / in all (strong)")
+    ap.add_argument("--config", choices=["cfg3", "cfg2", "cfg4", "cfg5"], default="cfg3",
+                    help="cfg3 (default): the headline GMRF smoother; the others: benchmarks/secondary.py, one GPU")
+    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (weak) / in all (strong); default: the config's")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --chains per GPU; strong: --chains in all, sharded evenly over the GPUs")
     ap.add_argument("--one-mode", action="store_true", help="N > 1: do not measure the other scaling mode as well")
@@ -212,6 +214,14 @@ def main():
     ap.add_argument("--sweeps-per-launch", type=int, default=0, help="omc_gmrf_run: sweeps per launch (0 = library default, 16)")
     args = ap.parse_args()
 
+    if args.config != "cfg3":
+        from benchmarks import secondary
+
+        if args.steps == 200 and args.config == "cfg5":
+            args.steps, args.warmup = 20, 3
+        return secondary.main(args)
+    if args.chains is None:
+        args.chains = CHAINS_PER_GPU
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Started directly: become the launcher.  Nothing has touched the GPU yet (torch is not even imported), and
         # the ranks are CHILD processes -- never an exec from a process that holds the GPU.
