@@ -188,6 +188,21 @@ omc_status omc_dense_sample_canonical(omc_ctx* ctx, int64_t p, const omc_dense_t
                                       double* x_out, int64_t ld_x,
                                       double* mean_out, int64_t ld_mean, double* logdet_out);
 
+/* Spectral route of the same conditional draw for Q_c = a_c I + b_c M with ONE shared symmetric M -- the regression
+ * likelihood's Gram matrix next to a scalar prior precision (examples/3, BASELINE configs[1]), where only two scalars
+ * differ from chain to chain and from sweep to sweep.  M = V diag(ev) V' once per model (omc_dense_spectral_prepare,
+ * rocSOLVER dsyevd), then  mu_c = V diag(1/(a_c + b_c ev)) V' b_c  and  x_c = mu_c + V diag((a_c + b_c ev)^-1/2) z_c:
+ * two (three with mean_out) GEMMs over all chains and one scaling kernel instead of C factorisations of order p
+ * (p^3/3 flop per chain).  mu_c and log det Q_c = sum_i log(a_c + b_c ev_i) are the reference's values
+ * (gmrf.py:196, 339) up to rounding; x_c is a draw from the same N(mu_c, Q_c^-1) but not the reference's
+ * path-wise image of z (that is L^-T z, gmrf.py:61): replays with injected draws use omc_dense_sample_canonical.
+ *   terms: as above; terms->mat[k_mat] is M, every other term a scaled identity (mat NULL), no diag_chain.       */
+omc_status omc_dense_spectral_prepare(omc_ctx* ctx, int64_t p, const double* M, double* V_out, double* ev_out);
+omc_status omc_dense_spectral_sample(omc_ctx* ctx, int64_t p, const omc_dense_terms* terms, int32_t k_mat, const double* V,
+                                     const double* ev, const double* rhs_chain, int64_t ld_rhs, const double* z_inject,
+                                     int64_t ld_z, uint64_t draw_index, double* x_out, int64_t ld_x, double* mean_out,
+                                     int64_t ld_mean, double* logdet_out);
+
 /* Design-matrix helpers; X is [n][p] row-major (a NumPy array as is), shared by all chains; w is an
  * optional [n] diagonal weight (NULL = ones).
  *   omc_gram:            G[p][p] = X' diag(w) X                 (location_scale.py:238-241; fp64 MFMA GEMM)

@@ -161,6 +161,9 @@ SIGNATURES = {
     "omc_mixture_normal_gamma": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, u64, c_dp]),
     "omc_gamma_logpdf_vec": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, i32]),
     "omc_mh_invalidate": (i32, [C.c_void_p]),
+    "omc_dense_spectral_prepare": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp]),
+    "omc_dense_spectral_sample": (i32, [C.c_void_p, i64, C.POINTER(DenseTerms), i32, c_dp, c_dp, c_dp, i64, c_dp, i64, u64,
+                                        c_dp, i64, c_dp, i64, c_dp]),
     "omc_comm_unique_id_bytes": (i64, []),
     "omc_comm_unique_id": (i32, [C.c_char_p, i64]),
     "omc_comm_create": (i32, [C.c_void_p, i32, i32, C.c_char_p, i64, C.POINTER(C.c_void_p)]),

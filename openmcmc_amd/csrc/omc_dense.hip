@@ -118,6 +118,54 @@ __global__ void k_add_draw(int64_t p, int64_t C, int64_t chain_offset, omc_rng_k
   }
 }
 
+// Spectral route: in the eigenbasis of the one shared matrix, Q_c = diag(d_c), d_c[i] = a_c + b_c ev[i].
+//   t holds V' rhs_c on entry; on exit m_c = t / d (into `mean` if given) and y_c = m_c + z / sqrt(d) (into t);
+//   logdet_c = sum log d; a non-positive d latches the chain like a failed factorisation.
+__global__ void __launch_bounds__(256) k_spectral_scale(DenseTermsDev T, int kmat, int64_t p, int64_t C, const double* ev,
+                                                        int64_t chain_offset, omc_rng_key key, const double* z, int64_t ld_z,
+                                                        double* t, int64_t ld_t, double* mean, int64_t ld_m, double* logdet,
+                                                        long long* bad) {
+  __shared__ double red[4];
+  const int64_t c = blockIdx.x;
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+    if (k >= T.n_terms) continue;
+    const double sk = T.scale[k] ? T.scale[k][c] : 1.0;
+    if (k == kmat) b = sk;
+    else a += sk;
+  }
+  double acc = 0.0;
+  bool neg = false;
+  const int64_t npairs = (p + 1) / 2;
+  for (int64_t q = threadIdx.x; q < npairs; q += blockDim.x) {
+    double z0, z1;
+    if (z) {
+      z0 = z[c * ld_z + 2 * q];
+      z1 = (2 * q + 1 < p) ? z[c * ld_z + 2 * q + 1] : 0.0;
+    } else {
+      omc_normal_pair(omc_rng_block(key, chain_offset + c, (uint32_t)q), z0, z1);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t i = 2 * q + h;
+      if (i >= p) continue;
+      const double d = fma(b, ev[i], a);
+      neg |= !(d > 0.0);
+      const double r = 1.0 / d, m = t[c * ld_t + i] * r;
+      if (mean) mean[c * ld_m + i] = m;
+      t[c * ld_t + i] = fma(h ? z1 : z0, sqrt(r), m);
+      acc += log(d);
+    }
+  }
+  if (neg) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+  if (!logdet) return;
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) logdet[c] = red[0] + red[1] + red[2] + red[3];
+}
+
 __global__ void k_copy_rows(int64_t p, const double* src, int64_t ld_s, double* dst, int64_t ld_d) {
   const int64_t c = blockIdx.y;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p; i += (int64_t)gridDim.x * blockDim.x)
@@ -442,6 +490,74 @@ omc_status omc_dense_sample_canonical(omc_ctx* ctx, int64_t p, const omc_dense_t
   OMC_HIP_CHECK(hipGetLastError());
   st = tri_solve(ctx, h, true, p, Q, x_out, ld_x, C);
   if (st != OMC_OK) return st;
+  return OMC_OK;
+}
+
+// ---- spectral route of the dense conjugate draw ---------------------------------------------------------------------
+omc_status omc_dense_spectral_prepare(omc_ctx* ctx, int64_t p, const double* M, double* V_out, double* ev_out) {
+  if (!ctx || p < 1 || p > 32768 || !M || !V_out || !ev_out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  omc_status st = omc_ensure_blas(ctx);
+  if (st != OMC_OK) return st;
+  rocblas_handle h = (rocblas_handle)ctx->blas;
+  st = omc_ensure_bytes(ctx, (void**)&ctx->dense_tmp, &ctx->dense_tmp_bytes, (size_t)p * sizeof(double));
+  if (st != OMC_OK) return st;
+  st = omc_ensure_bytes(ctx, (void**)&ctx->dense_info, &ctx->dense_info_bytes, sizeof(int));
+  if (st != OMC_OK) return st;
+  OMC_HIP_CHECK(hipMemcpyAsync(V_out, M, (size_t)p * p * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  OMC_BLAS_CHECK(rocsolver_dsyevd(h, rocblas_evect_original, rocblas_fill_lower, (rocblas_int)p, V_out, (rocblas_int)p, ev_out,
+                                  ctx->dense_tmp, ctx->dense_info));
+  int info = 0;
+  OMC_HIP_CHECK(hipMemcpyAsync(&info, ctx->dense_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (info != 0) { omc_set_error_text("omc_dense_spectral_prepare: the eigensolver did not converge"); return OMC_HIP_ERROR; }
+  return OMC_OK;
+}
+
+omc_status omc_dense_spectral_sample(omc_ctx* ctx, int64_t p, const omc_dense_terms* terms, int32_t k_mat, const double* V,
+                                     const double* ev, const double* rhs_chain, int64_t ld_rhs, const double* z_inject,
+                                     int64_t ld_z, uint64_t draw_index, double* x_out, int64_t ld_x, double* mean_out,
+                                     int64_t ld_mean, double* logdet_out) {
+  if (!ctx || p < 1 || !terms || terms->n_terms < 1 || terms->n_terms > OMC_MAX_TERMS || k_mat < 0 || k_mat >= terms->n_terms)
+    return OMC_INVALID_ARG;
+  if (!V || !ev || !x_out || ld_x < p || (rhs_chain && ld_rhs < p) || (z_inject && ld_z < p) || (mean_out && ld_mean < p))
+    return OMC_INVALID_ARG;
+  if (terms->diag_chain || !terms->mat[k_mat]) return OMC_INVALID_ARG;
+  for (int k = 0; k < terms->n_terms; ++k)
+    if (k != k_mat && terms->mat[k]) return OMC_INVALID_ARG;  // every other term must be a scaled identity
+  const int64_t C = ctx->n_chains;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  omc_status st = omc_ensure_blas(ctx);
+  if (st != OMC_OK) return st;
+  rocblas_handle h = (rocblas_handle)ctx->blas;
+  st = omc_ensure_bytes(ctx, (void**)&ctx->dense_factor, &ctx->dense_factor_bytes, (size_t)2 * C * p * sizeof(double));
+  if (st != OMC_OK) return st;
+  double* W = ctx->dense_factor;       // [C][p]: V' rhs, then y
+  double* Mw = W + C * p;              // [C][p]: m in the eigenbasis
+  DenseTermsDev T;
+  T.n_terms = terms->n_terms;
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+    const bool on = k < terms->n_terms;
+    T.mat[k] = on ? terms->mat[k] : nullptr;
+    T.rhs[k] = on ? terms->rhs[k] : nullptr;
+    T.scale[k] = on ? terms->scale[k] : nullptr;
+  }
+  T.diag_chain = nullptr;
+  // b_c into x_out, W = V' B  (all chains: one GEMM; [C][p] row-major = column-major p x C)
+  hipLaunchKernelGGL(k_dense_rhs, dim3(gx(p), (unsigned)C), dim3(256), 0, ctx->stream, T, p, C, rhs_chain, ld_rhs, x_out, ld_x);
+  OMC_HIP_CHECK(hipGetLastError());
+  const double one = 1.0, zero = 0.0;
+  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)p, (rocblas_int)C, (rocblas_int)p,
+                               &one, V, (rocblas_int)p, x_out, (rocblas_int)ld_x, &zero, W, (rocblas_int)p));
+  hipLaunchKernelGGL(k_spectral_scale, dim3((unsigned)C), dim3(256), 0, ctx->stream, T, (int)k_mat, p, C, ev, ctx->chain_offset,
+                     omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), z_inject, ld_z, W, p, mean_out ? Mw : nullptr, p,
+                     logdet_out, ctx->d_bad_chain);
+  OMC_HIP_CHECK(hipGetLastError());
+  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, (rocblas_int)p, (rocblas_int)C, (rocblas_int)p, &one,
+                               V, (rocblas_int)p, W, (rocblas_int)p, &zero, x_out, (rocblas_int)ld_x));
+  if (mean_out)
+    OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, (rocblas_int)p, (rocblas_int)C, (rocblas_int)p, &one,
+                                 V, (rocblas_int)p, Mw, (rocblas_int)p, &zero, mean_out, (rocblas_int)ld_mean));
   return OMC_OK;
 }
 

@@ -271,6 +271,25 @@ class Engine:
             int(draw_index), self._p(x_out, Cn, p), ld(x_out), self._p(mean_out, Cn, p), ld(mean_out),
             self._chain_scalar(logdet_out)))
 
+    def dense_spectral_prepare(self, M):
+        """(V, ev) with M = V diag(ev) V' (omc_dense_spectral_prepare): once per model, for the spectral route."""
+        p = M.shape[0]
+        V, ev = self.empty(p, p), self.empty(p)
+        check(lib.omc_dense_spectral_prepare(self._ctx, p, self._p(M), self._p(V), self._p(ev)))
+        return V, ev
+
+    def dense_spectral_sample(self, p, terms, k_mat, V, ev, x_out, z=None, rhs_chain=None, draw_index=0, mean_out=None,
+                              logdet_out=None):
+        """The conditional draw for Q_c = a_c I + b_c M in M's eigenbasis (omc_dense_spectral_sample)."""
+        T = terms if isinstance(terms, _abi.DenseTerms) else self.dense_terms(terms, p)
+        Cn = self.n_chains
+        T.diag_chain = None
+        ld = lambda t: 0 if t is None else t.stride(0)  # noqa: E731
+        check(lib.omc_dense_spectral_sample(
+            self._ctx, p, C.byref(T), int(k_mat), self._p(V), self._p(ev), self._p(rhs_chain, Cn, p), ld(rhs_chain),
+            self._p(z, Cn, p), ld(z), int(draw_index), self._p(x_out, Cn, p), ld(x_out), self._p(mean_out, Cn, p),
+            ld(mean_out), self._chain_scalar(logdet_out)))
+
     def gram(self, X, w=None):
         """G = X' diag(w) X for a shared (n, p) design matrix."""
         n, p = X.shape

@@ -297,6 +297,19 @@ class NormalNormal(MCMCSampler):
             keys.append(pc["key"])
         return {"kind": "dense", "n": n, "terms_list": terms, "terms": eng.dense_terms(terms, n), "keys": keys}
 
+    spectral = True  # class-level switch: False keeps every dense draw on the per-chain factorisation
+
+    def _spectral_plan(self, p):
+        """(k_mat, V, ev) if the dense plan is `scaled identities + one shared matrix` (order >= 64), else None; the
+        eigendecomposition is made once per plan."""
+        if "spectral" not in p:
+            mats = [k for k, t in enumerate(p["terms_list"]) if t["mat"] is not None]
+            p["spectral"] = None
+            if len(mats) == 1 and p["n"] >= 64 and p.get("mixture_prior") is None and p.get("limits") is None:
+                V, ev = self.engine.dense_spectral_prepare(p["terms_list"][mats[0]]["mat"])
+                p["spectral"] = (mats[0], V, ev)
+        return p["spectral"]
+
     def plan(self, state):
         p = self._plan
         if p is not None:
@@ -342,6 +355,12 @@ class NormalNormal(MCMCSampler):
             _, pmean, pprec, _ = p["mixture_prior"].mixture_pieces(current_state, eng)
             eng.dense_sample_canonical(n, p["terms"], x, z=z, rhs_chain=pprec * pmean, diag_chain=pprec,
                                        draw_index=self._draw_index())
+        elif z is None and self.spectral and self._spectral_plan(p) is not None:
+            # Q_c = a_c I + b_c M with one shared M: the draw in M's eigenbasis -- two GEMMs over all chains instead of
+            # one factorisation per chain.  Same conditional law and the reference's mean and log det; not its path-wise
+            # image of the draws, so a replay with injected draws (z given) takes the factorisation below.
+            k_mat, V, ev = self._spectral_plan(p)
+            eng.dense_spectral_sample(n, p["terms"], k_mat, V, ev, x, draw_index=self._draw_index())
         else:
             eng.dense_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())
         current_state[self.param] = ChainArray(x)

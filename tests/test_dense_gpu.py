@@ -188,3 +188,65 @@ def test_blocked_cholesky_route(p):
     with pytest.raises(np.linalg.LinAlgError, match="chain 1"):
         eng.check_status()
     eng.close()
+
+
+# ---- spectral route: Q_c = a_c I + b_c M in M's eigenbasis (omc_dense_spectral_sample) ------------------------------
+@pytest.mark.parametrize("p,C", [(70, 5), (300, 4)])
+def test_spectral_route_mean_logdet_and_mahalanobis(p, C):
+    """Same mean and log det as the factorisation route (the reference's values, gmrf.py:196, 339) and, for injected
+    draws, (x - mu)' Q (x - mu) = |z|^2 exactly: x - mu = V D^-1/2 z is a square-root image of z like L^-T z is."""
+    from openmcmc_amd.engine import Engine
+
+    rng = np.random.default_rng(p)
+    n_obs = 3 * p
+    X = rng.standard_normal((n_obs, p))
+    y = rng.standard_normal(n_obs)
+    eng = Engine(C, seed=4)
+    dX = eng.to_device(X)
+    G, Xty = eng.gram(dX), eng.design_rhs(dX, eng.to_device(y))
+    lam, tau = 0.3 + rng.random(C), 0.5 + 2 * rng.random(C)
+    terms = [{"mat": None, "scale": eng.to_device(lam)}, {"mat": G, "rhs": Xty, "scale": eng.to_device(tau)}]
+    extra = rng.standard_normal((C, p))
+    z = rng.standard_normal((C, p))
+    V, ev = eng.dense_spectral_prepare(G)
+    xs, ms, ls = eng.empty(C, p), eng.empty(C, p), eng.empty(C)
+    eng.dense_spectral_sample(p, terms, 1, V, ev, xs, z=eng.to_device(z), rhs_chain=eng.to_device(extra), mean_out=ms, logdet_out=ls)
+    xc, mc, lc = eng.empty(C, p), eng.empty(C, p), eng.empty(C)
+    eng.dense_sample_canonical(p, terms, xc, z=eng.to_device(z), rhs_chain=eng.to_device(extra), mean_out=mc, logdet_out=lc)
+    eng.check_status()
+    assert np.max(np.abs(ms.cpu().numpy() - mc.cpu().numpy())) / np.max(np.abs(mc.cpu().numpy())) < 1e-11
+    assert np.max(np.abs(ls.cpu().numpy() - lc.cpu().numpy()) / np.abs(lc.cpu().numpy())) < 1e-12
+    Gh = G.cpu().numpy()
+    for c in range(C):
+        Q = lam[c] * np.eye(p) + tau[c] * Gh
+        r = xs[c].cpu().numpy() - ms[c].cpu().numpy()
+        assert abs(r @ Q @ r - z[c] @ z[c]) < 1e-10 * (z[c] @ z[c])
+        mu = np.linalg.solve(Q, tau[c] * (X.T @ y) + extra[c])
+        assert np.max(np.abs(ms[c].cpu().numpy() - mu)) < 1e-10 * np.max(np.abs(mu))
+    eng.close()
+
+
+def test_spectral_route_draws_have_the_right_law():
+    """In-kernel draws: covariance of x - mu over many chains against Q^-1, chi^2 law of the Mahalanobis distance."""
+    from scipy import stats
+
+    from openmcmc_amd.engine import Engine
+
+    p, C = 64, 20000
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((200, p))
+    eng = Engine(C, seed=9)
+    G = eng.gram(eng.to_device(X))
+    lam, tau = 0.7, 1.3
+    terms = [{"mat": None, "scale": eng.full((C,), lam)}, {"mat": G, "rhs": eng.to_device(rng.standard_normal(p)), "scale": eng.full((C,), tau)}]
+    V, ev = eng.dense_spectral_prepare(G)
+    x, m = eng.empty(C, p), eng.empty(C, p)
+    eng.dense_spectral_sample(p, terms, 1, V, ev, x, mean_out=m, draw_index=3)
+    eng.check_status()
+    r = (x - m).cpu().numpy()
+    Q = lam * np.eye(p) + tau * G.cpu().numpy()
+    maha = np.einsum("ci,ij,cj->c", r, Q, r)
+    assert stats.kstest(maha, "chi2", args=(p,)).pvalue > 1e-3
+    cov, S = r.T @ r / C, np.linalg.inv(Q)
+    assert np.max(np.abs(cov - S)) < 6 * np.max(np.abs(S)) / np.sqrt(C)
+    eng.close()
