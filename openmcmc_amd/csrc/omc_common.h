@@ -36,6 +36,7 @@ struct omc_ctx {
   int tridiag_perturb_ppb;  // tests only: relative error (parts per billion) put on the Moebius start values of the segment joins
   int tridiag_generic;  // 1: never take the structure-specialised instantiation of the segmented kernel (tests)
   int band_algo;  // 0 auto, 1 lane-per-chain (narrow bands), 2 workgroup-per-chain
+  int mh_use_rocblas;  // 1: the products of the fused Metropolis-Hastings steps through rocBLAS DGEMM instead of omc_dgemm_small (cross-checks)
   int gram_use_rocblas;  // 1: X' diag(w) X through rocBLAS (scaled copy of X + DGEMM) instead of the own MFMA kernel (cross-checks)
   int dense_use_rocsolver;  // 1: factor dense precisions with rocSOLVER's batched potrf instead of the blocked route
   unsigned long long* stamps;  // diagnostic phase stamps of the segmented kernel (NULL = off)
@@ -44,6 +45,10 @@ struct omc_ctx {
 void omc_set_error(const char* what, hipError_t e);
 void omc_set_error_text(const char* text);  // any other library failure (RCCL) for omc_last_error()
 void omc_dense_release(omc_ctx* ctx);
+// omc_gemm.hip: small-state fp64 MFMA GEMM, C = A0 B0 (+ A1 B1) (+ addv per column), column-major
+omc_status omc_dgemm_small(omc_ctx* ctx, int M, int N, const double* A0, int64_t lda0, const double* B0, int64_t ldb0, int K0,
+                           const double* A1, int64_t lda1, const double* B1, int64_t ldb1, int K1, int tri, const double* addv,
+                           double* Cout, int64_t ldc);
 omc_status omc_ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need);  // grow-on-demand workspace (omc_dense.hip)
 extern "C" omc_status omc_gram_mfma_launch(omc_ctx* ctx, int64_t n, int64_t p, const double* X, const double* w, double* G_out);  // omc_gram.hip  // destroys the rocBLAS handle if one was created
 

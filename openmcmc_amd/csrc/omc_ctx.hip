@@ -51,6 +51,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->debug_zero_z = 0;
   c->dense_use_rocsolver = 0;
   c->gram_use_rocblas = 0;
+  c->mh_use_rocblas = 0;
   c->band_algo = 0;
   if (c->own_stream) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -172,6 +173,10 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "band_algo")) {
     if (value < 0 || value > 2) return OMC_INVALID_ARG;
     ctx->band_algo = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "mh_use_rocblas")) {
+    ctx->mh_use_rocblas = value != 0;
     return OMC_OK;
   }
   if (!strcmp(name, "gram_use_rocblas")) {

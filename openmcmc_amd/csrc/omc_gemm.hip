@@ -1,0 +1,104 @@
+// Small-state fp64 GEMM on the matrix cores for the Metropolis-Hastings steps:  C = A0 B0 (+ A1 B1) (+ v 1'),
+// A shared d x d (column-major), B the d x C state of all chains (column-major = chain-major rows), d ~ 500, C ~ 512.
+//
+// Why an own kernel: the products of a step are tiny by GEMM standards (500 x 500 x 512 = 0.26 Gflop); a library tile
+// choice made for throughput covers 16-32 of the 256 CUs with them, and the step is a chain of
+// such products.  Here the output is cut into 64 x 16 tiles -- 8 x 32 = 256 workgroups at cfg4, 768 for the triple
+// product -- each workgroup 4 waves, each wave ONE v_mfma_f64_16x16x4_f64 accumulator (16 rows x 16 chains) walked over
+// the whole contraction (64 x 32 tiles halve the workgroups and measured slower: 20.6 against 15.7 us per product); A and the state are L2-resident (2 MB each), so the small tile's extra operand traffic is
+// L2 -> LDS traffic, not HBM.  Two operand pairs in one launch fuse x' = A1p x + L^-T z into one pass (no second launch,
+// no read-modify-write of the output); an optional vector is added to every column in the epilogue (the constant part
+// of the proposal mean); `tri` skips the slabs of an upper-triangular A that are identically zero (the L' products).
+//   As[k][i] (row stride 64 + 16): lane l reads A[i0 + l%16][k + l/16]: the two rows of a half-wave in different bank halves
+//   Bs[j][k] (row stride BK + 2):  lane l reads B[k + l/16][j0 + l%16]: 16 columns x 2 rows tile all 64 banks exactly once
+#include "omc_common.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define GM_TM 64
+#define GM_TN 16
+#define GM_BK 32
+#define GM_LDA (GM_TM + 16)
+#define GM_LDB (GM_BK + 2)
+#define GM_NACC 4
+
+struct GemmPair {
+  const double* A; int64_t lda;
+  const double* B; int64_t ldb;
+  int K;
+};
+
+__global__ void __launch_bounds__(256) k_dgemm_64x16(int M, int N, GemmPair p0, GemmPair p1, int tri, const double* __restrict__ addv,
+                                                     double* __restrict__ Cout, int64_t ldc) {
+  __shared__ double As[GM_BK][GM_LDA];
+  __shared__ double Bs[GM_TN][GM_LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.x * GM_TM, j0 = blockIdx.y * GM_TN;
+  // GM_NACC accumulators per wave, each taking every GM_NACC-th group of four contraction indices: a chain of MFMAs
+  // on ONE accumulator is paced by the instruction's result latency, not by its issue rate (measured: one accumulator
+  // 15.7 us per 500 x 500 x 512 product)
+  double4_t acc[GM_NACC];
+#pragma unroll
+  for (int t = 0; t < GM_NACC; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+  double ra[GM_BK / 4], rb[GM_BK / 16];
+  for (int pass = 0; pass < 2; ++pass) {
+    const GemmPair P = pass ? p1 : p0;
+    if (P.K <= 0) continue;
+    // upper-triangular A (A(i,k) = 0 for k < i): nothing to add before the tile's first row
+    const int kbeg = tri ? (i0 / GM_BK) * GM_BK : 0;
+    auto fetch = [&](int k0) {
+#pragma unroll
+      for (int q = 0; q < GM_BK / 4; ++q) {  // A slab: BK x 64, element e = q*256 + tid: k = e / 64, i = e % 64 (contiguous in i)
+        const int e = q * 256 + tid, k = k0 + (e >> 6), i = i0 + (e & 63);
+        ra[q] = (k < P.K && i < M) ? P.A[(int64_t)k * P.lda + i] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < GM_BK / 16; ++q) {  // B slab: BK x 16, element e: j = e / BK, k = e % BK (contiguous in k)
+        const int e = q * 256 + tid, j = j0 + e / GM_BK, k = k0 + e % GM_BK;
+        rb[q] = (k < P.K && j < N) ? P.B[(int64_t)j * P.ldb + k] : 0.0;
+      }
+    };
+    if (kbeg < P.K) fetch(kbeg);
+    for (int k0 = kbeg; k0 < P.K; k0 += GM_BK) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < GM_BK / 4; ++q) {
+        const int e = q * 256 + tid;
+        As[e >> 6][e & 63] = ra[q];
+      }
+#pragma unroll
+      for (int q = 0; q < GM_BK / 16; ++q) {
+        const int e = q * 256 + tid;
+        Bs[e / GM_BK][e % GM_BK] = rb[q];
+      }
+      __syncthreads();
+      if (k0 + GM_BK < P.K) fetch(k0 + GM_BK);  // in flight under the multiplications
+#pragma unroll
+      for (int kk = 0; kk < GM_BK; kk += 4) {
+        const int kr = kk + (lane >> 4), cl = lane & 15;
+        acc[(kk / 4) % GM_NACC] = __builtin_amdgcn_mfma_f64_16x16x4f64(As[kr][wave * 16 + cl], Bs[cl][kr], acc[(kk / 4) % GM_NACC], 0, 0, 0);
+      }
+    }
+  }
+  // C/D of the f64 form: column = lane & 15, row = (lane >> 4) + 4 * register
+  const int j = j0 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + wave * 16 + (lane >> 4) + 4 * r;
+    double v = acc[0][r];
+#pragma unroll
+    for (int t = 1; t < GM_NACC; ++t) v += acc[t][r];
+    if (i < M && j < N) Cout[(int64_t)j * ldc + i] = v + (addv ? addv[i] : 0.0);
+  }
+}
+
+// C[M x N] = A0[M x K0] B0[K0 x N] (+ A1 B1) (+ addv per column); everything column-major, device pointers
+omc_status omc_dgemm_small(omc_ctx* ctx, int M, int N, const double* A0, int64_t lda0, const double* B0, int64_t ldb0, int K0,
+                           const double* A1, int64_t lda1, const double* B1, int64_t ldb1, int K1, int tri, const double* addv,
+                           double* Cout, int64_t ldc) {
+  GemmPair p0{A0, lda0, B0, ldb0, K0}, p1{A1, lda1, B1, ldb1, A1 ? K1 : 0};
+  const dim3 grid((unsigned)((M + GM_TM - 1) / GM_TM), (unsigned)((N + GM_TN - 1) / GM_TN));
+  hipLaunchKernelGGL(k_dgemm_64x16, grid, dim3(256), 0, ctx->stream, M, N, p0, p1, tri, addv, Cout, ldc);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}

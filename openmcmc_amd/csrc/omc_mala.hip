@@ -221,9 +221,17 @@ __global__ void k_lower_copy(int64_t d, const double* L, double* out) {
   out[i] = row >= col ? L[i] : 0.0;
 }
 
+// U = L' as a dense upper-triangular column-major matrix (zeros below the diagonal): the own GEMM takes A as it stands
+__global__ void k_lower_transpose(int64_t d, const double* L, double* out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d * d) return;
+  const int64_t k = e / d, i = e - k * d;  // out(i, k) = L(k, i) for k >= i
+  out[e] = k >= i ? L[i * d + k] : 0.0;
+}
+
 static omc_status mala_prepare(omc_ctx* ctx, int64_t d, const double* Q, const double* L, double step) {
   if (ctx->mala_Q == Q && ctx->mala_L == L && ctx->mala_step == step && ctx->mala_d == d && ctx->mala_prep) return OMC_OK;
-  omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->mala_prep, &ctx->mala_prep_bytes, (size_t)4 * d * d * sizeof(double));
+  omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->mala_prep, &ctx->mala_prep_bytes, (size_t)5 * d * d * sizeof(double));
   if (st != OMC_OK) return st;
   rocblas_handle h = (rocblas_handle)ctx->blas;
   const rocblas_int di = (rocblas_int)d;
@@ -238,6 +246,7 @@ static omc_status mala_prepare(omc_ctx* ctx, int64_t d, const double* Q, const d
   OMC_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
                                rocblas_diagonal_non_unit, di, di, &one, L, di, LinvT, di));
   hipLaunchKernelGGL(k_half_plus_identity, dim3(gx(d * d)), dim3(256), 0, ctx->stream, d, A1, ctx->mala_prep + 3 * d * d);
+  hipLaunchKernelGGL(k_lower_transpose, dim3(gx(d * d)), dim3(256), 0, ctx->stream, d, L, ctx->mala_prep + 4 * d * d);
   OMC_HIP_CHECK(hipGetLastError());
   ctx->mala_Q = Q; ctx->mala_L = L; ctx->mala_step = step; ctx->mala_d = d;
   return OMC_OK;
@@ -287,18 +296,32 @@ omc_status omc_mala_step(omc_ctx* ctx, int64_t d, const double* Q, const double*
   // proposal: x' = m(x) + L^{-T} z = A1p x + L^{-T} z (+ c0): two GEMMs into the same buffer, no element-wise pass
   hipLaunchKernelGGL(k_draw_normals, dim3(gx((d + 1) / 2) > 8 ? 8 : gx((d + 1) / 2), (unsigned)C), b2, 0, s, d,
                      ctx->chain_offset, omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), z_inject, ld_z, Z, d);
-  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, A1p, di, x,
-                               (rocblas_int)ld_x, &zero, w.XP, di));
-  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, LinvT, di, Z, di, &one,
-                               w.XP, di));
-  if (c0) hipLaunchKernelGGL(k_add_shared, g2, b2, 0, s, d, w.XP, d, c0);
-  // proposed state's mean: m' = A1p x' (+ c0, added when T3 is built)
-  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, A1p, di, w.XP, di, &zero,
-                               w.V, di));
+  const bool own = !ctx->mh_use_rocblas && d <= 46340;
+  const double* Lt = ctx->mala_prep + 4 * d * d;  // L' as a dense upper-triangular matrix
+  if (own) {  // one launch: x' = A1p x + L^-T z + c0
+    st = omc_dgemm_small(ctx, (int)d, (int)C, A1p, d, x, ld_x, (int)d, LinvT, d, Z, d, (int)d, 0, c0, w.XP, d);
+    if (st != OMC_OK) return st;
+    st = omc_dgemm_small(ctx, (int)d, (int)C, A1p, d, w.XP, d, (int)d, nullptr, 0, nullptr, 0, 0, 0, nullptr, w.V, d);
+    if (st != OMC_OK) return st;
+  } else {
+    OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, A1p, di, x,
+                                 (rocblas_int)ld_x, &zero, w.XP, di));
+    OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, LinvT, di, Z, di, &one,
+                                 w.XP, di));
+    if (c0) hipLaunchKernelGGL(k_add_shared, g2, b2, 0, s, d, w.XP, d, c0);
+    // proposed state's mean: m' = A1p x' (+ c0, added when T3 is built)
+    OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, di, Ci, di, &one, A1p, di, w.XP, di, &zero,
+                                 w.V, di));
+  }
   // |L'(x - mu)|^2, |L'(x' - mu)|^2, |L'(x - m')|^2 in one product; |L'(x' - m)|^2 = |z|^2 needs none
   hipLaunchKernelGGL(k_build_t3, g2, b2, 0, s, d, C, x, ld_x, mu, c0, w.XP, w.V, T3);
-  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, di, 3 * Ci, di, &one, Lz, di, T3, di,
-                               &zero, N3, di));
+  if (own) {
+    st = omc_dgemm_small(ctx, (int)d, (int)(3 * C), Lt, d, T3, d, (int)d, nullptr, 0, nullptr, 0, 0, 1, nullptr, N3, d);
+    if (st != OMC_OK) return st;
+  } else {
+    OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, di, 3 * Ci, di, &one, Lz, di, T3, di,
+                                 &zero, N3, di));
+  }
   // accept / reject and the move of accepted proposals.  L = chol(Q / step^2) => chol(Q) = step * L
   hipLaunchKernelGGL(k_mh_finish, dim3((unsigned)C), dim3(256), 0, s, d, ctx->chain_offset,
                      omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), u_inject, sumlogL, (double)d * log(step),
@@ -333,14 +356,20 @@ omc_status omc_rw_step(omc_ctx* ctx, int64_t d, const double* mu, const double* 
                      ctx->chain_offset, omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), z_inject, ld_z, Z, d);
   hipLaunchKernelGGL(k_rw_build, g2, b2, 0, s, d, C, x, ld_x, mu, step, Z, w.XP, T2);  // :250
   if (ctx->rw_LQ != LQ || ctx->rw_d != d || !ctx->rw_prep) {
-    st = omc_ensure_bytes(ctx, (void**)&ctx->rw_prep, &ctx->rw_prep_bytes, (size_t)d * d * sizeof(double));
+    st = omc_ensure_bytes(ctx, (void**)&ctx->rw_prep, &ctx->rw_prep_bytes, (size_t)2 * d * d * sizeof(double));
     if (st != OMC_OK) return st;
     hipLaunchKernelGGL(k_lower_copy, dim3(gx(d * d)), dim3(256), 0, s, d, LQ, ctx->rw_prep);
+    hipLaunchKernelGGL(k_lower_transpose, dim3(gx(d * d)), dim3(256), 0, s, d, LQ, ctx->rw_prep + d * d);
     ctx->rw_LQ = LQ; ctx->rw_d = d;
   }
   const double zero = 0.0;
-  OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, di, 2 * Ci, di, &one, ctx->rw_prep, di,
-                               T2, di, &zero, N2, di));
+  if (!ctx->mh_use_rocblas && d <= 46340) {
+    st = omc_dgemm_small(ctx, (int)d, (int)(2 * C), ctx->rw_prep + d * d, d, T2, d, (int)d, nullptr, 0, nullptr, 0, 0, 1, nullptr, N2, d);
+    if (st != OMC_OK) return st;
+  } else {
+    OMC_BLAS_CHECK(rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, di, 2 * Ci, di, &one, ctx->rw_prep, di,
+                                 T2, di, &zero, N2, di));
+  }
   hipLaunchKernelGGL(k_mh_finish, dim3((unsigned)C), dim3(256), 0, s, d, ctx->chain_offset,
                      omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), u_inject, sumlogLQ, 0.0, 1.0, N2, N2 + C * d,
                      (const double*)nullptr, (const double*)nullptr, w.XP, x, ld_x, (long long*)accept_count,
