@@ -161,6 +161,15 @@ omc_status omc_tridiag_quadform(omc_ctx* ctx, int64_t n, const omc_tridiag_terms
  *   *logdet [device, 1] = log det M via the same factorisation (gmrf.py:342), status latched */
 omc_status omc_tridiag_matvec(omc_ctx* ctx, int64_t n, const double* diag, const double* off,
                               const double* v, double* out);
+/* Per-chain vectors on the right-hand side (hierarchical models: a sampled prior mean, a sampled response):
+ *   omc_tridiag_matvec_chain: out[c] (+)= scale[c] * M v_c -- the term Q_rsp @ mean of sampler.py:181-183 when the mean is
+ *     itself per chain, and W (y_c - d) of sampler.py:190-192 when the response is (M tridiagonal; NULL diag = identity);
+ *   omc_chain_lincomb: out[c] = a x_c + b y_c (y per chain, or shared with ld_y = 0): the residual of location_scale.py:
+ *     153-160 when both sides of a Normal are per chain.                                                       */
+omc_status omc_tridiag_matvec_chain(omc_ctx* ctx, int64_t n, const double* diag, const double* off, const double* v, int64_t ld_v,
+                                    const double* scale, double* out, int64_t ld_out, int32_t accumulate);
+omc_status omc_chain_lincomb(omc_ctx* ctx, int64_t n, double a, const double* x, int64_t ld_x, double b, const double* y, int64_t ld_y,
+                             double* out, int64_t ld_out);
 omc_status omc_tridiag_logdet(omc_ctx* ctx, int64_t n, const double* diag, const double* off,
                               double* logdet);
 

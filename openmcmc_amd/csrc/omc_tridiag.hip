@@ -1717,6 +1717,31 @@ __global__ void k_tridiag_matvec(int64_t n, const double* diag, const double* of
   }
 }
 
+// out[c][:] (+)= scale[c] * M v_c for per-chain vectors v_c (M tridiagonal from diag / off; NULL diag = identity)
+__global__ void __launch_bounds__(256) k_tridiag_matvec_chain(int64_t n, const double* diag, const double* off, const double* v,
+                                                              int64_t ld_v, const double* scale, double* out, int64_t ld_o,
+                                                              int accumulate) {
+  const int64_t c = blockIdx.y;
+  const double s = scale ? scale[c] : 1.0;
+  const double* vc = v + c * ld_v;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double t = (diag ? diag[i] : 1.0) * vc[i];
+    if (off) {
+      if (i > 0) t = fma(off[i - 1], vc[i - 1], t);
+      if (i < n - 1) t = fma(off[i], vc[i + 1], t);
+    }
+    out[c * ld_o + i] = accumulate ? fma(s, t, out[c * ld_o + i]) : s * t;
+  }
+}
+
+// out[c][:] = a x_c + b y_c   (y per chain, or shared with ld_y == 0)
+__global__ void __launch_bounds__(256) k_chain_lincomb(int64_t n, double a, const double* x, int64_t ld_x, double b, const double* y,
+                                                       int64_t ld_y, double* out, int64_t ld_o) {
+  const int64_t c = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[c * ld_o + i] = fma(a, x[c * ld_x + i], b * y[c * ld_y + i]);
+}
+
 // one workgroup per chain: quad[k][c] = (x-m_k)' M_k (x-m_k)
 __global__ void __launch_bounds__(256) k_tridiag_quadform(TermsDev T, int64_t n, int64_t C, const double* x,
                                                          int64_t ld_x, double* quad) {
@@ -2076,6 +2101,30 @@ omc_status omc_tridiag_matvec(omc_ctx* ctx, int64_t n, const double* diag, const
   const int64_t grid = (n + 255) / 256;
   hipLaunchKernelGGL(k_tridiag_matvec, dim3((unsigned)(grid > 2048 ? 2048 : grid)), dim3(256), 0, ctx->stream, n,
                      diag, off, v, out);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_tridiag_matvec_chain(omc_ctx* ctx, int64_t n, const double* diag, const double* off, const double* v, int64_t ld_v,
+                                    const double* scale, double* out, int64_t ld_out, int32_t accumulate) {
+  if (!ctx || n < 1 || !v || !out || ld_v < n || ld_out < n || v == out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  int64_t gx_ = (n + 255) / 256;
+  if (gx_ > 64) gx_ = 64;
+  hipLaunchKernelGGL(k_tridiag_matvec_chain, dim3((unsigned)gx_, (unsigned)ctx->n_chains), dim3(256), 0, ctx->stream, n, diag, off, v, ld_v,
+                     scale, out, ld_out, (int)accumulate);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_chain_lincomb(omc_ctx* ctx, int64_t n, double a, const double* x, int64_t ld_x, double b, const double* y, int64_t ld_y,
+                             double* out, int64_t ld_out) {
+  if (!ctx || n < 1 || !x || !y || !out || ld_x < n || ld_out < n || (ld_y != 0 && ld_y < n)) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  int64_t gx_ = (n + 255) / 256;
+  if (gx_ > 64) gx_ = 64;
+  hipLaunchKernelGGL(k_chain_lincomb, dim3((unsigned)gx_, (unsigned)ctx->n_chains), dim3(256), 0, ctx->stream, n, a, x, ld_x, b, y, ld_y,
+                     out, ld_out);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

@@ -176,7 +176,9 @@ class Normal(Distribution):
             return resp, np.asarray(mean, dtype=np.float64)
         if is_chain(mean) and not is_chain(resp):
             return mean, np.asarray(resp, dtype=np.float64)
-        raise NotImplementedError("Normal with response and mean both per-chain (or both shared) on the GPU path")
+        if is_chain(mean) and is_chain(resp):
+            return resp, mean  # hierarchical: both sides sampled; the callers form the residual on the device
+        raise NotImplementedError("Normal with response and mean both shared on the GPU path")
 
     def residual_quad(self, state, engine, st=None, replicates=False):
         """(C,) tensor r' M r with r = response - mean, M the unscaled precision matrix: the sufficient
@@ -224,6 +226,15 @@ class Normal(Distribution):
         x, m = self.chain_and_center(state)
         if x.shape[1] != 1:
             raise NotImplementedError("replicated per-chain side of a Normal")
+        if is_chain(m):
+            # both sides per chain (a sampled mean under a sampled response): r_c = x_c - m_c on the device, then r'Mr
+            if m.shape[1] != 1:
+                raise NotImplementedError("replicated per-chain side of a Normal")
+            r = engine.chain_lincomb(1.0, x.vector(), -1.0, m.vector())
+            cache = engine.model_cache(self, state, st, np.zeros((st.n, 1)))
+            quad = engine.empty(1, engine.n_chains)
+            engine.tridiag_quadform(st.n, cache["terms_unit"], r, quad)
+            return quad[0]
         n_rep = m.shape[1]
         if n_rep != 1 and not replicates:
             # NormalGamma's b* = r'Pr is a scalar only for one replicate (the reference's .item() raises, sampler.py:284)

@@ -226,6 +226,24 @@ class Engine:
         check(lib.omc_tridiag_quadform(self._ctx, n, C.byref(T), self._p(x, self.n_chains, n), x.stride(0),
                                        self._p(quad_out)))
 
+    def tridiag_matvec_chain(self, n, diag, off, v, scale=None, out=None, accumulate=False):
+        """out[c] (+)= scale[c] * M v_c for a per-chain (C, n) vector (omc_tridiag_matvec_chain)."""
+        out = self.empty(self.n_chains, n) if out is None else out
+        check(lib.omc_tridiag_matvec_chain(self._ctx, n, self._vec(diag, n), self._vec(off, n - 1) if (off is not None and n > 1) else None,
+                                           self._p(v, self.n_chains, n), v.stride(0), self._chain_scalar(scale),
+                                           self._p(out, self.n_chains, n), out.stride(0), int(accumulate)))
+        return out
+
+    def chain_lincomb(self, a, x, b, y, out=None):
+        """a x_c + b y_c; y is (C, n) or a shared (n,) vector (omc_chain_lincomb)."""
+        n = x.shape[1]
+        out = self.empty(self.n_chains, n) if out is None else out
+        shared = y.dim() == 1
+        check(lib.omc_chain_lincomb(self._ctx, n, float(a), self._p(x, self.n_chains, n), x.stride(0), float(b),
+                                    self._vec(y, n) if shared else self._p(y, self.n_chains, n), 0 if shared else y.stride(0),
+                                    self._p(out, self.n_chains, n), out.stride(0)))
+        return out
+
     def tridiag_matvec(self, n, diag, off, v):
         out = self.empty(n)
         check(lib.omc_tridiag_matvec(self._ctx, n, self._vec(diag, n), self._vec(off, n - 1) if n > 1 else None,

@@ -133,10 +133,13 @@ class NormalNormal(MCMCSampler):
             st = dist.structure(state)
             piece = {"key": key, "dist": dist, "st": st, "design": None, "offset": False}
             if self._is_response[key]:
-                mean = dist.mean.predictor(state)  # sampler.py:183: b += Q_rsp @ mean
-                if is_chain(mean):
-                    raise NotImplementedError("per-chain prior mean")
-                piece["center"] = np.asarray(mean, dtype=np.float64)
+                if _mean_is_chain(dist.mean, state):
+                    # a prior mean that is itself sampled (hierarchical model): b_c += s_c M m_c every sweep on the
+                    # device (sampler.py:181-183); nothing shared goes into the plan for this term
+                    piece["center"], piece["chain_vec"] = np.zeros((n, 1)), ("mean", dist)
+                else:
+                    mean = dist.mean.predictor(state)  # sampler.py:183: b += Q_rsp @ mean
+                    piece["center"] = np.asarray(mean, dtype=np.float64)
             else:
                 # likelihood: the parameter enters the mean linearly (sampler.py:185-192)
                 if isinstance(dist.mean, Identity):
@@ -155,7 +158,14 @@ class NormalNormal(MCMCSampler):
                         rest = dist.mean.predictor_conditional(state, term_to_exclude=self.param)
                 y = state[key]
                 if is_chain(y):
-                    raise NotImplementedError("per-chain response")
+                    # a response that is itself sampled (the parameter is the mean of another sampled vector):
+                    # b_c += s_c W (y_c - d) with y_c per chain (sampler.py:185-192)
+                    if piece["design"] is not None or piece["offset"] or y.shape[1] != 1:
+                        raise NotImplementedError("per-chain response under a design matrix, with per-chain offsets, or replicated")
+                    piece["center"] = -np.asarray(rest, dtype=np.float64) * np.ones((n, 1))
+                    piece["chain_vec"] = ("response", key)
+                    pieces.append(piece)
+                    continue
                 y = np.asarray(y, dtype=np.float64)
                 n_rep = y.shape[1]
                 if n_rep != 1:
@@ -228,8 +238,10 @@ class NormalNormal(MCMCSampler):
             terms.append({"diag": cache["diag"], "off": cache["off"], "rhs": cache["rhs"], "center": cache["center"],
                           "scale": None if scale is None else scale.scalar()})
             keys.append(pc["key"])
+        chain_rhs = [(pc["chain_vec"], pc["st"].scale_key, eng.model_cache(pc["dist"], state, pc["st"], pc["center"]))
+                     for pc in pieces if pc.get("chain_vec") is not None]
         return {"kind": "tridiag", "n": n, "terms_list": terms, "terms": eng.tridiag_terms(terms, n), "keys": keys,
-                "offsets": offsets, "replicated": any(pc.get("replicated") for pc in pieces)}
+                "offsets": offsets, "replicated": any(pc.get("replicated") for pc in pieces), "chain_rhs": chain_rhs}
 
     def _ragged_plan(self, state, n_max):
         """Small variable-size parameter with a mixture prior (diagonal precision picked by an allocation) and
@@ -253,7 +265,13 @@ class NormalNormal(MCMCSampler):
             raise NotImplementedError("ragged NormalNormal: exactly one likelihood term")
         return {"kind": "ragged", "n": n_max, "like": likes[0], "terms_list": [], "keys": [], "limits": None}
 
+    @staticmethod
+    def _no_chain_vectors(pieces, route):
+        if any(pc.get("chain_vec") is not None for pc in pieces):
+            raise NotImplementedError(f"per-chain prior mean / per-chain response on the {route} route")
+
     def _band_plan(self, state, n, pieces):
+        self._no_chain_vectors(pieces, "band")
         """Q_c = sum_k s_k[c] M_k with banded M_k wider than tridiagonal (RW2, seasonal, lattice GMRFs): natural-order
         band Cholesky per chain (omc_band_sample_canonical)."""
         eng = self.engine
@@ -275,6 +293,7 @@ class NormalNormal(MCMCSampler):
         """Q_c = sum_k s_k[c] M_k with dense M_k: prior precision as is, a regression likelihood as the
         Gram matrix A' W A (one fp64 GEMM at plan time) -- sampler.py:185-192, location_scale.py:238-241."""
         eng = self.engine
+        self._no_chain_vectors(pieces, "dense")
         terms, keys = [], []
         for pc in pieces:
             if pc["offset"]:
@@ -337,6 +356,14 @@ class NormalNormal(MCMCSampler):
             scale = current_state[scale_key].scalar() if scale_key is not None else None
             t = dist.mean.predictor_device(current_state, eng, exclude=self.param, alpha=-1.0, chain_scale=scale)
             rhs_chain = t if rhs_chain is None else rhs_chain + t
+        for (kind, what), scale_key, cache in p.get("chain_rhs", ()):  # per-chain prior mean / per-chain response
+            v = what.mean.predictor_device(current_state, eng) if kind == "mean" and not isinstance(what.mean, Identity) else \
+                current_state[what.mean.form if kind == "mean" else what].vector()
+            scale = current_state[scale_key].scalar() if scale_key is not None else None
+            if rhs_chain is None:
+                rhs_chain = eng.tridiag_matvec_chain(n, cache["diag"], cache["off"], v, scale=scale)
+            else:
+                eng.tridiag_matvec_chain(n, cache["diag"], cache["off"], v, scale=scale, out=rhs_chain, accumulate=True)
         if p["limits"] is not None:
             # truncated prior: the scan starts from the current value and `z` carries the injected UNIFORMS
             lower, upper = p["limits"]
@@ -390,6 +417,16 @@ class NormalNormal(MCMCSampler):
         state[self.param] = cur.like(x.unsqueeze(2))
         self._sweep += 1
         return state
+
+
+def _mean_is_chain(mean, state):
+    """Does the mean parameter evaluate to a per-chain vector in this state?"""
+    if isinstance(mean, Identity):
+        return is_chain(state[mean.form])
+    form = getattr(mean, "form", None)
+    if isinstance(form, dict):
+        return any(is_chain(state[k]) for k in form)
+    return False
 
 
 @dataclass

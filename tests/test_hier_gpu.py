@@ -1,0 +1,77 @@
+"""Hierarchical models: a prior mean that is itself sampled, a likelihood whose response is itself sampled, a Normal whose
+two sides are both per chain -- ordinary in the reference (sampler/sampler.py:176-205 just calls mean.predictor(state)).
+Replay of the reference's own run (tests/golden/hier_chain.npz, made by tests/golden/make_golden_r2.py) with its
+recorded draws injected."""
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def build(G, k, C, seed=0):
+    from openmcmc_amd.distribution.distribution import Gamma
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import ScaledMatrix
+    from openmcmc_amd.sampler.sampler import NormalGamma, NormalNormal
+
+    n, kappa = int(G[k + "n"]), float(G[k + "kappa"])
+    pd, po = G[k + "P_diag"], G[k + "P_off"]
+    P = sparse.diags((po, pd, po), offsets=[-1, 0, 1], format="csc")
+    mdl = Model([
+        Normal("y", mean="b", precision=ScaledMatrix(matrix="P_tau", scalar="tau")),
+        Normal("b", mean="m", precision=ScaledMatrix(matrix="P_lambda", scalar="lambda")),
+        Normal("m", mean="m0", precision="P_m"),
+        Gamma("lambda", shape="a_lam", rate="b_lam"),
+        Gamma("tau", shape="a_tau", rate="b_tau"),
+    ])
+    state = {"y": G[k + "y"], "b": G[k + "y"], "m": np.full(n, 1.0), "m0": np.zeros(n), "P_m": sparse.csc_matrix(kappa * np.eye(n)),
+             "lambda": 50, "P_lambda": P, "a_lam": 10, "b_lam": 1, "tau": 1, "P_tau": sparse.csc_matrix(np.eye(n)),
+             "a_tau": 1, "b_tau": 1}
+    samplers = [NormalNormal("b", mdl), NormalNormal("m", mdl), NormalGamma("lambda", mdl), NormalGamma("tau", mdl)]
+    M = MCMC(state, samplers, model=mdl, n_burn=int(G[k + "n_burn"]), n_iter=int(G[k + "n_iter"]), n_chains=C, seed=seed)
+    return M, samplers
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hierarchical_smoother_replays_reference(golden, tag):
+    G = golden("hier_chain")
+    k = tag + "_"
+    C = 3
+    M, (nn_b, nn_m, g_lam, g_tau) = build(G, k, C)
+    assert M._fused is None  # two Normal-Normal blocks: the sweep is issued sampler by sampler
+    eng = M.engine
+    nn_b.inject = lambda smp, t: eng.to_device(np.tile(G[k + "z"][t, 0], (C, 1)))
+    nn_m.inject = lambda smp, t: eng.to_device(np.tile(G[k + "z"][t, 1], (C, 1)))
+    g_lam.inject = lambda smp, t: eng.full((C,), G[k + "g"][t, 0])
+    g_tau.inject = lambda smp, t: eng.full((C,), G[k + "g"][t, 1])
+    M.run_mcmc()
+    out = M.collect()
+    for c in range(C):
+        for key in ("b", "m", "lambda", "tau", "log_post"):
+            assert relerr(out[key][c], G[k + "store_" + key]) < TOL, (key, c)
+
+
+def test_hierarchical_smoother_runs_with_own_streams(golden):
+    """In-kernel draws, chains differ, everything finite; the mean level of m follows the data's."""
+    G = golden("hier_chain")
+    M, _ = build(G, "a_", 64, seed=5)
+    M.n_burn, M.n_iter = 30, 40
+    M.store = {}
+    for s in M.samplers:
+        M.store = s.init_store(current_state=M.state, store=M.store, n_iterations=M.n_iter)
+    M.store["log_post"] = M.engine.full((M.n_iter, 64), float("nan"))
+    M.run_mcmc()
+    out = M.collect()
+    assert np.all(np.isfinite(out["b"])) and np.all(np.isfinite(out["m"])) and np.all(out["lambda"] > 0)
+    assert not np.array_equal(out["m"][0], out["m"][1])
+    assert abs(out["b"].mean() - G["a_y"].mean()) < 0.5
