@@ -20,11 +20,11 @@ def shard_chains(n_chains_total, world_size, rank):
 
 
 def store_to_reference_layout(key, array):
-    """(n_iter, C, size) device layout -> the reference's per-chain layout (C, size, n_iter);
-    log_post (n_iter, C) -> (C, n_iter, 1)."""
+    """(n_iter, C, size) device layout -> the reference's per-chain layout (C, size, n_iter); (n_iter, C, rows, cols) of a
+    matrix-valued variable-size parameter -> (C, rows, cols, n_iter) (sampler.py:81-82); log_post (n_iter, C) -> (C, n_iter, 1)."""
     if key == "log_post":
         return np.transpose(array, (1, 0))[:, :, None]
-    return np.transpose(array, (1, 2, 0))
+    return np.moveaxis(array, 0, -1)  # (n_iter, C, ...) -> (C, ..., n_iter); a tuple max_variable_size keeps its two axes
 
 
 def make_communicator(engine, group=None):

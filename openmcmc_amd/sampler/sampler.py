@@ -63,7 +63,11 @@ class MCMCSampler(ABC):
         slab directly).  A variable-size parameter gets max_variable_size rows, NaN beyond its live length."""
         eng = self._need_engine()
         if isinstance(self.max_variable_size, tuple):
-            raise NotImplementedError("tuple max_variable_size (matrix-valued variable-size parameters)")
+            # matrix-valued variable-size parameter (sampler.py:81-82): (max_rows, max_cols, n_iterations) per chain
+            if len(self.max_variable_size) != 2:
+                raise ValueError("max_variable_size as a tuple wants (rows, columns)")
+            store[self.param] = eng.full((n_iterations, eng.n_chains) + tuple(int(v) for v in self.max_variable_size), float("nan"))
+            return store
         size = current_state[self.param].size if self.max_variable_size is None else int(self.max_variable_size)
         store[self.param] = eng.full((n_iterations, eng.n_chains, size), float("nan"))
         return store
@@ -71,6 +75,21 @@ class MCMCSampler(ABC):
     def store(self, current_state: dict, store: dict, iteration: int) -> dict:
         """sampler.py:89-118."""
         value = current_state[self.param]
+        if isinstance(self.max_variable_size, tuple):
+            # sampler.py:105-111: the current (p, q) block goes to the top-left corner, the NaN fill stays elsewhere
+            import torch
+
+            block = value.data
+            slab = store[self.param][iteration]
+            if block.shape[1] > slab.shape[1] or block.shape[2] > slab.shape[2]:
+                raise ValueError("parameter larger than max_variable_size")
+            if value.ragged is not None:
+                axis = value.ragged[1]
+                live = torch.arange(block.shape[1 + axis], device=block.device).reshape((1, -1, 1) if axis == 0 else (1, 1, -1)) \
+                    < value.count(current_state).reshape(-1, 1, 1)
+                block = torch.where(live, block, torch.full_like(block, float("nan")))
+            slab[:, : block.shape[1], : block.shape[2]] = block
+            return store
         flat = value.data.reshape(self.engine.n_chains, -1)
         slab = store[self.param][iteration]
         if value.ragged is None:

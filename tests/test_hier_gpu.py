@@ -75,3 +75,25 @@ def test_hierarchical_smoother_runs_with_own_streams(golden):
     assert np.all(np.isfinite(out["b"])) and np.all(np.isfinite(out["m"])) and np.all(out["lambda"] > 0)
     assert not np.array_equal(out["m"][0], out["m"][1])
     assert abs(out["b"].mean() - G["a_y"].mean()) < 0.5
+
+
+def test_tuple_max_variable_size_store_layout(golden):
+    """sampler.py:81-86, 105-111: a tuple max_variable_size gives a (rows, cols, n_iter) store per chain with the current
+    value in the top-left corner and the NaN fill elsewhere."""
+    G = golden("hier_chain")
+    k, C = "b_", 2
+    M, (nn_b, nn_m, g_lam, g_tau) = build(G, k, C)
+    n, n_iter = int(G[k + "n"]), int(G[k + "n_iter"])
+    nn_b.max_variable_size = (n + 3, 2)
+    M.store = nn_b.init_store(current_state=M.state, store=M.store, n_iterations=n_iter)
+    eng = M.engine
+    nn_b.inject = lambda smp, t: eng.to_device(np.tile(G[k + "z"][t, 0], (C, 1)))
+    nn_m.inject = lambda smp, t: eng.to_device(np.tile(G[k + "z"][t, 1], (C, 1)))
+    g_lam.inject = lambda smp, t: eng.full((C,), G[k + "g"][t, 0])
+    g_tau.inject = lambda smp, t: eng.full((C,), G[k + "g"][t, 1])
+    M.run_mcmc()
+    out = M.collect()
+    assert out["b"].shape == (C, n + 3, 2, n_iter)
+    for c in range(C):
+        assert relerr(out["b"][c, :n, 0, :], G[k + "store_b"]) < TOL
+        assert np.isnan(out["b"][c, n:, :, :]).all() and np.isnan(out["b"][c, :, 1, :]).all()
