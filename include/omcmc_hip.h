@@ -334,6 +334,10 @@ omc_status omc_tridiag_gibbs_truncated(omc_ctx* ctx, int64_t n, const omc_tridia
                                        const double* rhs_chain, int64_t ld_rhs, const double* lower,
                                        const double* upper, const double* u_inject, int64_t ld_u,
                                        uint64_t draw_index, double* x, int64_t ld_x);
+/* the same scan for a banded precision (band storage and terms of omc_band_sample_canonical), one lane per chain */
+omc_status omc_band_gibbs_truncated(omc_ctx* ctx, int64_t n, int64_t w, const omc_band_terms* terms, const double* rhs_chain,
+                                    int64_t ld_rhs, const double* lower, const double* upper, const double* u_inject, int64_t ld_u,
+                                    uint64_t draw_index, double* x, int64_t ld_x);
 omc_status omc_dense_gibbs_truncated(omc_ctx* ctx, int64_t p, const omc_dense_terms* terms,
                                      const double* rhs_chain, int64_t ld_rhs, const double* lower,
                                      const double* upper, const double* u_inject, int64_t ld_u,

@@ -73,6 +73,71 @@ __global__ void k_tridiag_gibbs_truncated(int64_t C, int64_t chain_offset, int64
   if (fail) atomicMin((unsigned long long*)bad, (unsigned long long)c);
 }
 
+// banded precision of bandwidth w (Q_c = sum_k s_k[c] M_k, M_k in the band storage of omc_band_terms: band[d*n + i] =
+// M[i+d, i]): the same scan, one lane per chain.  Row i of Q touches x_{i-w..i+w}; the sub-diagonal part of the row comes
+// from the columns i-d (band[d*n + i-d]), the super-diagonal part from column i itself (band[d*n + i]).  The row product
+// is accumulated in column order like the reference's Q[i, :] @ x (gmrf.py:258).
+struct TruncBand {
+  int n_terms;
+  const double* band[OMC_MAX_TERMS];
+  int bw[OMC_MAX_TERMS];
+  const double* rhs[OMC_MAX_TERMS];
+  const double* scale[OMC_MAX_TERMS];
+};
+
+__global__ void k_band_gibbs_truncated(int64_t C, int64_t chain_offset, int64_t n, int w, TruncBand T, const double* rhs_chain,
+                                       int64_t ld_rhs, const double* lower, const double* upper, const double* u_in, int64_t ld_u,
+                                       omc_rng_key key, double* x, int64_t ld_x, long long* bad) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s[OMC_MAX_TERMS];
+#pragma unroll
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) s[k] = (k < T.n_terms && T.scale[k]) ? T.scale[k][c] : 1.0;
+  double* xc = x + c * ld_x;
+  bool fail = false;
+  for (int64_t i = 0; i < n; ++i) {
+    double a = 0.0, b = rhs_chain ? rhs_chain[c * ld_rhs + i] : 0.0, row = 0.0;
+#pragma unroll
+    for (int k = 0; k < OMC_MAX_TERMS; ++k)
+      if (k < T.n_terms) {
+        a = fma(s[k], T.band[k] ? T.band[k][i] : 1.0, a);
+        if (T.rhs[k]) b = fma(s[k], T.rhs[k][i], b);
+      }
+    // columns i-w .. i-1 (already updated), then i, then i+1 .. i+w
+    for (int d = w; d >= 1; --d) {
+      if (i - d < 0) continue;
+      double q = 0.0;
+#pragma unroll
+      for (int k = 0; k < OMC_MAX_TERMS; ++k)
+        if (k < T.n_terms && T.band[k] && d <= T.bw[k]) q = fma(s[k], T.band[k][(int64_t)d * n + (i - d)], q);
+      row = fma(q, xc[i - d], row);
+    }
+    const double xi_old = xc[i];
+    row = fma(a, xi_old, row);
+    for (int d = 1; d <= w; ++d) {
+      if (i + d >= n) break;
+      double q = 0.0;
+#pragma unroll
+      for (int k = 0; k < OMC_MAX_TERMS; ++k)
+        if (k < T.n_terms && T.band[k] && d <= T.bw[k]) q = fma(s[k], T.band[k][(int64_t)d * n + i], q);
+      row = fma(q, xc[i + d], row);
+    }
+    if (!(a > 0.0)) fail = true;
+    const double lo = lower ? lower[i] : -INFINITY, hi = upper ? upper[i] : INFINITY;
+    double mean, sd;
+    if (n == 1) {
+      mean = b / a;
+      sd = 1.0 / sqrt(a);
+    } else {
+      const double v = 1.0 / a;
+      sd = sqrt(v);
+      mean = v * ((b - row) + a * xi_old);
+    }
+    xc[i] = omc_truncated_normal_rv(mean, sd, lo, hi, trunc_uniform(u_in, ld_u, c, i, key, chain_offset + c));
+  }
+  if (fail) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+}
+
 // dense precision, one wave per chain: Q_c = sum_k s_k[c] M_k assembled row by row on the fly
 __global__ void __launch_bounds__(64) k_dense_gibbs_truncated(int64_t C, int64_t chain_offset, int64_t p, int n_terms,
                                                               const double* m0, const double* m1, const double* m2,
@@ -166,6 +231,30 @@ omc_status omc_tridiag_gibbs_truncated(omc_ctx* ctx, int64_t n, const omc_tridia
   }
   hipLaunchKernelGGL(k_tridiag_gibbs_truncated, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains,
                      ctx->chain_offset, n, T, rhs_chain, ld_rhs, lower, upper, u_inject, ld_u,
+                     omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), x, ld_x, ctx->d_bad_chain);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_band_gibbs_truncated(omc_ctx* ctx, int64_t n, int64_t w, const omc_band_terms* terms, const double* rhs_chain,
+                                    int64_t ld_rhs, const double* lower, const double* upper, const double* u_inject, int64_t ld_u,
+                                    uint64_t draw_index, double* x, int64_t ld_x) {
+  if (!ctx || n < 1 || w < 0 || w > 128 || !terms || terms->n_terms < 1 || terms->n_terms > OMC_MAX_TERMS || !x || ld_x < n ||
+      (rhs_chain && ld_rhs < n) || (u_inject && ld_u < n))
+    return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  TruncBand T;
+  T.n_terms = terms->n_terms;
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+    const bool on = k < terms->n_terms;
+    T.band[k] = on ? terms->band[k] : nullptr;
+    T.bw[k] = on ? terms->bw[k] : 0;
+    T.rhs[k] = on ? terms->rhs[k] : nullptr;
+    T.scale[k] = on ? terms->scale[k] : nullptr;
+    if (on && (T.bw[k] < 0 || T.bw[k] > w)) return OMC_INVALID_ARG;
+  }
+  hipLaunchKernelGGL(k_band_gibbs_truncated, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains,
+                     ctx->chain_offset, n, (int)w, T, rhs_chain, ld_rhs, lower, upper, u_inject, ld_u,
                      omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), x, ld_x, ctx->d_bad_chain);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;

@@ -524,6 +524,16 @@ class Engine:
         return quad_out
 
     # ------------------------------------------------------------------ truncated Gaussian conditional
+    def band_gibbs_truncated(self, n, terms, x, lower=None, upper=None, u=None, rhs_chain=None, draw_index=0):
+        """One scan of single-site truncated updates under a banded precision (omc_band_gibbs_truncated); x in place."""
+        T, w = terms if isinstance(terms, tuple) else self.band_terms(terms, n)
+        Cn = self.n_chains
+        ld = lambda t: 0 if t is None else t.stride(0)  # noqa: E731
+        check(lib.omc_band_gibbs_truncated(self._ctx, n, w, C.byref(T), self._p(rhs_chain, Cn, n), ld(rhs_chain),
+                                           self._vec(lower, n), self._vec(upper, n), self._p(u, Cn, n), ld(u), int(draw_index),
+                                           self._p(x, Cn, n), ld(x)))
+        return x
+
     def tridiag_gibbs_truncated(self, n, terms, x, lower=None, upper=None, u=None, rhs_chain=None, draw_index=0):
         """One in-place scan of gmrf.gibbs_canonical_truncated_normal on x (C, n); lower / upper: device (n,) or None."""
         T = terms if isinstance(terms, _abi.TridiagTerms) else self.tridiag_terms(terms, n)

@@ -387,9 +387,7 @@ class NormalNormal(MCMCSampler):
             # truncated prior: the scan starts from the current value and `z` carries the injected UNIFORMS
             lower, upper = p["limits"]
             x.copy_(current_state[self.param].vector())
-            if p["kind"] == "band":
-                raise NotImplementedError("truncated conditional under a banded precision wider than tridiagonal")
-            gibbs = eng.tridiag_gibbs_truncated if p["kind"] == "tridiag" else eng.dense_gibbs_truncated
+            gibbs = {"tridiag": eng.tridiag_gibbs_truncated, "band": eng.band_gibbs_truncated}.get(p["kind"], eng.dense_gibbs_truncated)
             gibbs(n, p["terms"], x, lower=lower, upper=upper, u=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
         elif p["kind"] == "tridiag":
             eng.tridiag_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
