@@ -211,7 +211,7 @@ def main():
     ap.add_argument("--generic", action="store_true", help="diagnostic: never use the structure-specialised kernel instantiation")
     ap.add_argument("--stamps", action="store_true", help="diagnostic: print in-kernel phase stamps (not a timing run)")
     ap.add_argument("--seg", type=int, default=0, help="nodes per lane of the segmented kernel (0 = auto)")
-    ap.add_argument("--sweeps-per-launch", type=int, default=0, help="omc_gmrf_run: sweeps per launch (0 = library default, 16)")
+    ap.add_argument("--sweeps-per-launch", type=int, default=0, help="omc_gmrf_run: sweeps per launch (0 = library default, 32)")
     args = ap.parse_args()
 
     if args.config != "cfg3":
@@ -438,10 +438,10 @@ def main():
                        "repeats": m["spread"], "other_scaling": other},
         }
         if kern_ms is not None:
-            # One launch of omc_gmrf_run carries up to 16 sweeps (blocks = sweeps x chains): per launch the kernel
+            # One launch of omc_gmrf_run carries up to 32 sweeps (blocks = sweeps x chains): per launch the kernel
             # processes spl x C chain-updates.  `kernel_ms` stays the time per SWEEP (events around all launches of the
             # timed region / K); the launch figures are those of a full launch.
-            spl = args.sweeps_per_launch or 16
+            spl = args.sweeps_per_launch or 32
             spl = 1 if (args.python_loop or args.unfused) else min(spl, args.steps)
             alg_sweep = ALG_BYTES_PER_CHAIN_UPDATE * (n / N_NODES) * C
             achieved = alg_sweep / (kern_ms * 1e-3) / 1e9
