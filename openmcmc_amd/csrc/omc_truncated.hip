@@ -41,8 +41,10 @@ __global__ void k_tridiag_gibbs_truncated(int64_t C, int64_t chain_offset, int64
   double x_prev = 0.0, off_prev = 0.0;  // x_{i-1} (already updated) and Q_{i,i-1}
   double x_cur = xc[0];
   bool fail = false;
-  for (int64_t i = 0; i < n; ++i) {
-    double a = 0.0, o = 0.0, b = rhs_chain ? rhs_chain[c * ld_rhs + i] : 0.0;
+  // row i of Q_c and b_c from the shared vectors; the NEXT site's row is fetched while this site's draw is worked out
+  // (the scan is one dependent chain per lane: a load waited for at every site is most of a site's time)
+  auto site = [&](int64_t i, double& a, double& o, double& b, double& lo, double& hi, double& xn) {
+    a = 0.0; o = 0.0; b = rhs_chain ? rhs_chain[c * ld_rhs + i] : 0.0;
 #pragma unroll
     for (int k = 0; k < OMC_MAX_TERMS; ++k) {
       if (k < T.n_terms) {
@@ -51,20 +53,46 @@ __global__ void k_tridiag_gibbs_truncated(int64_t C, int64_t chain_offset, int64
         if (T.rhs[k]) b = fma(s[k], T.rhs[k][i], b);
       }
     }
-    const double x_next = (i + 1 < n) ? xc[i + 1] : 0.0;
+    lo = lower ? lower[i] : -INFINITY;
+    hi = upper ? upper[i] : INFINITY;
+    xn = (i + 1 < n) ? xc[i + 1] : 0.0;
+  };
+  double a_n, o_n, b_n, lo_n, hi_n, xn_n, u_odd = 0.5;
+  site(0, a_n, o_n, b_n, lo_n, hi_n, xn_n);
+  for (int64_t i = 0; i < n; ++i) {
+    const double a = a_n, o = o_n, b = b_n, lo = lo_n, hi = hi_n, x_next = xn_n;
+    if (i + 1 < n) site(i + 1, a_n, o_n, b_n, lo_n, hi_n, xn_n);
     if (!(a > 0.0)) fail = true;
-    const double lo = lower ? lower[i] : -INFINITY, hi = upper ? upper[i] : INFINITY;
     double mean, sd;
+    // 1/a and sqrt(1/a) by the refined hardware reciprocal / reciprocal square root (the divide and sqrt sequences are
+    // ~70 dependent instructions on a path that is one dependent chain per lane)
+    const double v = (a > 0.0) ? omc_rcp_nr(a) : 1.0;
+    {
+      const double g = __builtin_amdgcn_rsq((a > 0.0) ? a : 1.0);  // ~ 1/sqrt(a): two Newton steps
+      const double h = 0.5 * a;
+      double r = g;
+      r = fma(r, fma(-h * r, r, 0.5), r);
+      r = fma(r, fma(-h * r, r, 0.5), r);
+      sd = r;
+    }
     if (n == 1) {  // gmrf.py:244-247
-      mean = b / a;
-      sd = 1.0 / sqrt(a);
+      mean = b * v;
     } else {       // gmrf.py:255-262: v_i * (b_i - Q[i,:] @ x + Q_ii x_i), row product in column order
-      const double v = 1.0 / a;
-      sd = sqrt(v);
       const double row = fma(o, x_next, fma(a, x_cur, off_prev * x_prev));
       mean = v * ((b - row) + a * x_cur);
     }
-    const double xi = omc_truncated_normal_rv(mean, sd, lo, hi, trunc_uniform(u_in, ld_u, c, i, key, chain_offset + c));
+    // in-kernel uniforms: one Philox block serves the two sites of a pair
+    double uu;
+    if (u_in) {
+      uu = u_in[c * ld_u + i];
+    } else if ((i & 1) == 0) {
+      const uint4 w4 = omc_rng_block(key, chain_offset + c, (uint32_t)(i >> 1));
+      uu = omc_u53(w4.x, w4.y);
+      u_odd = omc_u53(w4.z, w4.w);
+    } else {
+      uu = u_odd;
+    }
+    const double xi = omc_truncated_normal_rv_inv(mean, sd, a * sd, lo, hi, uu);  // 1/sd = sqrt(a) = a / sqrt(a)
     xc[i] = xi;
     x_prev = xi;
     off_prev = o;

@@ -75,3 +75,25 @@ def test_normal_pair_map_is_standard_normal(host_exe):
     assert stats.kstest(ang, "uniform", args=(-np.pi, 2 * np.pi)).pvalue > 1e-3
     r2 = (n ** 2).sum(1)
     assert stats.kstest(r2, "chi2", args=(2,)).pvalue > 1e-3
+
+
+def test_inverse_normal_cdf_as241_host_build(tmp_path):
+    """omc_ndtri_as241 (omc_truncnorm.h), the fast path of the truncated-normal inverse CDF, built for the host: against
+    scipy.special.ndtri over the whole open interval, tails down to 1e-300 and up to 1 - 1e-15."""
+    from scipy.special import ndtri
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "ndtri_host")
+    subprocess.run([hipcc, "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.join(ROOT, "openmcmc_amd", "csrc"), os.path.join(ROOT, "tests", "native", "ndtri_host.hip"),
+                    "-o", exe], check=True)
+    rng = np.random.default_rng(0)
+    p = np.concatenate([rng.random(100000), 10.0 ** (-rng.uniform(0, 300, 10000)), 1 - 10.0 ** (-rng.uniform(0, 15, 10000)),
+                        [0.5, 0.075, 0.925, 0.0749999, 1e-15, 1 - 1e-15]])
+    p = p[(p > 0) & (p < 1)]
+    out = np.frombuffer(subprocess.run([exe], input=p.tobytes(), capture_output=True, check=True).stdout, dtype=np.float64)
+    ref = ndtri(p)
+    err = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert err.max() < 4e-15
