@@ -439,6 +439,13 @@ omc_status omc_small_sample_canonical(omc_ctx* ctx, int64_t kmax, const double* 
                                       const double* count, const double* z_inject, uint64_t draw_index,
                                       double* x, double* mu);
 
+/* Per-chain small SPD matrices A [C][k][k] (k <= 64): Av_out[c] = A_c v_c, quad_out[c] = v_c' A_c v_c, logdet_out[c] =
+ * log det A_c by the natural-order Cholesky (a non-positive pivot latches the chain); any output may be NULL.  The pieces
+ * of ManifoldMALA's proposal for a Hessian that depends on the parameter (metropolis_hastings.py:325-373): Lambda x,
+ * (. - m)' Lambda (. - m) and sum log L_ii with Lambda_c = H_c / step^2; the solve itself is omc_small_sample_canonical. */
+omc_status omc_small_spd_ops(omc_ctx* ctx, int64_t k, const double* A, const double* v, double* Av_out, double* quad_out,
+                             double* logdet_out);
+
 /* ReversibleJump.matched_birth_transition / matched_death_transition (reversible_jump.py:195-308):
  *   with X the larger of the two bases (the proposed one for a birth, the current one for a death),
  *   G = (X'X + 1e-10 I)^{-1} X'X_small by LU with partial pivoting (np.linalg.solve);

@@ -161,6 +161,7 @@ SIGNATURES = {
     "omc_mixture_normal_gamma": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, u64, c_dp]),
     "omc_gamma_logpdf_vec": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, i32]),
     "omc_mh_invalidate": (i32, [C.c_void_p]),
+    "omc_small_spd_ops": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "omc_band_gibbs_truncated": (i32, [C.c_void_p, i64, i64, C.POINTER(BandTerms), c_dp, i64, c_dp, c_dp, c_dp, i64, u64, c_dp, i64]),
     "omc_tridiag_matvec_chain": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, i64, c_dp, c_dp, i64, i32]),
     "omc_chain_lincomb": (i32, [C.c_void_p, i64, C.c_double, c_dp, i64, C.c_double, c_dp, i64, c_dp, i64]),

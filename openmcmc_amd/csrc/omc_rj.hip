@@ -630,6 +630,58 @@ __global__ void __launch_bounds__(64) k_rj_matched(int64_t C, int64_t chain_offs
 
 // ------------------------------------------------------------------------------------------------
 // host entry points
+// Per-chain small symmetric positive definite matrices A_c (k x k, k <= 64; a parameter-dependent Hessian / step^2 of
+// ManifoldMALA, metropolis_hastings.py:325-373): A_c v_c, v_c' A_c v_c and log det A_c (natural-order Cholesky), one wave
+// per chain, lane = row.  Any output may be NULL.
+__global__ void __launch_bounds__(64) k_small_spd_ops(int64_t C, int k, const double* A, const double* v, double* Av_out,
+                                                      double* quad_out, double* logdet_out, long long* bad) {
+  extern __shared__ double sm[];  // L: k x (k+1), then vec[k]
+  const int64_t c = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int ld = k + 1;
+  double* L = sm;
+  double* vec = sm + (int64_t)k * ld;
+  const double* Ac = A + c * k * k;
+  if (lane < k) {
+    for (int j = 0; j < k; ++j) L[lane * ld + j] = Ac[lane * k + j];
+    vec[lane] = v ? v[c * k + lane] : 0.0;
+  }
+  __syncthreads();
+  if (v && (Av_out || quad_out)) {
+    double av = 0.0;
+    if (lane < k)
+      for (int j = 0; j < k; ++j) av = fma(L[lane * ld + j], vec[j], av);
+    if (Av_out && lane < k) Av_out[c * k + lane] = av;
+    if (quad_out) {
+      double q = (lane < k) ? av * vec[lane] : 0.0;
+      for (int s = 32; s >= 1; s >>= 1) q += __shfl_xor(q, s, 64);
+      if (lane == 0) quad_out[c] = q;
+    }
+  }
+  if (!logdet_out) return;
+  __syncthreads();
+  bool fail = false;
+  double acc = 0.0;
+  for (int j = 0; j < k; ++j) {
+    const double d = L[j * ld + j];
+    if (!(d > 0.0)) { fail = true; break; }
+    const double sd = sqrt(d);
+    acc += log(d);
+    double lij = 0.0;
+    if (lane > j && lane < k) lij = L[lane * ld + j] / sd;
+    __syncthreads();
+    if (lane > j && lane < k) vec[lane] = lij;
+    __syncthreads();
+    if (lane > j && lane < k)
+      for (int t = j + 1; t <= lane; ++t) L[lane * ld + t] -= lij * vec[t];
+    __syncthreads();
+  }
+  if (lane == 0) {
+    logdet_out[c] = fail ? NAN : acc;
+    if (fail) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+  }
+}
+
 extern "C" {
 
 omc_status omc_rw_propose(omc_ctx* ctx, int64_t p, const double* x, int64_t x_chain_stride, int64_t x_elem_stride,
@@ -821,6 +873,17 @@ omc_status omc_rj_matched_transition(omc_ctx* ctx, int64_t kmax, const double* g
                      (const long long*)del_index, coef_cur, scale, (int)has_limits, lim_lo, lim_hi, draw_inject,
                      omc_make_key(ctx->seed, draw_index, has_limits ? OMC_RNG_UNIFORM : OMC_RNG_NORMAL), sub, coef_prop,
                      lq_fwd, lq_rev);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_small_spd_ops(omc_ctx* ctx, int64_t k, const double* A, const double* v, double* Av_out, double* quad_out,
+                             double* logdet_out) {
+  if (!ctx || k < 1 || k > SMALL_KMAX || !A || ((Av_out || quad_out) && !v)) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  const size_t lds = (size_t)(k * (k + 1) + k) * sizeof(double);
+  hipLaunchKernelGGL(k_small_spd_ops, dim3((unsigned)ctx->n_chains), dim3(64), lds, ctx->stream, ctx->n_chains, (int)k, A, v, Av_out,
+                     quad_out, logdet_out, ctx->d_bad_chain);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

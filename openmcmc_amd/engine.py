@@ -690,6 +690,16 @@ class Engine:
                                              self._p(mean_out)))
         return x
 
+    def small_spd_ops(self, A, v=None, want_Av=False, want_quad=False, want_logdet=False):
+        """(Av, quad, logdet) for per-chain small SPD matrices A (C, k, k) and vectors v (C, k) (omc_small_spd_ops)."""
+        Cn, k, _ = A.shape
+        Av = self.empty(Cn, k) if want_Av else None
+        quad = self.empty(Cn) if want_quad else None
+        logdet = self.empty(Cn) if want_logdet else None
+        check(lib.omc_small_spd_ops(self._ctx, k, self._p(A.contiguous().view(Cn, -1)), self._p(v), self._p(Av), self._chain_scalar(quad),
+                                    self._chain_scalar(logdet)))
+        return Av, quad, logdet
+
     def rj_matched_transition(self, gram_cur, gram_prop, count, birth, del_index, coef_cur, scale, limits, lq_fwd,
                               lq_rev, inject=None, draw_index=0, sub=0):
         """coef_prop (C, kmax); lq_fwd / lq_rev (C,) are added to in place."""

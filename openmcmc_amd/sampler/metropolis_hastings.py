@@ -353,6 +353,72 @@ class ManifoldMALA(MetropolisHastings):
         u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
         return self._accept_reject_proposal(current_state, prop_state, lq_f, lq_r, u=u, sub=(p + 1) // 2 + 1)
 
+    def _grad_hess_per_chain(self, state):
+        """(grad (C, d), H (C, d, d)) of the whole model w.r.t. the parameter, for every chain, whatever each member
+        distribution returns (model.py:72-112): a shared matrix, a per-chain scalar x shared matrix (ScaledHessian) or the
+        (C, d, d) tensor of the finite-difference default (distribution.py:124-198)."""
+        import torch
+        from scipy import sparse
+
+        from openmcmc_amd.distribution.location_scale import ScaledHessian
+
+        eng = self.engine
+        x = state[self.param]
+        Cn, d = x.n_chains, x.size
+        grad, H = None, eng.zeros(Cn, d, d)
+        for dist in self.model.values():
+            if self.param not in dist.param_list:
+                continue
+            g, h = dist.grad_log_p(state, self.param, hessian_required=True, engine=eng)
+            grad = g.data.reshape(Cn, d) if grad is None else grad + g.data.reshape(Cn, d)
+            if isinstance(h, ScaledHessian):
+                M = h.matrix.toarray() if sparse.issparse(h.matrix) else np.asarray(h.matrix, dtype=np.float64)
+                H = H + h.scale.reshape(Cn, 1, 1) * eng.to_device(M).unsqueeze(0)
+            elif isinstance(h, torch.Tensor):
+                H = H + h.reshape(Cn, d, d)
+            else:
+                M = h.toarray() if sparse.issparse(h) else np.asarray(h, dtype=np.float64)
+                H = H + eng.to_device(M).unsqueeze(0)
+        if grad is None:
+            raise ValueError(f"no distribution depends on '{self.param}'")
+        return grad.contiguous(), H.contiguous()
+
+    def _general_step(self, current_state: dict) -> dict:
+        """Any model whose device log_p exists, for a small fixed-size parameter (d <= 64): gradient and Hessian of every
+        member as the reference's generic path computes them (analytic where a distribution has one, central differences
+        otherwise, distribution.py:90-198), a per-chain Lambda_c = H_c / step^2 factorised per chain in natural order
+        (omc_small_sample_canonical: x' = m + L^-T z and m at once; again with z = 0 at the proposed state for the reverse
+        mean), log q = (1/2) log det Lambda - (1/2)(. - m)' Lambda (. - m) (metropolis_hastings.py:301-373)."""
+        eng = self.engine
+        x = current_state[self.param]
+        if x.ragged is not None or x.shape[1] != 1 or x.size > 64:
+            raise NotImplementedError("generic ManifoldMALA route: fixed-size (d, 1) parameter with d <= 64")
+        xv = x.vector().contiguous()
+        Cn, d = xv.shape
+        s2 = float(self.step.item()) ** 2
+        zero = eng.zeros(Cn, d)
+        grad, H = self._grad_hess_per_chain(current_state)
+        Lam = H / s2
+        Lx, _, logdet_f = eng.small_spd_ops(Lam, xv, want_Av=True, want_logdet=True)
+        z = self.inject(self, self._sweep) if self.inject is not None else None
+        mu_f = eng.empty(Cn, d)
+        xp = eng.small_sample_canonical(Lam, Lx + 0.5 * grad, zero, z=z, draw_index=self._draw_index(), mean_out=mu_f)
+        _, quad_f, _ = eng.small_spd_ops(Lam, (xp - mu_f).contiguous(), want_quad=True)
+        lq_f = 0.5 * logdet_f - 0.5 * quad_f
+        prop_state = dict(current_state)
+        prop_state[self.param] = x.like(xp.unsqueeze(2))
+        grad_p, H_p = self._grad_hess_per_chain(prop_state)
+        Lam_p = H_p / s2
+        Lxp, _, logdet_r = eng.small_spd_ops(Lam_p, xp, want_Av=True, want_logdet=True)
+        mu_r = eng.empty(Cn, d)
+        eng.small_sample_canonical(Lam_p, Lxp + 0.5 * grad_p, zero, z=zero, mean_out=mu_r)
+        _, quad_r, _ = eng.small_spd_ops(Lam_p, (xv - mu_r).contiguous(), want_quad=True)
+        lq_r = 0.5 * logdet_r - 0.5 * quad_r
+        if self.trace is not None:
+            self.trace.setdefault("steps", []).append({"prop": xp.clone(), "lq_fwd": lq_f.clone(), "lq_rev": lq_r.clone()})
+        u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
+        return self._accept_reject_proposal(current_state, prop_state, lq_f, lq_r, u=u, sub=(d + 1) // 2 + 1)
+
     def sample(self, current_state: dict) -> dict:
         eng = self._need_engine()
         if not self._gaussian_target(current_state):
@@ -360,7 +426,11 @@ class ManifoldMALA(MetropolisHastings):
             diag_only = x.ragged is not None or all(
                 getattr(d, "is_mixture", False) and k == self.param or type(d).__name__ == "NullDistribution"
                 for k, d in self.model.items())
-            current_state = self._diag_step(current_state) if diag_only else self._dense_step(current_state)
+            if diag_only:
+                current_state = self._diag_step(current_state)
+            else:
+                structured = all(hasattr(d, "grad_terms") for d in self.model.values() if self.param in d.param_list)
+                current_state = self._dense_step(current_state) if structured else self._general_step(current_state)
             self._sweep += 1
             return current_state
         Q, mu, d = self._target(current_state)
