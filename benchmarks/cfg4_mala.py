@@ -9,6 +9,8 @@ import torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--d", type=int, default=500); ap.add_argument("--chains", type=int, default=512)
 ap.add_argument("--steps", type=int, default=200); ap.add_argument("--kind", default="mala")
+ap.add_argument("--ksplit", type=int, default=0, help="omc_dgemm_small: wave groups cutting the contraction (0 = library default)")
+ap.add_argument("--rocblas", action="store_true", help="products through rocBLAS instead of the own GEMM")
 a = ap.parse_args()
 torch.cuda.set_stream(torch.cuda.Stream())
 from openmcmc_amd.engine import Engine
@@ -16,6 +18,8 @@ d, C = a.d, a.chains
 rng = np.random.default_rng(0)
 A = rng.standard_normal((d, 2 * d)); Sig = A @ A.T / (2 * d); Qh = np.linalg.inv(Sig); Qh = (Qh + Qh.T) / 2
 eng = Engine(C, seed=3)
+if a.ksplit: eng.set_option("mh_gemm_ksplit", a.ksplit)
+if a.rocblas: eng.set_option("mh_use_rocblas", 1)
 Q = eng.to_device(Qh)
 step = 0.5 if a.kind == "mala" else 0.05
 L, sl = eng.dense_cholesky(Q, 1.0 / step**2 if a.kind == "mala" else 1.0)

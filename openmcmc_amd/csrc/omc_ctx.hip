@@ -52,6 +52,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->dense_use_rocsolver = 0;
   c->gram_use_rocblas = 0;
   c->mh_use_rocblas = 0;
+  c->mh_gemm_ksplit = 4;
   c->band_algo = 0;
   if (c->own_stream) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -173,6 +174,11 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "band_algo")) {
     if (value < 0 || value > 2) return OMC_INVALID_ARG;
     ctx->band_algo = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "mh_gemm_ksplit")) {
+    if (value != 1 && value != 2 && value != 4) return OMC_INVALID_ARG;
+    ctx->mh_gemm_ksplit = (int)value;
     return OMC_OK;
   }
   if (!strcmp(name, "mh_use_rocblas")) {

@@ -30,58 +30,65 @@ struct GemmPair {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-// VEC: operands fetched 16 bytes per lane (M, the K's and the leading dimensions even, bases 16-byte aligned); 17 -> 15 us
-// per 500 x 500 x 512 product.  What bounds the kernel is the rate at which ONE workgroup of four waves pulls its
-// 320 KB of operands (9.5 B/clk per CU at 20 KB in flight), not the matrix cores (3.7 us).
-template <bool VEC>
-__global__ void __launch_bounds__(256) k_dgemm_64x16(int M, int N, GemmPair p0, GemmPair p1, int tri, const double* __restrict__ addv,
-                                                     double* __restrict__ Cout, int64_t ldc) {
-  __shared__ double As[GM_BK][GM_LDA];
-  __shared__ double Bs[GM_TN][GM_LDB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// VEC: operands fetched 16 bytes per lane (M, the K's and the leading dimensions even, bases 16-byte aligned).
+// KS: the contraction cut KS ways INSIDE the workgroup -- KS groups of four waves, each with its own LDS slabs and its
+// own quarter of every operand pair, partial tiles added in group order through LDS at the end (deterministic).  What
+// bounds these small products is how many operand bytes ONE resident workgroup per CU keeps in flight (DESIGN.md
+// section 5.3); KS = 4 puts four times as many loads on the wire without more workgroups or a second kernel.
+template <bool VEC, int KS>
+__global__ void __launch_bounds__(256 * KS) k_dgemm_64x16(int M, int N, GemmPair p0, GemmPair p1, int tri, const double* __restrict__ addv,
+                                                          double* __restrict__ Cout, int64_t ldc) {
+  __shared__ double As_all[KS][GM_BK][GM_LDA];
+  __shared__ double Bs_all[KS][GM_TN][GM_LDB];
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  double(*As)[GM_LDA] = As_all[grp];
+  double(*Bs)[GM_LDB] = Bs_all[grp];
   const int i0 = blockIdx.x * GM_TM, j0 = blockIdx.y * GM_TN;
-  // GM_NACC accumulators per wave, each taking every GM_NACC-th group of four contraction indices: a chain of MFMAs
-  // on ONE accumulator is paced by the instruction's result latency, not by its issue rate (measured: one accumulator
-  // 15.7 us per 500 x 500 x 512 product)
   double4_t acc[GM_NACC];
 #pragma unroll
   for (int t = 0; t < GM_NACC; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
   double ra[GM_BK / 4], rb[GM_BK / 16];
   for (int pass = 0; pass < 2; ++pass) {
     const GemmPair P = pass ? p1 : p0;
-    if (P.K <= 0) continue;
+    if (P.K <= 0) continue;  // uniform over the workgroup: the barriers below stay matched
     // upper-triangular A (A(i,k) = 0 for k < i): nothing to add before the tile's first row
     const int kbeg = tri ? (i0 / GM_BK) * GM_BK : 0;
+    // this group's share of [kbeg, K): whole slabs, the same count for every group (idle slabs load zeros)
+    const int nslab = (P.K - kbeg + GM_BK - 1) / GM_BK;
+    const int per = (nslab + KS - 1) / KS;
+    const int k_lo = kbeg + grp * per * GM_BK;
+    const int k_hi = (k_lo + per * GM_BK < P.K) ? k_lo + per * GM_BK : P.K;  // loads beyond k_hi give zeros
     auto fetch = [&](int k0) {
       if constexpr (VEC) {
 #pragma unroll
         for (int q = 0; q < GM_BK / 8; ++q) {  // A slab as pairs: pair e = q*256 + tid: k = e / 32, i = 2 (e % 32)
           const int e = q * 256 + tid, k = k0 + (e >> 5), i = i0 + 2 * (e & 31);
           double2_t v = {0.0, 0.0};
-          if (k < P.K && i < M) v = *reinterpret_cast<const double2_t*>(P.A + (int64_t)k * P.lda + i);
+          if (k < k_hi && i < M) v = *reinterpret_cast<const double2_t*>(P.A + (int64_t)k * P.lda + i);
           ra[2 * q] = v.x; ra[2 * q + 1] = v.y;
         }
         {  // B slab as pairs: j = tid / 16, k = 2 (tid % 16)
           const int j = j0 + (tid >> 4), k = k0 + 2 * (tid & 15);
           double2_t v = {0.0, 0.0};
-          if (k < P.K && j < N) v = *reinterpret_cast<const double2_t*>(P.B + (int64_t)j * P.ldb + k);
+          if (k < k_hi && j < N) v = *reinterpret_cast<const double2_t*>(P.B + (int64_t)j * P.ldb + k);
           rb[0] = v.x; rb[1] = v.y;
         }
       } else {
 #pragma unroll
         for (int q = 0; q < GM_BK / 4; ++q) {  // A slab: BK x 64, element e = q*256 + tid: k = e / 64, i = e % 64 (contiguous in i)
           const int e = q * 256 + tid, k = k0 + (e >> 6), i = i0 + (e & 63);
-          ra[q] = (k < P.K && i < M) ? P.A[(int64_t)k * P.lda + i] : 0.0;
+          ra[q] = (k < k_hi && i < M) ? P.A[(int64_t)k * P.lda + i] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < GM_BK / 16; ++q) {  // B slab: BK x 16, element e: j = e / BK, k = e % BK (contiguous in k)
           const int e = q * 256 + tid, j = j0 + e / GM_BK, k = k0 + e % GM_BK;
-          rb[q] = (k < P.K && j < N) ? P.B[(int64_t)j * P.ldb + k] : 0.0;
+          rb[q] = (k < k_hi && j < N) ? P.B[(int64_t)j * P.ldb + k] : 0.0;
         }
       }
     };
-    if (kbeg < P.K) fetch(kbeg);
-    for (int k0 = kbeg; k0 < P.K; k0 += GM_BK) {
+    if (per > 0) fetch(k_lo);
+    for (int sl = 0; sl < per; ++sl) {
+      const int k0 = k_lo + sl * GM_BK;
       __syncthreads();
       if constexpr (VEC) {
 #pragma unroll
@@ -103,7 +110,7 @@ __global__ void __launch_bounds__(256) k_dgemm_64x16(int M, int N, GemmPair p0, 
         }
       }
       __syncthreads();
-      if (k0 + GM_BK < P.K) fetch(k0 + GM_BK);  // in flight under the multiplications
+      if (sl + 1 < per) fetch(k0 + GM_BK);  // in flight under the multiplications
 #pragma unroll
       for (int kk = 0; kk < GM_BK; kk += 4) {
         const int kr = kk + (lane >> 4), cl = lane & 15;
@@ -111,15 +118,29 @@ __global__ void __launch_bounds__(256) k_dgemm_64x16(int M, int N, GemmPair p0, 
       }
     }
   }
+  double4_t v = acc[0];
+#pragma unroll
+  for (int t = 1; t < GM_NACC; ++t) v += acc[t];
+  if constexpr (KS > 1) {  // partial tiles of the groups through LDS (the slabs are dead), added in group order
+    __syncthreads();
+    double* red = &As_all[0][0][0];  // KS x 256 x 4 doubles <= KS * GM_BK * GM_LDA
+    if (grp > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((grp * 256 + tid) << 2) + r] = v[r];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < KS; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += red[((g * 256 + tid) << 2) + r];
+  }
   // C/D of the f64 form: column = lane & 15, row = (lane >> 4) + 4 * register
   const int j = j0 + (lane & 15);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = i0 + wave * 16 + (lane >> 4) + 4 * r;
-    double v = acc[0][r];
-#pragma unroll
-    for (int t = 1; t < GM_NACC; ++t) v += acc[t][r];
-    if (i < M && j < N) Cout[(int64_t)j * ldc + i] = v + (addv ? addv[i] : 0.0);
+    if (i < M && j < N) Cout[(int64_t)j * ldc + i] = v[r] + (addv ? addv[i] : 0.0);
   }
 }
 
@@ -131,8 +152,14 @@ omc_status omc_dgemm_small(omc_ctx* ctx, int M, int N, const double* A0, int64_t
   const dim3 grid((unsigned)((M + GM_TM - 1) / GM_TM), (unsigned)((N + GM_TN - 1) / GM_TN));
   auto even16 = [](const double* p, int64_t ld, int K) { return !p || (((uintptr_t)p & 15u) == 0 && (ld & 1) == 0 && (K & 1) == 0); };
   const bool vec = (M & 1) == 0 && even16(A0, lda0, K0) && even16(B0, ldb0, K0) && even16(A1, lda1, K1) && even16(B1, ldb1, K1);
-  if (vec) hipLaunchKernelGGL(k_dgemm_64x16<true>, grid, dim3(256), 0, ctx->stream, M, N, p0, p1, tri, addv, Cout, ldc);
-  else hipLaunchKernelGGL(k_dgemm_64x16<false>, grid, dim3(256), 0, ctx->stream, M, N, p0, p1, tri, addv, Cout, ldc);
+  const int ks = ctx->mh_gemm_ksplit;
+#define OMC_GEMM_LAUNCH(V, K) hipLaunchKernelGGL((k_dgemm_64x16<V, K>), grid, dim3(256 * K), 0, ctx->stream, M, N, p0, p1, tri, addv, Cout, ldc)
+  if (vec) {
+    if (ks >= 4) OMC_GEMM_LAUNCH(true, 4); else if (ks == 2) OMC_GEMM_LAUNCH(true, 2); else OMC_GEMM_LAUNCH(true, 1);
+  } else {
+    if (ks >= 4) OMC_GEMM_LAUNCH(false, 4); else if (ks == 2) OMC_GEMM_LAUNCH(false, 2); else OMC_GEMM_LAUNCH(false, 1);
+  }
+#undef OMC_GEMM_LAUNCH
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

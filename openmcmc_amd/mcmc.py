@@ -68,6 +68,15 @@ class MCMC:
         self._fused = self._fusion_plan() if self.fuse else None
         self._sweeps_done = 0
 
+    def _check_stream(self):
+        """The context issues every library call on the stream it was created with; the mirror's own torch operations run
+        on torch's current stream.  Sampling under another current stream would let the two race."""
+        import torch
+
+        if torch.cuda.current_stream(self.engine.device).cuda_stream != self.engine._stream.cuda_stream:
+            raise RuntimeError("the current torch stream is not the one the Engine was created under: create the Engine (or "
+                               "the MCMC object) and call run_mcmc under the same torch.cuda.stream")
+
     # ------------------------------------------------------------------ fusion
     def _fusion_plan(self):
         """[NormalNormal(x), NormalGamma(s_1), ...] with every s_j the ScaledMatrix scalar of one of
@@ -160,6 +169,7 @@ class MCMC:
 
     def run_mcmc(self):
         eng = self.engine
+        self._check_stream()
         if (self._fused is not None and self._fused["log_post"] and self.n_iter > 0
                 and all(getattr(s, "inject", None) is None for s in self.samplers)):
             self._run_fused_in_c()
