@@ -1,0 +1,86 @@
+"""BASELINE.json configs at their FULL sizes under pytest (size-independent properties; the path-wise parity of the same
+routes is held at small sizes against the golden vectors): cfg2 Bayesian linear regression p = 1000, n = 10 000, 256
+chains on both routes of the conjugate draw; cfg5 reversible jump + GMRF, 5000 nodes, n_max = 20, 512 chains."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg2_full_size_both_routes_agree_and_solve_the_normal_equations():
+    from openmcmc_amd.engine import Engine
+
+    n, p, C = 10000, 1000, 256
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((n, p))
+    beta = rng.standard_normal(p)
+    y = X @ beta + 0.1 * rng.standard_normal(n)
+    eng = Engine(C, seed=1)
+    dX, dy = eng.to_device(X), eng.to_device(y)
+    G, Xty = eng.gram(dX), eng.design_rhs(dX, dy)
+    Gh = G.cpu().numpy()
+    assert np.max(np.abs(Gh - X.T @ X)) < 1e-9 * np.max(np.abs(Gh))          # the MFMA Gram kernel at full size
+    lam, tau = 0.005 + 0.01 * rng.random(C), 50 + 100 * rng.random(C)
+    terms = [{"mat": None, "scale": eng.to_device(lam)}, {"mat": G, "rhs": Xty, "scale": eng.to_device(tau)}]
+    V, ev = eng.dense_spectral_prepare(G)
+    xs, ms, ls = eng.empty(C, p), eng.empty(C, p), eng.empty(C)
+    eng.dense_spectral_sample(p, terms, 1, V, ev, xs, mean_out=ms, logdet_out=ls, draw_index=3)
+    xc, mc, lc = eng.empty(C, p), eng.empty(C, p), eng.empty(C)
+    eng.dense_sample_canonical(p, terms, xc, mean_out=mc, logdet_out=lc, draw_index=3)
+    eng.check_status()
+    ms_h, mc_h = ms.cpu().numpy(), mc.cpu().numpy()
+    assert np.max(np.abs(ms_h - mc_h)) < 1e-9 * np.max(np.abs(mc_h))           # same conditional mean on both routes
+    assert np.max(np.abs(ls.cpu().numpy() - lc.cpu().numpy()) / np.abs(lc.cpu().numpy())) < 1e-11
+    XtY = X.T @ y
+    for c in (0, 100, C - 1):                                                   # Q_c mu_c = b_c
+        r = lam[c] * mc_h[c] + tau[c] * (Gh @ mc_h[c]) - tau[c] * XtY
+        assert np.max(np.abs(r)) < 1e-8 * np.max(np.abs(tau[c] * XtY))
+    # the draws scatter around the mean with the conditional covariance's scale (both routes, different square roots)
+    for x, m in ((xs, ms), (xc, mc)):
+        d = (x - m).cpu().numpy()
+        q = lam[:, None] * d + tau[:, None] * (d @ Gh)
+        maha = np.einsum("ci,ci->c", d, q)                                      # ~ chi^2_p per chain
+        assert abs(maha.mean() - p) < 5 * np.sqrt(2 * p / C) + 1
+    assert np.max(np.abs(ms_h.mean(0) - beta)) < 0.02                           # the posterior mean finds the coefficients
+    eng.close()
+
+
+def test_cfg5_full_size_runs_and_keeps_its_invariants():
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from rj_problem import build, make_basis_host
+
+    from openmcmc_amd import gmrf
+    from openmcmc_amd.engine import Engine
+    from openmcmc_amd.mcmc import MCMC
+
+    n, n_max, C = 5000, 20, 512
+    rng = np.random.default_rng(0)
+    X = np.linspace(-10, 10, n)
+    theta_true = np.array([[-6.0, -1.0, 4.5]])
+    beta_true = np.array([[3.0], [-2.0], [4.0]])
+    b_true = 0.05 * np.cumsum(rng.standard_normal(n)) * np.sqrt(48.0 / n)
+    y = (make_basis_host(X.reshape(n, 1), theta_true) @ beta_true).ravel() + b_true + 0.1 * rng.standard_normal(n)
+    P = gmrf.precision_irregular(np.arange(float(n))).tolil()
+    P[0, 0] += 1e-3
+    k0 = np.clip(rng.poisson(5, size=C), 1, n_max)
+    eng = Engine(C, seed=1)
+    mdl, state, samplers = build(y, X, P.tocsc(), n_max, eng, [rng.uniform(-10, 10, size=k) for k in k0],
+                                 [rng.standard_normal(k) for k in k0], k0.astype(float))
+    M = MCMC(state, samplers, model=mdl, n_burn=2, n_iter=4, n_chains=C, seed=1, engine=eng)
+    M.run_mcmc()
+    out = M.collect()
+    nb = out["n_basis"][:, 0, :]
+    assert np.all(nb >= 1) and np.all(nb <= n_max) and np.all(nb == np.round(nb))          # INT path
+    assert np.all(np.isfinite(out["log_post"])) and np.all(out["tau"] > 0) and np.all(out["lambda"] > 0)
+    theta = out["theta"]                                                                     # (C, n_max, n_iter), NaN beyond the live length
+    for it in range(theta.shape[2]):
+        live = np.arange(n_max)[None, :] < nb[:, it][:, None]
+        assert np.all(np.isfinite(theta[:, :, it][live])) and np.all(np.isnan(theta[:, :, it][~live]))
+        assert np.all(np.abs(theta[:, :, it][live]) <= 10.0)                                 # knots stay inside their limits
+    assert np.any(nb[:, -1] != k0)                                                           # some chain has jumped
+    assert 0 < samplers[4].accept_rate.accept.sum().item() < samplers[4].accept_rate.proposal.sum().item()
+    eng.close()
