@@ -82,7 +82,8 @@ omc_status omc_ctx_synchronize(omc_ctx* ctx);
  * instantiation specialised for the two-term smoother structure; for cross-checks), "tridiag_newton_max" (0..64,
  * default 4: Newton corrections of the segment joins before the sequential fallback takes over; 0 forces it),
  * "tridiag_perturb_ppb" (tests: relative error, in 1e-9, put on the segments' start pivots so that the join test must
- * reject them), "run_sweeps_per_launch" (1..16, default 16: sweeps omc_gmrf_run issues per launch).
+ * reject them), "run_sweeps_per_launch" (1..32, default 32: sweeps omc_gmrf_run issues per launch), "run_reenter" (0/1, default 1:
+ * within such a launch a chain's workgroup restarts itself for the next sweep instead of one workgroup per sweep and chain).
  * Unknown name -> OMC_INVALID_ARG.                                                            */
 omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value);
 /* Diagnostic counters, by name (synchronises): "tridiag_join_fallbacks" = chain-updates of the segmented

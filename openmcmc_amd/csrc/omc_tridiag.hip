@@ -89,6 +89,7 @@ struct TriArgs {
   double* log_post;
   // several sweeps per launch (n_sweeps > 0; workgroup-per-chain form only)
   int n_sweeps;
+  int reenter;                     // 1: the grid is C workgroups and each restarts itself as its chain's next sweep
   uint32_t epoch;                  // tag of sweep 0's inputs + 1 = tag its outputs carry; unique per context over launches
   uint64_t seed;
   uint64_t gdraw[OMC_MAX_TERMS];   // Gamma stream of term k = sweep's draw index + gdraw[k]
@@ -1702,6 +1703,31 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     sweep_epilogue(A, c, qsum);
   }
   OMC_STAMP(15);
+  if (MULTI && SIG == 1 && A.reenter && sw + 1 < A.n_sweeps) {
+    // Restart as the workgroup of the chain's next sweep: same code from its first instruction, with the three
+    // registers a fresh workgroup is handed (kernel-argument pointer, workgroup id, work-item id) set to what the
+    // dispatcher would have put there for block index + C.  Nothing else is live at a kernel's entry.  What this
+    // buys over a fresh workgroup: the x stores of this sweep drain under the next sweep's loads and draws instead of
+    // holding the CU until they are acknowledged, and there is no dispatch gap between the sweeps of a chain.
+    // (vmcnt is not zero on re-entry -- the waits of the next sweep only become conservative.)
+    lds_barrier();  // every wave is done with this sweep's LDS image
+    const uint64_t kptr = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint64_t kargs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kptr) |
+                           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(kptr >> 32)) << 32);
+    const uint32_t next_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x + (uint32_t)A.C));
+    const uint32_t tid = threadIdx.x;
+    // (device code may not name a kernel, so the entry point is reached through its linker symbol: a name that does
+    // not match an instantiation fails the link, not the run)
+#define OMC_REENTER(Mv, MAXTv, SIGv)                                                                                  \
+  if constexpr (M == Mv && MAXT == MAXTv && SIG == SIGv)                                                              \
+    asm volatile("s_mov_b64 exec, -1\n\ts_getpc_b64 s[4:5]\n\t"                                                      \
+                 "s_add_u32 s4, s4, _Z13k_tridiag_segILi" #Mv "ELb1ELi" #MAXTv "ELi" #SIGv "EEv7TriArgsi@rel32@lo+4\n\t" \
+                 "s_addc_u32 s5, s5, _Z13k_tridiag_segILi" #Mv "ELb1ELi" #MAXTv "ELi" #SIGv "EEv7TriArgsi@rel32@hi+12\n\t" \
+                 "s_setpc_b64 s[4:5]" ::"{s[0:1]}"(kargs), "{s2}"(next_blk), "{v0}"(tid) : "memory", "s4", "s5")
+    OMC_REENTER(8, 1024, 1);
+    OMC_REENTER(10, 1024, 1);
+#undef OMC_REENTER
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1813,7 +1839,7 @@ static void args_defaults(omc_ctx* ctx, TriArgs* A, int64_t n) {
   A->fused = 0;
   A->stamps = ctx->stamps;
   A->log_post = nullptr;
-  A->n_sweeps = 0; A->epoch = 0; A->seed = ctx->seed; A->handoff = nullptr; A->timeouts = ctx->d_fallbacks + 1;
+  A->n_sweeps = 0; A->reenter = 0; A->epoch = 0; A->seed = ctx->seed; A->handoff = nullptr; A->timeouts = ctx->d_fallbacks + 1;
   for (int k = 0; k < OMC_MAX_TERMS; ++k) A->gdraw[k] = 0;
   for (int i = 0; i < OMC_RUN_MAX; ++i) { A->rec[i].draw = 0; A->rec[i].x = nullptr; A->rec[i].log_post = nullptr; A->rec[i].slot_off = -1; }
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
@@ -1849,9 +1875,9 @@ static int64_t seg_max_n(int seg) {
 }
 
 template <int M>
-static void launch_seg(omc_ctx* ctx, const TriArgs& A) {
+static void launch_seg(omc_ctx* ctx, const TriArgs& A_in) {
+  TriArgs A = A_in;
   const int S = (int)((A.n + M - 1) / M);
-  const unsigned wg_grid = (unsigned)(A.C * (A.n_sweeps > 0 ? A.n_sweeps : 1));  // workgroup-per-chain form
   if (S <= 64) {
     const int G = pow2_ceil(S);
     const int64_t chains_per_block = 4 * (64 / G);
@@ -1861,7 +1887,13 @@ static void launch_seg(omc_ctx* ctx, const TriArgs& A) {
     const int threads = 64 * ((S + 63) / 64);
     // the specialised instantiation owns the CU (its LDS image is sized for a full workgroup); a short chain
     // leaves room for a second workgroup of the generic one, which then wins (n = 2000: 38 against 53 us)
-    if (SegCfg<M>::SMOOTHER && !ctx->tridiag_generic && is_smoother(A.T) && A.n >= 2 && 2 * threads > SegCfg<M>::MAXT)
+    const bool special = SegCfg<M>::SMOOTHER && !ctx->tridiag_generic && is_smoother(A.T) && A.n >= 2 && 2 * threads > SegCfg<M>::MAXT;
+    // self-restarting workgroups: the specialised instantiation only (it keeps no private memory, so the three entry
+    // registers are all a restart has to reproduce)
+    if (!special) A.reenter = 0;
+    // workgroup-per-chain form: one workgroup per (sweep, chain), or per chain when the workgroups restart themselves
+    const unsigned wg_grid = (unsigned)(A.C * ((A.n_sweeps > 0 && !A.reenter) ? A.n_sweeps : 1));
+    if (special)
       hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT, SegCfg<M>::SMOOTHER>), dim3(wg_grid), dim3(threads), 0,
                          ctx->stream, A, threads);
     else
@@ -2053,6 +2085,7 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
         A.rec[i].slot_off = stored ? slot * C : -1;
       }
       A.n_sweeps = k_sw;
+      A.reenter = ctx->run_reenter;
       A.epoch = ctx->run_epoch;
       ctx->run_epoch += (uint32_t)k_sw;
       // the non-specialised paths still read these

@@ -9,11 +9,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def run(n, C, per_launch, n_burn, n_iter, n_thin, generic=False, seed=11, chain_offset=0, C_all=None):
+def run(n, C, per_launch, n_burn, n_iter, n_thin, generic=False, seed=11, chain_offset=0, C_all=None, reenter=None):
     from openmcmc_amd.engine import Engine
 
     eng = Engine(C, seed=seed, chain_id_offset=chain_offset)
     eng.set_option("run_sweeps_per_launch", per_launch)
+    if reenter is not None:
+        eng.set_option("run_reenter", reenter)
     if generic:
         eng.set_option("tridiag_generic", 1)
     rng = np.random.default_rng(0)
@@ -54,6 +56,16 @@ def test_sweeps_per_launch_do_not_change_a_bit(n, C, generic):
         for a, b in zip(ref, got):
             assert np.array_equal(a, b, equal_nan=True)
     assert np.all(np.isfinite(ref[0])) and np.all(ref[1] > 0)
+
+
+@pytest.mark.parametrize("n,C", [(10000, 300), (10000, 1100), (5000, 40), (9999, 7)])
+def test_self_restarting_workgroups_do_not_change_a_bit(n, C):
+    """run_reenter: the grid is one workgroup per chain and each restarts itself as its chain's next sweep."""
+    ref = run(n, C, 1, 3, 9, 2, reenter=0)
+    for per, reenter in ((32, 1), (5, 1), (32, 0)):  # (32, 0): one workgroup per (sweep, chain), the other form
+        got = run(n, C, per, 3, 9, 2, reenter=reenter)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b, equal_nan=True)
 
 
 def test_sharding_invariance_of_a_several_sweeps_run():
