@@ -408,6 +408,21 @@ omc_status omc_ragged_resize(omc_ctx* ctx, int64_t rows, int64_t kmax, const dou
 omc_status omc_gaussian_basis(omc_ctx* ctx, int64_t n, int64_t kmax, const double* X, const double* knots,
                               const double* scales, double scale0, const double* count, int64_t column, double* B);
 
+/* RandomWalkLoop over the knots of that basis under a regression likelihood, every knot of every chain in one launch
+ * (metropolis_hastings.py:276-289 -> :212-269 proposal, :127-173 accept/reject) for
+ *   y ~ N(B_c beta_c + add_chain[c] + add_shared, (tau[c] diag(w))^-1),  knots a priori uniform on [lower, upper]:
+ *   for k < count[c], in order: z ~ truncated N(theta[c][k], step^2) on [lower, upper]; accepted with probability
+ *   min(1, exp(dloglik + log q(theta|z) - log q(z|theta))); an accepted move writes theta[c][k] = z and column k of B_c.
+ *   The same draws as the launch-by-launch route: stream (draw_index, uniform), Philox block 2k for the proposal of knot k
+ *   and 2k+1 for its accept uniform; inject_z / inject_u (kmax x C, [k][c]) replace them (tests).  w, tau, add_* may be
+ *   NULL (ones / zeros).  accept_count / proposal_count (C) are incremented; accept_out / log_alpha_out (kmax x C,
+ *   [k][c], entries k < count[c] written) may be NULL.  The chain's residual lives in LDS: n <= ~20 000.           */
+omc_status omc_knot_loop(omc_ctx* ctx, int64_t n, int64_t kmax, const double* X, double scale, const double* y,
+                         const double* add_shared, const double* add_chain, const double* w, const double* tau,
+                         const double* beta, double* theta, const double* count, double* B, double step, double lower,
+                         double upper, const double* inject_z, const double* inject_u, uint64_t draw_index,
+                         int64_t* accept_count, int64_t* proposal_count, int32_t* accept_out, double* log_alpha_out);
+
 /* Per-chain design matrices B_c (n x kmax; column j of chain c contiguous at B[(c*kmax + j)*n]):
  *   omc_design_predict_batched: out[c] = chain_scale[c] * (alpha * B_c coef_c + add_chain[c] + add_shared)
  *     (LinearCombination.predictor / predictor_conditional, parameter.py:162-197, for a basis that depends on

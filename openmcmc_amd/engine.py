@@ -567,6 +567,15 @@ class Engine:
             raise TypeError("expected an int32 ROCm tensor with one entry per chain")
         return C.c_void_p(t.data_ptr())
 
+    def _i32_block(self, t, rows):
+        """(rows, C) int32 output block, or None."""
+        if t is None:
+            return None
+        torch = _torch()
+        if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous() or tuple(t.shape) != (rows, self.n_chains):
+            raise TypeError(f"expected a contiguous ({rows}, {self.n_chains}) int32 ROCm tensor")
+        return C.c_void_p(t.data_ptr())
+
     def _i64(self, t):
         torch = _torch()
         if t.dtype != torch.int64 or not t.is_cuda or t.numel() != self.n_chains:
@@ -642,6 +651,22 @@ class Engine:
                                      float(scale), self._chain_scalar(count), -1 if column is None else int(column),
                                      self._p(out.view(Cn, -1))))
         return out
+
+    def knot_loop(self, X, scale, y, B, beta, theta, count, step, lower, upper, add_shared=None, add_chain=None, w=None,
+                  tau=None, inject_z=None, inject_u=None, draw_index=0, accept_count=None, proposal_count=None,
+                  accept_out=None, log_alpha_out=None):
+        """RandomWalkLoop over the knots of a Gaussian-kernel basis under a regression likelihood in one launch
+        (omc_knot_loop): theta (C, kmax) and B (C, kmax, n) are updated in place."""
+        Cn, kmax, n = B.shape
+        if not B.is_contiguous() or not theta.is_contiguous():
+            raise ValueError("B (C, kmax, n) and theta (C, kmax) must be contiguous")
+        check(lib.omc_knot_loop(self._ctx, n, kmax, self._vec(X, n), float(scale), self._vec(y, n), self._vec(add_shared, n),
+                                self._p(add_chain, Cn, n), self._vec(w, n), self._chain_scalar(tau), self._p(beta, Cn, kmax),
+                                self._p(theta, Cn, kmax), self._chain_scalar(count), self._p(B.view(Cn, -1)), float(step),
+                                float(lower), float(upper), self._p(inject_z), self._p(inject_u), int(draw_index),
+                                None if accept_count is None else self._i64(accept_count),
+                                None if proposal_count is None else self._i64(proposal_count),
+                                self._i32_block(accept_out, kmax), self._p(log_alpha_out)))
 
     def design_predict_batched(self, B, coef, add_chain=None, add_shared=None, alpha=1.0, chain_scale=None, out=None):
         """out[c] = chain_scale[c] * (alpha * B_c coef_c + add_chain[c] + add_shared);

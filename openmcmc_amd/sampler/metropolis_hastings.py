@@ -264,9 +264,107 @@ class RandomWalk(MetropolisHastings):
 @dataclass
 class RandomWalkLoop(RandomWalk):
     """One random-walk step per column of the parameter (metropolis_hastings.py:272-289).  For a ragged parameter
-    the loop runs to the largest live length over the chains; chains with fewer columns sit the extra steps out."""
+    the loop runs to the largest live length over the chains; chains with fewer columns sit the extra steps out.
+    `fused` (default True): let one kernel launch run the whole loop when the model allows it (`_knot_plan`)."""
+
+    fused: bool = True
+
+    def _knot_plan(self, state):
+        """Can the whole loop go to omc_knot_loop?  Yes when the sampler moves the knots of a library basis
+        (state_update_function is a GaussianKnotBasis on this parameter) and the only distributions a move can change
+        are the knots' own Uniform prior (constant over the proposal's domain) and ONE Normal regression likelihood
+        whose mean carries the basis: shared response, diagonal precision with a per-chain scalar, mean =
+        basis @ coefficients + at most one per-chain offset + shared terms.  Returns the kernel's arguments, or None
+        (then the loop runs launch by launch through the callback)."""
+        from openmcmc_amd.basis import GaussianKnotBasis
+        from openmcmc_amd.distribution.distribution import Uniform
+        from openmcmc_amd.parameter import LinearCombination, _is_identity
+
+        basis = self.state_update_function
+        if not isinstance(basis, GaussianKnotBasis) or basis.knots != self.param or self.trace is not None:
+            return None
+        x = state[self.param]
+        if (not is_chain(x) or x.ragged is None or x.ragged[1] != 1 or x.shape[0] != 1 or not x.data.is_contiguous()
+                or self.step.size != 1 or self.domain_limits is None):
+            return None
+        lim = np.asarray(self.domain_limits, dtype=np.float64).reshape(-1, 2)
+        if lim.shape[0] != 1:
+            return None
+        lower, upper = float(lim[0, 0]), float(lim[0, 1])
+        Bm = state.get(basis.matrix)
+        if not is_chain(Bm) or Bm.shape[1] != x.shape[1] or not Bm.data.transpose(1, 2).is_contiguous():
+            return None
+        lik = None
+        for key in self.model.affected_by([self.param, basis.matrix]):
+            dist = self.model[key]
+            if isinstance(dist, Uniform) and key == self.param:
+                if not (np.all(dist.domain_response_lower <= lower) and np.all(dist.domain_response_upper >= upper)):
+                    return None
+            elif isinstance(dist, Normal) and not dist.is_mixture and lik is None and self.param not in dist.param_list:
+                lik = dist
+            else:
+                return None
+        if lik is None or not isinstance(lik.mean, LinearCombination):
+            return None
+        resp = state[lik.response]
+        if is_chain(resp) or resp.shape[1] != 1:
+            return None
+        host_sum, offset, coef = 0, None, None
+        for prm, pre in lik.mean.form.items():
+            A, v = state[pre], state[prm]
+            if pre == basis.matrix:
+                if coef is not None or not is_chain(v) or v.shape[1] != 1:
+                    return None
+                coef = v.vector()
+            elif is_chain(A):
+                return None
+            elif not is_chain(v):
+                host_sum = host_sum + A @ v
+            elif v.shape[1] == 1 and _is_identity(A, v.shape[0]) and offset is None:
+                offset = v.vector()
+            else:
+                return None
+        if coef is None:
+            return None
+        st = lik.structure(state)
+        if st.diag is False or st.off is not None or (st.scale_key is not None and not is_chain(state[st.scale_key])):
+            return None
+        eng = self._need_engine()
+        return {"basis": basis, "x": x, "B": Bm, "coef": coef, "offset": offset, "lower": lower, "upper": upper,
+                "y": eng.shared(resp).reshape(-1), "w": None if st.diag is None else eng.shared(st.diag),
+                "shared": None if isinstance(host_sum, int) else eng.to_device(np.asarray(host_sum, dtype=np.float64).reshape(-1)),
+                "tau": state[st.scale_key].scalar() if st.scale_key is not None else None}
+
+    def _knot_loop(self, current_state, plan):
+        eng = self.engine
+        x, Bm = plan["x"], plan["B"]
+        kmax = x.shape[1]
+        count = x.count(current_state)
+        inj = {}
+        if self.inject is not None or self.inject_uniform is not None:  # test hooks: one (C,) vector per column visited
+            n_cols = int(count.max().item())
+            for name, hook in (("inject_z", self.inject), ("inject_u", self.inject_uniform)):
+                if hook is not None:
+                    rows = eng.zeros(kmax, eng.n_chains)
+                    for j in range(n_cols):
+                        rows[j] = hook(self, self._sweep, j).reshape(-1)
+                    inj[name] = rows
+        eng.knot_loop(plan["basis"].X, plan["basis"].scale, plan["y"], Bm.data.transpose(1, 2), plan["coef"], x.data[:, 0, :],
+                      count, float(self.step.item()), plan["lower"], plan["upper"], add_shared=plan["shared"],
+                      add_chain=plan["offset"], w=plan["w"], tau=plan["tau"], draw_index=self._draw_index(),
+                      accept_count=self.accept_rate.accept, proposal_count=self.accept_rate.proposal, **inj)
+        # theta and the basis were updated in place; new wrappers, so that anything keyed on the identity of a state
+        # entry sees them as replaced (the convention of every other sampler)
+        current_state[self.param] = x.like(x.data)
+        current_state[plan["basis"].matrix] = Bm.like(Bm.data)
+        return current_state
 
     def sample(self, current_state: dict) -> dict:
+        plan = self._knot_plan(current_state) if self.fused else None
+        if plan is not None:
+            current_state = self._knot_loop(current_state, plan)
+            self._sweep += 1
+            return current_state
         x = current_state[self.param]
         n_cols = x.shape[1]
         if x.ragged is not None and x.ragged[1] == 1:

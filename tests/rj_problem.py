@@ -32,11 +32,14 @@ def make_basis(state, X_dev, engine, column=None):
     return ChainArray(out.transpose(1, 2), ragged=(theta.ragged[0], 1))
 
 
-def build(y, X, P, n_max, engine, init_theta, init_beta, init_k):
+def build(y, X, P, n_max, engine, init_theta, init_beta, init_k, fused=True):
     """(model, state, samplers): the model of make_golden_rj.rj_gmrf_problem on the chains of `engine`
-    (pass the same engine to MCMC)."""
+    (pass the same engine to MCMC).  The two callbacks the reference's samplers take (state_update_function of the
+    knot moves, state_birth_function of the jumps) are the library's GaussianKnotBasis; `fused=False` keeps
+    RandomWalkLoop on its launch-by-launch route through the callback."""
     import torch
 
+    from openmcmc_amd.basis import GaussianKnotBasis
     from openmcmc_amd.chains import ChainArray, ragged_from_lists
     from openmcmc_amd.distribution.distribution import Gamma, Poisson, Uniform
     from openmcmc_amd.distribution.location_scale import Normal
@@ -48,7 +51,6 @@ def build(y, X, P, n_max, engine, init_theta, init_beta, init_k):
 
     n = y.size
     dev = engine.device
-    X_dev = torch.as_tensor(np.asarray(X, dtype=np.float64).reshape(-1), device=dev)
     mdl = Model(
         [
             Normal("y", mean=LinearCombination({"beta": "B", "b": "A"}), precision=ScaledMatrix("P_tau", "tau")),
@@ -62,29 +64,7 @@ def build(y, X, P, n_max, engine, init_theta, init_beta, init_k):
         ]
     )
     mdl.response = {"y": "mean"}
-
-    scratch = {}
-
-    def move_function(state, col):          # state_update_function of RandomWalkLoop: knot `col` moved
-        # The proposed basis differs from the current one in column `col` only.  It lives in one scratch buffer that
-        # is cloned from the current basis at the first knot of a sweep and afterwards re-synchronised by copying
-        # back the single column the previous step may have left different (RandomWalkLoop visits 0, 1, 2, ...),
-        # so a knot costs one column of traffic instead of a copy of the whole (C, k_max, n) basis.
-        store = state["B"].columns()        # the CURRENT basis: `state` is a shallow copy of the current state
-        buf = scratch.get("buf")
-        if buf is None or buf.shape != store.shape or col == 0 or scratch.get("last") != col - 1:
-            buf = scratch["buf"] = store.clone()
-        else:
-            buf[:, col - 1, :].copy_(store[:, col - 1, :])
-        theta = state["theta"]
-        engine.gaussian_basis(X_dev, theta.data[:, 0, :], buf, count=theta.count(state), scale=1.0, column=col)
-        scratch["last"] = col
-        state["B"] = state["B"].like(buf.transpose(1, 2))
-        return state, 0.0, 0.0
-
-    def birth_function(cur, prop):          # state_birth_function: births and deaths alike (see reversible_jump.py)
-        prop["B"] = make_basis(prop, X_dev, engine)
-        return prop, 0.0, 0.0
+    basis = GaussianKnotBasis(engine, X, knots="theta", matrix="B", scale=1.0)
 
     state = {
         "y": np.asarray(y, dtype=np.float64).reshape(n, 1), "X": np.asarray(X, dtype=np.float64).reshape(n, 1),
@@ -96,15 +76,15 @@ def build(y, X, P, n_max, engine, init_theta, init_beta, init_k):
         "beta": ragged_from_lists(init_beta, n_max, 0, "n_basis", dev),
         "alloc_beta": ragged_from_lists([np.zeros(int(k)) for k in init_k], n_max, 0, "n_basis", dev),
     }  # fmt: skip
-    state["B"] = make_basis(state, X_dev, engine)
+    state["B"] = basis.make(state)
     samplers = [
         NormalNormal("b", mdl),
         NormalNormal("beta", mdl, max_variable_size=n_max),
         NormalGamma("lambda", mdl),
         NormalGamma("tau", mdl),
         RandomWalkLoop("theta", mdl, step=np.array(0.2), max_variable_size=n_max, domain_limits=np.array([[-10.0, 10.0]]),
-                       state_update_function=move_function),
-        ReversibleJump("n_basis", mdl, associated_params=["theta"], n_max=n_max, state_birth_function=birth_function,
+                       state_update_function=basis, fused=fused),
+        ReversibleJump("n_basis", mdl, associated_params=["theta"], n_max=n_max, state_birth_function=basis.birth,
                        matching_params={"variable": "beta", "matrix": "B", "scale": 1.0, "limits": [-10.0, 10.0]}),
     ]
     return mdl, state, samplers

@@ -1,0 +1,179 @@
+"""RandomWalkLoop over the knots of a Gaussian-kernel basis in one launch (omc_knot_loop) against
+  * the launch-by-launch route of the same sampler (same draws: the two must take the same decisions and end at the
+    same knots; the only difference is the rounding of the log-likelihood difference), on the cfg5-shaped model; and
+  * a numpy restatement of metropolis_hastings.py:276-289 / :212-269 / :127-173 with SciPy's truncnorm, for the
+    argument forms the model above does not exercise (observation weights, shared offset, no per-chain offset)."""
+
+import numpy as np
+import pytest
+from scipy import stats
+
+from rj_problem import build, make_basis_host
+
+pytestmark = pytest.mark.gpu
+
+
+def small_problem(C, n, n_max, seed=0):
+    from openmcmc_amd import gmrf
+
+    rng = np.random.default_rng(seed)
+    X = np.linspace(-10, 10, n)
+    theta_true = np.array([[-6.0, -1.0, 4.5]])
+    beta_true = np.array([[3.0], [-2.0], [4.0]])
+    y = (make_basis_host(X.reshape(n, 1), theta_true) @ beta_true).ravel() + 0.1 * rng.standard_normal(n)
+    P = gmrf.precision_irregular(np.arange(float(n))).tolil()
+    P[0, 0] += 1e-3
+    k0 = np.clip(rng.poisson(4, size=C), 1, n_max)
+    k0[0], k0[-1] = n_max, 1  # a full chain and a minimal one
+    init_theta = [rng.uniform(-10, 10, size=k) for k in k0]
+    init_beta = [rng.standard_normal(k) for k in k0]
+    return y, X, P.tocsc(), k0, init_theta, init_beta
+
+
+def run_chain(fused, C=24, n=700, n_max=8, sweeps=25):
+    from openmcmc_amd.engine import Engine
+    from openmcmc_amd.mcmc import MCMC
+
+    y, X, P, k0, th0, be0 = small_problem(C, n, n_max)
+    eng = Engine(C, seed=5)
+    mdl, state, samplers = build(y, X, P, n_max, eng, th0, be0, k0.astype(float), fused=fused)
+    M = MCMC(state, samplers, model=mdl, n_burn=0, n_iter=sweeps, n_chains=C, seed=5, engine=eng)
+    M.run_mcmc()
+    out = M.collect()
+    rw = samplers[4]
+    B_state = M.state["B"].columns().cpu().numpy()
+    theta_state = M.state["theta"].data[:, 0, :].cpu().numpy()
+    counts = M.state["n_basis"].scalar().cpu().numpy().astype(int)
+    acc = (rw.accept_rate.accept.cpu().numpy().copy(), rw.accept_rate.proposal.cpu().numpy().copy())
+    eng.close()
+    return out, acc, B_state, theta_state, counts, X
+
+
+def test_fused_knot_loop_takes_the_same_decisions_as_the_launch_by_launch_route():
+    ref, acc_ref, *_ = run_chain(False)
+    got, acc_got, B, theta, counts, X = run_chain(True)
+    # same proposals, same uniforms: identical dimension trace and acceptance counters ...
+    assert np.array_equal(got["n_basis"], ref["n_basis"])
+    assert np.array_equal(acc_got[0], acc_ref[0]) and np.array_equal(acc_got[1], acc_ref[1])
+    assert acc_got[0].sum() > 50  # ... and the knots do move
+    # ... and the same chain up to rounding carried through 25 sweeps of Gibbs updates that read the basis
+    for key in ("theta", "beta", "b", "tau", "lambda", "log_post"):
+        a, b = got[key], ref[key]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), key
+        err = np.nanmax(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+        assert err < 1e-9, (key, err)
+    # the basis left in the state is the basis of the knots left in the state (columns rewritten on acceptance only)
+    for c in range(B.shape[0]):
+        k = counts[c]
+        want = make_basis_host(X.reshape(-1, 1), theta[c, :k].reshape(1, -1)).T
+        assert np.allclose(B[c, :k], want, rtol=0, atol=1e-15)
+        assert not B[c, k:].any()
+
+
+def knot_loop_numpy(X, scale, y, shared, offset, w, tau, beta, theta, count, B, step, lower, upper, uz, uu):
+    """One pass of the loop for one chain, on the host (SciPy truncnorm as in gmrf.py:269-318)."""
+    theta, B = theta.copy(), B.copy()
+    w = np.ones_like(y) if w is None else w
+    acc, las = [], []
+
+    def quad(Bm):
+        r = y - (Bm.T @ beta + (0 if offset is None else offset) + (0 if shared is None else shared))
+        return float(np.sum(w * r * r))
+
+    for j in range(int(count)):
+        mu = theta[j]
+        a, b = (lower - mu) / step, (upper - mu) / step
+        z = stats.truncnorm.ppf(uz[j], a, b, loc=mu, scale=step)
+        lq_f = stats.truncnorm.logpdf(z, a, b, loc=mu, scale=step)
+        lq_r = stats.truncnorm.logpdf(mu, (lower - z) / step, (upper - z) / step, loc=z, scale=step)
+        Bp = B.copy()
+        Bp[j] = np.exp(-(((X - z) / scale) ** 2) / 2.0) / np.sqrt(2 * np.pi) / scale
+        la = -0.5 * tau * quad(Bp) + lq_r - (-0.5 * tau * quad(B) + lq_f)
+        ok = np.log(uu[j]) < la
+        las.append(la)
+        acc.append(ok)
+        if ok:
+            theta[j], B = z, Bp
+    return theta, B, acc, las
+
+
+@pytest.mark.parametrize("weights,shared,offset,with_tau", [(True, True, False, True), (False, False, True, False),
+                                                            (True, False, True, True)])
+def test_knot_loop_kernel_against_numpy(weights, shared, offset, with_tau):
+    import torch
+
+    from openmcmc_amd.engine import Engine
+
+    C, n, kmax = 7, 900, 6
+    rng = np.random.default_rng(3)
+    eng = Engine(C, seed=2)
+    X = np.linspace(-5, 5, n)
+    count = np.array([6, 1, 3, 0, 5, 2, 4], dtype=float)
+    theta = rng.uniform(-5, 5, size=(C, kmax))
+    beta = rng.standard_normal((C, kmax))
+    for c in range(C):
+        theta[c, int(count[c]):] = 0.0
+        beta[c, int(count[c]):] = 0.0
+    scale = 0.8
+    B = np.zeros((C, kmax, n))
+    for c in range(C):
+        for j in range(int(count[c])):
+            B[c, j] = np.exp(-(((X - theta[c, j]) / scale) ** 2) / 2.0) / np.sqrt(2 * np.pi) / scale
+    y = np.sin(X) + 0.3 * rng.standard_normal(n)
+    w = 0.5 + rng.random(n) if weights else None
+    sh = 0.1 * np.cos(X) if shared else None
+    off = 0.2 * rng.standard_normal((C, n)) if offset else None
+    tau = 2.0 + 8.0 * rng.random(C) if with_tau else None
+    uz, uu = rng.random((kmax, C)), rng.random((kmax, C))
+    step, lower, upper = 0.4, -5.0, 5.0
+
+    d = eng.to_device
+    dB, dth = d(B), d(theta)
+    n_acc = torch.zeros(C, dtype=torch.int64, device=eng.device)
+    n_prop = torch.zeros(C, dtype=torch.int64, device=eng.device)
+    acc_out = torch.full((kmax, C), -1, dtype=torch.int32, device=eng.device)
+    la_out = eng.full((kmax, C), float("nan"))
+    eng.knot_loop(d(X), scale, d(y), dB, d(beta), dth, d(count), step, lower, upper, add_shared=None if sh is None else d(sh),
+                  add_chain=None if off is None else d(off), w=None if w is None else d(w), tau=None if tau is None else d(tau),
+                  inject_z=d(uz), inject_u=d(uu), accept_count=n_acc, proposal_count=n_prop, accept_out=acc_out,
+                  log_alpha_out=la_out)
+    eng.check_status()
+    gB, gth, gacc, gla = dB.cpu().numpy(), dth.cpu().numpy(), acc_out.cpu().numpy(), la_out.cpu().numpy()
+    assert np.array_equal(n_prop.cpu().numpy(), count.astype(np.int64))
+    for c in range(C):
+        k = int(count[c])
+        th_ref, B_ref, acc_ref, la_ref = knot_loop_numpy(X, scale, y, sh, None if off is None else off[c], w,
+                                                         1.0 if tau is None else tau[c], beta[c], theta[c], k, B[c], step,
+                                                         lower, upper, uz[:, c], uu[:, c])
+        assert np.array_equal(gacc[:k, c], np.array(acc_ref, dtype=np.int32)), c
+        assert np.all(gacc[k:, c] == -1)
+        assert np.allclose(gla[:k, c], la_ref, rtol=1e-9, atol=1e-9), c
+        assert np.allclose(gth[c], th_ref, rtol=0, atol=1e-12)
+        assert np.allclose(gB[c], B_ref, rtol=0, atol=1e-14)
+        assert int(n_acc[c].item()) == int(np.sum(acc_ref))
+    eng.close()
+
+
+def test_plan_falls_back_when_the_model_does_not_match():
+    """A trace hook, a prior narrower than the proposal's domain or a foreign callback keep the loop on the generic
+    route (no error, same API)."""
+    from openmcmc_amd.engine import Engine
+
+    y, X, P, k0, th0, be0 = small_problem(4, 300, 5)
+    eng = Engine(4, seed=1)
+    from openmcmc_amd.mcmc import MCMC
+
+    mdl, state, samplers = build(y, X, P, 5, eng, th0, be0, k0.astype(float))
+    rw = samplers[4]
+    state = MCMC(state, samplers, model=mdl, n_burn=0, n_iter=1, n_chains=4, engine=eng).state  # chain-batched state
+    assert rw._knot_plan(state) is not None
+    rw.trace = {}
+    assert rw._knot_plan(state) is None
+    rw.trace = None
+    mdl["theta"].domain_response_upper = np.array([[9.0]])
+    assert rw._knot_plan(state) is None
+    mdl["theta"].domain_response_upper = np.array([[10.0]])
+    basis = rw.state_update_function
+    rw.state_update_function = lambda st, col: basis(st, col)
+    assert rw._knot_plan(state) is None
+    eng.close()
