@@ -404,9 +404,12 @@ omc_status omc_ragged_resize(omc_ctx* ctx, int64_t rows, int64_t kmax, const dou
 /* Gaussian-kernel basis on per-chain knots, the design matrix of the reference's reversible-jump example
  * (tests/test_reversible_jump.py:24-40: norm.pdf(X, loc=knot, scale=scale) per column):
  *   B[c][j][i] = exp(-t^2/2) / sqrt(2 pi) / s,  t = (X[i] - knots[c][j]) / s,  s = scales[c][j] or scale0 (scales NULL)
- *   for j < count[c], 0 beyond.  column >= 0 rewrites only that column (one knot moved), -1 all of them.      */
+ *   for j < count[c], 0 beyond.  column >= 0 rewrites only that column (one knot moved), -1 all of them.
+ *   prev_count (C, or NULL; needs count): B already holds zeros in the columns >= prev_count[c] of chain c (a buffer
+ *   this function filled before with that count) -- only columns < max(count[c], prev_count[c]) are written.    */
 omc_status omc_gaussian_basis(omc_ctx* ctx, int64_t n, int64_t kmax, const double* X, const double* knots,
-                              const double* scales, double scale0, const double* count, int64_t column, double* B);
+                              const double* scales, double scale0, const double* count, const double* prev_count,
+                              int64_t column, double* B);
 
 /* RandomWalkLoop over the knots of that basis under a regression likelihood, every knot of every chain in one launch
  * (metropolis_hastings.py:276-289 -> :212-269 proposal, :127-173 accept/reject) for
@@ -416,7 +419,7 @@ omc_status omc_gaussian_basis(omc_ctx* ctx, int64_t n, int64_t kmax, const doubl
  *   The same draws as the launch-by-launch route: stream (draw_index, uniform), Philox block 2k for the proposal of knot k
  *   and 2k+1 for its accept uniform; inject_z / inject_u (kmax x C, [k][c]) replace them (tests).  w, tau, add_* may be
  *   NULL (ones / zeros).  accept_count / proposal_count (C) are incremented; accept_out / log_alpha_out (kmax x C,
- *   [k][c], entries k < count[c] written) may be NULL.  The chain's residual lives in LDS: n <= ~20 000.           */
+ *   [k][c], entries k < count[c] written) may be NULL.  The chain's residual lives in registers: n <= 10 240.       */
 omc_status omc_knot_loop(omc_ctx* ctx, int64_t n, int64_t kmax, const double* X, double scale, const double* y,
                          const double* add_shared, const double* add_chain, const double* w, const double* tau,
                          const double* beta, double* theta, const double* count, double* B, double step, double lower,
@@ -445,6 +448,12 @@ omc_status omc_design_resid_sq_batched(omc_ctx* ctx, int64_t n, int64_t kmax, co
 omc_status omc_design_gram_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* w,
                                    const double* resid_shared, const double* resid_chain, const double* count,
                                    double* gram, double* rhs);
+/* The same Gram matrix with the basis picked per chain: chain c uses (B_alt, count_alt) where select[c] != 0, (B, count)
+ * otherwise -- the matched reversible-jump transition (reversible_jump.py:240-242, 290-292) needs X'X of the LARGER of
+ * the current and the proposed basis only (proposed for a birth, current for a death).                          */
+omc_status omc_design_gram_select(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* count,
+                                  const double* B_alt, const double* count_alt, const int32_t* select, const double* w,
+                                  double* gram);
 
 /* NormalNormal.sample (sampler.py:176-197 -> gmrf.py:167-198) for a small ragged parameter:
  *   Q_c = diag(prior_prec[c]) + lik_scale[c]*gram[c],  b_c = prior_prec[c]*prior_mean[c] + lik_scale[c]*gram_rhs[c]

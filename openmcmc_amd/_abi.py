@@ -137,7 +137,8 @@ SIGNATURES = {
     "omc_mh_accept": (i32, [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, i64, c_dp, u64, u32, c_dp, c_dp, c_dp, c_dp]),
     "omc_chain_select": (i32, [C.c_void_p, c_dp, i64, c_dp, c_dp]),
     "omc_ragged_resize": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, i64]),
-    "omc_gaussian_basis": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, C.c_double, c_dp, i64, c_dp]),
+    "omc_gaussian_basis": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, C.c_double, c_dp, c_dp, i64, c_dp]),
+    "omc_design_gram_select": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "omc_knot_loop": (i32, [C.c_void_p, i64, i64, c_dp, C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp,
                             C.c_double, C.c_double, C.c_double, c_dp, c_dp, u64, c_dp, c_dp, c_dp, c_dp]),
     "omc_design_predict_batched": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, C.c_double, c_dp, c_dp]),

@@ -26,6 +26,7 @@ class GaussianKnotBasis:
         self.X = torch.as_tensor(np.asarray(X, dtype=np.float64).reshape(-1), device=engine.device)
         self.knots, self.matrix, self.scale = knots, matrix, float(scale)
         self._buf, self._last = None, None
+        self._prop, self._prop_count = None, None
 
     def make(self, state):
         """The whole basis of `state`: an (n, k_max) ChainArray, column-major per chain, zero columns beyond the live
@@ -57,6 +58,19 @@ class GaussianKnotBasis:
         return state, 0.0, 0.0
 
     def birth(self, current_state, prop_state):
-        """state_birth_function of ReversibleJump (births and deaths alike): the basis of the proposed knots."""
-        prop_state[self.matrix] = self.make(prop_state)
+        """state_birth_function of ReversibleJump (births and deaths alike): the basis of the proposed knots.  It is
+        written into one buffer kept from sweep to sweep (the sampler copies an accepted proposal into the current
+        state, it does not keep the proposal): the buffer is known to hold zeros beyond the live columns of the previous
+        proposal, so only the live columns of this one -- a quarter of the k_max at BASELINE configs[4] -- and the
+        columns that have just died are written."""
+        theta = prop_state[self.knots]
+        C, _, k_max = theta.data.shape
+        count = theta.count(prop_state)
+        shape = (C, k_max, self.X.numel())
+        if self._prop is None or tuple(self._prop.shape) != shape:
+            self._prop, self._prop_count = self.engine.zeros(*shape), self.engine.zeros(C)
+        self.engine.gaussian_basis(self.X, theta.data[:, 0, :], self._prop, count=count, scale=self.scale,
+                                   prev_count=self._prop_count)
+        self._prop_count.copy_(count)
+        prop_state[self.matrix] = ChainArray(self._prop.transpose(1, 2), ragged=(theta.ragged[0], 1))
         return prop_state, 0.0, 0.0

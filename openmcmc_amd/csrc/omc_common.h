@@ -26,6 +26,7 @@ struct omc_ctx {
   double* dense_factor; size_t dense_factor_bytes;
   int* dense_info; size_t dense_info_bytes;
   double* dense_tmp; size_t dense_tmp_bytes;
+  double* rj_tmp; size_t rj_tmp_bytes;   // omc_knot_loop: the proposals of all knots
   double* mh_work; size_t mh_work_bytes;  // omc_mala.hip
   double* mala_prep; size_t mala_prep_bytes;  // cached drift matrix and L^{-T} of the current (Q, L, step)
   const double* mala_Q; const double* mala_L; double mala_step; int64_t mala_d;

@@ -39,6 +39,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->dense_factor = nullptr; c->dense_factor_bytes = 0;
   c->dense_info = nullptr; c->dense_info_bytes = 0;
   c->dense_tmp = nullptr; c->dense_tmp_bytes = 0;
+  c->rj_tmp = nullptr; c->rj_tmp_bytes = 0;
   c->mh_work = nullptr; c->mh_work_bytes = 0;
   c->rw_prep = nullptr; c->rw_prep_bytes = 0; c->rw_LQ = nullptr; c->rw_d = 0;
   c->mala_prep = nullptr; c->mala_prep_bytes = 0; c->mala_Q = nullptr; c->mala_L = nullptr; c->mala_step = 0.0; c->mala_d = 0;
@@ -80,6 +81,7 @@ omc_status omc_ctx_destroy(omc_ctx* ctx) {
   if (ctx->dense_factor) hipFree(ctx->dense_factor);
   if (ctx->dense_info) hipFree(ctx->dense_info);
   if (ctx->dense_tmp) hipFree(ctx->dense_tmp);
+  if (ctx->rj_tmp) hipFree(ctx->rj_tmp);
   if (ctx->mh_work) hipFree(ctx->mh_work);
   if (ctx->mala_prep) hipFree(ctx->mala_prep);
   if (ctx->rw_prep) hipFree(ctx->rw_prep);

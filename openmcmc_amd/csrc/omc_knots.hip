@@ -1,5 +1,5 @@
 // RandomWalkLoop over the knots of a Gaussian-kernel basis under a regression likelihood, every column of every
-// chain in ONE launch.
+// chain in one launch (plus one for the proposals).
 //
 // What it replaces: the loop metropolis_hastings.py:276-289 (one truncated random-walk proposal per knot,
 // metropolis_hastings.py:212-269, accept/reject :127-173) for the model of the reference's reversible-jump tests
@@ -9,10 +9,10 @@
 // accept, merges).  The structure that makes one launch possible:
 //   * knot k's proposal depends on theta_k only, which no other knot's step changes: all proposals of a chain (the
 //     truncated-normal inverse CDF and its two densities are long serial evaluations) are made up front, one per lane;
-//   * moving knot k changes the fitted values by beta_k (phi_new - phi_old): the residual r = y - fitted lives in LDS
-//     and a step is one pass over it (new column evaluated on the fly, old column read from B), the quadratic form of
-//     the proposed state accumulated directly as sum w (r - beta_k d)^2 -- no expanded difference, so the conditioning
-//     is that of the two separate evaluations the host route makes;
+//   * moving knot k changes the fitted values by beta_k (phi_new - phi_old): the residual r = y - fitted lives in
+//     registers (a few rows per thread) and a step is one pass over it (new column evaluated on the fly, old column read
+//     from B), the quadratic form of the proposed state accumulated directly as sum w (r - beta_k d)^2 -- no expanded
+//     difference, so the conditioning is that of the two separate evaluations the host route makes;
 //   * an accepted move updates r, theta_k and column k of B in place.
 // Draw streams, truncated-normal arithmetic and the accept test are the host route's (k_rw_propose, k_mh_accept): both
 // routes see the same proposals and uniforms; the log-density DIFFERENCE differs by rounding only (summation order).
@@ -20,7 +20,9 @@
 #include "omc_common.h"
 #include "omc_truncnorm.h"
 
-#define KN_THREADS 512
+omc_status omc_ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need);  // omc_dense.hip
+
+#define KN_THREADS 1024
 
 __device__ __forceinline__ double kn_block_sum(double v, double* red, int tid) {
 #pragma unroll
@@ -34,99 +36,163 @@ __device__ __forceinline__ double kn_block_sum(double v, double* red, int tid) {
   return s;
 }
 
-__global__ void __launch_bounds__(KN_THREADS) k_knot_loop(int64_t C, int64_t chain_offset, int64_t n, int64_t kmax, const double* X,
-                                                         double scale0, const double* y, const double* add_shared,
-                                                         const double* add_chain, const double* w, const double* tau,
-                                                         const double* beta, double* theta, const double* count, double* B,
-                                                         double step, double lower, double upper, const double* inj_z,
-                                                         const double* inj_u, omc_rng_key key, long long* n_accept,
-                                                         long long* n_proposal, int* accept_out, double* log_alpha_out) {
-  extern __shared__ double sm[];
-  double* r = sm;               // [n] residual of the chain's current state
-  double* red = r + n;          // [KN_THREADS / 64]
-  double* pz = red + KN_THREADS / 64;  // [kmax] proposed knots
-  double* plf = pz + kmax;      // [kmax] log q(z | theta)
-  double* plr = plf + kmax;     // [kmax] log q(theta | z)
-  double* plu = plr + kmax;     // [kmax] log of the accept uniform
+// one basis value, k_gaussian_basis's arithmetic (a unit scale divides exactly: the divisions are skipped)
+__device__ __forceinline__ double kn_basis(double x, double knot, double scale0, bool unit) {
+  if (unit) {
+    const double t = x - knot;
+    return exp(-(t * t) / 2.0) / 2.5066282746310002;
+  }
+  const double t = (x - knot) / scale0;
+  return exp(-(t * t) / 2.0) / 2.5066282746310002 / scale0;
+}
+
+// All proposals of all chains, one per lane (k_rw_propose with p = 1: Philox block 2 k for the proposal of column k,
+// block 2 k + 1 for its accept uniform): prop[c][k] = {z, log q(z | theta), log q(theta | z), log u}.  Its own launch:
+// the truncated-normal evaluations are long and register-hungry, the loop kernel below is neither.
+__global__ void __launch_bounds__(64) k_knot_propose(int64_t C, int64_t chain_offset, int64_t kmax, const double* theta,
+                                                     const double* count, double step, double lower, double upper,
+                                                     const double* inj_z, const double* inj_u, omc_rng_key key, double* prop) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= C * kmax) return;
+  const int64_t c = e / kmax, j = e - c * kmax;
+  if (!((double)j < count[c])) return;
+  const double mu = theta[e];
+  double d, u;
+  if (inj_z) {
+    d = inj_z[j * C + c];
+  } else {
+    const uint4 wv = omc_rng_block(key, chain_offset + c, (uint32_t)(2 * j));
+    d = omc_u53(wv.x, wv.y);
+  }
+  if (inj_u) {
+    u = inj_u[j * C + c];
+  } else {
+    const uint4 wv = omc_rng_block(key, chain_offset + c, (uint32_t)(2 * j + 1));
+    u = omc_u53(wv.x, wv.y);
+  }
+  const double z = omc_truncated_normal_rv(mu, step, lower, upper, d);
+  double* out = prop + 4 * e;
+  out[0] = z;
+  out[1] = omc_truncated_normal_log_pdf(z, mu, step, lower, upper);
+  out[2] = omc_truncated_normal_log_pdf(mu, z, step, lower, upper);
+  out[3] = log(u);
+}
+
+// NR = rows per thread (NR * KN_THREADS >= n; row i = tid + q * KN_THREADS).  The chain's residual, its rows of X and
+// the proposed column of the current step stay in registers; the chain's proposals and coefficients sit in LDS; the
+// current column of the NEXT step is fetched before the reduction of this one (a step is otherwise one global-load
+// latency + one reduction long, and a chain has up to kmax of them in sequence).  NR > 5 would not fit that in 128
+// registers: the lean form keeps the residual and the proposed column only and re-reads the rest every step.
+template <int NR>
+__global__ void __launch_bounds__(KN_THREADS) k_knot_loop(int64_t C, int64_t n, int64_t kmax, const double* X, double scale0,
+                                                         const double* y, const double* add_shared, const double* add_chain,
+                                                         const double* w, const double* tau, const double* beta, double* theta,
+                                                         const double* count, double* B, const double* prop,
+                                                         long long* n_accept, long long* n_proposal, int* accept_out,
+                                                         double* log_alpha_out) {
+  __shared__ double red[KN_THREADS / 64];
+  extern __shared__ double sm[];  // [5 * kmax]: proposals {z, lq_fwd, lq_rev, log u} and the coefficients
   const int64_t c = blockIdx.x;
   const int tid = threadIdx.x;
   int k_live = (int)count[c];
   if (k_live > kmax) k_live = (int)kmax;
   double* Bc = B + c * kmax * n;
-  const double* bc = beta + c * kmax;
   double* thc = theta + c * kmax;
+  double* sp = sm;
+  double* sb = sm + 4 * kmax;
+  for (int e = tid; e < 4 * k_live; e += KN_THREADS) sp[e] = prop[4 * c * kmax + e];
+  for (int e = tid; e < (int)kmax; e += KN_THREADS) sb[e] = beta[c * kmax + e];
+  __syncthreads();
+  const bool unit = scale0 == 1.0;
 
-  // all proposals of the chain, one per lane (k_rw_propose with p = 1: Philox block 2 k for the proposal of column k,
-  // block 2 k + 1 for its accept uniform)
-  for (int j = tid; j < k_live; j += KN_THREADS) {
-    const double mu = thc[j];
-    double d, u;
-    if (inj_z) {
-      d = inj_z[(int64_t)j * C + c];
-    } else {
-      const uint4 wv = omc_rng_block(key, chain_offset + c, (uint32_t)(2 * j));
-      d = omc_u53(wv.x, wv.y);
-    }
-    if (inj_u) {
-      u = inj_u[(int64_t)j * C + c];
-    } else {
-      const uint4 wv = omc_rng_block(key, chain_offset + c, (uint32_t)(2 * j + 1));
-      u = omc_u53(wv.x, wv.y);
-    }
-    const double z = omc_truncated_normal_rv(mu, step, lower, upper, d);
-    pz[j] = z;
-    plf[j] = omc_truncated_normal_log_pdf(z, mu, step, lower, upper);
-    plr[j] = omc_truncated_normal_log_pdf(mu, z, step, lower, upper);
-    plu[j] = log(u);
-  }
-
-  // residual and quadratic form of the current state (k_design_resid_sq's arithmetic: columns in order, zero
-  // coefficients skipped)
+  // residual and quadratic form of the current state -- k_design_resid_sq's arithmetic: columns in order, zero
+  // coefficients skipped
+  constexpr bool LEAN = NR > 5;
+  constexpr int NK = LEAN ? 1 : NR;
+  double r[NR], x[NK], wt[NK];
   double acc = 0.0;
-  for (int64_t i = tid; i < n; i += KN_THREADS) {
-    double s = 0.0;
-    for (int64_t j = 0; j < kmax; ++j) {
-      const double cf = bc[j];
-      if (cf != 0.0) s = fma(Bc[j * n + i], cf, s);
+#pragma unroll
+  for (int q = 0; q < NR; ++q) r[q] = 0.0;
+  for (int64_t j = 0; j < kmax; ++j) {  // column by column (the branch is uniform): NR independent loads per column
+    const double cf = sb[j];
+    if (cf != 0.0) {
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        const int64_t i = tid + (int64_t)q * KN_THREADS;
+        if (i < n) r[q] = fma(Bc[j * n + i], cf, r[q]);
+      }
     }
-    const double f = s + (add_chain ? add_chain[c * n + i] : 0.0) + (add_shared ? add_shared[i] : 0.0);
-    const double ri = y[i] - f;
-    r[i] = ri;
-    acc = fma((w ? w[i] : 1.0) * ri, ri, acc);
   }
-  double quad = kn_block_sum(acc, red, tid);  // (its barriers also publish r and the proposals)
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    const int64_t i = tid + (int64_t)q * KN_THREADS;
+    if (!LEAN) { x[q] = 0.0; wt[q] = 0.0; }
+    if (i < n) {
+      const double f = r[q] + (add_chain ? add_chain[c * n + i] : 0.0) + (add_shared ? add_shared[i] : 0.0);
+      r[q] = y[i] - f;
+      const double wq = w ? w[i] : 1.0;
+      if (!LEAN) { x[q] = X[i]; wt[q] = wq; }
+      acc = fma(wq * r[q], r[q], acc);
+    } else {
+      r[q] = 0.0;
+    }
+  }
+  double cn[NK];  // the current column of the step about to run
+  if (!LEAN) {
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const int64_t i = tid + (int64_t)q * KN_THREADS;
+      cn[q] = (k_live > 0 && i < n) ? Bc[i] : 0.0;
+    }
+  }
+  double quad = kn_block_sum(acc, red, tid);
   const double tc = tau ? tau[c] : 1.0;
   int n_acc = 0;
 
   for (int j = 0; j < k_live; ++j) {
-    const double z = pz[j], bj = bc[j];
+    const double z = sp[4 * j], bj = sb[j];
     double* col = Bc + (int64_t)j * n;
+    double pn[NR], rn[NK];
     acc = 0.0;
-    for (int64_t i = tid; i < n; i += KN_THREADS) {
-      const double t = (X[i] - z) / scale0;
-      const double pn = exp(-(t * t) / 2.0) / 2.5066282746310002 / scale0;  // k_gaussian_basis
-      const double rn = fma(-bj, pn - col[i], r[i]);
-      acc = fma((w ? w[i] : 1.0) * rn, rn, acc);
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const int64_t i = tid + (int64_t)q * KN_THREADS;
+      pn[q] = 0.0;
+      if (!LEAN) rn[q] = 0.0;
+      if (i < n) {
+        pn[q] = kn_basis(LEAN ? X[i] : x[q], z, scale0, unit);
+        const double rq = fma(-bj, pn[q] - (LEAN ? col[i] : cn[q]), r[q]);
+        if (!LEAN) rn[q] = rq;
+        acc = fma((LEAN ? (w ? w[i] : 1.0) : wt[q]) * rq, rq, acc);
+      }
+    }
+    if (!LEAN && j + 1 < k_live) {  // next step's column: in flight under the reduction
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        const int64_t i = tid + (int64_t)q * KN_THREADS;
+        if (i < n) cn[q] = col[n + i];
+      }
     }
     const double quad_n = kn_block_sum(acc, red, tid);
-    const double la = (-0.5 * tc * quad_n) + plr[j] - ((-0.5 * tc * quad) + plf[j]);
-    const bool ok = plu[j] < la;  // a NaN log_alpha rejects
+    const double la = (-0.5 * tc * quad_n) + sp[4 * j + 2] - ((-0.5 * tc * quad) + sp[4 * j + 1]);
+    const bool ok = sp[4 * j + 3] < la;  // a NaN log_alpha rejects
     if (tid == 0) {
       if (accept_out) accept_out[(int64_t)j * C + c] = ok;
       if (log_alpha_out) log_alpha_out[(int64_t)j * C + c] = la;
     }
     if (ok) {
-      for (int64_t i = tid; i < n; i += KN_THREADS) {
-        const double t = (X[i] - z) / scale0;
-        const double pn = exp(-(t * t) / 2.0) / 2.5066282746310002 / scale0;
-        r[i] = fma(-bj, pn - col[i], r[i]);
-        col[i] = pn;
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        const int64_t i = tid + (int64_t)q * KN_THREADS;
+        if (i < n) {
+          r[q] = LEAN ? fma(-bj, pn[q] - col[i], r[q]) : rn[q];  // (the value the sum above was taken over)
+          col[i] = pn[q];
+        }
       }
       if (tid == 0) thc[j] = z;
       quad = quad_n;
       ++n_acc;
     }
-    // (each thread re-reads only the r and col entries it wrote itself: no barrier needed before the next column)
   }
   if (tid == 0) {
     if (n_proposal) n_proposal[c] += k_live;
@@ -143,15 +209,25 @@ extern "C" omc_status omc_knot_loop(omc_ctx* ctx, int64_t n, int64_t kmax, const
   if (!ctx || n < 1 || kmax < 1 || !X || !(scale > 0.0) || !y || !beta || !theta || !count || !B || !(step > 0.0) ||
       !(lower < upper))
     return OMC_INVALID_ARG;
-  const size_t lds = (size_t)(n + KN_THREADS / 64 + 4 * kmax) * sizeof(double);
-  if (lds > 160 * 1024) return OMC_INVALID_ARG;  // the residual must fit the LDS of a CU (n <= ~20 000)
+  const int64_t rows = (n + KN_THREADS - 1) / KN_THREADS;
+  const size_t lds = (size_t)(5 * kmax) * sizeof(double);
+  if (rows > 10 || lds > 32 * 1024) return OMC_INVALID_ARG;  // the chain's residual lives in registers: n <= 10 240
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  if (lds > 48 * 1024)
-    OMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_knot_loop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_knot_loop, dim3((unsigned)ctx->n_chains), dim3(KN_THREADS), lds, ctx->stream, ctx->n_chains,
-                     ctx->chain_offset, n, kmax, X, scale, y, add_shared, add_chain, w, tau, beta, theta, count, B, step, lower,
-                     upper, inject_z, inject_u, omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), (long long*)accept_count,
-                     (long long*)proposal_count, (int*)accept_out, log_alpha_out);
+  const int64_t Cn = ctx->n_chains;
+  omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->rj_tmp, &ctx->rj_tmp_bytes, (size_t)(4 * Cn * kmax) * sizeof(double));
+  if (st != OMC_OK) return st;
+  double* prop = (double*)ctx->rj_tmp;
+  hipLaunchKernelGGL(k_knot_propose, dim3((unsigned)((Cn * kmax + 63) / 64)), dim3(64), 0, ctx->stream, Cn, ctx->chain_offset,
+                     kmax, theta, count, step, lower, upper, inject_z, inject_u,
+                     omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), prop);
+  OMC_HIP_CHECK(hipGetLastError());
+#define KN_LAUNCH(NR)                                                                                                    \
+  hipLaunchKernelGGL(k_knot_loop<NR>, dim3((unsigned)Cn), dim3(KN_THREADS), lds, ctx->stream, Cn, n, kmax, X, scale, y,   \
+                     add_shared, add_chain, w, tau, beta, theta, count, B, prop, (long long*)accept_count,               \
+                     (long long*)proposal_count, (int*)accept_out, log_alpha_out)
+  if (rows <= 5) KN_LAUNCH(5);
+  else KN_LAUNCH(10);
+#undef KN_LAUNCH
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

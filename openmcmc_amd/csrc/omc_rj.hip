@@ -284,10 +284,13 @@ __global__ void __launch_bounds__(256) k_design_resid_sq(int64_t n, int64_t kmax
 // Gaussian-kernel basis B[c][j][i] = phi((X_i - knot_cj) / scale_cj) / scale_cj for the live knots, zero beyond;
 // column >= 0 rewrites only that column (a random-walk move of one knot)
 __global__ void k_gaussian_basis(int64_t C, int64_t n, int64_t kmax, const double* X, const double* knots,
-                                 const double* scales, double scale0, const double* count, int64_t column, double* B) {
+                                 const double* scales, double scale0, const double* count, const double* prev_count,
+                                 int64_t column, double* B) {
   const int64_t c = blockIdx.z;
   const int64_t j = column >= 0 ? column : (int64_t)blockIdx.y;
   const bool live = !count || (double)j < count[c];
+  // prev_count: the buffer already holds zeros in every column >= prev_count[c] -- a dead column beyond that is left alone
+  if (!live && prev_count && !((double)j < prev_count[c])) return;
   const double th = knots[c * kmax + j];
   const double sc = scales ? scales[c * kmax + j] : scale0;
   double* out = B + (c * kmax + j) * n;
@@ -310,9 +313,12 @@ __global__ void k_gaussian_basis(int64_t C, int64_t n, int64_t kmax, const doubl
 // walks 40 tiles of 128 rows behind two barriers each and hides no memory latency: 258 us at cfg5); a part writes
 // its sums to gram[(c * parts + part) * kmax^2 ...] / rhs[(c * parts + part) * kmax ...] and k_gram_reduce adds the
 // parts in order.
+// (B_alt, count_alt, select): chain c takes its basis from B_alt / count_alt where select[c] != 0 (the matched
+// reversible-jump transition needs the Gram matrix of the LARGER of two bases: proposed for a birth, current for a death)
 __global__ void __launch_bounds__(256) k_design_gram_batched(int64_t n, int64_t kmax, const double* B, const double* w,
                                                              const double* resid_shared, const double* resid_chain,
-                                                             const double* count, double* gram, double* rhs) {
+                                                             const double* count, double* gram, double* rhs,
+                                                             const double* B_alt, const double* count_alt, const int* select) {
   extern __shared__ double tile[];  // (kmax + 1) x (GRAM_TR + 1) columns + residual, then weights[GRAM_TR]
   const int64_t c = blockIdx.x;
   const int64_t parts = gridDim.y, part = blockIdx.y;
@@ -320,6 +326,7 @@ __global__ void __launch_bounds__(256) k_design_gram_batched(int64_t n, int64_t 
   const int64_t row_lo = part * rows_per, row_hi = (row_lo + rows_per < n) ? row_lo + rows_per : n;
   gram += (c * parts + part) * kmax * kmax - c * kmax * kmax;  // the indexing below adds c * kmax^2
   if (rhs) rhs += (c * parts + part) * kmax - c * kmax;
+  if (select && select[c]) { B = B_alt; count = count_alt; }
   const double* Bc = B + c * kmax * n;
   const int k = count ? (int)count[c] : (int)kmax;   // live columns
   const int K1 = k + 1;                              // + residual
@@ -753,14 +760,16 @@ omc_status omc_ragged_resize(omc_ctx* ctx, int64_t rows, int64_t kmax, const dou
 }
 
 omc_status omc_gaussian_basis(omc_ctx* ctx, int64_t n, int64_t kmax, const double* X, const double* knots,
-                              const double* scales, double scale0, const double* count, int64_t column, double* B) {
-  if (!ctx || n < 1 || kmax < 1 || !X || !knots || !B || column >= kmax || (!scales && !(scale0 > 0.0)))
+                              const double* scales, double scale0, const double* count, const double* prev_count,
+                              int64_t column, double* B) {
+  if (!ctx || n < 1 || kmax < 1 || !X || !knots || !B || column >= kmax || (!scales && !(scale0 > 0.0)) ||
+      (prev_count && !count))
     return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   unsigned gx = grid1(n, 256);
   if (gx > 32) gx = 32;
   hipLaunchKernelGGL(k_gaussian_basis, dim3(gx, column >= 0 ? 1u : (unsigned)kmax, (unsigned)ctx->n_chains), dim3(256), 0,
-                     ctx->stream, ctx->n_chains, n, kmax, X, knots, scales, scale0, count, column, B);
+                     ctx->stream, ctx->n_chains, n, kmax, X, knots, scales, scale0, count, prev_count, column, B);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }
@@ -810,10 +819,10 @@ omc_status omc_design_resid_sq_batched(omc_ctx* ctx, int64_t n, int64_t kmax, co
   return OMC_OK;
 }
 
-omc_status omc_design_gram_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* w,
-                                   const double* resid_shared, const double* resid_chain, const double* count,
-                                   double* gram, double* rhs) {
-  if (!ctx || n < 1 || kmax < 1 || kmax > 36 || !B || !gram) return OMC_INVALID_ARG;
+static omc_status design_gram_launch(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* w,
+                                     const double* resid_shared, const double* resid_chain, const double* count,
+                                     double* gram, double* rhs, const double* B_alt, const double* count_alt,
+                                     const int* select) {
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   const size_t lds = (size_t)((kmax + 1) * (GRAM_TR + 1) + GRAM_TR) * sizeof(double);
   const int64_t C = ctx->n_chains;
@@ -824,7 +833,7 @@ omc_status omc_design_gram_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const 
   if (parts > 16) parts = 16;
   if (parts < 2) {
     hipLaunchKernelGGL(k_design_gram_batched, dim3((unsigned)C), dim3(256), lds, ctx->stream, n, kmax, B, w, resid_shared,
-                       resid_chain, count, gram, rhs);
+                       resid_chain, count, gram, rhs, B_alt, count_alt, select);
   } else {
     const size_t per = (size_t)(kmax * kmax + kmax);
     omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->mh_work, &ctx->mh_work_bytes, (size_t)C * parts * per * sizeof(double));
@@ -832,7 +841,7 @@ omc_status omc_design_gram_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const 
     double* gp = ctx->mh_work;
     double* rp = rhs ? gp + (size_t)C * parts * kmax * kmax : nullptr;
     hipLaunchKernelGGL(k_design_gram_batched, dim3((unsigned)C, (unsigned)parts), dim3(256), lds, ctx->stream, n, kmax, B, w,
-                       resid_shared, resid_chain, count, gp, rp);
+                       resid_shared, resid_chain, count, gp, rp, B_alt, count_alt, select);
     const int64_t lg = kmax * kmax;
     hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((C * lg + 255) / 256)), dim3(256), 0, ctx->stream, C, lg, (int)parts, gp,
                        gram);
@@ -842,6 +851,20 @@ omc_status omc_design_gram_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const 
   }
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
+}
+
+omc_status omc_design_gram_batched(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* w,
+                                   const double* resid_shared, const double* resid_chain, const double* count,
+                                   double* gram, double* rhs) {
+  if (!ctx || n < 1 || kmax < 1 || kmax > 36 || !B || !gram) return OMC_INVALID_ARG;
+  return design_gram_launch(ctx, n, kmax, B, w, resid_shared, resid_chain, count, gram, rhs, nullptr, nullptr, nullptr);
+}
+
+omc_status omc_design_gram_select(omc_ctx* ctx, int64_t n, int64_t kmax, const double* B, const double* count,
+                                  const double* B_alt, const double* count_alt, const int32_t* select, const double* w,
+                                  double* gram) {
+  if (!ctx || n < 1 || kmax < 1 || kmax > 36 || !B || !B_alt || !select || !gram) return OMC_INVALID_ARG;
+  return design_gram_launch(ctx, n, kmax, B, w, nullptr, nullptr, count, gram, nullptr, B_alt, count_alt, (const int*)select);
 }
 
 omc_status omc_small_sample_canonical(omc_ctx* ctx, int64_t kmax, const double* gram, const double* gram_rhs,

@@ -642,13 +642,15 @@ class Engine:
                                     C.c_void_p(dst.data_ptr()), st[0], rs, js))
         return dst
 
-    def gaussian_basis(self, X, knots, out, count=None, scales=None, scale=1.0, column=None):
-        """Gaussian-kernel basis on per-chain knots written into out (C, kmax, n); column: rewrite only that column."""
+    def gaussian_basis(self, X, knots, out, count=None, scales=None, scale=1.0, column=None, prev_count=None):
+        """Gaussian-kernel basis on per-chain knots written into out (C, kmax, n); column: rewrite only that column;
+        prev_count (C,): out already holds zeros in the columns >= prev_count[c] -- those beyond count[c] too are skipped."""
         Cn, kmax, n = out.shape
         if not out.is_contiguous():
             raise ValueError("out must be a contiguous (C, kmax, n) tensor")
         check(lib.omc_gaussian_basis(self._ctx, n, kmax, self._vec(X, n), self._p(knots, Cn, kmax), self._p(scales),
-                                     float(scale), self._chain_scalar(count), -1 if column is None else int(column),
+                                     float(scale), self._chain_scalar(count), self._chain_scalar(prev_count),
+                                     -1 if column is None else int(column),
                                      self._p(out.view(Cn, -1))))
         return out
 
@@ -704,6 +706,17 @@ class Engine:
                                           self._vec(resid_shared, n), self._p(resid_chain), self._chain_scalar(count),
                                           self._p(gram.view(Cn, -1)), self._p(rhs)))
         return gram, rhs
+
+    def design_gram_select(self, B, count, B_alt, count_alt, select, w=None):
+        """gram (C, kmax, kmax) of B_alt[c] (live columns count_alt[c]) where select[c] != 0, of B[c] otherwise."""
+        Cn, kmax, n = B.shape
+        if not B.is_contiguous() or not B_alt.is_contiguous() or B_alt.shape != B.shape:
+            raise ValueError("B and B_alt must be contiguous (C, kmax, n) tensors of one shape")
+        gram = self.empty(Cn, kmax, kmax)
+        check(lib.omc_design_gram_select(self._ctx, n, kmax, self._p(B.view(Cn, -1)), self._chain_scalar(count),
+                                         self._p(B_alt.view(Cn, -1)), self._chain_scalar(count_alt), self._i32(select),
+                                         self._vec(w, n), self._p(gram.view(Cn, -1))))
+        return gram
 
     def small_sample_canonical(self, gram, gram_rhs, prior_prec, lik_scale=None, prior_mean=None, count=None, z=None,
                                draw_index=0, mean_out=None):

@@ -125,10 +125,10 @@ class ReversibleJump(MetropolisHastings):
         coef, B_cur, B_prop = current_state[vector], current_state[matrix], prop_state[matrix]
         if not (is_chain(coef) and is_chain(B_cur) and is_chain(B_prop)) or coef.shape[1] != 1:
             raise NotImplementedError("matched transitions need per-chain coefficient vector and basis matrices")
-        gram_cur, _ = eng.design_gram_batched(B_cur.columns(), count=B_cur.count(current_state))
-        gram_prop, _ = eng.design_gram_batched(B_prop.columns(), count=B_prop.count(prop_state))
+        # X'X of the larger basis only: the proposed one where a chain makes a birth, the current one for a death
+        gram = eng.design_gram_select(B_cur.columns(), B_cur.count(current_state), B_prop.columns(), B_prop.count(prop_state), birth)
         inject = self.inject_match(self, self._sweep) if self.inject_match is not None else None
-        out = eng.rj_matched_transition(gram_cur, gram_prop, count, birth, del_index, coef.vector(), scale, limits, lq_f, lq_r,
+        out = eng.rj_matched_transition(gram, gram, count, birth, del_index, coef.vector(), scale, limits, lq_f, lq_r,
                                         inject=inject, draw_index=self._draw_index(), sub=_SUB_MATCH)
         prop_state[vector] = coef.like(out.unsqueeze(2))
         return prop_state

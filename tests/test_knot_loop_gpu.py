@@ -97,14 +97,15 @@ def knot_loop_numpy(X, scale, y, shared, offset, w, tau, beta, theta, count, B, 
     return theta, B, acc, las
 
 
-@pytest.mark.parametrize("weights,shared,offset,with_tau", [(True, True, False, True), (False, False, True, False),
-                                                            (True, False, True, True)])
-def test_knot_loop_kernel_against_numpy(weights, shared, offset, with_tau):
+@pytest.mark.parametrize("n,weights,shared,offset,with_tau", [(900, True, True, False, True), (900, False, False, True, False),
+                                                              (900, True, False, True, True), (6100, True, True, True, True)])
+def test_knot_loop_kernel_against_numpy(n, weights, shared, offset, with_tau):
+    """(n = 6100: more than 5 rows per thread, the kernel's lean instantiation)"""
     import torch
 
     from openmcmc_amd.engine import Engine
 
-    C, n, kmax = 7, 900, 6
+    C, kmax = 7, 6
     rng = np.random.default_rng(3)
     eng = Engine(C, seed=2)
     X = np.linspace(-5, 5, n)
