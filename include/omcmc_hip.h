@@ -44,6 +44,7 @@ typedef enum {
 typedef struct omc_ctx omc_ctx;
 
 #define OMC_MAX_TERMS 4
+#define OMC_SELECT_MAX 8   /* state entries per omc_chain_select_multi call */
 
 /* A conditional precision in "shared structure x per-chain scalar" form
  *     Q_c = sum_k scale[k][c] * M_k,   M_k symmetric tridiagonal, shared by all chains,
@@ -294,6 +295,19 @@ omc_status omc_gamma_logpdf(omc_ctx* ctx, const double* x, double shape, double 
 omc_status omc_rj_move(omc_ctx* ctx, int64_t n_max, double birth_probability, const int64_t* n,
                        const double* u_inject, const int64_t* idx_inject, uint64_t draw_index,
                        int32_t* birth_out, double* p_birth_out, double* p_death_out, int64_t* del_index_out);
+/* The same move with the outputs ReversibleJump.proposal makes of it (reversible_jump.py:122-144, 165-191): count [C] is
+ * the float64 count the state holds; count_prop = count +- 1; with d = density_const + density_chain[c] (the log prior
+ * density of the last element of every associated parameter, :132,143; density_chain may be NULL)
+ *   birth: lq_fwd = log p_birth + d, lq_rev = log p_death;   death: lq_fwd = log p_death, lq_rev = log p_birth + d.  */
+omc_status omc_rj_move_densities(omc_ctx* ctx, int64_t n_max, double birth_probability, const double* count,
+                                 const double* u_inject, const int64_t* idx_inject, uint64_t draw_index,
+                                 const double* density_chain, double density_const, int32_t* birth_out,
+                                 int64_t* del_index_out, double* count_prop_out, double* lq_fwd_out, double* lq_rev_out);
+
+/* One draw of a variable-size parameter into its store slab (sampler.py:112-116): dst[c][j] = src[c][j] for
+ * j < count[c], NaN beyond, j < width; chain c at src + c*src_chain_stride / dst + c*dst_chain_stride.          */
+omc_status omc_store_ragged(omc_ctx* ctx, int64_t width, const double* src, int64_t src_chain_stride, const double* count,
+                            double* dst, int64_t dst_chain_stride);
 
 /* ---- banded precisions of any bandwidth (RW2, seasonal, lattice GMRFs) --------
  * The same conditional draw as omc_tridiag_sample_canonical for Q_c = sum_k scale[k][c] * M_k with every M_k
@@ -391,6 +405,10 @@ omc_status omc_mh_accept(omc_ctx* ctx, const double* lp_cur, const double* lp_pr
 /* current_state = prop_state for accepted chains (metropolis_hastings.py:157-159):
  *   dst[c][0..width) = src[c][0..width) where accept[c] != 0.                                          */
 omc_status omc_chain_select(omc_ctx* ctx, const int32_t* accept, int64_t width, const double* src, double* dst);
+/* the same for n_items (<= OMC_SELECT_MAX) entries in one launch: entry e is widths[e] doubles per chain, chain-major,
+ * copied from srcs[e] to dsts[e] on the accepted chains (host arrays of n_items elements).                      */
+omc_status omc_chain_select_multi(omc_ctx* ctx, const int32_t* accept, int32_t n_items, const int64_t* widths,
+                                  const double* const* srcs, double* const* dsts);
 
 /* np.concatenate / np.delete along the ragged axis (reversible_jump.py:131, 175) for every chain:
  *   birth[c] != 0: dst = src with new_vals[c][0..rows) appended at position count[c] (NULL = zeros);
@@ -547,6 +565,10 @@ omc_status omc_poisson_logpmf(omc_ctx* ctx, const double* x, double rate, double
 omc_status omc_count_logpdf(omc_ctx* ctx, const double* count, double per_element, double* out, int32_t accumulate);
 omc_status omc_mixture_gather(omc_ctx* ctx, int64_t kmax, int64_t m, const double* param, int64_t param_stride,
                               const double* alloc, const double* count, double fill, double* out);
+/* two tables gathered by one allocation in one launch (the mean and the precision of a mixture Normal) */
+omc_status omc_mixture_gather2(omc_ctx* ctx, int64_t kmax, int64_t m, const double* alloc, const double* count,
+                               const double* param_a, int64_t stride_a, double fill_a, double* out_a, const double* param_b,
+                               int64_t stride_b, double fill_b, double* out_b);
 
 /* ---- on-device posterior summaries of the device-resident store ----
  * store is [n_iter][C][size] (iteration-major, as MCMC writes it: mcmc.py:105-106 per chain).

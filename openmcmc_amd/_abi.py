@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OMC_HIP_LIB") or os.path.join(_HERE, "libomcmc_hip.so")
 
 OMC_MAX_TERMS = 4
+OMC_SELECT_MAX = 8
 OK, INVALID_ARG, NOT_POSDEF, HIP_ERROR, UNSUPPORTED = range(5)
 
 c_dp = C.c_void_p  # device pointer
@@ -120,6 +121,9 @@ SIGNATURES = {
     "omc_scaled_gauss_logpdf": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, i32]),
     "omc_gamma_logpdf": (i32, [C.c_void_p, c_dp, C.c_double, C.c_double, c_dp, i32]),
     "omc_rj_move": (i32, [C.c_void_p, i64, C.c_double, c_dp, c_dp, c_dp, u64, c_dp, c_dp, c_dp, c_dp]),
+    "omc_rj_move_densities": (i32, [C.c_void_p, i64, C.c_double, c_dp, c_dp, c_dp, u64, c_dp, C.c_double, c_dp, c_dp, c_dp, c_dp,
+                                    c_dp]),
+    "omc_store_ragged": (i32, [C.c_void_p, i64, c_dp, i64, c_dp, c_dp, i64]),
     "omc_store_moments": (i32, [C.c_void_p, i64, i64, c_dp, i32, c_dp, c_dp]),
     "omc_band_sample_canonical": (
         i32, [C.c_void_p, i64, i64, C.POINTER(BandTerms), c_dp, i64, c_dp, i64, u64, c_dp, i64, c_dp, i64, c_dp]),
@@ -136,6 +140,7 @@ SIGNATURES = {
     "omc_mala_diag": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, C.c_double, i32, c_dp, u64, u32, c_dp, c_dp]),
     "omc_mh_accept": (i32, [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, i64, c_dp, u64, u32, c_dp, c_dp, c_dp, c_dp]),
     "omc_chain_select": (i32, [C.c_void_p, c_dp, i64, c_dp, c_dp]),
+    "omc_chain_select_multi": (i32, [C.c_void_p, c_dp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "omc_ragged_resize": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, i64]),
     "omc_gaussian_basis": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, C.c_double, c_dp, c_dp, i64, c_dp]),
     "omc_design_gram_select": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
@@ -159,6 +164,7 @@ SIGNATURES = {
     "omc_poisson_logpmf": (i32, [C.c_void_p, c_dp, C.c_double, c_dp, i32]),
     "omc_count_logpdf": (i32, [C.c_void_p, c_dp, C.c_double, c_dp, i32]),
     "omc_mixture_gather": (i32, [C.c_void_p, i64, i64, c_dp, i64, c_dp, c_dp, C.c_double, c_dp]),
+    "omc_mixture_gather2": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, i64, C.c_double, c_dp, c_dp, i64, C.c_double, c_dp]),
     "omc_mixture_allocation": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, i64, c_dp, i64, c_dp, i64, c_dp, u64, c_dp]),
     "omc_categorical_logpmf": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, i64, c_dp, i32]),
     "omc_mixture_normal_gamma": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, c_dp, c_dp, u64, c_dp]),

@@ -142,6 +142,24 @@ __global__ void k_chain_select(int64_t C, int64_t width, const int* accept, cons
     dst[c * width + i] = src[c * width + i];
 }
 
+// the same for up to OMC_SELECT_MAX state entries in one launch (blockIdx.z = entry)
+struct SelectItems {
+  int n;
+  int64_t width[OMC_SELECT_MAX];
+  const double* src[OMC_SELECT_MAX];
+  double* dst[OMC_SELECT_MAX];
+};
+__global__ void k_chain_select_multi(int64_t C, const int* accept, SelectItems it) {
+  const int64_t c = blockIdx.y;
+  if (!accept[c]) return;
+  const int e = blockIdx.z;
+  const int64_t width = it.width[e];
+  const double* src = it.src[e];
+  double* dst = it.dst[e];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < width; i += (int64_t)gridDim.x * blockDim.x)
+    dst[c * width + i] = src[c * width + i];
+}
+
 // np.concatenate / np.delete on the ragged axis (reversible_jump.py:131, 175)
 __global__ void k_ragged_resize(int64_t C, int64_t rows, int64_t kmax, const double* count, const int* birth,
                                 const long long* del, const double* new_vals, const double* src, double* dst,
@@ -394,10 +412,15 @@ __global__ void __launch_bounds__(256) k_design_gram_batched(int64_t n, int64_t 
   }
 }
 
-// out[c][t] = sum over the parts, in order (deterministic)
-__global__ void k_gram_reduce(int64_t C, int64_t len, int parts, const double* in, double* out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C * len) return;
+// out[c][t] = sum over the parts, in order (deterministic); a second array (the right-hand sides) rides along
+__global__ void k_gram_reduce(int64_t C, int64_t len, int parts, const double* in, double* out, int64_t len2,
+                              const double* in2, double* out2) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * len) {
+    i -= C * len;
+    if (!out2 || i >= C * len2) return;
+    len = len2; in = in2; out = out2;
+  }
   const int64_t c = i / len, t = i - c * len;
   double s = 0.0;
   for (int p = 0; p < parts; ++p) s += in[(c * parts + p) * len + t];
@@ -744,6 +767,29 @@ omc_status omc_chain_select(omc_ctx* ctx, const int32_t* accept, int64_t width, 
   return OMC_OK;
 }
 
+omc_status omc_chain_select_multi(omc_ctx* ctx, const int32_t* accept, int32_t n_items, const int64_t* widths,
+                                  const double* const* srcs, double* const* dsts) {
+  if (!ctx || !accept || n_items < 1 || n_items > OMC_SELECT_MAX || !widths || !srcs || !dsts) return OMC_INVALID_ARG;
+  SelectItems it;
+  it.n = n_items;
+  int64_t wmax = 1;
+  for (int e = 0; e < OMC_SELECT_MAX; ++e) {
+    const bool on = e < n_items;
+    if (on && (widths[e] < 1 || !srcs[e] || !dsts[e])) return OMC_INVALID_ARG;
+    it.width[e] = on ? widths[e] : 0;
+    it.src[e] = on ? srcs[e] : nullptr;
+    it.dst[e] = on ? dsts[e] : nullptr;
+    if (on && widths[e] > wmax) wmax = widths[e];
+  }
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  unsigned gx = grid1(wmax, 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_chain_select_multi, dim3(gx, (unsigned)ctx->n_chains, (unsigned)n_items), dim3(256), 0, ctx->stream,
+                     ctx->n_chains, (const int*)accept, it);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
 omc_status omc_ragged_resize(omc_ctx* ctx, int64_t rows, int64_t kmax, const double* count, const int32_t* birth,
                              const int64_t* del_index, const double* new_vals, const double* src, double* dst,
                              int64_t chain_stride, int64_t row_stride, int64_t col_stride) {
@@ -814,7 +860,7 @@ omc_status omc_design_resid_sq_batched(omc_ctx* ctx, int64_t n, int64_t kmax, co
   hipLaunchKernelGGL(k_design_resid_sq, dim3((unsigned)parts, (unsigned)C), dim3(256), 0, ctx->stream, n, kmax, B, coef,
                      add_chain, add_shared, y, w, ctx->mh_work);
   hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, ctx->stream, C, (int64_t)1, (int)parts,
-                     ctx->mh_work, out);
+                     (const double*)ctx->mh_work, out, (int64_t)0, (const double*)nullptr, (double*)nullptr);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }
@@ -842,12 +888,9 @@ static omc_status design_gram_launch(omc_ctx* ctx, int64_t n, int64_t kmax, cons
     double* rp = rhs ? gp + (size_t)C * parts * kmax * kmax : nullptr;
     hipLaunchKernelGGL(k_design_gram_batched, dim3((unsigned)C, (unsigned)parts), dim3(256), lds, ctx->stream, n, kmax, B, w,
                        resid_shared, resid_chain, count, gp, rp, B_alt, count_alt, select);
-    const int64_t lg = kmax * kmax;
-    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((C * lg + 255) / 256)), dim3(256), 0, ctx->stream, C, lg, (int)parts, gp,
-                       gram);
-    if (rhs)
-      hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((C * kmax + 255) / 256)), dim3(256), 0, ctx->stream, C, kmax, (int)parts,
-                         rp, rhs);
+    const int64_t lg = kmax * kmax, total = C * lg + (rhs ? C * kmax : 0);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, C, lg, (int)parts, gp,
+                       gram, kmax, (const double*)rp, rhs);
   }
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;

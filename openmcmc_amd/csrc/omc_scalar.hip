@@ -62,15 +62,24 @@ __global__ void k_fill_u32(int64_t C, int64_t chain_offset, int64_t n_words, omc
 }
 
 // reversible_jump.py:310-373 and :173
+// Two output forms: the move probabilities themselves (p_birth_out / p_death_out), or what ReversibleJump.proposal
+// goes on to make of them (count_f given: the count is read as the float64 the state holds; outputs the proposed count
+// and the two proposal log-densities of reversible_jump.py:142-144 / 189-191,
+//   birth: lq_fwd = log p_birth + density, lq_rev = log p_death;  death: lq_fwd = log p_death, lq_rev = log p_birth + density
+// with density = dens_const + dens_chain[c]: the log prior density of the last element of every associated parameter).
 __global__ void k_rj_move(int64_t C, int64_t chain_offset, long long n_max, double q, const long long* n,
                           const double* u_in, const long long* idx_in, omc_rng_key key, int* birth_out,
-                          double* p_birth_out, double* p_death_out, long long* del_out, long long* bad) {
+                          double* p_birth_out, double* p_death_out, long long* del_out, long long* bad,
+                          const double* count_f, const double* dens_chain, double dens_const, double* count_prop_out,
+                          double* lq_fwd_out, double* lq_rev_out) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const long long nc = n[c];
-  if (nc < 1 || nc > n_max) {
+  const long long nc = count_f ? (long long)count_f[c] : n[c];
+  if (nc < 1 || nc > n_max || (count_f && (double)nc != count_f[c])) {
     atomicMin((unsigned long long*)bad, (unsigned long long)c);
-    birth_out[c] = 0; p_birth_out[c] = 0.0; p_death_out[c] = 0.0; del_out[c] = -1;
+    birth_out[c] = 0; del_out[c] = -1;
+    if (p_birth_out) { p_birth_out[c] = 0.0; p_death_out[c] = 0.0; }
+    if (count_prop_out) { count_prop_out[c] = count_f[c]; lq_fwd_out[c] = NAN; lq_rev_out[c] = NAN; }
     return;
   }
   bool birth;
@@ -115,9 +124,18 @@ __global__ void k_rj_move(int64_t C, int64_t chain_offset, long long n_max, doub
     }
   }
   birth_out[c] = birth ? 1 : 0;
-  p_birth_out[c] = pb;
-  p_death_out[c] = pd;
   del_out[c] = idx;
+  if (p_birth_out) {
+    p_birth_out[c] = pb;
+    p_death_out[c] = pd;
+  }
+  if (count_prop_out) {
+    const double dens = dens_const + (dens_chain ? dens_chain[c] : 0.0);
+    const double lb = log(pb) + dens, ld = log(pd);
+    count_prop_out[c] = count_f[c] + (birth ? 1.0 : -1.0);
+    lq_fwd_out[c] = birth ? lb : ld;
+    lq_rev_out[c] = birth ? ld : lb;
+  }
 }
 
 // mean / variance over stored iterations (and chains when pooled): one lane per output element,
@@ -188,7 +206,45 @@ omc_status omc_rj_move(omc_ctx* ctx, int64_t n_max, double birth_probability, co
   hipLaunchKernelGGL(k_rj_move, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, ctx->chain_offset,
                      (long long)n_max, birth_probability, (const long long*)n, u_inject, (const long long*)idx_inject,
                      omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), birth_out, p_birth_out, p_death_out,
-                     (long long*)del_index_out, ctx->d_bad_chain);
+                     (long long*)del_index_out, ctx->d_bad_chain, nullptr, nullptr, 0.0, nullptr, nullptr, nullptr);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_rj_move_densities(omc_ctx* ctx, int64_t n_max, double birth_probability, const double* count,
+                                 const double* u_inject, const int64_t* idx_inject, uint64_t draw_index,
+                                 const double* density_chain, double density_const, int32_t* birth_out,
+                                 int64_t* del_index_out, double* count_prop_out, double* lq_fwd_out, double* lq_rev_out) {
+  if (!ctx || n_max < 1 || n_max > 0x7fffffffLL || !(birth_probability >= 0.0 && birth_probability <= 1.0) || !count ||
+      !birth_out || !del_index_out || !count_prop_out || !lq_fwd_out || !lq_rev_out)
+    return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_rj_move, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, ctx->chain_offset,
+                     (long long)n_max, birth_probability, (const long long*)nullptr, u_inject, (const long long*)idx_inject,
+                     omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), birth_out, (double*)nullptr, (double*)nullptr,
+                     (long long*)del_index_out, ctx->d_bad_chain, count, density_chain, density_const, count_prop_out,
+                     lq_fwd_out, lq_rev_out);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+// dst[c][j] = src[c][j] for j < count[c], NaN beyond: one draw of a variable-size parameter into its store slab
+// (sampler.py:112-116; the reference leaves its NaN fill beyond the live length)
+__global__ void k_store_ragged(int64_t C, int64_t width, const double* src, int64_t src_stride, const double* count,
+                               double* dst, int64_t dst_stride) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= C * width) return;
+  const int64_t c = e / width, j = e - c * width;
+  dst[c * dst_stride + j] = ((double)j < count[c]) ? src[c * src_stride + j] : NAN;
+}
+
+omc_status omc_store_ragged(omc_ctx* ctx, int64_t width, const double* src, int64_t src_chain_stride, const double* count,
+                            double* dst, int64_t dst_chain_stride) {
+  if (!ctx || width < 1 || !src || !count || !dst || src_chain_stride < width || dst_chain_stride < width)
+    return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_store_ragged, dim3(grid1(ctx->n_chains * width, 256)), dim3(256), 0, ctx->stream, ctx->n_chains, width,
+                     src, src_chain_stride, count, dst, dst_chain_stride);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }
@@ -263,18 +319,26 @@ __global__ void k_count_logpdf(int64_t C, const double* count, double per_elemen
   out[c] = accumulate ? out[c] + lp : lp;
 }
 
+// (param2, fill2, out2): a second table gathered by the same allocation in the same launch (the mean and the precision
+// of a mixture Normal always go together)
 __global__ void k_mixture_gather(int64_t C, int64_t kmax, int64_t m, const double* param, int64_t pstride,
-                                 const double* alloc, const double* count, double fill, double* out, long long* bad) {
+                                 const double* alloc, const double* count, double fill, double* out, long long* bad,
+                                 const double* param2, int64_t pstride2, double fill2, double* out2) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= C * kmax) return;
   const int64_t c = t / kmax, j = t % kmax;
-  double v = fill;
+  double v = fill, v2 = fill2;
   if (!count || (double)j < count[c]) {
     const int64_t a = (int64_t)alloc[t];
-    if (a < 0 || a >= m) atomicMin((unsigned long long*)bad, (unsigned long long)c);
-    else v = param[c * pstride + a];
+    if (a < 0 || a >= m) {
+      atomicMin((unsigned long long*)bad, (unsigned long long)c);
+    } else {
+      v = param[c * pstride + a];
+      if (param2) v2 = param2[c * pstride2 + a];
+    }
   }
   out[t] = v;
+  if (out2) out2[t] = v2;
 }
 
 // Gamma.log_p of a ragged (1, k) response (distribution.py:241-261): sum over the live entries, or (last_only) the
@@ -580,7 +644,18 @@ omc_status omc_mixture_gather(omc_ctx* ctx, int64_t kmax, int64_t m, const doubl
   if (!ctx || kmax < 1 || m < 1 || !param || !alloc || !out) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(k_mixture_gather, dim3(grid1(ctx->n_chains * kmax, 256)), dim3(256), 0, ctx->stream, ctx->n_chains,
-                     kmax, m, param, param_stride, alloc, count, fill, out, ctx->d_bad_chain);
+                     kmax, m, param, param_stride, alloc, count, fill, out, ctx->d_bad_chain, nullptr, 0, 0.0, nullptr);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_mixture_gather2(omc_ctx* ctx, int64_t kmax, int64_t m, const double* alloc, const double* count,
+                               const double* param_a, int64_t stride_a, double fill_a, double* out_a, const double* param_b,
+                               int64_t stride_b, double fill_b, double* out_b) {
+  if (!ctx || kmax < 1 || m < 1 || !alloc || !param_a || !out_a || !param_b || !out_b) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_mixture_gather, dim3(grid1(ctx->n_chains * kmax, 256)), dim3(256), 0, ctx->stream, ctx->n_chains,
+                     kmax, m, param_a, stride_a, alloc, count, fill_a, out_a, ctx->d_bad_chain, param_b, stride_b, fill_b, out_b);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

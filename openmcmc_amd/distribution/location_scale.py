@@ -136,6 +136,18 @@ class Normal(Distribution):
             raise NotImplementedError("mixture Normal needs a per-chain (k, 1) response")
         if not isinstance(self.mean, MixtureParameterVector):
             raise NotImplementedError("mixture precision with a non-mixture mean")
+        if self.mean.allocation == self.precision.allocation:
+            # one allocation picks the mean and the precision of every element: both tables in one launch
+            alloc = state[self.mean.allocation]
+            if not is_chain(alloc):
+                raise NotImplementedError("mixture parameters need a per-chain allocation")
+
+            def table(par):
+                return par.vector() if is_chain(par) else engine.shared(par).reshape(-1)
+
+            mean, prec = engine.mixture_gather2(alloc.vector(), alloc.count(state), table(state[self.mean.param]), 0.0,
+                                                table(state[self.precision.param]), 1.0)
+            return x.vector(), mean, prec, x.count(state)
         return (x.vector(), self.mean.gather_device(state, engine, 0.0), self.precision.gather_device(state, engine, 1.0),
                 x.count(state))
 

@@ -485,6 +485,31 @@ class Engine:
                               C.c_void_p(dele.data_ptr())))
         return birth, pb, pd, dele
 
+    def rj_move_densities(self, count, n_max, birth_probability, density_chain=None, density_const=0.0, u=None, idx=None,
+                          draw_index=0):
+        """(birth int32 (C,), del_index int64, count_prop, lq_fwd, lq_rev) for every chain from the float64 counts the
+        state holds: the move of rj_move with the proposed count and the two proposal log-densities
+        (reversible_jump.py:142-144, 189-191) made in the same launch."""
+        torch = _torch()
+        Cn = self.n_chains
+        birth = torch.empty(Cn, dtype=torch.int32, device=self.device)
+        dele = torch.empty(Cn, dtype=torch.int64, device=self.device)
+        cp, lf, lr = self.empty(Cn), self.empty(Cn), self.empty(Cn)
+        check(lib.omc_rj_move_densities(self._ctx, int(n_max), float(birth_probability), self._chain_scalar(count),
+                                        self._chain_scalar(u), None if idx is None else C.c_void_p(idx.data_ptr()),
+                                        int(draw_index), self._chain_scalar(density_chain), float(density_const),
+                                        C.c_void_p(birth.data_ptr()), C.c_void_p(dele.data_ptr()), self._p(cp), self._p(lf),
+                                        self._p(lr)))
+        return birth, dele, cp, lf, lr
+
+    def store_ragged(self, src, count, dst):
+        """dst[c, j] = src[c, j] for j < count[c], NaN beyond (src (C, width) rows contiguous, dst (C, >= width))."""
+        Cn, width = src.shape
+        if src.stride(1) != 1 or dst.stride(1) != 1 or dst.shape[0] != Cn or dst.shape[1] < width:
+            raise ValueError("store_ragged wants row-contiguous (C, width) source and (C, >= width) destination")
+        check(lib.omc_store_ragged(self._ctx, width, self._p(src), src.stride(0), self._chain_scalar(count), self._p(dst),
+                                   dst.stride(0)))
+
     # ------------------------------------------------------------------ banded precisions
     def band_terms(self, terms, n):
         """terms: list of dicts with optional keys band ((bw+1, n) shared tensor, sub-diagonal d in row d; None =
@@ -622,6 +647,20 @@ class Engine:
         check(lib.omc_chain_select(self._ctx, self._i32(accept), width, self._p(src.view(self.n_chains, -1)),
                                    self._p(dst.view(self.n_chains, -1))))
         return dst
+
+    def chain_select_many(self, accept, pairs):
+        """dst[c] = src[c] on the accepted chains for every (src, dst) pair, in one launch per OMC_SELECT_MAX pairs."""
+        n = self.n_chains
+        for k in range(0, len(pairs), _abi.OMC_SELECT_MAX):
+            part = pairs[k:k + _abi.OMC_SELECT_MAX]
+            m = len(part)
+            widths, srcs, dsts = (C.c_int64 * m)(), (C.c_void_p * m)(), (C.c_void_p * m)()
+            for e, (src, dst) in enumerate(part):
+                if src.shape != dst.shape or not src.is_contiguous() or not dst.is_contiguous():
+                    raise ValueError("src and dst must be contiguous and of the same shape")
+                widths[e] = src.numel() // n
+                srcs[e], dsts[e] = self._p(src.view(n, -1)), self._p(dst.view(n, -1))
+            check(lib.omc_chain_select_multi(self._ctx, self._i32(accept), m, widths, srcs, dsts))
 
     def ragged_resize(self, src, count, birth, del_index, axis, new_vals=None, physical_transposed=False):
         """np.concatenate / np.delete along the ragged axis of a (C, p, n_rep) tensor for every chain.
@@ -820,6 +859,19 @@ class Engine:
         check(lib.omc_mixture_gather(self._ctx, kmax, m, self._p(param), m if per_chain else 0, self._p(alloc),
                                      self._chain_scalar(count), float(fill), self._p(out)))
         return out
+
+    def mixture_gather2(self, alloc, count, param_a, fill_a, param_b, fill_b):
+        """(param_a[alloc], param_b[alloc]) with the fills beyond each chain's live length, in one launch; both tables
+        (m,) shared or (C, m) per chain, of one length m."""
+        Cn, kmax = alloc.shape
+        out_a, out_b = self.empty(Cn, kmax), self.empty(Cn, kmax)
+        m = param_a.shape[-1]
+        if param_b.shape[-1] != m:
+            raise ValueError("the two tables must have one length")
+        check(lib.omc_mixture_gather2(self._ctx, kmax, m, self._p(alloc), self._chain_scalar(count), self._p(param_a),
+                                      m if param_a.dim() == 2 else 0, float(fill_a), self._p(out_a), self._p(param_b),
+                                      m if param_b.dim() == 2 else 0, float(fill_b), self._p(out_b)))
+        return out_a, out_b
 
     def mixture_allocation(self, y, prior, mean, prec, u=None, draw_index=0):
         """MixtureAllocation.sample: y (C, p), prior (1 or p, K) shared, mean / prec (K,) shared or (C, K) -> alloc (C, p)."""

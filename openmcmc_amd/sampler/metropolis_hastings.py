@@ -136,14 +136,16 @@ class MetropolisHastings(MCMCSampler):
                             log_alpha=log_alpha)
         if trace is not None:
             trace.update(log_alpha=log_alpha, accept=acc, lp_cur=lp_cur.clone(), lp_prop=lp_prop)
+        pairs = []
         for key, value in prop_state.items():
             cur = current_state.get(key)
             if value is cur or not is_chain(value):
                 continue
             if not is_chain(cur) or cur.data.shape != value.data.shape:
                 raise NotImplementedError(f"proposed state entry '{key}' changes kind or padded shape")
-            eng.chain_select(acc, value.storage(), cur.storage())
-        eng.chain_select(acc, lp_prop, lp_cur)
+            pairs.append((value.storage(), cur.storage()))
+        pairs.append((lp_prop, lp_cur))
+        eng.chain_select_many(acc, pairs)  # every changed entry and the log-density in one launch
         self._lp_state = lp_cur
         return current_state
 

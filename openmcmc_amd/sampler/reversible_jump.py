@@ -62,8 +62,6 @@ class ReversibleJump(MetropolisHastings):
 
     # ------------------------------------------------------------------ proposal
     def proposal(self, current_state: dict, param_index: int = None):
-        import torch
-
         eng = self._need_engine()
         n_cur = current_state[self.param]
         if not is_chain(n_cur) or n_cur.size != 1:
@@ -71,28 +69,36 @@ class ReversibleJump(MetropolisHastings):
         count = n_cur.scalar()
         di, t = self._draw_index(), self._sweep
         u_move, idx = self.inject_move(self, t) if self.inject_move is not None else (None, None)
-        birth, p_birth, p_death, del_index = eng.rj_move(count.to(torch.int64), int(self.n_max),
-                                                         float(self.birth_probability), u=u_move, idx=idx, draw_index=di)
-        is_birth = birth.to(torch.bool)
-        prop_state = dict(current_state)
-        prop_state[self.param] = ChainArray((count + torch.where(is_birth, 1.0, -1.0)).reshape(-1, 1, 1))
-        prop_state["__rj_move__"] = {"birth": birth, "deletion_index": del_index}
-        log_prop_density = 0.0
-        inj_assoc = self.inject_associated(self, t) if self.inject_associated is not None else {}
-        for j, key in enumerate(self.associated_params):
+        # log_p(current_state, by_observation=True)[-1] of every associated parameter (:132, :143): the density of the
+        # LAST element of the CURRENT value -- a constant for a Uniform prior, a per-chain number for a Gamma one
+        dens_const, dens_chain = 0.0, None
+        for key in self.associated_params:
             dist, cur = self.model[key], current_state[key]
             if not is_chain(cur) or cur.ragged is None or cur.ragged[0] != self.param:
                 raise NotImplementedError(f"associated parameter '{key}' must be a ragged ChainArray counted by '{self.param}'")
             if not isinstance(dist, (Uniform, Gamma)):
                 raise NotImplementedError("associated parameters need a Uniform or Gamma prior")
+            d = dist.log_p_last(current_state, eng)
+            if hasattr(d, "data_ptr"):
+                dens_chain = d if dens_chain is None else dens_chain + d
+            else:
+                dens_const += float(d)
+        # move type, deletion index, proposed count and the move's part of the two proposal densities
+        # (reversible_jump.py:142-144 for a birth, 189-191 for a death) in one launch; the callbacks' and the matched
+        # transition's contributions are added to lq_f / lq_r below
+        birth, del_index, count_prop, lq_f, lq_r = eng.rj_move_densities(
+            count, int(self.n_max), float(self.birth_probability), density_chain=dens_chain, density_const=dens_const,
+            u=u_move, idx=idx, draw_index=di)
+        prop_state = dict(current_state)
+        prop_state[self.param] = ChainArray(count_prop.reshape(-1, 1, 1))
+        prop_state["__rj_move__"] = {"birth": birth, "deletion_index": del_index}
+        inj_assoc = self.inject_associated(self, t) if self.inject_associated is not None else {}
+        for j, key in enumerate(self.associated_params):
+            dist, cur = self.model[key], current_state[key]
             new = dist.rvs(current_state, n=1, engine=eng, draw_index=di, sub=_SUB_ASSOCIATED + 2 * j,
                            inject=inj_assoc.get(key))  # reversible_jump.py:130
             prop_state[key] = cur.like(eng.ragged_resize(cur.data, count, birth, del_index, axis=cur.ragged[1],
                                                          new_vals=new.data.reshape(eng.n_chains, -1)))
-            # log_p(current_state, by_observation=True)[-1] (:132, :143): the density of the LAST element of the
-            # CURRENT value -- a constant for a Uniform prior, a per-chain number for a Gamma one
-            log_prop_density = log_prop_density + dist.log_p_last(current_state, eng)
-        lq_f, lq_r = eng.zeros(eng.n_chains), eng.zeros(eng.n_chains)
         if callable(self.state_birth_function):
             prop_state, f_extra, r_extra = self.state_birth_function(current_state, prop_state)
             lq_f, lq_r = _add_contribution(eng, lq_f, f_extra), _add_contribution(eng, lq_r, r_extra)
@@ -101,10 +107,6 @@ class ReversibleJump(MetropolisHastings):
             lq_f, lq_r = _add_contribution(eng, lq_f, f_extra), _add_contribution(eng, lq_r, r_extra)
         if self.matching_params is not None:
             prop_state = self._matched_transition(current_state, prop_state, count, birth, del_index, lq_f, lq_r)
-        # reversible_jump.py:142-144 (birth) and 189-191 (death)
-        lpb, lpd = torch.log(p_birth), torch.log(p_death)
-        lq_f += torch.where(is_birth, lpb + log_prop_density, lpd)
-        lq_r += torch.where(is_birth, lpd, lpb + log_prop_density)
         del prop_state["__rj_move__"]
         if self.trace is not None:
             self.trace.update(birth=birth, deletion_index=del_index, lq_fwd=lq_f.clone(), lq_rev=lq_r.clone(),

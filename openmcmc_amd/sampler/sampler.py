@@ -95,10 +95,7 @@ class MCMCSampler(ABC):
         if value.ragged is None:
             slab.copy_(flat)
         else:  # live entries, NaN beyond (the reference leaves its NaN fill there, sampler.py:116)
-            import torch
-
-            live = torch.arange(flat.shape[1], device=flat.device).unsqueeze(0) < value.count(current_state).unsqueeze(1)
-            slab[:, : flat.shape[1]] = torch.where(live, flat, torch.full_like(flat, float("nan")))
+            self.engine.store_ragged(flat if flat.stride(1) == 1 else flat.contiguous(), value.count(current_state), slab)
         return store
 
 
