@@ -304,21 +304,31 @@ __global__ void __launch_bounds__(256) k_design_resid_sq(int64_t n, int64_t kmax
 __global__ void k_gaussian_basis(int64_t C, int64_t n, int64_t kmax, const double* X, const double* knots,
                                  const double* scales, double scale0, const double* count, const double* prev_count,
                                  int64_t column, double* B) {
-  const int64_t c = blockIdx.z;
-  const int64_t j = column >= 0 ? column : (int64_t)blockIdx.y;
-  const bool live = !count || (double)j < count[c];
-  // prev_count: the buffer already holds zeros in every column >= prev_count[c] -- a dead column beyond that is left alone
-  if (!live && prev_count && !((double)j < prev_count[c])) return;
-  const double th = knots[c * kmax + j];
-  const double sc = scales ? scales[c * kmax + j] : scale0;
-  double* out = B + (c * kmax + j) * n;
+  // one workgroup = a block of rows of one chain, all its columns in turn (a grid over the columns would be mostly
+  // workgroups with nothing to do: a quarter of the k_max columns are live at BASELINE configs[4])
+  const int64_t c = blockIdx.y;
+  const int64_t k_live = count ? (int64_t)count[c] : kmax;
+  // prev_count: the buffer already holds zeros in every column >= prev_count[c] -- dead columns beyond that are left alone
+  int64_t j_hi = kmax;
+  if (prev_count) {
+    const int64_t kp = (int64_t)prev_count[c];
+    j_hi = k_live > kp ? k_live : kp;
+    if (j_hi > kmax) j_hi = kmax;
+  }
+  const int64_t j_lo = column >= 0 ? column : 0;
+  if (column >= 0) j_hi = column + 1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double v = 0.0;
-    if (live) {
-      const double t = (X[i] - th) / sc;
-      v = exp(-(t * t) / 2.0) / 2.5066282746310002 / sc;  // scipy norm.pdf: exp(-x^2/2)/sqrt(2 pi), then / scale
+    const double x = X[i];
+    for (int64_t j = j_lo; j < j_hi; ++j) {
+      double v = 0.0;
+      if (j < k_live) {
+        const double th = knots[c * kmax + j];
+        const double sc = scales ? scales[c * kmax + j] : scale0;
+        const double t = (x - th) / sc;
+        v = exp(-(t * t) / 2.0) / 2.5066282746310002 / sc;  // scipy norm.pdf: exp(-x^2/2)/sqrt(2 pi), then / scale
+      }
+      B[(c * kmax + j) * n + i] = v;
     }
-    out[i] = v;
   }
 }
 
@@ -782,8 +792,9 @@ omc_status omc_chain_select_multi(omc_ctx* ctx, const int32_t* accept, int32_t n
     if (on && widths[e] > wmax) wmax = widths[e];
   }
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  unsigned gx = grid1(wmax, 256);
-  if (gx > 64) gx = 64;
+  // few workgroups per (chain, entry): most chains reject and their workgroups only cost their dispatch
+  unsigned gx = grid1(wmax, 256 * 16);
+  if (gx > 16) gx = 16;
   hipLaunchKernelGGL(k_chain_select_multi, dim3(gx, (unsigned)ctx->n_chains, (unsigned)n_items), dim3(256), 0, ctx->stream,
                      ctx->n_chains, (const int*)accept, it);
   OMC_HIP_CHECK(hipGetLastError());
@@ -814,8 +825,8 @@ omc_status omc_gaussian_basis(omc_ctx* ctx, int64_t n, int64_t kmax, const doubl
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   unsigned gx = grid1(n, 256);
   if (gx > 32) gx = 32;
-  hipLaunchKernelGGL(k_gaussian_basis, dim3(gx, column >= 0 ? 1u : (unsigned)kmax, (unsigned)ctx->n_chains), dim3(256), 0,
-                     ctx->stream, ctx->n_chains, n, kmax, X, knots, scales, scale0, count, prev_count, column, B);
+  hipLaunchKernelGGL(k_gaussian_basis, dim3(gx, (unsigned)ctx->n_chains), dim3(256), 0, ctx->stream, ctx->n_chains, n, kmax,
+                     X, knots, scales, scale0, count, prev_count, column, B);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }
