@@ -216,7 +216,10 @@ def _scaled(engine, chain_scale, alpha):
     """(C,) tensor alpha * chain_scale (chain_scale None = ones)."""
     if chain_scale is None:
         return engine.full((engine.n_chains,), alpha)
-    return chain_scale if alpha == 1.0 else chain_scale * alpha
+    if alpha == 1.0:
+        return chain_scale
+    cs = chain_scale.reshape(-1, 1)  # the library's own a x + b y on the (C, 1) column: alpha * s + 0 * s
+    return engine.chain_lincomb(alpha, cs, 0.0, cs).reshape(-1)
 
 
 @dataclass

@@ -158,6 +158,14 @@ def _as_chain_tensor(engine, value):
     return None if v == 0.0 else engine.full((engine.n_chains,), v)
 
 
+def _lin(engine, a, x, b, y):
+    """a x + b y per chain by the library's own kernel (omc_chain_lincomb); x, y: (C, n) or (C,) tensors.  With a, b in
+    {+-1, +-0.5} both products are exact, so this is the one-rounding sum an element-wise a*x + b*y gives."""
+    if x.dim() == 1:
+        return engine.chain_lincomb(a, x.reshape(-1, 1), b, y.reshape(-1, 1)).reshape(-1)
+    return engine.chain_lincomb(a, x if x.stride(1) == 1 else x.contiguous(), b, y if y.stride(1) == 1 else y.contiguous())
+
+
 def _add_contribution(engine, total, extra):
     """total (a (C,) tensor) += extra (float or (C,) tensor)."""
     if hasattr(extra, "data_ptr"):
@@ -440,16 +448,16 @@ class ManifoldMALA(MetropolisHastings):
 
         z = self.inject(self, self._sweep) if self.inject is not None else None
         xp, mu, logdet = eng.empty(Cn, p), eng.empty(Cn, p), eng.empty(Cn)
-        eng.dense_sample_canonical(p, T, xp, z=z, rhs_chain=lam_times(xv) + 0.5 * grad, draw_index=self._draw_index(),
+        eng.dense_sample_canonical(p, T, xp, z=z, rhs_chain=_lin(eng, 1.0, lam_times(xv), 0.5, grad), draw_index=self._draw_index(),
                                    mean_out=mu, logdet_out=logdet, diag_chain=dscaled)
-        lq_f = 0.5 * logdet - 0.5 * lam_quad(xp - mu)
+        lq_f = _lin(eng, 0.5, logdet, -0.5, lam_quad(_lin(eng, 1.0, xp, -1.0, mu)))
         prop_state = dict(current_state)
         prop_state[self.param] = x.like(xp.unsqueeze(2))
         grad_p, _, _ = self.model.grad_terms(prop_state, self.param, eng)   # the Hessian does not depend on the parameter
         mu_p, scratch = eng.empty(Cn, p), eng.empty(Cn, p)
-        eng.dense_sample_canonical(p, T, scratch, z=eng.zeros(Cn, p), rhs_chain=lam_times(xp) + 0.5 * grad_p,
+        eng.dense_sample_canonical(p, T, scratch, z=eng.zeros(Cn, p), rhs_chain=_lin(eng, 1.0, lam_times(xp), 0.5, grad_p),
                                    mean_out=mu_p, diag_chain=dscaled)
-        lq_r = 0.5 * logdet - 0.5 * lam_quad(xv - mu_p)
+        lq_r = _lin(eng, 0.5, logdet, -0.5, lam_quad(_lin(eng, 1.0, xv, -1.0, mu_p)))
         u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
         return self._accept_reject_proposal(current_state, prop_state, lq_f, lq_r, u=u, sub=(p + 1) // 2 + 1)
 
@@ -502,18 +510,18 @@ class ManifoldMALA(MetropolisHastings):
         Lx, _, logdet_f = eng.small_spd_ops(Lam, xv, want_Av=True, want_logdet=True)
         z = self.inject(self, self._sweep) if self.inject is not None else None
         mu_f = eng.empty(Cn, d)
-        xp = eng.small_sample_canonical(Lam, Lx + 0.5 * grad, zero, z=z, draw_index=self._draw_index(), mean_out=mu_f)
-        _, quad_f, _ = eng.small_spd_ops(Lam, (xp - mu_f).contiguous(), want_quad=True)
-        lq_f = 0.5 * logdet_f - 0.5 * quad_f
+        xp = eng.small_sample_canonical(Lam, _lin(eng, 1.0, Lx, 0.5, grad), zero, z=z, draw_index=self._draw_index(), mean_out=mu_f)
+        _, quad_f, _ = eng.small_spd_ops(Lam, _lin(eng, 1.0, xp, -1.0, mu_f), want_quad=True)
+        lq_f = _lin(eng, 0.5, logdet_f, -0.5, quad_f)
         prop_state = dict(current_state)
         prop_state[self.param] = x.like(xp.unsqueeze(2))
         grad_p, H_p = self._grad_hess_per_chain(prop_state)
         Lam_p = H_p / s2
         Lxp, _, logdet_r = eng.small_spd_ops(Lam_p, xp, want_Av=True, want_logdet=True)
         mu_r = eng.empty(Cn, d)
-        eng.small_sample_canonical(Lam_p, Lxp + 0.5 * grad_p, zero, z=zero, mean_out=mu_r)
-        _, quad_r, _ = eng.small_spd_ops(Lam_p, (xv - mu_r).contiguous(), want_quad=True)
-        lq_r = 0.5 * logdet_r - 0.5 * quad_r
+        eng.small_sample_canonical(Lam_p, _lin(eng, 1.0, Lxp, 0.5, grad_p), zero, z=zero, mean_out=mu_r)
+        _, quad_r, _ = eng.small_spd_ops(Lam_p, _lin(eng, 1.0, xv, -1.0, mu_r), want_quad=True)
+        lq_r = _lin(eng, 0.5, logdet_r, -0.5, quad_r)
         if self.trace is not None:
             self.trace.setdefault("steps", []).append({"prop": xp.clone(), "lq_fwd": lq_f.clone(), "lq_rev": lq_r.clone()})
         u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None

@@ -371,7 +371,7 @@ class NormalNormal(MCMCSampler):
         for dist, scale_key in p.get("offsets", ()):  # b_c -= tau_c * d_c  (sampler.py:190-192)
             scale = current_state[scale_key].scalar() if scale_key is not None else None
             t = dist.mean.predictor_device(current_state, eng, exclude=self.param, alpha=-1.0, chain_scale=scale)
-            rhs_chain = t if rhs_chain is None else rhs_chain + t
+            rhs_chain = t if rhs_chain is None else eng.chain_lincomb(1.0, rhs_chain, 1.0, t)
         for (kind, what), scale_key, cache in p.get("chain_rhs", ()):  # per-chain prior mean / per-chain response
             v = what.mean.predictor_device(current_state, eng) if kind == "mean" and not isinstance(what.mean, Identity) else \
                 current_state[what.mean.form if kind == "mean" else what].vector()
@@ -491,7 +491,7 @@ class NormalGamma(MCMCSampler):
         if key not in consts:
             consts[key] = (eng.to_device(a0), eng.to_device(b0))
         g = self.inject(self, self._sweep) if self.inject is not None else None
-        out = eng.mixture_normal_gamma(x - pmean, alloc, consts[key][0], consts[key][1], g=g, draw_index=self._draw_index())
+        out = eng.mixture_normal_gamma(eng.chain_lincomb(1.0, x, -1.0, pmean), alloc, consts[key][0], consts[key][1], g=g, draw_index=self._draw_index())
         state[self.param] = ChainArray(out.unsqueeze(2))
         self._sweep += 1
         return state
