@@ -254,6 +254,18 @@ omc_status omc_mala_step(omc_ctx* ctx, int64_t d, const double* Q, const double*
                          const double* sumlogL, double step, const double* z_inject, int64_t ld_z,
                          const double* u_inject, uint64_t draw_index, double* x, int64_t ld_x,
                          int64_t* accept_count, int64_t* proposal_count);
+/* The same step when L = chol(Q / step^2) (what ManifoldMALA factorises for a Gaussian target: H = Q), in whitened
+ * coordinates a = L'(x - mu): the drift -(L L')^{-1} Q is then -step^2 I, so
+ *   a' = (1 - step^2/2) a + z;  |L'(x-mu)|^2 = |a|^2, |L'(x'-mu)|^2 = |a'|^2, |L'(x'-m)|^2 = |z|^2,
+ *   |L'(x-m')|^2 = |a - (1 - step^2/2) a'|^2  -- every term of log alpha (metropolis_hastings.py:155, 350-373) element-wise,
+ * and only accepted proposals are mapped back, x = mu + L^{-T} a' (one triangular product; rejected chains keep their x
+ * bit for bit).  Same draws and decision rule as omc_mala_step; results agree to the rounding of the two evaluation
+ * orders.  The context keeps a for the state at x: state_is_current != 0 promises that x has not been written by anyone
+ * else since this function last returned for the same x (otherwise a = L'(x - mu) is recomputed: one more product).
+ * L and mu must stay unchanged while in use (omc_mh_invalidate drops what was derived from them).                */
+omc_status omc_mala_step_white(omc_ctx* ctx, int64_t d, const double* mu, const double* L, const double* sumlogL, double step,
+                               const double* z_inject, int64_t ld_z, const double* u_inject, uint64_t draw_index, double* x,
+                               int64_t ld_x, int32_t state_is_current, int64_t* accept_count, int64_t* proposal_count);
 omc_status omc_rw_step(omc_ctx* ctx, int64_t d, const double* mu, const double* LQ, const double* sumlogLQ,
                        double step, const double* z_inject, int64_t ld_z, const double* u_inject,
                        uint64_t draw_index, double* x, int64_t ld_x, int64_t* accept_count,

@@ -30,6 +30,8 @@ struct omc_ctx {
   double* mh_work; size_t mh_work_bytes;  // omc_mala.hip
   double* mala_prep; size_t mala_prep_bytes;  // cached drift matrix and L^{-T} of the current (Q, L, step)
   const double* mala_Q; const double* mala_L; double mala_step; int64_t mala_d;
+  double* white_prep; size_t white_prep_bytes; const double* white_L; const double* white_mu; int64_t white_d;  // omc_mala_step_white
+  double* white_a; size_t white_a_bytes; const double* white_x; int64_t white_ld;  // a = L'(x - mu) of the state at white_x
   double* rw_prep; size_t rw_prep_bytes; const double* rw_LQ; int64_t rw_d;  // omc_rw_step: LQ with a zero upper triangle
   int tridiag_algo;  // 0 auto, 1 serial, 2 segmented
   int tridiag_seg;   // 0 auto, else nodes per lane
@@ -51,7 +53,7 @@ void omc_dense_release(omc_ctx* ctx);
 // omc_gemm.hip: small-state fp64 MFMA GEMM, C = A0 B0 (+ A1 B1) (+ addv per column), column-major
 omc_status omc_dgemm_small(omc_ctx* ctx, int M, int N, const double* A0, int64_t lda0, const double* B0, int64_t ldb0, int K0,
                            const double* A1, int64_t lda1, const double* B1, int64_t ldb1, int K1, int tri, const double* addv,
-                           double* Cout, int64_t ldc);
+                           double* Cout, int64_t ldc, const int* colmask = nullptr);
 omc_status omc_ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need);  // grow-on-demand workspace (omc_dense.hip)
 extern "C" omc_status omc_gram_mfma_launch(omc_ctx* ctx, int64_t n, int64_t p, const double* X, const double* w, double* G_out);  // omc_gram.hip  // destroys the rocBLAS handle if one was created
 

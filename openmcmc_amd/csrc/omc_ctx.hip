@@ -41,6 +41,8 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->dense_tmp = nullptr; c->dense_tmp_bytes = 0;
   c->rj_tmp = nullptr; c->rj_tmp_bytes = 0;
   c->mh_work = nullptr; c->mh_work_bytes = 0;
+  c->white_prep = nullptr; c->white_prep_bytes = 0; c->white_L = nullptr; c->white_mu = nullptr; c->white_d = 0;
+  c->white_a = nullptr; c->white_a_bytes = 0; c->white_x = nullptr; c->white_ld = 0;
   c->rw_prep = nullptr; c->rw_prep_bytes = 0; c->rw_LQ = nullptr; c->rw_d = 0;
   c->mala_prep = nullptr; c->mala_prep_bytes = 0; c->mala_Q = nullptr; c->mala_L = nullptr; c->mala_step = 0.0; c->mala_d = 0;
   c->tridiag_algo = 0;
@@ -84,6 +86,8 @@ omc_status omc_ctx_destroy(omc_ctx* ctx) {
   if (ctx->rj_tmp) hipFree(ctx->rj_tmp);
   if (ctx->mh_work) hipFree(ctx->mh_work);
   if (ctx->mala_prep) hipFree(ctx->mala_prep);
+  if (ctx->white_prep) hipFree(ctx->white_prep);
+  if (ctx->white_a) hipFree(ctx->white_a);
   if (ctx->rw_prep) hipFree(ctx->rw_prep);
   omc_dense_release(ctx);
   hipFree(ctx->d_bad_chain);

@@ -37,7 +37,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 // section 5.3); KS = 4 puts four times as many loads on the wire without more workgroups or a second kernel.
 template <bool VEC, int KS>
 __global__ void __launch_bounds__(256 * KS) k_dgemm_64x16(int M, int N, GemmPair p0, GemmPair p1, int tri, const double* __restrict__ addv,
-                                                          double* __restrict__ Cout, int64_t ldc) {
+                                                          double* __restrict__ Cout, int64_t ldc, const int* __restrict__ colmask) {
   __shared__ double As_all[KS][GM_BK][GM_LDA];
   __shared__ double Bs_all[KS][GM_TN][GM_LDB];
   const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
@@ -140,20 +140,21 @@ __global__ void __launch_bounds__(256 * KS) k_dgemm_64x16(int M, int N, GemmPair
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = i0 + wave * 16 + (lane >> 4) + 4 * r;
-    if (i < M && j < N) Cout[(int64_t)j * ldc + i] = v[r] + (addv ? addv[i] : 0.0);
+    if (i < M && j < N && (!colmask || colmask[j])) Cout[(int64_t)j * ldc + i] = v[r] + (addv ? addv[i] : 0.0);
   }
 }
 
-// C[M x N] = A0[M x K0] B0[K0 x N] (+ A1 B1) (+ addv per column); everything column-major, device pointers
+// C[M x N] = A0[M x K0] B0[K0 x N] (+ A1 B1) (+ addv per column); everything column-major, device pointers;
+// colmask (N ints or NULL): only the columns with a non-zero entry are written
 omc_status omc_dgemm_small(omc_ctx* ctx, int M, int N, const double* A0, int64_t lda0, const double* B0, int64_t ldb0, int K0,
                            const double* A1, int64_t lda1, const double* B1, int64_t ldb1, int K1, int tri, const double* addv,
-                           double* Cout, int64_t ldc) {
+                           double* Cout, int64_t ldc, const int* colmask) {
   GemmPair p0{A0, lda0, B0, ldb0, K0}, p1{A1, lda1, B1, ldb1, A1 ? K1 : 0};
   const dim3 grid((unsigned)((M + GM_TM - 1) / GM_TM), (unsigned)((N + GM_TN - 1) / GM_TN));
   auto even16 = [](const double* p, int64_t ld, int K) { return !p || (((uintptr_t)p & 15u) == 0 && (ld & 1) == 0 && (K & 1) == 0); };
   const bool vec = (M & 1) == 0 && even16(A0, lda0, K0) && even16(B0, ldb0, K0) && even16(A1, lda1, K1) && even16(B1, ldb1, K1);
   const int ks = ctx->mh_gemm_ksplit;
-#define OMC_GEMM_LAUNCH(V, K) hipLaunchKernelGGL((k_dgemm_64x16<V, K>), grid, dim3(256 * K), 0, ctx->stream, M, N, p0, p1, tri, addv, Cout, ldc)
+#define OMC_GEMM_LAUNCH(V, K) hipLaunchKernelGGL((k_dgemm_64x16<V, K>), grid, dim3(256 * K), 0, ctx->stream, M, N, p0, p1, tri, addv, Cout, ldc, colmask)
   if (vec) {
     if (ks >= 4) OMC_GEMM_LAUNCH(true, 4); else if (ks == 2) OMC_GEMM_LAUNCH(true, 2); else OMC_GEMM_LAUNCH(true, 1);
   } else {

@@ -389,7 +389,11 @@ class RandomWalkLoop(RandomWalk):
 
 @dataclass
 class ManifoldMALA(MetropolisHastings):
-    """Manifold MALA (Girolami & Calderhead 2011; metropolis_hastings.py:292-373)."""
+    """Manifold MALA (Girolami & Calderhead 2011; metropolis_hastings.py:292-373).  `whitened` (default True): the fused
+    route for a Gaussian target runs in the coordinates a = L'(x - mu), where the step is element-wise
+    (omc_mala_step_white); False keeps it on the products of omc_mala_step."""
+
+    whitened: bool = True
 
     def _diag_step(self, current_state: dict) -> dict:
         """Generic route when the Hessian is diagonal per chain (e.g. the mixture-Normal prior of a variable-size
@@ -546,7 +550,18 @@ class ManifoldMALA(MetropolisHastings):
         L, sl = self._factor_plan(eng, current_state, Q, 1.0 / step**2)  # chol(H/step^2), H = Q (metropolis_hastings.py:345-346)
         z = self.inject(self, self._sweep) if self.inject is not None else None
         u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
-        eng.mala_step(Q, mu, L, sl, step, self._x(current_state), z=z, u=u, draw_index=self._draw_index(),
-                      accept_count=self.accept_rate.accept, proposal_count=self.accept_rate.proposal)
+        x = self._x(current_state)
+        if self.whitened:
+            # L = chol(Q / step^2): the step is element-wise in a = L'(x - mu) (omc_mala_step_white).  The library keeps a
+            # for the x it wrote last; it may be reused if nobody else has written x since (torch's version counter sees
+            # every write but the library's own).
+            tag = (x.data_ptr(), x._version, L.data_ptr())
+            eng.mala_step_white(mu, L, sl, step, x, state_is_current=getattr(self, "_white_tag", None) == tag, z=z, u=u,
+                                draw_index=self._draw_index(), accept_count=self.accept_rate.accept,
+                                proposal_count=self.accept_rate.proposal)
+            self._white_tag = tag
+        else:
+            eng.mala_step(Q, mu, L, sl, step, x, z=z, u=u, draw_index=self._draw_index(),
+                          accept_count=self.accept_rate.accept, proposal_count=self.accept_rate.proposal)
         self._sweep += 1
         return current_state

@@ -218,3 +218,84 @@ def test_manifold_mala_with_finite_difference_hessian_replays_reference(golden):
     for c in range(C):
         assert np.array_equal(flags[:, c], G["accept"])
     eng.close()
+
+
+@pytest.mark.parametrize("d", [1, 5, 32])
+@pytest.mark.parametrize("reuse", [False, True])
+def test_whitened_mala_step_replays_reference(golden, d, reuse):
+    """omc_mala_step_white (the step in a = L'(x - mu), one triangular product per step) on the reference's trace
+    (tests/golden/mala.npz): accept flags identical, states to 1e-9 -- with the whitened state carried from step to step
+    and with it recomputed from x every step."""
+    import torch
+
+    G = golden("mala")
+    k = f"d{d}_"
+    C = 3
+    eng = make_engine(C)
+    Q = eng.to_device(G[k + "Q"])
+    step = float(G[k + "mala_step"])
+    x = eng.to_device(np.tile(G[k + "x0"], (C, 1)))
+    acc = torch.zeros(C, dtype=torch.int64, device="cuda")
+    prop = torch.zeros(C, dtype=torch.int64, device="cuda")
+    L, sl = eng.dense_cholesky(Q, 1.0 / step**2)
+    zs, us = G[k + "mala_z"], G[k + "mala_u"]
+    flags = []
+    for i in range(zs.shape[0]):
+        before = acc.clone()
+        z = eng.to_device(np.tile(zs[i], (C, 1)))
+        u = eng.full((C,), us[i])
+        eng.mala_step_white(None, L, sl, step, x, state_is_current=reuse and i > 0, z=z, u=u, accept_count=acc,
+                            proposal_count=prop)
+        flags.append((acc - before).cpu().numpy())
+        assert relerr(x[2].cpu().numpy(), G[k + "mala_x"][i]) < 1e-9, i
+    eng.check_status()
+    flags = np.array(flags)
+    for c in range(C):
+        assert np.array_equal(flags[:, c], G[k + "mala_accept"])
+    eng.close()
+
+
+@pytest.mark.parametrize("d,C", [(137, 70), (500, 33), (64, 16)])
+def test_whitened_mala_step_matches_the_products_route(d, C):
+    """Same target (non-zero mean), same injected draws: omc_mala_step_white against omc_mala_step -- decisions identical,
+    states equal to rounding; rejected chains keep their x bit for bit; an x written by someone else between two steps is
+    picked up when the caller says so."""
+    import torch
+
+    rng = np.random.default_rng(d * 7 + C)
+    A = rng.standard_normal((d, 2 * d))
+    Qh = np.linalg.inv(A @ A.T / (2 * d))
+    Qh = (Qh + Qh.T) / 2
+    mu = rng.standard_normal(d)
+    x0 = mu + np.linalg.solve(np.linalg.cholesky(Qh).T, rng.standard_normal((d, C))).T
+    step = 0.5
+    zs, us = rng.standard_normal((8, C, d)), rng.random((8, C))
+    x_mid = mu + np.linalg.solve(np.linalg.cholesky(Qh).T, rng.standard_normal((d, C))).T  # written "by another sampler"
+    out = {}
+    for white in (0, 1):
+        eng = make_engine(C)
+        Q, dmu = eng.to_device(Qh), eng.to_device(mu)
+        L, sl = eng.dense_cholesky(Q, 1.0 / step**2)
+        x = eng.to_device(x0)
+        acc = torch.zeros(C, dtype=torch.int64, device="cuda")
+        prop = torch.zeros(C, dtype=torch.int64, device="cuda")
+        kept = True
+        for i in range(8):
+            if i == 5:
+                x.copy_(eng.to_device(x_mid))
+            z, u = eng.to_device(zs[i]), eng.to_device(us[i])
+            before, xb = acc.clone(), x.clone()
+            if white:
+                eng.mala_step_white(dmu, L, sl, step, x, state_is_current=i not in (0, 5), z=z, u=u, accept_count=acc,
+                                    proposal_count=prop)
+            else:
+                eng.mala_step(Q, dmu, L, sl, step, x, z=z, u=u, accept_count=acc, proposal_count=prop)
+            rejected = (acc - before) == 0
+            kept = kept and bool(torch.equal(x[rejected], xb[rejected]))
+        eng.check_status()
+        out[white] = (x.cpu().numpy(), acc.cpu().numpy(), kept)
+        eng.close()
+    assert out[0][2] and out[1][2]
+    assert np.array_equal(out[0][1], out[1][1])
+    assert relerr(out[0][0], out[1][0]) < 1e-10
+    assert 0 < out[1][1].sum() < 8 * C
