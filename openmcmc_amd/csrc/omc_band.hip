@@ -270,8 +270,9 @@ template <int W>
 __global__ void __launch_bounds__(64) k_band_lane(int64_t C, int64_t chain_offset, int64_t n, BandLaneArgs P,
                                                   const double* z_in, int64_t ld_z, omc_rng_key key, double* Lws,
                                                   double* x, int64_t ld_x, double* mean, int64_t ld_mean, double* logdet,
-                                                  long long* bad) {
+                                                  long long* bad, const int* group_flag) {
   constexpr int W1 = W + 1;
+  if (group_flag && !group_flag[blockIdx.x]) return;  // fallback use: only the groups the segmented route gave up on
   __shared__ double tile_x[64][65];
   __shared__ double tile_m[64][65];
   const int lane = threadIdx.x;
@@ -440,6 +441,416 @@ __global__ void __launch_bounds__(64) k_band_lane(int64_t C, int64_t chain_offse
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same lane-per-chain factorisation with the n columns of a chain cut into SEGMENTS, one wave per (64 chains,
+// segment), each wave its own workgroup so that the segments of a chain group spread over the CUs: k_band_lane is one
+// dependent chain of 2 n steps per lane with nothing to overlap it -- 12.6 ms for n = 10 000 whatever the number of
+// chains.  (Sixteen segment waves inside ONE workgroup were tried first: they share a CU, and at ~100 instructions a
+// step the four waves of a SIMD take 0.7 us per step between them -- 3 ms.)  What lets a segment start without its
+// predecessors:
+//   * pivots (nonlinear): the window of partially eliminated columns forgets its starting value geometrically (the
+//     decay of the precision's Green's function), so a segment starts `ov` columns early from the raw matrix entries and
+//     throws the warm-up away.  That this was enough is CHECKED: the window a segment ends with must agree with the one
+//     its successor started from to `tol` relative to the pivot; if any join of any of a group's 64 chains fails (a very
+//     weak likelihood: long memory) the group is redone in one piece by k_band_lane.  No silent loss of accuracy.
+//   * forward and backward substitution (linear): exact.  A segment is run from a zero incoming state together with W
+//     unit incoming states (its affine map: W x W matrix + W vector); the maps of the segments are composed in order
+//     (at most 64 small products, redone by every wave that needs them) and the segment's true solution follows from its
+//     true incoming state.
+// Three launches, the launch boundaries being the only synchronisation:
+//   PHASE 0  factor + forward map:  L, the zero-state u and its W unit responses, join windows, log-det parts
+//   PHASE 1  joins checked, incoming forward state composed, backward map of the segment (draws made, nothing stored)
+//   PHASE 2  incoming backward state composed, the segment's x (draws made again) and mean stored as [column][chain]
+// then a transpose into the caller's chain-major arrays.  No loop both loads and stores what it waits for: on this
+// hardware a load returns behind every older store (one in-order counter), which made a combined loop pay a store
+// acknowledgement per step.  Natural-order Cholesky throughout: the factor, u = L^-1 b and x = L^-T (u + z) are
+// k_band_lane's to rounding (the updates of a column are added in another order).
+#define BSEG_MAX 64
+template <int W, int PHASE>
+__global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset, int64_t n, BandLaneArgs P, int nseg,
+                                                 int64_t mseg, int ov, double tol, const double* z_in, int64_t ld_z,
+                                                 omc_rng_key key, double* Lws, double* Xws, double* Mws, double* scratch,
+                                                 int* group_flag, double* logdet, long long* bad,
+                                                 unsigned long long* n_fallback) {
+  constexpr int W1 = W + 1;
+  constexpr int NJ = W * (W + 1) / 2;  // window entries that carry eliminated columns' updates: A[b][d] with b + d < W
+  constexpr int NF = W * W + W;        // forward map: G (W x W) and g (W)
+  constexpr int NB = W * W + 2 * W;    // backward map: H, h (draw) and hm (mean)
+  constexpr int NS = 2 * NJ + NF + NB + 2;  // per (group, segment): start window, end window, G/g, H/h/hm, log-det part, fail
+  constexpr int O_JS = 0, O_JE = NJ, O_F = 2 * NJ, O_B = 2 * NJ + NF, O_LD = 2 * NJ + NF + NB, O_FAIL = O_LD + 1;
+  __shared__ double stage_all[2 * (W1 + OMC_MAX_TERMS) * 64];
+  const int lane = threadIdx.x, seg = blockIdx.x;
+  const int64_t grp = blockIdx.y;
+  const int64_t c0 = grp * 64;
+  const int64_t c = c0 + lane;
+  const bool live = c < C;
+  const int64_t cc = live ? c : C - 1;
+  double* sc = scratch + grp * (int64_t)nseg * NS * 64;  // [seg][entry][lane]
+  auto sput = [&](int sg, int e, double v) { sc[((int64_t)sg * NS + e) * 64 + lane] = v; };
+  auto sget = [&](int sg, int e) -> double { return sc[((int64_t)sg * NS + e) * 64 + lane]; };
+  const double sb = P.s_band ? P.s_band[cc] : 1.0;
+  double sid = 0.0;
+#pragma unroll
+  for (int k = 0; k < OMC_MAX_TERMS - 1; ++k)
+    if (k < P.n_ident) sid += P.s_ident[k] ? P.s_ident[k][cc] : 1.0;
+  double sr[OMC_MAX_TERMS];
+#pragma unroll
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) sr[k] = (k < P.n_rhs && P.s_rhs[k]) ? P.s_rhs[k][cc] : 1.0;
+  // workspace: L[(j*W1 + d)*C + c] (d = 0 holds 1/L_jj), then per column the zero-state u and its W unit responses
+  double* const L0 = Lws + cc;
+  double* const U0 = Lws + (int64_t)n * W1 * C + cc;   // U[(j*W1 + k)*C + c]: k = 0 zero-state u, k = 1..W responses
+  const double* brow[W1];
+#pragma unroll
+  for (int d = 0; d < W1; ++d) brow[d] = (d <= P.bw) ? P.band + (int64_t)d * n : nullptr;
+  const int64_t lo = (int64_t)seg * mseg, hi = (lo + mseg < n) ? lo + mseg : n;
+
+  if constexpr (PHASE == 0) {
+    // Shared (chain-independent) entries of a column, staged 64 columns at a time: lane t fetches column 64 k + t of every
+    // array (coalesced) a whole chunk ahead, the chunk is handed to LDS when the recurrence reaches it, and a step reads
+    // its column as broadcasts.
+    const int NV = W1 + P.n_rhs;
+    double* const stage = stage_all;
+    double sreg[W1 + OMC_MAX_TERMS];
+    int64_t staged = -1, inreg = -1;
+    auto fetch_chunk = [&](int64_t ch) {
+      const int64_t col = ch * 64 + lane;
+#pragma unroll
+      for (int d = 0; d < W1; ++d) sreg[d] = (brow[d] && col < n) ? brow[d][col] : 0.0;
+#pragma unroll
+      for (int k2 = 0; k2 < OMC_MAX_TERMS; ++k2) sreg[W1 + k2] = (k2 < P.n_rhs && col < n) ? P.rhs[k2][col] : 0.0;
+      inreg = ch;
+    };
+    auto need_chunk = [&](int64_t ch) {  // uniform over the wave
+      if (ch <= staged) return;
+      if (inreg != ch) fetch_chunk(ch);
+      double* dst = stage + (ch & 1) * NV * 64;
+#pragma unroll
+      for (int d = 0; d < W1; ++d) dst[d * 64 + lane] = sreg[d];
+#pragma unroll
+      for (int k2 = 0; k2 < OMC_MAX_TERMS; ++k2)
+        if (k2 < P.n_rhs) dst[(W1 + k2) * 64 + lane] = sreg[W1 + k2];
+      staged = ch;
+      fetch_chunk(ch + 1);
+    };
+    auto column = [&](int64_t col, double (&q)[W1], double& r) {
+      if (col < n) {
+        need_chunk(col >> 6);
+        const double* src = stage + ((col >> 6) & 1) * NV * 64 + (col & 63);
+#pragma unroll
+        for (int d = 0; d < W1; ++d) q[d] = sb * src[d * 64];
+        q[0] += sid;
+        double b = 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 < OMC_MAX_TERMS; ++k2)
+          if (k2 < P.n_rhs) b = fma(sr[k2], src[(W1 + k2) * 64], b);
+        r = b;
+      } else {
+#pragma unroll
+        for (int d = 0; d < W1; ++d) q[d] = 0.0;
+        r = 0.0;
+      }
+    };
+    const int64_t j0 = (seg == 0 || lo < ov) ? 0 : lo - ov;
+    bool fail = false;
+    double A[W1][W1], raw[W1];
+    need_chunk(j0 >> 6);
+#pragma unroll
+    for (int b = 0; b < W1; ++b) column(j0 + b, A[b], raw[b]);
+    double pre[W1], preR;
+    column(j0 + W1, pre, preR);
+    double Rc[W1], E[W][W1];
+#pragma unroll
+    for (int b = 0; b < W1; ++b) Rc[b] = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+#pragma unroll
+      for (int b = 0; b < W1; ++b) E[k][b] = (b == k) ? 1.0 : 0.0;
+    double ld_mant = 1.0;
+    long long ld_exp = 0;
+    double* Lp = L0 + lo * (int64_t)W1 * C;
+    double* Up = U0 + lo * (int64_t)W1 * C;
+    for (int64_t j = j0; j < hi; ++j) {
+      double pre_next[W1], preR_next;
+      column(j + 1 + W1, pre_next, preR_next);
+      const bool mine = j >= lo;
+      if (j == lo) {  // what this segment starts from: checked against its predecessor's end
+        int e = 0;
+#pragma unroll
+        for (int b = 0; b < W; ++b)
+#pragma unroll
+          for (int d = 0; d < W; ++d)
+            if (b + d < W) sput(seg, O_JS + e++, A[b][d]);
+      }
+      const double pivot = A[0][0];
+      const bool ok = pivot > 0.0;
+      if (mine) fail |= !ok;
+      double rinv = 1.0;
+      if (ok) {
+        const double g = __builtin_amdgcn_rsq(pivot);
+        const double h = 0.5 * g;
+        double sq = pivot * g;
+        double e = fma(-sq, sq, pivot);
+        sq = fma(e, h, sq);
+        e = fma(-sq, sq, pivot);
+        sq = fma(e, h, sq);
+        rinv = omc_rcp_nr(sq);
+      }
+      double l[W1];
+      l[0] = rinv;
+#pragma unroll
+      for (int d = 1; d < W1; ++d) l[d] = A[0][d] * rinv;
+      double u = 0.0, uk[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) uk[k] = 0.0;
+      if (mine) {
+#pragma unroll
+        for (int d = 0; d < W1; ++d) Lp[(int64_t)d * C] = l[d];
+        Lp += (int64_t)W1 * C;
+        u = (raw[0] + Rc[0]) * rinv;
+        Up[0] = u;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          uk[k] = E[k][0] * rinv;
+          Up[(int64_t)(k + 1) * C] = uk[k];
+        }
+        Up += (int64_t)W1 * C;
+        ld_mant *= __builtin_amdgcn_frexp_mant(ok ? pivot : 1.0);
+        ld_exp += __builtin_amdgcn_frexp_exp(ok ? pivot : 1.0);
+        if ((j & 15) == 15) {
+          ld_exp += __builtin_amdgcn_frexp_exp(ld_mant);
+          ld_mant = __builtin_amdgcn_frexp_mant(ld_mant);
+        }
+      }
+#pragma unroll
+      for (int b = 1; b < W1; ++b) {
+#pragma unroll
+        for (int d = 0; d < W1; ++d) {
+          double v = A[b][d];
+          if (b + d < W1) v = fma(-l[b + d], l[b], v);
+          A[b - 1][d] = v;
+        }
+        raw[b - 1] = raw[b];
+        if (mine) {
+          Rc[b - 1] = fma(-l[b], u, Rc[b]);
+#pragma unroll
+          for (int k = 0; k < W; ++k) E[k][b - 1] = fma(-l[b], uk[k], E[k][b]);
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < W1; ++d) { A[W][d] = pre[d]; pre[d] = pre_next[d]; }
+      raw[W] = preR;
+      preR = preR_next;
+      if (mine) {
+        Rc[W] = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) E[k][W] = 0.0;
+      }
+    }
+    int e = 0;
+#pragma unroll
+    for (int b = 0; b < W; ++b)
+#pragma unroll
+      for (int d = 0; d < W; ++d)
+        if (b + d < W) sput(seg, O_JE + e++, A[b][d]);
+    e = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+#pragma unroll
+      for (int b = 0; b < W; ++b) sput(seg, O_F + e++, E[k][b]);  // d(out state b) / d(in state k)
+#pragma unroll
+    for (int b = 0; b < W; ++b) sput(seg, O_F + e++, Rc[b]);
+    sput(seg, O_LD, log(ld_mant) + (double)ld_exp * 0.69314718055994530942);
+    sput(seg, O_FAIL, fail ? 1.0 : 0.0);
+    return;
+  } else {
+    // ---- joins of the whole group (every wave looks at all of them: the group goes to k_band_lane as a whole)
+    bool okj = true, failed = false;
+    for (int sg = 0; sg < nseg; ++sg) {
+      failed |= sget(sg, O_FAIL) != 0.0;
+      if (sg + 1 < nseg) {
+        const double scale = fabs(sget(sg, O_JE));
+#pragma unroll
+        for (int e = 0; e < NJ; ++e) okj = okj && (fabs(sget(sg + 1, O_JS + e) - sget(sg, O_JE + e)) <= tol * scale);
+      }
+    }
+    const bool chain_bad = live && !failed && !okj;  // (a chain that is not positive definite is reported, not retried)
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(chain_bad) != 0ull))) {
+      if (PHASE == 1 && seg == 0 && lane == 0) {
+        group_flag[grp] = 1;
+        atomicAdd(n_fallback, 1ull);
+      }
+      return;
+    }
+    if (PHASE == 1 && seg == 0) {
+      if (lane == 0) group_flag[grp] = 0;
+      if (live) {
+        if (logdet) {
+          double t = 0.0;
+          for (int sg = 0; sg < nseg; ++sg) t += sget(sg, O_LD);
+          logdet[c] = t;
+        }
+        if (failed) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+      }
+    }
+    // ---- the segment's true incoming forward state
+    double din[W];
+#pragma unroll
+    for (int b = 0; b < W; ++b) din[b] = 0.0;
+    for (int sg = 0; sg < seg; ++sg) {
+      double nx[W];
+#pragma unroll
+      for (int b = 0; b < W; ++b) {
+        double a = sget(sg, O_F + W * W + b);
+#pragma unroll
+        for (int k = 0; k < W; ++k) a = fma(sget(sg, O_F + k * W + b), din[k], a);
+        nx[b] = a;
+      }
+#pragma unroll
+      for (int b = 0; b < W; ++b) din[b] = nx[b];
+    }
+    // ---- its incoming backward state (PHASE 2): composed from the last segment down
+    const bool last = seg == nseg - 1;
+    double xs[W1], ms[W1], Xk[W][W1];
+#pragma unroll
+    for (int d = 0; d < W1; ++d) { xs[d] = 0.0; ms[d] = 0.0; }
+    if (PHASE == 2 && !last) {
+      double xin[W], min_[W];
+#pragma unroll
+      for (int b = 0; b < W; ++b) { xin[b] = sget(nseg - 1, O_B + W * W + b); min_[b] = sget(nseg - 1, O_B + W * W + W + b); }
+      for (int sg = nseg - 2; sg > seg; --sg) {
+        double nx[W], nm[W];
+#pragma unroll
+        for (int b = 0; b < W; ++b) {
+          double a = sget(sg, O_B + W * W + b), am = sget(sg, O_B + W * W + W + b);
+#pragma unroll
+          for (int k = 0; k < W; ++k) {
+            const double hkb = sget(sg, O_B + k * W + b);
+            a = fma(hkb, xin[k], a);
+            am = fma(hkb, min_[k], am);
+          }
+          nx[b] = a; nm[b] = am;
+        }
+#pragma unroll
+        for (int b = 0; b < W; ++b) { xin[b] = nx[b]; min_[b] = nm[b]; }
+      }
+#pragma unroll
+      for (int d = 1; d < W1; ++d) { xs[d] = xin[d - 1]; ms[d] = min_[d - 1]; }
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+#pragma unroll
+      for (int d = 0; d < W1; ++d) Xk[k][d] = (d - 1 == k) ? 1.0 : 0.0;
+    // ---- backward over the segment's columns hi-1 ... lo.  PHASE 1 carries the W unit incoming states and stores
+    // nothing (the last segment's state is final as it stands and needs no map); PHASE 2 stores x and the mean.
+    constexpr int PD = 4;  // columns in flight
+    const bool fail_chain = failed;
+    const int64_t gc = chain_offset + cc;
+    const double* zrow = z_in ? z_in + cc * ld_z : nullptr;
+    const double* Lp = L0 + (hi - 1) * (int64_t)W1 * C;
+    const double* Up = U0 + (hi - 1) * (int64_t)W1 * C;
+    double* Xp = Xws + (hi - 1) * C + cc;
+    double* Mp = Mws ? Mws + (hi - 1) * C + cc : nullptr;
+    double lb[PD][W1], ub[PD];
+    auto fetch = [&](int t, int64_t back) {  // column (hi - 1 - back) into slot t
+#pragma unroll
+      for (int d = 0; d < W1; ++d) lb[t][d] = Lp[(d - back * W1) * C];
+      double u = Up[(0 - back * W1) * C];
+#pragma unroll
+      for (int k = 0; k < W; ++k) u = fma(Up[(k + 1 - back * W1) * C], din[k], u);  // u = zero-state u + responses . incoming
+      ub[t] = u;
+    };
+#pragma unroll
+    for (int t = 0; t < PD; ++t) {
+#pragma unroll
+      for (int d = 0; d < W1; ++d) lb[t][d] = 0.0;
+      ub[t] = 0.0;
+      if (hi - 1 - t >= lo) fetch(t, t);
+    }
+    double z_even = 0.0;
+    bool have_even = false;
+    int64_t back0 = 0;
+    for (int64_t jt = hi - 1; jt >= lo; jt -= PD, back0 += PD) {
+#pragma unroll
+      for (int t = 0; t < PD; ++t) {
+        const int64_t j = jt - t;
+        if (j >= lo) {
+          const double u = ub[t];
+          double z;
+          if (zrow) {
+            z = zrow[j];
+          } else if ((j & 1) || !have_even) {  // a Philox block gives the draws of columns 2q and 2q+1
+            double n0, n1;
+            omc_normal_pair(omc_rng_block(key, gc, (uint32_t)(j >> 1)), n0, n1);
+            z = (j & 1) ? n1 : n0;
+            z_even = n0;
+            have_even = (j & 1) != 0;
+          } else {
+            z = z_even;
+            have_even = false;
+          }
+          double ax = u + z, am = u, ak[W];
+#pragma unroll
+          for (int k2 = 0; k2 < W; ++k2) ak[k2] = 0.0;
+#pragma unroll
+          for (int d = 1; d < W1; ++d) {
+            ax = fma(-lb[t][d], xs[d], ax);
+            am = fma(-lb[t][d], ms[d], am);
+            if (PHASE == 1) {
+#pragma unroll
+              for (int k2 = 0; k2 < W; ++k2) ak[k2] = fma(-lb[t][d], Xk[k2][d], ak[k2]);
+            }
+          }
+          const double l0 = lb[t][0];
+          const double xv = ax * l0, mv = am * l0;
+#pragma unroll
+          for (int d = W; d > 1; --d) {
+            xs[d] = xs[d - 1]; ms[d] = ms[d - 1];
+#pragma unroll
+            for (int k2 = 0; k2 < W; ++k2) Xk[k2][d] = Xk[k2][d - 1];
+          }
+          xs[1] = xv; ms[1] = mv;
+#pragma unroll
+          for (int k2 = 0; k2 < W; ++k2) Xk[k2][1] = ak[k2] * l0;
+          if (PHASE == 2) {
+            Xp[-(back0 + t) * C] = fail_chain ? NAN : xv;
+            if (Mp) Mp[-(back0 + t) * C] = mv;
+          }
+        }
+        if (j - PD >= lo) fetch(t, back0 + t + PD);
+      }
+    }
+    if (PHASE == 1) {
+      int e = 0;
+#pragma unroll
+      for (int k = 0; k < W; ++k)
+#pragma unroll
+        for (int b = 0; b < W; ++b) sput(seg, O_B + e++, Xk[k][b + 1]);
+#pragma unroll
+      for (int b = 0; b < W; ++b) sput(seg, O_B + e++, xs[b + 1]);
+#pragma unroll
+      for (int b = 0; b < W; ++b) sput(seg, O_B + e++, ms[b + 1]);
+    }
+  }
+}
+
+// [column][chain] -> the caller's chain-major rows
+__global__ void __launch_bounds__(256) k_band_transpose(int64_t C, int64_t n, const double* src, double* dst, int64_t ld,
+                                                        const int* group_flag) {
+  __shared__ double tile[64][65];
+  if (group_flag && group_flag[blockIdx.y]) return;  // this group's rows were written by k_band_lane
+  const int64_t j0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t j = j0 + r, c = c0 + tx;
+    tile[r][tx] = (j < n && c < C) ? src[j * C + c] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t c = c0 + r, j = j0 + tx;
+    if (c < C && j < n) dst[c * ld + j] = tile[tx][r];
+  }
+}
+
 // Does the term list fit k_band_lane (exactly one banded term, the others identities)?
 static bool band_lane_args(const BandTermsDev& T, BandLaneArgs* P) {
   P->band = nullptr; P->bw = 0; P->s_band = nullptr; P->n_ident = 0; P->n_rhs = 0;
@@ -457,9 +868,11 @@ static bool band_lane_args(const BandTermsDev& T, BandLaneArgs* P) {
 
 template <int W>
 static void launch_band_lane(omc_ctx* ctx, int64_t n, const BandLaneArgs& P, const double* z, int64_t ld_z, omc_rng_key key,
-                             double* x, int64_t ld_x, double* mean, int64_t ld_mean, double* logdet) {
+                             double* x, int64_t ld_x, double* mean, int64_t ld_mean, double* logdet,
+                             const int* group_flag = nullptr) {
   hipLaunchKernelGGL((k_band_lane<W>), dim3((unsigned)((ctx->n_chains + 63) / 64)), dim3(64), 0, ctx->stream, ctx->n_chains,
-                     ctx->chain_offset, n, P, z, ld_z, key, ctx->workspace, x, ld_x, mean, ld_mean, logdet, ctx->d_bad_chain);
+                     ctx->chain_offset, n, P, z, ld_z, key, ctx->workspace, x, ld_x, mean, ld_mean, logdet, ctx->d_bad_chain,
+                     group_flag);
 }
 
 // quad[c] = (x_c - m)' M (x_c - m) for a shared band matrix (NormalGamma.sample sampler.py:276,284; gmrf.py:343-344)
@@ -505,11 +918,51 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
     if (on && (terms->bw[k] < 0 || terms->bw[k] > w)) return OMC_INVALID_ARG;
   }
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  const size_t need = (size_t)ctx->n_chains * n * (w + 2) * sizeof(double);
-  omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->workspace, &ctx->workspace_bytes, need);
-  if (st != OMC_OK) return st;
+  const int64_t Cn = ctx->n_chains;
+  const int64_t groups = (Cn + 63) / 64;
   BandLaneArgs LP;
-  if (w >= 1 && w <= 8 && !rhs_chain && ctx->band_algo != 2 && band_lane_args(T, &LP)) {
+  const bool lane_fits = w >= 1 && w <= 8 && !rhs_chain && ctx->band_algo != 2 && band_lane_args(T, &LP);
+  // Segmented route: about a thousand waves in all, segments of at least 128 columns and at least half the warm-up
+  const int ov = ctx->band_seg_overlap;
+  int64_t min_seg = ov / 2 > 128 ? ov / 2 : 128;
+  int nseg = (int)(1024 / groups);
+  if (nseg > BSEG_MAX) nseg = BSEG_MAX;
+  if ((int64_t)nseg * min_seg > n) nseg = (int)(n / min_seg);
+  const bool segmented = lane_fits && w <= 3 && nseg >= 2 && ctx->band_algo != 1;
+  // factor, then per column the zero-state u and its w unit responses (segmented route) / u alone
+  const size_t base_doubles = (size_t)Cn * n * (segmented ? 2 * (w + 1) : (w + 2));
+  const size_t seg_doubles = segmented ? 2 * (size_t)Cn * n + (size_t)groups * nseg * 48 * 64 + (size_t)groups : 0;
+  omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->workspace, &ctx->workspace_bytes, (base_doubles + seg_doubles) * sizeof(double));
+  if (st != OMC_OK) return st;
+  if (segmented) {
+    const int64_t mseg = (n + nseg - 1) / nseg;
+    while ((int64_t)(nseg - 1) * mseg >= n) --nseg;  // no empty segment
+    double* Lws = ctx->workspace;
+    double* Xws = ctx->workspace + base_doubles;
+    double* Mws = mean ? Xws + (size_t)Cn * n : nullptr;
+    double* scratch = Xws + 2 * (size_t)Cn * n;
+    int* flags = (int*)(scratch + (size_t)groups * nseg * 48 * 64);
+    const omc_rng_key lane_key = omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL);
+    const double tol = 1e-13;
+    const dim3 sg((unsigned)nseg, (unsigned)groups);
+#define OMC_BSEG(Wv, PH)                                                                                                          \
+  hipLaunchKernelGGL((k_band_seg<Wv, PH>), sg, dim3(64), 0, ctx->stream, Cn, ctx->chain_offset, n, LP, nseg, mseg, ov, tol,       \
+                     z_inject, ld_z, lane_key, Lws, Xws, Mws, scratch, flags, logdet, ctx->d_bad_chain, ctx->d_fallbacks + 2)
+    if (w == 1) { OMC_BSEG(1, 0); OMC_BSEG(1, 1); OMC_BSEG(1, 2); }
+    else if (w == 2) { OMC_BSEG(2, 0); OMC_BSEG(2, 1); OMC_BSEG(2, 2); }
+    else { OMC_BSEG(3, 0); OMC_BSEG(3, 1); OMC_BSEG(3, 2); }
+#undef OMC_BSEG
+    const dim3 tg((unsigned)((n + 63) / 64), (unsigned)groups);
+    hipLaunchKernelGGL(k_band_transpose, tg, dim3(256), 0, ctx->stream, Cn, n, Xws, x, ld_x, flags);
+    if (mean) hipLaunchKernelGGL(k_band_transpose, tg, dim3(256), 0, ctx->stream, Cn, n, Mws, mean, ld_mean, flags);
+    // groups whose joins did not close: in one piece (the kernel returns at once for the others)
+    if (w == 1) launch_band_lane<1>(ctx, n, LP, z_inject, ld_z, lane_key, x, ld_x, mean, ld_mean, logdet, flags);
+    else if (w == 2) launch_band_lane<2>(ctx, n, LP, z_inject, ld_z, lane_key, x, ld_x, mean, ld_mean, logdet, flags);
+    else launch_band_lane<3>(ctx, n, LP, z_inject, ld_z, lane_key, x, ld_x, mean, ld_mean, logdet, flags);
+    OMC_HIP_CHECK(hipGetLastError());
+    return OMC_OK;
+  }
+  if (lane_fits) {
     // narrow band: one lane per chain, window in registers (see k_band_lane)
     const omc_rng_key lane_key = omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL);
     switch ((int)w) {

@@ -56,7 +56,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->gram_use_rocblas = 0;
   c->mh_use_rocblas = 0;
   c->mh_gemm_ksplit = 4;
-  c->band_algo = 0;
+  c->band_algo = 0; c->band_seg_overlap = 192;
   if (c->own_stream) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { omc_set_error("hipStreamCreate", e); delete c; return OMC_HIP_ERROR; }
@@ -136,6 +136,13 @@ omc_status omc_ctx_counter(omc_ctx* ctx, const char* name, int64_t* value) {
     *value = (int64_t)v;
     return OMC_OK;
   }
+  if (!strcmp(name, "band_join_fallbacks")) {
+    unsigned long long v = 0;
+    OMC_HIP_CHECK(hipMemcpyAsync(&v, ctx->d_fallbacks + 2, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *value = (int64_t)v;
+    return OMC_OK;
+  }
   if (!strcmp(name, "tridiag_join_fallbacks")) {
     unsigned long long v = 0;
     OMC_HIP_CHECK(hipMemcpyAsync(&v, ctx->d_fallbacks, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
@@ -185,6 +192,11 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "band_algo")) {
     if (value < 0 || value > 2) return OMC_INVALID_ARG;
     ctx->band_algo = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "band_seg_overlap")) {
+    if (value < 8 || value > 65536) return OMC_INVALID_ARG;
+    ctx->band_seg_overlap = (int)value;
     return OMC_OK;
   }
   if (!strcmp(name, "mh_gemm_ksplit")) {

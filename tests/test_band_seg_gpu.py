@@ -1,0 +1,92 @@
+"""The segmented lane-per-chain band kernel (k_band_lane_seg: up to 16 segments of a chain's columns, one wave each;
+warm-up + checked joins for the pivots, exact affine maps for the two substitutions) against the same kernel in one piece
+(band_algo = 1) and against a dense numpy factorisation: gmrf.sample_normal_canonical for banded precisions
+(gmrf.py:167-198, 489-520) at sizes the one-piece kernel needs milliseconds for."""
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+
+
+def rw_band(n, order, ridge=1e-3):
+    D = sparse.identity(n, format="csr")
+    for _ in range(order):
+        D = D[1:] - D[:-1]
+    P = (D.T @ D + ridge * sparse.identity(n)).tocsc()
+    band = np.zeros((order + 1, n))
+    for d in range(order + 1):
+        band[d, : n - d] = P.diagonal(-d)
+    return P, band
+
+
+def draw(n, C, order, lam, tau, algo, overlap=None, inject=True, seed=0, want_mean=True):
+    from openmcmc_amd.engine import Engine
+
+    rng = np.random.default_rng(seed)
+    eng = Engine(C, seed=4)
+    eng.set_option("band_algo", algo)
+    if overlap is not None:
+        eng.set_option("band_seg_overlap", overlap)
+    P, band = rw_band(n, order)
+    t = np.arange(n) * 60.0 / n
+    y = np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + rng.standard_normal(n)
+    lam_c = lam * (0.5 + rng.random(C))
+    tau_c = tau * (0.5 + rng.random(C))
+    terms = [{"band": eng.to_device(band), "scale": eng.to_device(lam_c)}, {"rhs": eng.to_device(y), "scale": eng.to_device(tau_c)}]
+    T = eng.band_terms(terms, n)
+    z = rng.standard_normal((C, n)) if inject else None
+    x, m, ld = eng.empty(C, n), (eng.empty(C, n) if want_mean else None), eng.empty(C)
+    eng.band_sample_canonical(n, T, x, z=None if z is None else eng.to_device(z), draw_index=3, mean_out=m, logdet_out=ld)
+    eng.check_status()
+    fb = eng.counter("band_join_fallbacks")
+    out = (x.cpu().numpy(), None if m is None else m.cpu().numpy(), ld.cpu().numpy(), fb, (P, y, lam_c, tau_c, z))
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("n,C,order,lam", [(10000, 70, 2, 100.0), (3000, 64, 2, 100.0), (4099, 5, 3, 100.0), (2500, 130, 1, 10.0)])
+@pytest.mark.parametrize("inject", [True, False])
+def test_segmented_band_draw_equals_the_one_piece_kernel(n, C, order, lam, inject):
+    """(a first-order prior remembers longest: lam / tau = 10 keeps its pivots' memory inside the default warm-up)"""
+    xs, ms, ls, fb, _ = draw(n, C, order, lam, 1.0, 0, inject=inject)
+    x1, m1, l1, fb1, _ = draw(n, C, order, lam, 1.0, 1, inject=inject)
+    assert fb == 0 and fb1 == 0  # the joins closed: this is the segmented route's result
+    scale = np.abs(x1).max()
+    assert np.abs(xs - x1).max() < 1e-10 * scale
+    assert np.abs(ms - m1).max() < 1e-10 * scale
+    assert np.abs(ls - l1).max() < 1e-9 * np.abs(l1).max()
+
+
+def test_segmented_band_draw_against_dense_numpy():
+    n, C, order = 2048, 3, 2
+    x, m, ld, fb, (P, y, lam, tau, z) = draw(n, C, order, 50.0, 2.0, 0)
+    assert fb == 0
+    Pd = P.toarray()
+    for c in range(C):
+        Q = lam[c] * Pd + tau[c] * np.eye(n)
+        L = np.linalg.cholesky(Q)
+        u = np.linalg.solve(L, tau[c] * y)
+        assert np.allclose(m[c], np.linalg.solve(L.T, u), rtol=0, atol=1e-9)
+        assert np.allclose(x[c], np.linalg.solve(L.T, u + z[c]), rtol=0, atol=1e-9)
+        assert abs(ld[c] - 2 * np.log(np.diag(L)).sum()) < 1e-8 * abs(ld[c])
+
+
+def test_joins_that_do_not_close_fall_back_to_one_piece():
+    """A likelihood 1e-9 times weaker than the prior: the pivots remember their start for far longer than the warm-up.
+    The join test must notice and the workgroup redo its chains in one piece -- same numbers as band_algo = 1."""
+    n, C, order = 6000, 64, 2
+    xs, ms, ls, fb, _ = draw(n, C, order, 1e5, 1e-4, 0, overlap=64)
+    x1, m1, l1, _, _ = draw(n, C, order, 1e5, 1e-4, 1)
+    assert fb >= 1
+    # (the one-piece run of the segmented kernel adds a column's updates in another order than k_band_lane: rounding)
+    scale = np.abs(x1).max()
+    assert np.abs(xs - x1).max() < 1e-9 * scale and np.abs(ms - m1).max() < 1e-9 * scale
+    assert np.abs(ls - l1).max() < 1e-9 * np.abs(l1).max()
+
+
+def test_without_mean_output():
+    xs, ms, ls, fb, _ = draw(5000, 66, 2, 100.0, 1.0, 0, want_mean=False)
+    x1, _, l1, _, _ = draw(5000, 66, 2, 100.0, 1.0, 1, want_mean=False)
+    assert ms is None and np.abs(xs - x1).max() < 1e-10 * np.abs(x1).max()
