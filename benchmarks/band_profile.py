@@ -1,0 +1,40 @@
+"""RW(w) band draws only (for rocprofv3): python benchmarks/band_profile.py [--n 10000 --chains 1024 --w 2 --steps 20]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import argparse, json, time
+import numpy as np
+import torch
+from scipy import sparse
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=10000); ap.add_argument("--chains", type=int, default=1024)
+ap.add_argument("--steps", type=int, default=20); ap.add_argument("--w", type=int, default=2)
+ap.add_argument("--overlap", type=int, default=0); ap.add_argument("--algo", type=int, default=0)
+a = ap.parse_args()
+from openmcmc_amd.engine import Engine
+n, C = a.n, a.chains
+eng = Engine(C, seed=2)
+eng.set_option("band_algo", a.algo)
+if a.overlap:
+    eng.set_option("band_seg_overlap", a.overlap)
+rng = np.random.default_rng(0)
+t = np.arange(n) * 60.0 / n
+y = np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + rng.standard_normal(n)
+D = sparse.identity(n, format="csr")
+for _ in range(a.w):
+    D = D[1:] - D[:-1]
+P = (D.T @ D + 1e-3 * sparse.identity(n)).tocsc()
+band = np.zeros((a.w + 1, n))
+for d in range(a.w + 1):
+    band[d, : n - d] = P.diagonal(-d)
+terms = [{"band": eng.to_device(band), "scale": eng.full((C,), 100.0)}, {"rhs": eng.to_device(y), "scale": eng.full((C,), 1.0)}]
+T = eng.band_terms(terms, n)
+x = eng.empty(C, n)
+for i in range(3):
+    eng.band_sample_canonical(n, T, x, draw_index=i)
+eng.check_status(); torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(a.steps):
+    eng.band_sample_canonical(n, T, x, draw_index=3 + i)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+print(json.dumps({"workload": f"band draw RW{a.w} n={n} chains={C}", "ms_per_draw": 1e3 * dt, "chain_updates_per_s": C / dt,
+                  "join_fallbacks": eng.counter("band_join_fallbacks"), "overlap": a.overlap or 192}))

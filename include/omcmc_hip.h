@@ -84,12 +84,16 @@ omc_status omc_ctx_synchronize(omc_ctx* ctx);
  * default 4: Newton corrections of the segment joins before the sequential fallback takes over; 0 forces it),
  * "tridiag_perturb_ppb" (tests: relative error, in 1e-9, put on the segments' start pivots so that the join test must
  * reject them), "run_sweeps_per_launch" (1..32, default 32: sweeps omc_gmrf_run issues per launch), "run_reenter" (0/1, default 1:
- * within such a launch a chain's workgroup restarts itself for the next sweep instead of one workgroup per sweep and chain).
+ * within such a launch a chain's workgroup restarts itself for the next sweep instead of one workgroup per sweep and chain),
+ * "band_algo" (0 auto; 1 narrow bands one lane per chain in ONE piece; 2 one workgroup per chain), "band_seg_overlap"
+ * (8..65536, default 192: columns of warm-up before a segment of the segmented narrow-band route).
  * Unknown name -> OMC_INVALID_ARG.                                                            */
 omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value);
 /* Diagnostic counters, by name (synchronises): "tridiag_join_fallbacks" = chain-updates of the segmented
  * tridiagonal kernel whose pivot joins did not meet the Newton tolerance within its iteration limit and were
- * made consistent by the sequential recurrence instead (same pivots as the serial kernel; slow, rare).       */
+ * made consistent by the sequential recurrence instead (same pivots as the serial kernel; slow, rare);
+ * "band_join_fallbacks" = groups of 64 chains of the segmented narrow-band route whose segment joins did not close
+ * within the warm-up and were factorised in one piece instead; "run_handoff_timeouts".                          */
 omc_status omc_ctx_counter(omc_ctx* ctx, const char* name, int64_t* value);
 const char* omc_last_error(void);          /* [host] text of the last HIP failure, thread-local */
 int32_t omc_abi_version(void);

@@ -664,14 +664,18 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
     return;
   } else {
     // ---- joins of the whole group (every wave looks at all of them: the group goes to k_band_lane as a whole)
+    // (no short-circuits and a fixed unroll: the loads of eight segments go out together -- one at a time this loop is
+    // 64 round trips to memory, longer than the segment's own work)
     bool okj = true, failed = false;
+#pragma unroll 8
     for (int sg = 0; sg < nseg; ++sg) {
       failed |= sget(sg, O_FAIL) != 0.0;
-      if (sg + 1 < nseg) {
-        const double scale = fabs(sget(sg, O_JE));
+      const int nx = (sg + 1 < nseg) ? sg + 1 : sg;  // the last segment compares its own start with itself... skipped below
+      const double scale = fabs(sget(sg, O_JE));
+      bool good = true;
 #pragma unroll
-        for (int e = 0; e < NJ; ++e) okj = okj && (fabs(sget(sg + 1, O_JS + e) - sget(sg, O_JE + e)) <= tol * scale);
-      }
+      for (int e = 0; e < NJ; ++e) good &= fabs(sget(nx, O_JS + e) - sget(sg, O_JE + e)) <= tol * scale;
+      okj &= good | (sg + 1 >= nseg);
     }
     const bool chain_bad = live && !failed && !okj;  // (a chain that is not positive definite is reported, not retried)
     if (__builtin_amdgcn_readfirstlane((int)(__ballot(chain_bad) != 0ull))) {
@@ -696,6 +700,7 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
     double din[W];
 #pragma unroll
     for (int b = 0; b < W; ++b) din[b] = 0.0;
+#pragma unroll 8
     for (int sg = 0; sg < seg; ++sg) {
       double nx[W];
 #pragma unroll
@@ -717,6 +722,7 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
       double xin[W], min_[W];
 #pragma unroll
       for (int b = 0; b < W; ++b) { xin[b] = sget(nseg - 1, O_B + W * W + b); min_[b] = sget(nseg - 1, O_B + W * W + W + b); }
+#pragma unroll 8
       for (int sg = nseg - 2; sg > seg; --sg) {
         double nx[W], nm[W];
 #pragma unroll
