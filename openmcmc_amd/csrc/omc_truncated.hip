@@ -29,76 +29,140 @@ __device__ __forceinline__ double trunc_uniform(const double* u_in, int64_t ld, 
   return (i & 1) ? omc_u53(w.z, w.w) : omc_u53(w.x, w.y);
 }
 
-__global__ void k_tridiag_gibbs_truncated(int64_t C, int64_t chain_offset, int64_t n, TruncTerms T, const double* rhs_chain,
-                                          int64_t ld_rhs, const double* lower, const double* upper, const double* u_in,
-                                          int64_t ld_u, omc_rng_key key, double* x, int64_t ld_x, long long* bad) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// One wave = 64 chains, one lane each, 64 sites at a time:
+//   * the block's x (and the per-chain right-hand side, if any) comes in as 64 coalesced rows through an LDS transpose
+//     tile and leaves the same way once the block is done.  A site-by-site store followed by the next site's load
+//     costs a store acknowledgement per site on this hardware (a load returns behind every older store: 2 us a site,
+//     20 ms a scan); the shared vectors of the block are staged in LDS too and read as broadcasts;
+//   * a site's draw is x = mean + sd * t with t the standard truncated-normal quantile.  When the limits are far out
+//     (the usual case) t = Phi^-1(u) does not depend on the mean, i.e. not on the neighbours: it is evaluated ahead of
+//     the one dependent chain of the scan (mean_i needs x_{i-1}) instead of inside it; a site near a limit takes the full
+//     log-space route as before.
+#define TG_LD 65
+template <bool INJ>
+__global__ void __launch_bounds__(64) k_tridiag_gibbs_truncated(int64_t C, int64_t chain_offset, int64_t n, TruncTerms T,
+                                                                const double* rhs_chain, int64_t ld_rhs, const double* lower,
+                                                                const double* upper, const double* u_in, int64_t ld_u,
+                                                                omc_rng_key key, double* x, int64_t ld_x, long long* bad) {
+  extern __shared__ double sm[];
+  double* xt = sm;                                   // [64 chains][65]: x of the block's 64 sites + the first of the next
+  double* rt = sm + 64 * TG_LD;                      // [64][65] per-chain right-hand side (only if rhs_chain)
+  double* stage = rt + (rhs_chain ? 64 * TG_LD : 0); // [3 n_terms + 2][64]: diag / off / rhs of every term, lower, upper
+  const int lane = threadIdx.x;
+  const int64_t c0 = (int64_t)blockIdx.x * 64;
+  const int64_t c = c0 + lane;
+  const bool live = c < C;
+  const int64_t cc = live ? c : C - 1;
   double s[OMC_MAX_TERMS];
 #pragma unroll
-  for (int k = 0; k < OMC_MAX_TERMS; ++k) s[k] = (k < T.n_terms && T.scale[k]) ? T.scale[k][c] : 1.0;
-  double* xc = x + c * ld_x;
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) s[k] = (k < T.n_terms && T.scale[k]) ? T.scale[k][cc] : 1.0;
+  const int NT = T.n_terms;
+  double* st_lo = stage + 3 * NT * 64;
+  double* st_hi = st_lo + 64;
   double x_prev = 0.0, off_prev = 0.0;  // x_{i-1} (already updated) and Q_{i,i-1}
-  double x_cur = xc[0];
   bool fail = false;
-  // row i of Q_c and b_c from the shared vectors; the NEXT site's row is fetched while this site's draw is worked out
-  // (the scan is one dependent chain per lane: a load waited for at every site is most of a site's time)
-  auto site = [&](int64_t i, double& a, double& o, double& b, double& lo, double& hi, double& xn) {
-    a = 0.0; o = 0.0; b = rhs_chain ? rhs_chain[c * ld_rhs + i] : 0.0;
+  const int64_t gc = chain_offset + cc;
+  const double* urow = u_in ? u_in + cc * ld_u : nullptr;
+  // Everything of a site that does not depend on the state -- uniform, far-limits quantile, row of Q, 1/Q_ii and
+  // 1/sqrt(Q_ii) -- for TG_U sites at a time in one straight piece of code: the wave is alone on its SIMD, so the only
+  // thing that can fill the latency of one site's long dependent chains (Philox rounds, two Horner chains, log, sqrt) is
+  // the same work of its neighbours
+  constexpr int TG_U = 4;
+  const bool single = n == 1;
+  struct Site { double uu, zf, a, o, b, lo, hi, v, sd; bool zok; };
+  for (int64_t i0 = 0; i0 < n; i0 += 64) {
+    const int len = (int)((n - i0 < 64) ? n - i0 : 64);
+    // ---- block in: rows of 64 sites (coalesced), one more column for the last site's right neighbour
+    for (int r = 0; r < 64; ++r) {
+      const bool okr = c0 + r < C && lane < len;
+      xt[r * TG_LD + lane] = okr ? x[(c0 + r) * ld_x + i0 + lane] : 0.0;
+      if (rhs_chain) rt[r * TG_LD + lane] = okr ? rhs_chain[(c0 + r) * ld_rhs + i0 + lane] : 0.0;
+    }
+    xt[lane * TG_LD + 64] = (live && i0 + 64 < n) ? x[c * ld_x + i0 + 64] : 0.0;
+    {
+      const int64_t i = i0 + lane;
+      const bool oki = lane < len;
+      for (int k = 0; k < NT; ++k) {
+        stage[(3 * k + 0) * 64 + lane] = (oki && T.diag[k]) ? T.diag[k][i] : 1.0;
+        stage[(3 * k + 1) * 64 + lane] = (oki && T.off[k] && i + 1 < n) ? T.off[k][i] : 0.0;
+        stage[(3 * k + 2) * 64 + lane] = (oki && T.rhs[k]) ? T.rhs[k][i] : 0.0;
+      }
+      st_lo[lane] = (oki && lower) ? lower[i] : -INFINITY;
+      st_hi[lane] = (oki && upper) ? upper[i] : INFINITY;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double* xrow = xt + lane * TG_LD;
+    const double* rrow = rt + lane * TG_LD;
+    for (int t0 = 0; t0 < len; t0 += TG_U) {
+      Site S[TG_U];
 #pragma unroll
-    for (int k = 0; k < OMC_MAX_TERMS; ++k) {
-      if (k < T.n_terms) {
-        a = fma(s[k], T.diag[k] ? T.diag[k][i] : 1.0, a);
-        if (T.off[k] && i + 1 < n) o = fma(s[k], T.off[k][i], o);
-        if (T.rhs[k]) b = fma(s[k], T.rhs[k][i], b);
+      for (int q = 0; q < TG_U; ++q) {
+        const int t = (t0 + q < len) ? t0 + q : len - 1;  // (a short last group repeats its last site: unused)
+        const int64_t i = i0 + t;
+        double uu;
+        if (INJ) {
+          uu = urow[i];
+        } else {
+          const uint4 w4 = omc_rng_block(key, gc, (uint32_t)(i >> 1));  // TG_U even, t0 even: sites 2m, 2m+1 share a block
+          uu = (i & 1) ? omc_u53(w4.z, w4.w) : omc_u53(w4.x, w4.y);
+        }
+        S[q].uu = uu;
+        S[q].zok = uu > 1e-15 && uu < 1.0 - 1e-15;
+        S[q].zf = omc_ndtri_as241_nb(S[q].zok ? uu : 0.5);
+        double a = 0.0, o = 0.0, b = rhs_chain ? rrow[t] : 0.0;
+#pragma unroll
+        for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+          if (k < NT) {
+            a = fma(s[k], stage[(3 * k + 0) * 64 + t], a);  // (staged with the defaults of absent vectors: 1, 0, 0)
+            o = fma(s[k], stage[(3 * k + 1) * 64 + t], o);
+            b = fma(s[k], stage[(3 * k + 2) * 64 + t], b);
+          }
+        }
+        S[q].a = a; S[q].o = o; S[q].b = b;
+        S[q].lo = st_lo[t]; S[q].hi = st_hi[t];
+        // 1/a and 1/sqrt(a) by the refined hardware reciprocal / reciprocal square root
+        S[q].v = (a > 0.0) ? omc_rcp_nr(a) : 1.0;
+        const double g = __builtin_amdgcn_rsq((a > 0.0) ? a : 1.0);
+        const double h = 0.5 * a;
+        double r = g;
+        r = fma(r, fma(-h * r, r, 0.5), r);
+        r = fma(r, fma(-h * r, r, 0.5), r);
+        S[q].sd = r;
+      }
+      // ---- the scan proper: one dependent chain
+#pragma unroll
+      for (int q = 0; q < TG_U; ++q) {
+        const int t = t0 + q;
+        if (t < len) {
+          const double a = S[q].a, o = S[q].o, sd = S[q].sd;
+          const double x_cur = xrow[t], x_next = xrow[t + 1];
+          if (!(a > 0.0)) fail = true;
+          const double inv_sd = a * sd;  // sqrt(a)
+          // gmrf.py:255-262: v_i * (b_i - Q[i,:] @ x + Q_ii x_i), row product in column order; n = 1: b v (gmrf.py:244-247)
+          const double row = fma(o, x_next, fma(a, x_cur, off_prev * x_prev));
+          const double mean = single ? S[q].b * S[q].v : S[q].v * ((S[q].b - row) + a * x_cur);
+          const double as = (S[q].lo - mean) * inv_sd, bs = (S[q].hi - mean) * inv_sd;
+          double xi = fma(S[q].zf, sd, mean);  // omc_truncnorm_ppf's far-limits branch: t = Phi^-1(u), x = t * sd + mean
+          if (!(as < -13.0 && bs > 13.0 && S[q].zok)) xi = omc_truncnorm_ppf(S[q].uu, as, bs) * sd + mean;
+          xrow[t] = xi;
+          x_prev = xi;
+          off_prev = o;
+        }
       }
     }
-    lo = lower ? lower[i] : -INFINITY;
-    hi = upper ? upper[i] : INFINITY;
-    xn = (i + 1 < n) ? xc[i + 1] : 0.0;
-  };
-  double a_n, o_n, b_n, lo_n, hi_n, xn_n, u_odd = 0.5;
-  site(0, a_n, o_n, b_n, lo_n, hi_n, xn_n);
-  for (int64_t i = 0; i < n; ++i) {
-    const double a = a_n, o = o_n, b = b_n, lo = lo_n, hi = hi_n, x_next = xn_n;
-    if (i + 1 < n) site(i + 1, a_n, o_n, b_n, lo_n, hi_n, xn_n);
-    if (!(a > 0.0)) fail = true;
-    double mean, sd;
-    // 1/a and sqrt(1/a) by the refined hardware reciprocal / reciprocal square root (the divide and sqrt sequences are
-    // ~70 dependent instructions on a path that is one dependent chain per lane)
-    const double v = (a > 0.0) ? omc_rcp_nr(a) : 1.0;
-    {
-      const double g = __builtin_amdgcn_rsq((a > 0.0) ? a : 1.0);  // ~ 1/sqrt(a): two Newton steps
-      const double h = 0.5 * a;
-      double r = g;
-      r = fma(r, fma(-h * r, r, 0.5), r);
-      r = fma(r, fma(-h * r, r, 0.5), r);
-      sd = r;
-    }
-    if (n == 1) {  // gmrf.py:244-247
-      mean = b * v;
-    } else {       // gmrf.py:255-262: v_i * (b_i - Q[i,:] @ x + Q_ii x_i), row product in column order
-      const double row = fma(o, x_next, fma(a, x_cur, off_prev * x_prev));
-      mean = v * ((b - row) + a * x_cur);
-    }
-    // in-kernel uniforms: one Philox block serves the two sites of a pair
-    double uu;
-    if (u_in) {
-      uu = u_in[c * ld_u + i];
-    } else if ((i & 1) == 0) {
-      const uint4 w4 = omc_rng_block(key, chain_offset + c, (uint32_t)(i >> 1));
-      uu = omc_u53(w4.x, w4.y);
-      u_odd = omc_u53(w4.z, w4.w);
-    } else {
-      uu = u_odd;
-    }
-    const double xi = omc_truncated_normal_rv_inv(mean, sd, a * sd, lo, hi, uu);  // 1/sd = sqrt(a) = a / sqrt(a)
-    xc[i] = xi;
-    x_prev = xi;
-    off_prev = o;
-    x_cur = x_next;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- block out
+    for (int r = 0; r < 64; ++r)
+      if (c0 + r < C && lane < len) x[(c0 + r) * ld_x + i0 + lane] = xt[r * TG_LD + lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  if (fail) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+  if (fail && live) atomicMin((unsigned long long*)bad, (unsigned long long)c);
 }
 
 // banded precision of bandwidth w (Q_c = sum_k s_k[c] M_k, M_k in the band storage of omc_band_terms: band[d*n + i] =
@@ -257,9 +321,19 @@ omc_status omc_tridiag_gibbs_truncated(omc_ctx* ctx, int64_t n, const omc_tridia
     T.rhs[k] = on ? terms->rhs[k] : nullptr;
     T.scale[k] = on ? terms->scale[k] : nullptr;
   }
-  hipLaunchKernelGGL(k_tridiag_gibbs_truncated, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains,
-                     ctx->chain_offset, n, T, rhs_chain, ld_rhs, lower, upper, u_inject, ld_u,
-                     omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), x, ld_x, ctx->d_bad_chain);
+  const size_t lds = (size_t)((rhs_chain ? 2 : 1) * 64 * TG_LD + (3 * T.n_terms + 2) * 64) * sizeof(double);
+  if (lds > 48 * 1024) {
+    OMC_HIP_CHECK(hipFuncSetAttribute((const void*)(k_tridiag_gibbs_truncated<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    OMC_HIP_CHECK(hipFuncSetAttribute((const void*)(k_tridiag_gibbs_truncated<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  if (u_inject)
+    hipLaunchKernelGGL(k_tridiag_gibbs_truncated<true>, dim3(grid1(ctx->n_chains, 64)), dim3(64), lds, ctx->stream, ctx->n_chains,
+                       ctx->chain_offset, n, T, rhs_chain, ld_rhs, lower, upper, u_inject, ld_u,
+                       omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), x, ld_x, ctx->d_bad_chain);
+  else
+    hipLaunchKernelGGL(k_tridiag_gibbs_truncated<false>, dim3(grid1(ctx->n_chains, 64)), dim3(64), lds, ctx->stream, ctx->n_chains,
+                       ctx->chain_offset, n, T, rhs_chain, ld_rhs, lower, upper, u_inject, ld_u,
+                       omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), x, ld_x, ctx->d_bad_chain);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

@@ -93,6 +93,48 @@ __host__ __device__ inline double omc_ndtri_as241(double p) {
   return q < 0.0 ? -x : x;
 }
 
+// The same function with both of its common branches evaluated and one selected: a wave of 64 uniforms practically
+// always holds a lane outside the central region, so the branches cost their sum anyway, and without them several
+// quantiles can be worked out side by side in one basic block (the caller's way of hiding the latency of these long
+// dependent chains).  Same rational approximations, same results.
+__device__ inline double omc_ndtri_as241_nb(double p) {
+  const double q = p - 0.5;
+  const double rc = 0.180625 - q * q;
+  const double numc = (((((((2.5090809287301226727e+3 * rc + 3.3430575583588128105e+4) * rc + 6.7265770927008700853e+4) * rc +
+                           4.5921953931549871457e+4) * rc + 1.3731693765509461125e+4) * rc + 1.9715909503065514427e+3) * rc +
+                         1.3314166789178437745e+2) * rc + 3.3871328727963666080e0);
+  const double denc = (((((((5.2264952788528545610e+3 * rc + 2.8729085735721942674e+4) * rc + 3.9307895800092710610e+4) * rc +
+                           2.1213794301586595867e+4) * rc + 5.3941960214247511077e+3) * rc + 6.8718700749205790830e+2) * rc +
+                         4.2313330701600911252e+1) * rc + 1.0);
+  const double xc = q * numc * omc_rcp_nr(denc);
+  // p in (1e-15, 1 - 1e-15): the argument is a finite positive normal number <= 1/2 -- the library's branch-free
+  // logarithm kernel and refined reciprocal square root apply (the libm routines carry special-case branches)
+  const double rt = omc_sqrt_nr(-omc_log_unit(q < 0.0 ? p : 1.0 - p));
+  double xm, xf;
+  {
+    const double r = rt - 1.6;
+    const double num = (((((((7.74545014278341407640e-4 * r + 2.27238449892691845833e-2) * r + 2.41780725177450611770e-1) * r +
+                            1.27045825245236838258e0) * r + 3.64784832476320460504e0) * r + 5.76949722146069140550e0) * r +
+                          4.63033784615654529590e0) * r + 1.42343711074968357734e0);
+    const double den = (((((((1.05075007164441684324e-9 * r + 5.47593808499534494600e-4) * r + 1.51986665636164571966e-2) * r +
+                            1.48103976427480074590e-1) * r + 6.89767334985100004550e-1) * r + 1.67638483018380384940e0) * r +
+                          2.05319162663775882187e0) * r + 1.0);
+    xm = num * omc_rcp_nr(den);
+  }
+  {
+    const double r = rt - 5.0;
+    const double num = (((((((2.01033439929228813265e-7 * r + 2.71155556874348757815e-5) * r + 1.24266094738807843860e-3) * r +
+                            2.65321895265761230930e-2) * r + 2.96560571828504891230e-1) * r + 1.78482653991729133580e0) * r +
+                          5.46378491116411436990e0) * r + 6.65790464350110377720e0);
+    const double den = (((((((2.04426310338993978564e-15 * r + 1.42151175831644588870e-7) * r + 1.84631831751005468180e-5) * r +
+                            7.86869131145613259100e-4) * r + 1.48753612908506148525e-2) * r + 1.36929880922735805310e-1) * r +
+                          5.99832206555887937690e-1) * r + 1.0);
+    xf = num * omc_rcp_nr(den);
+  }
+  const double xt = (rt <= 5.0) ? xm : xf;
+  return (fabs(q) <= 0.425) ? xc : (q < 0.0 ? -xt : xt);
+}
+
 __device__ inline double omc_truncnorm_ppf(double u, double a, double b) {
   // Both bounds far out: Phi(x) = u + Phi(a)(1 - u) - u Phi(-b) with Phi(a), Phi(-b) < 1e-38, so for u in
   // [1e-15, 1 - 1e-15] (the 2^-53 grid of the in-kernel uniforms lies inside, all but its end points) the window
