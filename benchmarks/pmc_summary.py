@@ -43,6 +43,11 @@ def main():
         rec["hbm_bytes_per_sweep"] = per_launch / spl
     if "SQ_INSTS_VALU" in out and "SQ_WAVES" in out:
         rec["valu_instructions_per_wave"] = out["SQ_INSTS_VALU"]["mean_per_launch"] / out["SQ_WAVES"]["mean_per_launch"]
+        # one wave = one sweep of 64 lanes' share of a chain: with self-restarting workgroups a hardware wave lives through all
+        # the sweeps of the launch, so the count per wave AND SWEEP is what compares across launch forms
+        chains = args.grid // 1024 if args.grid else 0
+        restarting = chains and out["SQ_WAVES"]["mean_per_launch"] <= 16 * chains
+        rec["valu_instructions_per_wave_and_sweep"] = rec["valu_instructions_per_wave"] / (spl if restarting else 1)
     if "SQ_ACTIVE_INST_VALU" in out and "SQ_WAVE_CYCLES" in out:
         rec["valu_active_share_of_wave_cycles_x4waves"] = 4 * out["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / out["SQ_WAVE_CYCLES"]["mean_per_launch"]
     print(json.dumps(rec, indent=1))
