@@ -151,7 +151,8 @@ omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* term
  *   x      -> x_store + slot * x_slot_stride        ([C][ld_x] slab; written directly by the sweep)
  *   scale  -> blocks[k].store + slot * C            (when blocks[k].store != NULL)
  *   log_p  -> log_post_store + slot * C             (when != NULL)
- * with slot = (first_slot + i) % n_slots.  Sweeps that are not stored draw into scratch_x [C][ld_x].  */
+ * with slot = (first_slot + i) % n_slots.  A sweep that is not stored leaves its draw in scratch_x [C][ld_x] if it is
+ * the last of the run (the state to continue from); the draws of other unstored sweeps may not be written at all.  */
 omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms, const omc_gamma_block* blocks,
                         int64_t n_burn, int64_t n_iter, int64_t n_thin, uint64_t draw_index0,
                         uint64_t draws_per_sweep, double* x_store, int64_t ld_x, int64_t x_slot_stride,

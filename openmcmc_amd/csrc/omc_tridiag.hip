@@ -2080,7 +2080,9 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
         const int64_t it = stored ? (t - burn + 1) / n_thin - 1 : 0;
         const int64_t slot = (first_slot + it) % n_slots;
         A.rec[i].draw = draw_index0 + (uint64_t)t * draws_per_sweep;
-        A.rec[i].x = stored ? x_store + slot * x_slot_stride : scratch_x;
+        // a draw that is neither stored nor the run's last is not written at all: the next sweep redraws x from its full
+        // conditional without reading it (80 KB per chain and sweep of stores that burn-in and thinning would throw away)
+        A.rec[i].x = stored ? x_store + slot * x_slot_stride : (t == total - 1 ? scratch_x : nullptr);
         A.rec[i].log_post = (stored && log_post_store) ? log_post_store + slot * C : nullptr;
         A.rec[i].slot_off = stored ? slot * C : -1;
       }
