@@ -89,8 +89,10 @@ class MetropolisHastings(MCMCSampler):
                                       "and a scalar step")
         dist = self.model[self.param]
         Q, mu = state[dist.precision.form], state[dist.mean.form]
-        mu = np.asarray(mu, dtype=np.float64).reshape(-1)
-        return eng.shared(Q), (eng.shared(mu) if mu.any() else None), Q.shape[0]
+        # device copies are cached by the identity of the STATE ENTRY (a reshaped copy would be a new object every step:
+        # one upload per step, and a new address for everything the library derives from the mean)
+        mu_dev = eng.shared(mu).reshape(-1) if np.any(mu) else None
+        return eng.shared(Q), mu_dev, Q.shape[0]
 
     def _factor_plan(self, eng, state, Q, scale):
         """chol(scale * Q) of the fused routes, kept from step to step (the reference refactorises every step,
