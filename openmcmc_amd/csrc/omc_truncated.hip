@@ -39,7 +39,7 @@ __device__ __forceinline__ double trunc_uniform(const double* u_in, int64_t ld, 
 //     the one dependent chain of the scan (mean_i needs x_{i-1}) instead of inside it; a site near a limit takes the full
 //     log-space route as before.
 #define TG_LD 65
-template <bool INJ>
+template <bool INJ, int NT>
 __global__ void __launch_bounds__(64) k_tridiag_gibbs_truncated(int64_t C, int64_t chain_offset, int64_t n, TruncTerms T,
                                                                 const double* rhs_chain, int64_t ld_rhs, const double* lower,
                                                                 const double* upper, const double* u_in, int64_t ld_u,
@@ -56,7 +56,6 @@ __global__ void __launch_bounds__(64) k_tridiag_gibbs_truncated(int64_t C, int64
   double s[OMC_MAX_TERMS];
 #pragma unroll
   for (int k = 0; k < OMC_MAX_TERMS; ++k) s[k] = (k < T.n_terms && T.scale[k]) ? T.scale[k][cc] : 1.0;
-  const int NT = T.n_terms;
   double* st_lo = stage + 3 * NT * 64;
   double* st_hi = st_lo + 64;
   double x_prev = 0.0, off_prev = 0.0;  // x_{i-1} (already updated) and Q_{i,i-1}
@@ -64,10 +63,10 @@ __global__ void __launch_bounds__(64) k_tridiag_gibbs_truncated(int64_t C, int64
   const int64_t gc = chain_offset + cc;
   const double* urow = u_in ? u_in + cc * ld_u : nullptr;
   // Everything of a site that does not depend on the state -- uniform, far-limits quantile, row of Q, 1/Q_ii and
-  // 1/sqrt(Q_ii) -- for TG_U sites at a time in one straight piece of code: the wave is alone on its SIMD, so the only
+  // 1/sqrt(Q_ii) -- for TG_U sites at a time in one straight piece of code (vectors of TG_U: statement by statement): the wave is alone on its SIMD, so the only
   // thing that can fill the latency of one site's long dependent chains (Philox rounds, two Horner chains, log, sqrt) is
   // the same work of its neighbours
-  constexpr int TG_U = 4;
+  constexpr int TG_U = 8;
   const bool single = n == 1;
   struct Site { double uu, zf, a, o, b, lo, hi, v, sd; bool zok; };
   for (int64_t i0 = 0; i0 < n; i0 += 64) {
@@ -97,39 +96,69 @@ __global__ void __launch_bounds__(64) k_tridiag_gibbs_truncated(int64_t C, int64
     const double* rrow = rt + lane * TG_LD;
     for (int t0 = 0; t0 < len; t0 += TG_U) {
       Site S[TG_U];
+      // uniforms: sites 2m and 2m+1 share a Philox block (t0 and i0 are multiples of TG_U): TG_U / 2 blocks, their rounds interleaved
+      typedef omc_dv<TG_U> dvu;
+      dvu u4;
+      if (INJ) {
+#pragma unroll
+        for (int q = 0; q < TG_U; ++q) u4[q] = urow[i0 + ((t0 + q < len) ? t0 + q : len - 1)];
+      } else {
+        const uint32_t blk = (uint32_t)((i0 + t0) >> 1);
+        const uint32_t c2 = (uint32_t)gc, c3 = key.c3_base | ((uint32_t)((uint64_t)gc >> 32) & 0xffu) << 16;
+        uint32_t w0[TG_U / 2], w1[TG_U / 2], w2[TG_U / 2], w3[TG_U / 2], k0[TG_U / 2], k1[TG_U / 2];
+#pragma unroll
+        for (int b = 0; b < TG_U / 2; ++b) { w0[b] = blk + b; w1[b] = key.c1; w2[b] = c2; w3[b] = c3; k0[b] = key.k0; k1[b] = key.k1; }
+#pragma unroll
+        for (int r = 0; r < 10; ++r)
+#pragma unroll
+          for (int b = 0; b < TG_U / 2; ++b) omc_philox_round(w0[b], w1[b], w2[b], w3[b], k0[b], k1[b]);
+#pragma unroll
+        for (int b = 0; b < TG_U / 2; ++b) { u4[2 * b] = omc_u53(w0[b], w1[b]); u4[2 * b + 1] = omc_u53(w2[b], w3[b]); }
+      }
+      dvu usafe;
+#pragma unroll
+      for (int q = 0; q < TG_U; ++q) {
+        S[q].uu = u4[q];
+        S[q].zok = u4[q] > 1e-15 && u4[q] < 1.0 - 1e-15;
+        usafe[q] = S[q].zok ? u4[q] : 0.5;
+      }
+      const dvu z4 = omc_ndtri_as241_nbv<TG_U>(usafe);
+      dvu a4, o4, b4;
 #pragma unroll
       for (int q = 0; q < TG_U; ++q) {
         const int t = (t0 + q < len) ? t0 + q : len - 1;  // (a short last group repeats its last site: unused)
-        const int64_t i = i0 + t;
-        double uu;
-        if (INJ) {
-          uu = urow[i];
-        } else {
-          const uint4 w4 = omc_rng_block(key, gc, (uint32_t)(i >> 1));  // TG_U even, t0 even: sites 2m, 2m+1 share a block
-          uu = (i & 1) ? omc_u53(w4.z, w4.w) : omc_u53(w4.x, w4.y);
-        }
-        S[q].uu = uu;
-        S[q].zok = uu > 1e-15 && uu < 1.0 - 1e-15;
-        S[q].zf = omc_ndtri_as241_nb(S[q].zok ? uu : 0.5);
         double a = 0.0, o = 0.0, b = rhs_chain ? rrow[t] : 0.0;
 #pragma unroll
-        for (int k = 0; k < OMC_MAX_TERMS; ++k) {
-          if (k < NT) {
-            a = fma(s[k], stage[(3 * k + 0) * 64 + t], a);  // (staged with the defaults of absent vectors: 1, 0, 0)
-            o = fma(s[k], stage[(3 * k + 1) * 64 + t], o);
-            b = fma(s[k], stage[(3 * k + 2) * 64 + t], b);
-          }
+        for (int k = 0; k < NT; ++k) {  // (staged with the defaults of absent vectors: 1, 0, 0; NT is a template parameter:
+          a = fma(s[k], stage[(3 * k + 0) * 64 + t], a);  //  a run-time count made every term of every site its own
+          o = fma(s[k], stage[(3 * k + 1) * 64 + t], o);  //  basic block with an exposed LDS round trip)
+          b = fma(s[k], stage[(3 * k + 2) * 64 + t], b);
         }
-        S[q].a = a; S[q].o = o; S[q].b = b;
+        a4[q] = a; o4[q] = o; b4[q] = b;
         S[q].lo = st_lo[t]; S[q].hi = st_hi[t];
-        // 1/a and 1/sqrt(a) by the refined hardware reciprocal / reciprocal square root
-        S[q].v = (a > 0.0) ? omc_rcp_nr(a) : 1.0;
-        const double g = __builtin_amdgcn_rsq((a > 0.0) ? a : 1.0);
-        const double h = 0.5 * a;
-        double r = g;
-        r = fma(r, fma(-h * r, r, 0.5), r);
-        r = fma(r, fma(-h * r, r, 0.5), r);
-        S[q].sd = r;
+      }
+      // 1/a and 1/sqrt(a) by the refined hardware reciprocal / reciprocal square root, the four together
+      dvu asafe;
+#pragma unroll
+      for (int q = 0; q < TG_U; ++q) asafe[q] = (a4[q] > 0.0) ? a4[q] : 1.0;
+      const dvu v4 = omc_rcp_nrv<TG_U>(asafe);
+      dvu sd4;
+      {
+        dvu g;
+#pragma unroll
+        for (int q = 0; q < TG_U; ++q) g[q] = __builtin_amdgcn_rsq(asafe[q]);
+        const dvu h = dvu(0.5) * a4;
+        dvu r = g;
+        r = omc_fmav<TG_U>(r, omc_fmav<TG_U>(-h * r, r, dvu(0.5)), r);
+        r = omc_fmav<TG_U>(r, omc_fmav<TG_U>(-h * r, r, dvu(0.5)), r);
+        sd4 = r;
+      }
+#pragma unroll
+      for (int q = 0; q < TG_U; ++q) {
+        S[q].zf = z4[q];
+        S[q].a = a4[q]; S[q].o = o4[q]; S[q].b = b4[q];
+        S[q].v = (a4[q] > 0.0) ? v4[q] : 1.0;
+        S[q].sd = sd4[q];
       }
       // ---- the scan proper: one dependent chain
 #pragma unroll
@@ -322,18 +351,25 @@ omc_status omc_tridiag_gibbs_truncated(omc_ctx* ctx, int64_t n, const omc_tridia
     T.scale[k] = on ? terms->scale[k] : nullptr;
   }
   const size_t lds = (size_t)((rhs_chain ? 2 : 1) * 64 * TG_LD + (3 * T.n_terms + 2) * 64) * sizeof(double);
-  if (lds > 48 * 1024) {
-    OMC_HIP_CHECK(hipFuncSetAttribute((const void*)(k_tridiag_gibbs_truncated<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    OMC_HIP_CHECK(hipFuncSetAttribute((const void*)(k_tridiag_gibbs_truncated<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-  if (u_inject)
-    hipLaunchKernelGGL(k_tridiag_gibbs_truncated<true>, dim3(grid1(ctx->n_chains, 64)), dim3(64), lds, ctx->stream, ctx->n_chains,
-                       ctx->chain_offset, n, T, rhs_chain, ld_rhs, lower, upper, u_inject, ld_u,
-                       omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), x, ld_x, ctx->d_bad_chain);
-  else
-    hipLaunchKernelGGL(k_tridiag_gibbs_truncated<false>, dim3(grid1(ctx->n_chains, 64)), dim3(64), lds, ctx->stream, ctx->n_chains,
-                       ctx->chain_offset, n, T, rhs_chain, ld_rhs, lower, upper, u_inject, ld_u,
-                       omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), x, ld_x, ctx->d_bad_chain);
+#define OMC_TG_LAUNCH(INJv, NTv)                                                                                               \
+  do {                                                                                                                          \
+    if (lds > 48 * 1024)                                                                                                        \
+      OMC_HIP_CHECK(hipFuncSetAttribute((const void*)(k_tridiag_gibbs_truncated<INJv, NTv>),                                    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
+    hipLaunchKernelGGL((k_tridiag_gibbs_truncated<INJv, NTv>), dim3(grid1(ctx->n_chains, 64)), dim3(64), lds, ctx->stream,      \
+                       ctx->n_chains, ctx->chain_offset, n, T, rhs_chain, ld_rhs, lower, upper, u_inject, ld_u,                 \
+                       omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), x, ld_x, ctx->d_bad_chain);                        \
+  } while (0)
+#define OMC_TG_TERMS(INJv)                                                                                                      \
+  do {                                                                                                                          \
+    if (T.n_terms == 1) OMC_TG_LAUNCH(INJv, 1);                                                                                 \
+    else if (T.n_terms == 2) OMC_TG_LAUNCH(INJv, 2);                                                                            \
+    else if (T.n_terms == 3) OMC_TG_LAUNCH(INJv, 3);                                                                            \
+    else OMC_TG_LAUNCH(INJv, 4);                                                                                                \
+  } while (0)
+  if (u_inject) OMC_TG_TERMS(true); else OMC_TG_TERMS(false);
+#undef OMC_TG_TERMS
+#undef OMC_TG_LAUNCH
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

@@ -135,6 +135,93 @@ __device__ inline double omc_ndtri_as241_nb(double p) {
   return (fabs(q) <= 0.425) ? xc : (q < 0.0 ? -xt : xt);
 }
 
+// ---- four quantiles side by side --------------------------------------------------------------------------------
+// omc_ndtri_as241_nb on a vector of four: every statement turns into four independent instructions back to back, which is
+// what a wave that is alone on its SIMD needs to keep issuing while each of the four long dependent chains (two Horner
+// chains, a logarithm, a square root, three refined reciprocals) waits for itself.  Same operations per element as the
+// scalar function (up to where the compiler fuses a multiply into an add: <= 1 ulp in the logarithm).
+template <int N> using omc_dv = double __attribute__((ext_vector_type(N)));
+#define OMC_DV(x) (omc_dv<N>(x))   /* broadcast */
+template <int N> __device__ __forceinline__ omc_dv<N> omc_fmav(omc_dv<N> a, omc_dv<N> b, omc_dv<N> c) { return __builtin_elementwise_fma(a, b, c); }
+template <int N> __device__ __forceinline__ omc_dv<N> omc_rcp_nrv(omc_dv<N> d) {
+  omc_dv<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = __builtin_amdgcn_rcp(d[i]);
+  const omc_dv<N> e = omc_fmav<N>(-d, r, OMC_DV(1.0));
+  return omc_fmav<N>(r, omc_fmav<N>(e, e, e), r);
+}
+template <int N> __device__ __forceinline__ omc_dv<N> omc_sqrt_nrv(omc_dv<N> r) {
+  omc_dv<N> g;
+#pragma unroll
+  for (int i = 0; i < N; ++i) g[i] = __builtin_amdgcn_rsq(r[i]);
+  omc_dv<N> s = r * g;
+  const omc_dv<N> h = OMC_DV(0.5) * g;
+  omc_dv<N> e = omc_fmav<N>(-s, s, r);
+  s = omc_fmav<N>(e, h, s);
+  e = omc_fmav<N>(-s, s, r);
+  return omc_fmav<N>(e, h, s);
+}
+template <int N> __device__ __forceinline__ omc_dv<N> omc_log_unitv(omc_dv<N> u) {  // omc_log_unit, element by element
+  omc_dv<N> m, dk;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    int k = __builtin_amdgcn_frexp_exp(u[i]);
+    double mi = __builtin_amdgcn_frexp_mant(u[i]);
+    const bool low = mi < 0.70710678118654752440;
+    m[i] = low ? mi * 2.0 : mi;
+    dk[i] = (double)(low ? k - 1 : k);
+  }
+  const omc_dv<N> f = m - OMC_DV(1.0);
+  const omc_dv<N> s = f * omc_rcp_nrv<N>(OMC_DV(2.0) + f);
+  const omc_dv<N> z = s * s, w = z * z;
+  const omc_dv<N> t1 = w * omc_fmav<N>(w, omc_fmav<N>(w, OMC_DV(1.531383769920937332e-01), OMC_DV(2.222219843214978396e-01)),
+                                 OMC_DV(3.999999999940941908e-01));
+  const omc_dv<N> t2 = z * omc_fmav<N>(w, omc_fmav<N>(w, omc_fmav<N>(w, OMC_DV(1.479819860511658591e-01), OMC_DV(1.818357216161805012e-01)),
+                                             OMC_DV(2.857142874366239149e-01)), OMC_DV(6.666666666666735130e-01));
+  const omc_dv<N> R = t2 + t1, hfsq = OMC_DV(0.5) * f * f;
+  return dk * OMC_DV(6.93147180369123816490e-01) -
+         ((hfsq - omc_fmav<N>(s, hfsq + R, dk * OMC_DV(1.90821492927058770002e-10))) - f);
+}
+#define OMC_HORNER8(r, c7, c6, c5, c4, c3, c2, c1, c0)                                                                 \
+  omc_fmav<N>(omc_fmav<N>(omc_fmav<N>(omc_fmav<N>(omc_fmav<N>(omc_fmav<N>(omc_fmav<N>(OMC_DV(c7), r, OMC_DV(c6)), r, OMC_DV(c5)), r, OMC_DV(c4)), r, \
+                                      OMC_DV(c3)), r, OMC_DV(c2)), r, OMC_DV(c1)), r, OMC_DV(c0))
+template <int N> __device__ __forceinline__ omc_dv<N> omc_ndtri_as241_nbv(omc_dv<N> p) {
+  const omc_dv<N> q = p - OMC_DV(0.5);
+  const omc_dv<N> rc = omc_fmav<N>(-q, q, OMC_DV(0.180625));
+  const omc_dv<N> numc = OMC_HORNER8(rc, 2.5090809287301226727e+3, 3.3430575583588128105e+4, 6.7265770927008700853e+4,
+                                  4.5921953931549871457e+4, 1.3731693765509461125e+4, 1.9715909503065514427e+3,
+                                  1.3314166789178437745e+2, 3.3871328727963666080e0);
+  const omc_dv<N> denc = OMC_HORNER8(rc, 5.2264952788528545610e+3, 2.8729085735721942674e+4, 3.9307895800092710610e+4,
+                                  2.1213794301586595867e+4, 5.3941960214247511077e+3, 6.8718700749205790830e+2,
+                                  4.2313330701600911252e+1, 1.0);
+  const omc_dv<N> xc = q * numc * omc_rcp_nrv<N>(denc);
+  omc_dv<N> tail;
+#pragma unroll
+  for (int i = 0; i < N; ++i) tail[i] = q[i] < 0.0 ? p[i] : 1.0 - p[i];
+  const omc_dv<N> rt = omc_sqrt_nrv<N>(-omc_log_unitv<N>(tail));
+  const omc_dv<N> rm = rt - OMC_DV(1.6), rf = rt - OMC_DV(5.0);
+  const omc_dv<N> numm = OMC_HORNER8(rm, 7.74545014278341407640e-4, 2.27238449892691845833e-2, 2.41780725177450611770e-1,
+                                  1.27045825245236838258e0, 3.64784832476320460504e0, 5.76949722146069140550e0,
+                                  4.63033784615654529590e0, 1.42343711074968357734e0);
+  const omc_dv<N> denm = OMC_HORNER8(rm, 1.05075007164441684324e-9, 5.47593808499534494600e-4, 1.51986665636164571966e-2,
+                                  1.48103976427480074590e-1, 6.89767334985100004550e-1, 1.67638483018380384940e0,
+                                  2.05319162663775882187e0, 1.0);
+  const omc_dv<N> numf = OMC_HORNER8(rf, 2.01033439929228813265e-7, 2.71155556874348757815e-5, 1.24266094738807843860e-3,
+                                  2.65321895265761230930e-2, 2.96560571828504891230e-1, 1.78482653991729133580e0,
+                                  5.46378491116411436990e0, 6.65790464350110377720e0);
+  const omc_dv<N> denf = OMC_HORNER8(rf, 2.04426310338993978564e-15, 1.42151175831644588870e-7, 1.84631831751005468180e-5,
+                                  7.86869131145613259100e-4, 1.48753612908506148525e-2, 1.36929880922735805310e-1,
+                                  5.99832206555887937690e-1, 1.0);
+  const omc_dv<N> xm = numm * omc_rcp_nrv<N>(denm), xf = numf * omc_rcp_nrv<N>(denf);
+  omc_dv<N> out;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double xt = (rt[i] <= 5.0) ? xm[i] : xf[i];
+    out[i] = (fabs(q[i]) <= 0.425) ? xc[i] : (q[i] < 0.0 ? -xt : xt);
+  }
+  return out;
+}
+
 __device__ inline double omc_truncnorm_ppf(double u, double a, double b) {
   // Both bounds far out: Phi(x) = u + Phi(a)(1 - u) - u Phi(-b) with Phi(a), Phi(-b) < 1e-38, so for u in
   // [1e-15, 1 - 1e-15] (the 2^-53 grid of the in-kernel uniforms lies inside, all but its end points) the window
