@@ -304,7 +304,8 @@ class RandomWalkLoop(RandomWalk):
             return None
         lower, upper = float(lim[0, 0]), float(lim[0, 1])
         Bm = state.get(basis.matrix)
-        if not is_chain(Bm) or Bm.shape[1] != x.shape[1] or not Bm.data.transpose(1, 2).is_contiguous():
+        if (not is_chain(Bm) or Bm.shape[1] != x.shape[1] or not Bm.data.transpose(1, 2).is_contiguous()
+                or Bm.shape[0] > 10240):  # omc_knot_loop keeps a chain's residual in registers: n <= 10 240
             return None
         lik = None
         for key in self.model.affected_by([self.param, basis.matrix]):

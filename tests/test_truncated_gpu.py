@@ -165,3 +165,49 @@ def test_band_truncated_scan_matches_reference(golden):
         for c in range(C):
             assert np.max(np.abs(got[c] - G[k + "x"])) < 1e-9 * max(1.0, np.max(np.abs(G[k + "x"]))), (ci, c)
         eng.close()
+
+
+@pytest.mark.parametrize("n,C,terms_n", [(150, 70, 2), (64, 3, 1), (1, 5, 2), (333, 65, 3)])
+def test_tridiagonal_scan_blocks_per_chain_rhs_and_limits_per_site(n, C, terms_n):
+    """The scan kernel's block structure (64 sites at a time through LDS tiles, groups of 8 sites, 64 chains per wave)
+    at sizes that are not multiples of anything, with a per-chain right-hand side, 1 to 3 terms, limits that differ from
+    site to site and bite at some sites (slow route) and not at others (far-limits route): against the CPU restatement of
+    gmrf.gibbs_canonical_truncated_normal (oracle/gmrf_ref.py, pinned to the reference by tests/test_oracle_golden.py)
+    with the same uniforms."""
+    from oracle import gmrf_ref
+
+    rng = np.random.default_rng(n * 31 + C)
+    eng = make_engine(C, seed=9)
+    d1 = 2.0 + rng.random(n)
+    o1 = -0.8 * rng.random(max(n - 1, 0))
+    lam = 1.0 + 3.0 * rng.random(C)
+    tau = 0.5 + rng.random(C)
+    y = rng.standard_normal(n)
+    d3 = 0.3 * rng.random(n)
+    rc = 0.5 * rng.standard_normal((C, n))
+    lower = np.where(rng.random(n) < 0.5, -0.2, -30.0)
+    upper = np.where(rng.random(n) < 0.3, 0.4, 40.0)
+    x0 = np.clip(rng.standard_normal((C, n)), lower + 0.01, upper - 0.01)
+    u = rng.random((C, n))
+    terms = [{"diag": eng.to_device(d1), "off": eng.to_device(o1) if n > 1 else None, "scale": eng.to_device(lam)}]
+    if terms_n >= 2:
+        terms.append({"rhs": eng.to_device(y), "scale": eng.to_device(tau)})
+    if terms_n >= 3:
+        terms.append({"diag": eng.to_device(d3)})
+    x = eng.to_device(x0)
+    eng.tridiag_gibbs_truncated(n, terms, x, lower=eng.to_device(lower), upper=eng.to_device(upper), u=eng.to_device(u),
+                                rhs_chain=eng.to_device(rc))
+    eng.check_status()
+    got = x.cpu().numpy()
+    worst = 0.0
+    for c in range(0, C, max(1, C // 7)):
+        diag = lam[c] * d1 + (tau[c] if terms_n >= 2 else 0.0) + (d3 if terms_n >= 3 else 0.0)
+        Q = np.diag(diag)
+        if n > 1:
+            Q += np.diag(lam[c] * o1, 1) + np.diag(lam[c] * o1, -1)
+        b = rc[c] + (tau[c] * y if terms_n >= 2 else 0.0)
+        ref = gmrf_ref.gibbs_truncated_scan(b, Q, x0[c], lower, upper, u[c]).ravel()
+        worst = max(worst, np.max(np.abs(got[c] - ref) / np.maximum(1e-3, np.abs(ref))))
+    assert worst < RTOL, worst
+    assert np.all(got >= lower) and np.all(got <= upper)
+    eng.close()
