@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(64) k_band_lane(int64_t C, int64_t chain_offse
 // hardware a load returns behind every older store (one in-order counter), which made a combined loop pay a store
 // acknowledgement per step.  Natural-order Cholesky throughout: the factor, u = L^-1 b and x = L^-T (u + z) are
 // k_band_lane's to rounding (the updates of a column are added in another order).
-#define BSEG_MAX 64
+#define BSEG_MAX 128
 template <int W, int PHASE>
 __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset, int64_t n, BandLaneArgs P, int nseg,
                                                  int64_t mseg, int ov, double tol, const double* z_in, int64_t ld_z,
@@ -930,8 +930,8 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
   const bool lane_fits = w >= 1 && w <= 8 && !rhs_chain && ctx->band_algo != 2 && band_lane_args(T, &LP);
   // Segmented route: about a thousand waves in all, segments of at least 128 columns and at least half the warm-up
   const int ov = ctx->band_seg_overlap;
-  int64_t min_seg = ov / 2 > 128 ? ov / 2 : 128;
-  int nseg = (int)(1024 / groups);
+  int64_t min_seg = ov / 2 > 96 ? ov / 2 : 96;
+  int nseg = (int)(2048 / groups);
   if (nseg > BSEG_MAX) nseg = BSEG_MAX;
   if ((int64_t)nseg * min_seg > n) nseg = (int)(n / min_seg);
   const bool segmented = lane_fits && w <= 3 && nseg >= 2 && ctx->band_algo != 1;
