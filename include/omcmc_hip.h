@@ -92,8 +92,9 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value);
 /* Diagnostic counters, by name (synchronises): "tridiag_join_fallbacks" = chain-updates of the segmented
  * tridiagonal kernel whose pivot joins did not meet the Newton tolerance within its iteration limit and were
  * made consistent by the sequential recurrence instead (same pivots as the serial kernel; slow, rare);
- * "band_join_fallbacks" = groups of 64 chains of the segmented narrow-band route whose segment joins did not close
- * within the warm-up and were factorised in one piece instead; "run_handoff_timeouts".                          */
+ * "band_join_retries" = groups of 64 chains of the segmented narrow-band route whose segment joins did not close
+ * within the warm-up and were redone with four times the warm-up; "band_join_fallbacks" = those that did not close
+ * then either and were factorised in one piece instead; "run_handoff_timeouts".                                 */
 omc_status omc_ctx_counter(omc_ctx* ctx, const char* name, int64_t* value);
 const char* omc_last_error(void);          /* [host] text of the last HIP failure, thread-local */
 int32_t omc_abi_version(void);

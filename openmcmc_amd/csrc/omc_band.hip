@@ -470,7 +470,7 @@ template <int W, int PHASE>
 __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset, int64_t n, BandLaneArgs P, int nseg,
                                                  int64_t mseg, int ov, double tol, const double* z_in, int64_t ld_z,
                                                  omc_rng_key key, double* Lws, double* Xws, double* Mws, double* scratch,
-                                                 int* group_flag, double* logdet, long long* bad,
+                                                 const int* gate, int* group_flag, double* logdet, long long* bad,
                                                  unsigned long long* n_fallback) {
   constexpr int W1 = W + 1;
   constexpr int NJ = W * (W + 1) / 2;  // window entries that carry eliminated columns' updates: A[b][d] with b + d < W
@@ -481,6 +481,9 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
   __shared__ double stage_all[2 * (W1 + OMC_MAX_TERMS) * 64];
   const int lane = threadIdx.x, seg = blockIdx.x;
   const int64_t grp = blockIdx.y;
+  // second attempt with a longer warm-up: only the groups whose joins did not close the first time (gate is what the
+  // first attempt's PHASE 1 left; this attempt's PHASE 1 writes its verdict elsewhere, so the gate is stable for a launch)
+  if (PHASE != 2 && gate && !gate[grp]) return;
   const int64_t c0 = grp * 64;
   const int64_t c = c0 + lane;
   const bool live = c < C;
@@ -681,7 +684,7 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
     if (__builtin_amdgcn_readfirstlane((int)(__ballot(chain_bad) != 0ull))) {
       if (PHASE == 1 && seg == 0 && lane == 0) {
         group_flag[grp] = 1;
-        atomicAdd(n_fallback, 1ull);
+        atomicAdd(n_fallback, 1ull);  // first attempt: a retry; second attempt: a group handed to k_band_lane
       }
       return;
     }
@@ -937,7 +940,7 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
   const bool segmented = lane_fits && w <= 3 && nseg >= 2 && ctx->band_algo != 1;
   // factor, then per column the zero-state u and its w unit responses (segmented route) / u alone
   const size_t base_doubles = (size_t)Cn * n * (segmented ? 2 * (w + 1) : (w + 2));
-  const size_t seg_doubles = segmented ? 2 * (size_t)Cn * n + (size_t)groups * nseg * 48 * 64 + (size_t)groups : 0;
+  const size_t seg_doubles = segmented ? 2 * (size_t)Cn * n + (size_t)groups * nseg * 48 * 64 + 2 * (size_t)groups : 0;
   omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->workspace, &ctx->workspace_bytes, (base_doubles + seg_doubles) * sizeof(double));
   if (st != OMC_OK) return st;
   if (segmented) {
@@ -951,13 +954,26 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
     const omc_rng_key lane_key = omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL);
     const double tol = 1e-13;
     const dim3 sg((unsigned)nseg, (unsigned)groups);
-#define OMC_BSEG(Wv, PH)                                                                                                          \
-  hipLaunchKernelGGL((k_band_seg<Wv, PH>), sg, dim3(64), 0, ctx->stream, Cn, ctx->chain_offset, n, LP, nseg, mseg, ov, tol,       \
-                     z_inject, ld_z, lane_key, Lws, Xws, Mws, scratch, flags, logdet, ctx->d_bad_chain, ctx->d_fallbacks + 2)
-    if (w == 1) { OMC_BSEG(1, 0); OMC_BSEG(1, 1); OMC_BSEG(1, 2); }
-    else if (w == 2) { OMC_BSEG(2, 0); OMC_BSEG(2, 1); OMC_BSEG(2, 2); }
-    else { OMC_BSEG(3, 0); OMC_BSEG(3, 1); OMC_BSEG(3, 2); }
+    // flags: [0..groups) verdict of the first attempt (gate of the second), [groups..2 groups) final verdict
+    int* flag1 = flags;
+    int* flag2 = flags + groups;
+    const int ov2 = 4 * ov;  // second attempt for the groups whose joins did not close (a long-memory prior): 4 x the warm-up
+#define OMC_BSEG(Wv, PH, OV, GATE, FLAG, CNT)                                                                                     \
+  hipLaunchKernelGGL((k_band_seg<Wv, PH>), sg, dim3(64), 0, ctx->stream, Cn, ctx->chain_offset, n, LP, nseg, mseg, OV, tol,       \
+                     z_inject, ld_z, lane_key, Lws, Xws, Mws, scratch, (const int*)(GATE), FLAG, logdet, ctx->d_bad_chain, CNT)
+#define OMC_BSEG_ALL(Wv)                                                                                                          \
+  do {                                                                                                                            \
+    OMC_BSEG(Wv, 0, ov, nullptr, flag1, ctx->d_fallbacks + 3);                                                                    \
+    OMC_BSEG(Wv, 1, ov, nullptr, flag1, ctx->d_fallbacks + 3);                                                                    \
+    hipMemcpyAsync(flag2, flag1, (size_t)groups * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);                             \
+    OMC_BSEG(Wv, 0, ov2, flag1, flag2, ctx->d_fallbacks + 2);                                                                     \
+    OMC_BSEG(Wv, 1, ov2, flag1, flag2, ctx->d_fallbacks + 2);                                                                     \
+    OMC_BSEG(Wv, 2, ov, nullptr, flag2, ctx->d_fallbacks + 2);                                                                    \
+  } while (0)
+    if (w == 1) OMC_BSEG_ALL(1); else if (w == 2) OMC_BSEG_ALL(2); else OMC_BSEG_ALL(3);
+#undef OMC_BSEG_ALL
 #undef OMC_BSEG
+    flags = flag2;
     const dim3 tg((unsigned)((n + 63) / 64), (unsigned)groups);
     hipLaunchKernelGGL(k_band_transpose, tg, dim3(256), 0, ctx->stream, Cn, n, Xws, x, ld_x, flags);
     if (mean) hipLaunchKernelGGL(k_band_transpose, tg, dim3(256), 0, ctx->stream, Cn, n, Mws, mean, ld_mean, flags);

@@ -64,10 +64,10 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
     c->stream = (hipStream_t)stream;
   }
   c->d_handoff = nullptr; c->run_epoch = 1; c->run_sweeps_per_launch = 32; c->run_reenter = 1;
-  hipError_t e = hipMalloc(&c->d_bad_chain, 4 * sizeof(long long));
+  hipError_t e = hipMalloc(&c->d_bad_chain, 8 * sizeof(long long));
   if (e != hipSuccess) { omc_set_error("hipMalloc", e); delete c; return OMC_HIP_ERROR; }
   c->d_fallbacks = (unsigned long long*)(c->d_bad_chain + 1);
-  long long init[4] = {OMC_NO_BAD_CHAIN, 0, 0, 0};
+  long long init[8] = {OMC_NO_BAD_CHAIN, 0, 0, 0, 0, 0, 0, 0};
   e = hipMemcpy(c->d_bad_chain, init, sizeof(init), hipMemcpyHostToDevice);
   if (e != hipSuccess) { omc_set_error("hipMemcpy", e); hipFree(c->d_bad_chain); delete c; return OMC_HIP_ERROR; }
   *out = c;
@@ -132,6 +132,13 @@ omc_status omc_ctx_counter(omc_ctx* ctx, const char* name, int64_t* value) {
   if (!strcmp(name, "run_handoff_timeouts")) {
     unsigned long long v = 0;
     OMC_HIP_CHECK(hipMemcpyAsync(&v, ctx->d_fallbacks + 1, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *value = (int64_t)v;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "band_join_retries")) {
+    unsigned long long v = 0;
+    OMC_HIP_CHECK(hipMemcpyAsync(&v, ctx->d_fallbacks + 3, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
     OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     *value = (int64_t)v;
     return OMC_OK;

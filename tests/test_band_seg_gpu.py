@@ -21,7 +21,7 @@ def rw_band(n, order, ridge=1e-3):
     return P, band
 
 
-def draw(n, C, order, lam, tau, algo, overlap=None, inject=True, seed=0, want_mean=True):
+def draw(n, C, order, lam, tau, algo, overlap=None, inject=True, seed=0, want_mean=True, ridge=1e-3):
     from openmcmc_amd.engine import Engine
 
     rng = np.random.default_rng(seed)
@@ -29,7 +29,7 @@ def draw(n, C, order, lam, tau, algo, overlap=None, inject=True, seed=0, want_me
     eng.set_option("band_algo", algo)
     if overlap is not None:
         eng.set_option("band_seg_overlap", overlap)
-    P, band = rw_band(n, order)
+    P, band = rw_band(n, order, ridge)
     t = np.arange(n) * 60.0 / n
     y = np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + rng.standard_normal(n)
     lam_c = lam * (0.5 + rng.random(C))
@@ -73,17 +73,30 @@ def test_segmented_band_draw_against_dense_numpy():
         assert abs(ld[c] - 2 * np.log(np.diag(L)).sum()) < 1e-8 * abs(ld[c])
 
 
-def test_joins_that_do_not_close_fall_back_to_one_piece():
-    """A likelihood 1e-9 times weaker than the prior: the pivots remember their start for far longer than the warm-up.
-    The join test must notice and the workgroup redo its chains in one piece -- same numbers as band_algo = 1."""
+def test_joins_that_do_not_close_are_retried_then_fall_back():
+    """Long-memory priors: with lam / tau = 1e4 the pivots remember their start beyond the default warm-up but not beyond
+    four times it -- the second attempt closes the joins; a likelihood 1e-9 times weaker than the prior (and next to no ridge) defeats
+    that too and the group is factorised in one piece.  Either way the numbers are band_algo = 1's."""
+    from openmcmc_amd.engine import Engine
+
     n, C, order = 6000, 64, 2
-    xs, ms, ls, fb, _ = draw(n, C, order, 1e5, 1e-4, 0, overlap=64)
-    x1, m1, l1, _, _ = draw(n, C, order, 1e5, 1e-4, 1)
-    assert fb >= 1
-    # (the one-piece run of the segmented kernel adds a column's updates in another order than k_band_lane: rounding)
-    scale = np.abs(x1).max()
-    assert np.abs(xs - x1).max() < 1e-9 * scale and np.abs(ms - m1).max() < 1e-9 * scale
-    assert np.abs(ls - l1).max() < 1e-9 * np.abs(l1).max()
+    for lam, tau, overlap, ridge, want_fallback in ((1e4, 1.0, 64, 1e-3, False), (1e5, 1e-4, 64, 1e-10, True)):
+        xs, ms, ls, fb, _ = draw(n, C, order, lam, tau, 0, overlap=overlap, ridge=ridge)
+        x1, m1, l1, _, _ = draw(n, C, order, lam, tau, 1, ridge=ridge)
+        assert (fb >= 1) == want_fallback, (lam, tau, fb)
+        scale = np.abs(x1).max()
+        assert np.abs(xs - x1).max() < 1e-9 * scale and np.abs(ms - m1).max() < 1e-9 * scale
+        assert np.abs(ls - l1).max() < 1e-9 * np.abs(l1).max()
+    # the retry counter moves when the first attempt fails
+    eng = Engine(C, seed=4)
+    eng.set_option("band_seg_overlap", 64)
+    P, band = rw_band(n, order)
+    terms = [{"band": eng.to_device(band), "scale": eng.full((C,), 1e4)}, {"rhs": eng.to_device(np.ones(n)), "scale": eng.full((C,), 1.0)}]
+    x = eng.empty(C, n)
+    eng.band_sample_canonical(n, eng.band_terms(terms, n), x, draw_index=1)
+    eng.check_status()
+    assert eng.counter("band_join_retries") >= 1 and eng.counter("band_join_fallbacks") == 0
+    eng.close()
 
 
 def test_without_mean_output():
