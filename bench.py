@@ -213,7 +213,7 @@ def main():
     ap.add_argument("--seg", type=int, default=0, help="nodes per lane of the segmented kernel (0 = auto)")
     ap.add_argument("--mala-products", action="store_true",
                     help="cfg4: the step as dense products (omc_mala_step) instead of the whitened step")
-    ap.add_argument("--reenter", type=int, default=None, choices=[0, 1],
+    ap.add_argument("--reenter", type=int, default=None, choices=[0, 1, 2],
                     help="omc_gmrf_run: 1 = workgroups restart themselves for the next sweep of a launch (default: the library's)")
     ap.add_argument("--sweeps-per-launch", type=int, default=0, help="omc_gmrf_run: sweeps per launch (0 = library default, 32)")
     args = ap.parse_args()

@@ -194,7 +194,8 @@ __device__ __forceinline__ double sweep_gamma_draws_wave(const TriArgs& A, int64
 }
 
 __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c, double q0, double q1, double q2, double q3,
-                                                    double s_old, double ldet, double gd, bool failed, int lane, int sw = 0) {
+                                                    double s_old, double ldet, double gd, bool failed, int lane, int sw = 0,
+                                                    unsigned long long* lds_hand = nullptr) {
   const int k = lane >> 4, j = lane & 15;
   const bool term_on = k < A.T.n_terms;
   // per-lane copy of this lane's term, selected with compile-time indices (a dynamically indexed
@@ -224,6 +225,10 @@ __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c,
         const unsigned long long hi = ((unsigned long long)tag << 32) | (uint32_t)__double2hiint(s);
         __hip_atomic_store(h, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(h + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lds_hand) {  // self-restarting workgroup: the consumer is this workgroup -- the same granules through LDS
+          __hip_atomic_store(lds_hand + 2 * k, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(lds_hand + 2 * k + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
     }
   }
@@ -1019,6 +1024,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   __shared__ double lds_tile[NWMAX][64 * (M + 1) + 2];  // + the successor slot of the last row (quad_wg)
   __shared__ Mob lds_mob[16], lds_mob2[16];
   __shared__ double lds_g[64];     // wave 0's Normal-Gamma standard draws, start of kernel -> epilogue
+  __shared__ unsigned long long lds_hand[2 * OMC_MAX_TERMS];  // self-restarting workgroups: the scales from sweep to sweep
   __shared__ Aff lds_aff[4][16];   // scans alternate buffers instead of paying a trailing barrier
   __shared__ double lds_x[2][32];  // neighbour exchange of the Newton passes (alternating)
   __shared__ double lds_d[6][16];  // reductions: one slot per call site
@@ -1066,6 +1072,14 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // the chain (written by the workgroup of the previous sweep, possibly on another XCD); the loads are issued here
   // and examined where the scales are first needed (`take_scales`), behind the first pair of draws.
   const bool handed = MULTI && sw > 0;
+  // a self-restarting workgroup takes them from its own LDS (written by its wave 0 a moment ago: a poll there costs a
+  // hundred cycles, a poll of the global line a trip to L2)
+  const bool hand_lds = SIG == 1 && A.reenter != 0;
+  // LDS comes as the previous workgroup on this CU left it -- possibly this very kernel under another context, whose
+  // tags count from 1 like ours: the launch's first sweep wipes the granules (tag 0 is never waited for) long before
+  // its epilogue writes them and the second sweep looks
+  if (hand_lds && sw == 0 && threadIdx.x < 2 * OMC_MAX_TERMS)
+    __hip_atomic_store(lds_hand + threadIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   unsigned long long hw[2 * OMC_MAX_TERMS];
 #pragma unroll
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
@@ -1073,9 +1087,11 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     hw[2 * k] = hw[2 * k + 1] = 0ull;
     if (k < nt && A.T.scale[k]) {
       if (handed && A.gb[k].enabled) {
-        const unsigned long long* h = A.handoff + cc * OMC_HANDOFF_WORDS + 2 * k;
-        hw[2 * k] = __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        hw[2 * k + 1] = __hip_atomic_load(h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!hand_lds) {  // (the LDS granules are read where they are needed: a read there costs nothing worth hiding)
+          const unsigned long long* h = A.handoff + cc * OMC_HANDOFF_WORDS + 2 * k;
+          hw[2 * k] = __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hw[2 * k + 1] = __hip_atomic_load(h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       } else {
         sc[k] = A.T.scale[k][cc];
       }
@@ -1084,27 +1100,50 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   auto take_scales = [&]() {
     if (!handed) return;
     const uint32_t want = A.epoch + (uint32_t)sw;
-    // In-order dispatch puts the producer (a lower block index) on the chip first, so this loop normally never
-    // turns; it is bounded all the same (about a second), and a hand-over that never comes is reported.
-    for (int spin = 0;; ++spin) {
+    auto tags_ok = [&]() {
       bool ok = true;
 #pragma unroll
       for (int k = 0; k < OMC_MAX_TERMS; ++k)
         if (k < nt && A.T.scale[k] && A.gb[k].enabled)
           ok = ok && (uint32_t)(hw[2 * k] >> 32) == want && (uint32_t)(hw[2 * k + 1] >> 32) == want;
-      if (__builtin_amdgcn_readfirstlane((int)ok)) break;  // every lane loaded the same words
-      if (spin >= (1 << 19)) {
-        if (threadIdx.x == 0 && chain_ok) atomicAdd(A.timeouts, 1ull);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(64);
+      return __builtin_amdgcn_readfirstlane((int)ok) != 0;  // every lane loaded the same words
+    };
+    if (hand_lds) {
+      // The producer is this workgroup's wave 0, still in the previous sweep's epilogue if this wave is ahead of it: a
+      // loop of LDS reads only (no vector-memory wait in it: the previous sweep's x stores are still draining).
+      // Bounded; a hand-over that never comes is reported.
+      for (int spin = 0;; ++spin) {
 #pragma unroll
-      for (int k = 0; k < OMC_MAX_TERMS; ++k)
-        if (k < nt && A.T.scale[k] && A.gb[k].enabled) {
-          const unsigned long long* h = A.handoff + cc * OMC_HANDOFF_WORDS + 2 * k;
-          hw[2 * k] = __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          hw[2 * k + 1] = __hip_atomic_load(h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < OMC_MAX_TERMS; ++k)
+          if (k < nt && A.T.scale[k] && A.gb[k].enabled) {
+            hw[2 * k] = __hip_atomic_load(lds_hand + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            hw[2 * k + 1] = __hip_atomic_load(lds_hand + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        if (tags_ok()) break;
+        if (spin >= (1 << 22)) {
+          if (threadIdx.x == 0 && chain_ok) atomicAdd(A.timeouts, 1ull);
+          break;
         }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    } else {
+      // In-order dispatch puts the producer (a lower block index) on the chip first, so this loop normally never
+      // turns; it is bounded all the same (about a second), and a hand-over that never comes is reported.
+      for (int spin = 0;; ++spin) {
+        if (tags_ok()) break;
+        if (spin >= (1 << 19)) {
+          if (threadIdx.x == 0 && chain_ok) atomicAdd(A.timeouts, 1ull);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(64);
+#pragma unroll
+        for (int k = 0; k < OMC_MAX_TERMS; ++k)
+          if (k < nt && A.T.scale[k] && A.gb[k].enabled) {
+            const unsigned long long* h = A.handoff + cc * OMC_HANDOFF_WORDS + 2 * k;
+            hw[2 * k] = __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hw[2 * k + 1] = __hip_atomic_load(h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+      }
     }
 #pragma unroll
     for (int k = 0; k < OMC_MAX_TERMS; ++k)
@@ -1676,7 +1715,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   if (MULTI) {
     if (epi_wave && chain_ok) {
       const double g = lds_g[lane];
-      sweep_epilogue_wave(A, c, qsum[0], qsum[1], qsum[2], qsum[3], my_scale, my_logdet, fabs(g), g < 0.0, lane, sw);
+      sweep_epilogue_wave(A, c, qsum[0], qsum[1], qsum[2], qsum[3], my_scale, my_logdet, fabs(g), g < 0.0, lane, sw,
+                          (SIG == 1 && A.reenter) ? lds_hand : nullptr);
     }
     // x leaves last: a load issued behind a store would have to wait for the store to be
     // acknowledged (vmcnt retires in order); this way nothing ever waits on the x stream.
@@ -1710,7 +1750,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     // buys over a fresh workgroup: the x stores of this sweep drain under the next sweep's loads and draws instead of
     // holding the CU until they are acknowledged, and there is no dispatch gap between the sweeps of a chain.
     // (vmcnt is not zero on re-entry -- the waits of the next sweep only become conservative.)
-    lds_barrier();  // every wave is done with this sweep's LDS image
+    if (A.reenter != 2) lds_barrier();  // every wave is done with this sweep's LDS image (2: see DESIGN, no barrier)
     const uint64_t kptr = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
     const uint64_t kargs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kptr) |
                            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(kptr >> 32)) << 32);

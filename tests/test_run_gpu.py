@@ -62,7 +62,7 @@ def test_sweeps_per_launch_do_not_change_a_bit(n, C, generic):
 def test_self_restarting_workgroups_do_not_change_a_bit(n, C):
     """run_reenter: the grid is one workgroup per chain and each restarts itself as its chain's next sweep."""
     ref = run(n, C, 1, 3, 9, 2, reenter=0)
-    for per, reenter in ((32, 1), (5, 1), (32, 0)):  # (32, 0): one workgroup per (sweep, chain), the other form
+    for per, reenter in ((32, 1), (5, 1), (32, 0), (32, 2), (7, 2)):  # 0: one workgroup per (sweep, chain); 2: no barrier before the restart
         got = run(n, C, per, 3, 9, 2, reenter=reenter)
         for a, b in zip(ref, got):
             assert np.array_equal(a, b, equal_nan=True)
