@@ -142,6 +142,32 @@ __device__ __forceinline__ double read_lane_d(double v, int l) {  // l wave-unif
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
+// log-posterior of one sweep from the per-term scales, quadratic forms and log-determinants: lanes 16 k (k = term)
+// hold s, qk, ldet of their term; lane 0 stores the sum (model.py:57-70 -> gmrf.py:321-348, distribution.py:241-261).
+// Split from the epilogue so that a self-restarting workgroup can leave it to a wave that has slack (see the kernel).
+__device__ __forceinline__ void sweep_log_post_wave(const TriArgs& A, int64_t c, int lane, double s, double qk, double ldet,
+                                                    double* lp_out) {
+  const int k = lane >> 4, j = lane & 15;
+  const bool term_on = k < A.T.n_terms;
+  GammaDev g = A.gb[0];
+#pragma unroll
+  for (int t = 1; t < OMC_MAX_TERMS; ++t) {
+    if (k == t) g = A.gb[t];
+  }
+  double lp = 0.0;
+  if (term_on && j == 0) {
+    const double nd = (double)A.n;
+    // the lean fdlibm log kernel (< 1 ulp) for finite positive scales, the library's log for the rest (zero-rate guard:
+    // scale = inf)
+    const double ls = (s > 0.0 && s < INFINITY) ? omc_log_unit(s) : log(s);
+    lp = 0.5 * (nd * ls + ldet - nd * 1.8378770664093453 - s * qk);
+    if (g.enabled) lp += g.lnorm + (g.a0 - 1.0) * ls - g.b0 * s;
+  }
+  // terms are summed in order 0,1,2,3 as the serial epilogue does
+  const double t0 = read_lane_d(lp, 0), t1 = read_lane_d(lp, 16), t2 = read_lane_d(lp, 32), t3 = read_lane_d(lp, 48);
+  if (lane == 0) lp_out[c] = ((t0 + t1) + t2) + t3;
+}
+
 // The same epilogue spread over the 64 lanes of one wave (the workgroup-per-chain kernel runs it on
 // wave 0 while the other waves are already storing x): lanes 16k..16k+15 belong to term k and each
 // evaluates one Marsaglia-Tsang attempt; the lowest accepted attempt is the serial answer.
@@ -195,7 +221,8 @@ __device__ __forceinline__ double sweep_gamma_draws_wave(const TriArgs& A, int64
 
 __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c, double q0, double q1, double q2, double q3,
                                                     double s_old, double ldet, double gd, bool failed, int lane, int sw = 0,
-                                                    unsigned long long* lds_hand = nullptr) {
+                                                    unsigned long long* lds_hand = nullptr, bool defer_lp = false,
+                                                    double* lds_q = nullptr) {
   const int k = lane >> 4, j = lane & 15;
   const bool term_on = k < A.T.n_terms;
   // per-lane copy of this lane's term, selected with compile-time indices (a dynamically indexed
@@ -209,6 +236,9 @@ __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c,
   const double qk = (k == 0) ? q0 : ((k == 1) ? q1 : ((k == 2) ? q2 : q3));
   if (!term_on) s = 1.0;
   double* const lp_out = sweep_log_post(A, sw);
+  // deferred log-posterior: the quadratic forms go to LDS ahead of the scale granules (one wave's LDS writes land in
+  // order: whoever has seen the granules finds these)
+  if (lp_out && defer_lp && term_on && j == 0) __hip_atomic_store(lds_q + k, qk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (term_on && g.enabled) {
     const double b = g.b0 + 0.5 * qk;
     s = gd * ((b == 0.0) ? INFINITY : omc_rcp_nr(b));  // sampler.py:285-287
@@ -232,20 +262,7 @@ __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c,
       }
     }
   }
-  if (lp_out) {
-    double lp = 0.0;
-    if (term_on && j == 0) {
-      const double nd = (double)A.n;
-      // this is the serial tail of the workgroup (fifteen waves are done): the lean fdlibm log kernel (< 1 ulp) for
-      // finite positive scales, the library's log for the rest (zero-rate guard: scale = inf)
-      const double ls = (s > 0.0 && s < INFINITY) ? omc_log_unit(s) : log(s);
-      lp = 0.5 * (nd * ls + ldet - nd * 1.8378770664093453 - s * qk);
-      if (g.enabled) lp += g.lnorm + (g.a0 - 1.0) * ls - g.b0 * s;
-    }
-    // terms are summed in order 0,1,2,3 as the serial epilogue does
-    const double t0 = read_lane_d(lp, 0), t1 = read_lane_d(lp, 16), t2 = read_lane_d(lp, 32), t3 = read_lane_d(lp, 48);
-    if (lane == 0) lp_out[c] = ((t0 + t1) + t2) + t3;
-  }
+  if (lp_out && !defer_lp) sweep_log_post_wave(A, c, lane, s, qk, ldet, lp_out);
   if (failed) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
 }
 
@@ -1025,6 +1042,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   __shared__ Mob lds_mob[16], lds_mob2[16];
   __shared__ double lds_g[64];     // wave 0's Normal-Gamma standard draws, start of kernel -> epilogue
   __shared__ unsigned long long lds_hand[2 * OMC_MAX_TERMS];  // self-restarting workgroups: the scales from sweep to sweep
+  __shared__ double lds_q[OMC_MAX_TERMS];  // ... and the quadratic forms of the sweep whose log-posterior is finished by the next
   __shared__ Aff lds_aff[4][16];   // scans alternate buffers instead of paying a trailing barrier
   __shared__ double lds_x[2][32];  // neighbour exchange of the Newton passes (alternating)
   __shared__ double lds_d[6][16];  // reductions: one slot per call site
@@ -1097,6 +1115,14 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       }
     }
   }
+  // is there a scale that travels from sweep to sweep at all (then waiting for it orders everything else its producer
+  // wrote to LDS before it)?
+  auto any_handed_f = [&]() {  // (recomputed from the kernel arguments where it is asked: nothing to keep live)
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < OMC_MAX_TERMS; ++k) any |= (k < nt && A.T.scale[k] && A.gb[k].enabled);
+    return any;
+  };
   auto take_scales = [&]() {
     if (!handed) return;
     const uint32_t want = A.epoch + (uint32_t)sw;
@@ -1211,6 +1237,19 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       const double bm1_raw = vPo[(i0 > 0 && i0 < n) ? i0 - 1 : 0];
       vec_and_draws(po, vPo + wbase, nvo, 0);
       take_scales();
+      if (SIG == 1 && A.reenter == 2 && handed && wave_u == 1 && chain_ok && any_handed_f()) {
+        // the previous sweep's log-posterior, left here by its epilogue (scales: just taken; quadratic forms: LDS)
+        double* const lp_prev = A.rec[sw - 1].log_post;
+        if (lp_prev) {
+          const int k = lane >> 4;
+          const double sk = (k == 0) ? sc[0] : ((k == 1) ? sc[1] : ((k == 2) ? sc[2] : sc[3]));
+          const double qk = (k < nt) ? __hip_atomic_load(lds_q + (k < nt ? k : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0.0;
+          double ldk = 0.0;
+          _Pragma("unroll") for (int t = 0; t < OMC_MAX_TERMS; ++t)
+            if (t < nt && k == t && A.gb[t].logdet_unscaled) ldk = A.gb[t].logdet_unscaled[0];
+          sweep_log_post_wave(A, c, lane, (k < nt) ? sk : 1.0, qk, ldk, lp_prev);
+        }
+      }
       sP = p_first ? sc[0] : sc[1];
       sI = p_first ? sc[1] : sc[0];
       wave_lds_fence();
@@ -1715,8 +1754,11 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   if (MULTI) {
     if (epi_wave && chain_ok) {
       const double g = lds_g[lane];
+      // restart without a barrier: the log-posterior of this sweep is left to wave 1 of the next one (it has the slack
+      // this wave does not: everyone waits for the wave that ran the epilogue at the next sweep's first barrier)
+      const bool defer_lp = SIG == 1 && A.reenter == 2 && sw + 1 < A.n_sweeps && nw > 1 && any_handed_f();
       sweep_epilogue_wave(A, c, qsum[0], qsum[1], qsum[2], qsum[3], my_scale, my_logdet, fabs(g), g < 0.0, lane, sw,
-                          (SIG == 1 && A.reenter) ? lds_hand : nullptr);
+                          (SIG == 1 && A.reenter) ? lds_hand : nullptr, defer_lp, lds_q);
     }
     // x leaves last: a load issued behind a store would have to wait for the store to be
     // acknowledged (vmcnt retires in order); this way nothing ever waits on the x stream.
