@@ -85,7 +85,9 @@ omc_status omc_ctx_synchronize(omc_ctx* ctx);
  * "tridiag_perturb_ppb" (tests: relative error, in 1e-9, put on the segments' start pivots so that the join test must
  * reject them), "run_sweeps_per_launch" (1..32, default 32: sweeps omc_gmrf_run issues per launch), "run_reenter" (0..2, default 2:
  * within such a launch a chain's workgroup restarts itself for the next sweep instead of one workgroup per sweep and chain;
- * 2: without a barrier in front of the restart, the scales handed from sweep to sweep through LDS),
+ * 2: without a barrier in front of the restart, the scales handed from sweep to sweep through LDS; by default the
+ * restarting form is taken when the chains fill the CUs in whole rounds and the (sweep, chain) grid otherwise, an
+ * explicit setting holds for every chain count),
  * "band_algo" (0 auto; 1 narrow bands one lane per chain in ONE piece; 2 one workgroup per chain), "band_seg_overlap"
  * (8..65536, default 192: columns of warm-up before a segment of the segmented narrow-band route).
  * Unknown name -> OMC_INVALID_ARG.                                                            */
