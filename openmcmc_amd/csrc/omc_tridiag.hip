@@ -89,7 +89,8 @@ struct TriArgs {
   double* log_post;
   // several sweeps per launch (n_sweeps > 0; workgroup-per-chain form only)
   int n_sweeps;
-  int reenter;                     // 1: the grid is C workgroups and each restarts itself as its chain's next sweep
+  int reenter;                     // 1, 2: the grid is C workgroups and each restarts itself as its chain's next sweep
+  int early_draws;                 // 1: all buffered pairs of draws are made before the scales are waited for (see the kernel)
   uint32_t epoch;                  // tag of sweep 0's inputs + 1 = tag its outputs carry; unique per context over launches
   uint64_t seed;
   uint64_t gdraw[OMC_MAX_TERMS];   // Gamma stream of term k = sweep's draw index + gdraw[k]
@@ -1212,6 +1213,23 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   const bool park_diag = OMC_PARK_DIAG && SIG == 1 && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n) == 64 * M &&
                          (reinterpret_cast<uintptr_t>(vPd) & 15u) == 0;
 
+  // Fewer chains than CUs ((sweep, chain) grid): this workgroup has been placed on an idle CU while the chain's previous
+  // sweep is still running elsewhere, and all it can do until that sweep's scales arrive is what does not depend on them --
+  // the loads and the draws.  Then ALL buffered pairs are made up here (nothing else is live yet), not spread over the
+  // phases behind the hand-over where they would sit on the chain's critical path from sweep to sweep.
+  const bool early = SIG == 1 && gen_z && A.early_draws != 0;
+  const bool gen_late = gen_z && !early;
+  if constexpr (SIG == 1) {
+    if (early) {
+#pragma unroll
+      for (int jb = 0; jb < NZB; ++jb) {
+        double z0, z1;
+        omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + (uint32_t)jb), z0, z1);
+        lds_z[wave][2 * jb][lane] = z0;
+        lds_z[wave][2 * jb + 1][lane] = z1;
+      }
+    }
+  }
   // ---- conditional precision: b -> Y (registers), a -> LDS tile ----
   double bm1 = 0.0;  // coupling b_{i0-1} into the segment
   double pre[M];  // SIG 1: the right-hand side vector
@@ -1220,7 +1238,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     const int nv = wave_valid<M>(wave_u, (int)n), nvo = wave_valid<M>(wave_u, (int)n - 1);
     // one vector (20 registers) in flight beside the generation of one pair of draws: more than that spills
     auto vec_and_draws = [&](double (&v)[M], const double* base, int nvalid, int jb) {
-      if (gen_z && jb < NZB) {
+      if (gen_late && jb < NZB) {
         double z0, z1;
         if (nvalid == 64 * M) draws_over_load<M, true>(nkey_f(), gc, blk0 + (uint32_t)jb, z0, z1, v, base, lane, nvalid);
         else draws_over_load<M, false>(nkey_f(), gc, blk0 + (uint32_t)jb, z0, z1, v, base, lane, nvalid);
@@ -1422,7 +1440,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     if (!with_offsets) {
       const int nvr = wave_valid<M>(wave_u, (int)n);
       const double* base = vIr + wave_u * 64 * M;
-      if (gen_z && NZB > 2) {
+      if (gen_late && NZB > 2) {
         double z0, z1;
         if (nvr == 64 * M) draws_over_load<M, true>(nkey_f(), gc, blk0 + 2u, z0, z1, pre, base, lane, nvr);
         else draws_over_load<M, false>(nkey_f(), gc, blk0 + 2u, z0, z1, pre, base, lane, nvr);
@@ -1433,7 +1451,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (gen_z) {
+    if (gen_late) {
 #pragma unroll
       for (int jb = 2; jb < NZB; ++jb) {
         if (jb == 2 && !with_offsets) continue;  // made under the load above
@@ -1921,7 +1939,7 @@ static void args_defaults(omc_ctx* ctx, TriArgs* A, int64_t n) {
   A->fused = 0;
   A->stamps = ctx->stamps;
   A->log_post = nullptr;
-  A->n_sweeps = 0; A->reenter = 0; A->epoch = 0; A->seed = ctx->seed; A->handoff = nullptr; A->timeouts = ctx->d_fallbacks + 1;
+  A->n_sweeps = 0; A->reenter = 0; A->early_draws = 0; A->epoch = 0; A->seed = ctx->seed; A->handoff = nullptr; A->timeouts = ctx->d_fallbacks + 1;
   for (int k = 0; k < OMC_MAX_TERMS; ++k) A->gdraw[k] = 0;
   for (int i = 0; i < OMC_RUN_MAX; ++i) { A->rec[i].draw = 0; A->rec[i].x = nullptr; A->rec[i].log_post = nullptr; A->rec[i].slot_off = -1; }
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
@@ -2180,6 +2198,7 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
         const int64_t rounds = (C + dev_cus - 1) / dev_cus;
         const bool whole_rounds = C >= dev_cus && (double)C >= 0.95 * (double)(rounds * dev_cus);
         A.reenter = (whole_rounds || ctx->run_reenter_force) ? ctx->run_reenter : 0;
+        A.early_draws = (A.reenter == 0 && 2 * C <= dev_cus) ? 1 : 0;  // a waiting workgroup per chain has a CU to itself
       }
       A.epoch = ctx->run_epoch;
       ctx->run_epoch += (uint32_t)k_sw;
