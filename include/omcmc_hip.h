@@ -279,6 +279,12 @@ omc_status omc_rw_step(omc_ctx* ctx, int64_t d, const double* mu, const double* 
                        double step, const double* z_inject, int64_t ld_z, const double* u_inject,
                        uint64_t draw_index, double* x, int64_t ld_x, int64_t* accept_count,
                        int64_t* proposal_count);
+/* The same random-walk step with a = L_Q'(x - mu) carried by the context (LQ = chol(Q)): a' = a + step L_Q' z,
+ * log p(x') - log p(x) = (|a|^2 - |a'|^2)/2 -- one triangular product per step instead of two; x' = x + step z is
+ * formed exactly as in omc_rw_step.  state_is_current as for omc_mala_step_white.                                  */
+omc_status omc_rw_step_white(omc_ctx* ctx, int64_t d, const double* mu, const double* LQ, const double* sumlogLQ, double step,
+                             const double* z_inject, int64_t ld_z, const double* u_inject, uint64_t draw_index, double* x,
+                             int64_t ld_x, int32_t state_is_current, int64_t* accept_count, int64_t* proposal_count);
 /* omc_mh_invalidate: drops the matrices cached for the last (Q, L, step) / LQ.  The cache is keyed by device
  * addresses; call this whenever Q, L or LQ were rewritten in place or re-created (a new buffer may land on a recycled
  * address).  The reference has nothing to invalidate: it refactorises every step (metropolis_hastings.py:345-346). */

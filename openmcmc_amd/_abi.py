@@ -101,6 +101,10 @@ SIGNATURES = {
     "omc_design_predict": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, i64, c_dp, i64]),
     "omc_weighted_resid_sq": (i32, [C.c_void_p, i64, c_dp, c_dp, i64, c_dp, c_dp]),
     "omc_dense_cholesky": (i32, [C.c_void_p, i64, c_dp, C.c_double, c_dp, c_dp]),
+    "omc_rw_step_white": (
+        i32,
+        [C.c_void_p, i64, c_dp, c_dp, c_dp, C.c_double, c_dp, i64, c_dp, u64, c_dp, i64, i32, c_dp, c_dp],
+    ),
     "omc_mala_step_white": (
         i32,
         [C.c_void_p, i64, c_dp, c_dp, c_dp, C.c_double, c_dp, i64, c_dp, u64, c_dp, i64, i32, c_dp, c_dp],

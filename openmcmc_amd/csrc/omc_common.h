@@ -34,6 +34,7 @@ struct omc_ctx {
   const double* mala_Q; const double* mala_L; double mala_step; int64_t mala_d;
   double* white_prep; size_t white_prep_bytes; const double* white_L; const double* white_mu; int64_t white_d;  // omc_mala_step_white
   double* white_a; size_t white_a_bytes; const double* white_x; int64_t white_ld;  // a = L'(x - mu) of the state at white_x
+  double* rww_a; size_t rww_a_bytes; const double* rww_x; int64_t rww_ld; const double* rww_mu; double* rww_mu_neg; size_t rww_mu_bytes;  // omc_rw_step_white
   double* rw_prep; size_t rw_prep_bytes; const double* rw_LQ; int64_t rw_d;  // omc_rw_step: LQ with a zero upper triangle
   int tridiag_algo;  // 0 auto, 1 serial, 2 segmented
   int tridiag_seg;   // 0 auto, else nodes per lane

@@ -256,6 +256,7 @@ omc_status omc_mh_invalidate(omc_ctx* ctx) {
   if (!ctx) return OMC_INVALID_ARG;
   ctx->mala_Q = nullptr; ctx->mala_L = nullptr; ctx->mala_step = 0.0; ctx->mala_d = 0;
   ctx->white_L = nullptr; ctx->white_mu = nullptr; ctx->white_d = 0; ctx->white_x = nullptr;
+  ctx->rww_x = nullptr; ctx->rww_mu = nullptr;
   ctx->rw_LQ = nullptr; ctx->rw_d = 0;
   return OMC_OK;
 }
@@ -518,6 +519,118 @@ omc_status omc_rw_step(omc_ctx* ctx, int64_t d, const double* mu, const double* 
                      (const double*)nullptr, (const double*)nullptr, w.XP, x, ld_x, (long long*)accept_count,
                      (long long*)proposal_count);
   OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+// ---- the random-walk step with the target's quadratic form carried in whitened coordinates -----------------------
+// a = L_Q'(x - mu) (L_Q = chol(Q)):  x' = x + step z  =>  a' = a + step L_Q' z, log p(x') - log p(x) = (|a|^2 - |a'|^2) / 2.
+// One triangular product per step (L_Q' z) instead of the two of omc_rw_step (L_Q'[x - mu | x' - mu]); x' itself is the
+// same two-rounding x + step z as there, so for equal decisions the states are bit-identical.
+__global__ void __launch_bounds__(256) k_rw_white(int64_t d, int64_t chain_offset, omc_rng_key ukey, const double* u_in,
+                                                  const double* sumlogL, double step, const double* z, const double* wz,
+                                                  double* a, double* x, int64_t ld_x, long long* acc_cnt, long long* prop_cnt) {
+  __shared__ double red[2][4];
+  __shared__ int accept;
+  const int64_t c = blockIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  for (int64_t i = threadIdx.x; i < d; i += 256) {
+    const double av = a[c * d + i];
+    const double ap = fma(step, wz[c * d + i], av);
+    s0 = fma(av, av, s0);
+    s1 = fma(ap, ap, s1);
+  }
+  for (int s = 32; s >= 1; s >>= 1) { s0 += __shfl_xor(s0, s, 64); s1 += __shfl_xor(s1, s, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // k_mh_finish's decision for the symmetric proposal
+    const double ss_cur = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double ss_prop = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double logdetQ = 2.0 * sumlogL[0], dnum = (double)d;
+    const double lp_cur = 0.5 * (logdetQ - dnum * 1.8378770664093453 - ss_cur);
+    const double lp_prop = 0.5 * (logdetQ - dnum * 1.8378770664093453 - ss_prop);
+    const double log_alpha = lp_prop - lp_cur;
+    double u;
+    if (u_in) {
+      u = u_in[c];
+    } else {
+      const uint4 w = omc_rng_block(ukey, chain_offset + c, 0u);
+      u = omc_u53(w.x, w.y);
+    }
+    const int ok = log(u) < log_alpha;
+    accept = ok;
+    if (prop_cnt) prop_cnt[c] += 1;
+    if (acc_cnt && ok) acc_cnt[c] += 1;
+  }
+  __syncthreads();
+  if (accept)
+    for (int64_t i = threadIdx.x; i < d; i += 256) {
+      a[c * d + i] = fma(step, wz[c * d + i], a[c * d + i]);
+      double pv;
+      {
+#pragma clang fp contract(off)
+        const double prod = z[c * d + i] * step;
+        pv = x[c * ld_x + i] + prod;
+      }
+      x[c * ld_x + i] = pv;
+    }
+}
+
+omc_status omc_rw_step_white(omc_ctx* ctx, int64_t d, const double* mu, const double* LQ, const double* sumlogLQ, double step,
+                             const double* z_inject, int64_t ld_z, const double* u_inject, uint64_t draw_index, double* x,
+                             int64_t ld_x, int32_t state_is_current, int64_t* accept_count, int64_t* proposal_count) {
+  if (!ctx || d < 1 || d > 46340 || !LQ || !sumlogLQ || !x || ld_x < d || (z_inject && ld_z < d) || !(step > 0.0))
+    return OMC_INVALID_ARG;
+  const int64_t C = ctx->n_chains;
+  if (C > 65535) return OMC_UNSUPPORTED;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  omc_status st = omc_ensure_blas(ctx);
+  if (st != OMC_OK) return st;
+  MhWork w;
+  st = mh_workspace(ctx, d, &w);
+  if (st != OMC_OK) return st;
+  hipStream_t s = ctx->stream;
+  bool fresh = false;
+  if (ctx->rw_LQ != LQ || ctx->rw_d != d || !ctx->rw_prep) {
+    st = omc_ensure_bytes(ctx, (void**)&ctx->rw_prep, &ctx->rw_prep_bytes, (size_t)2 * d * d * sizeof(double));
+    if (st != OMC_OK) return st;
+    hipLaunchKernelGGL(k_lower_copy, dim3(gx(d * d)), dim3(256), 0, s, d, LQ, ctx->rw_prep);
+    hipLaunchKernelGGL(k_lower_transpose, dim3(gx(d * d)), dim3(256), 0, s, d, LQ, ctx->rw_prep + d * d);
+    ctx->rw_LQ = LQ; ctx->rw_d = d;
+    fresh = true;
+  }
+  const double* Lt = ctx->rw_prep + d * d;
+  st = omc_ensure_bytes(ctx, (void**)&ctx->rww_mu_neg, &ctx->rww_mu_bytes, (size_t)2 * d * sizeof(double));
+  if (st != OMC_OK) return st;
+  double* negLtmu = nullptr;
+  if (mu) {  // -L_Q' mu, once per (L_Q, mu)
+    negLtmu = ctx->rww_mu_neg;
+    if (fresh || ctx->rww_mu != mu) {
+      hipLaunchKernelGGL(k_scale_copy, dim3(gx(d)), dim3(256), 0, s, d, mu, -1.0, ctx->rww_mu_neg + d);
+      st = omc_dgemm_small(ctx, (int)d, 1, Lt, d, ctx->rww_mu_neg + d, d, (int)d, nullptr, 0, nullptr, 0, 0, 1, nullptr, negLtmu, d);
+      if (st != OMC_OK) return st;
+      fresh = true;
+    }
+  }
+  if (ctx->rww_mu != mu) fresh = true;
+  ctx->rww_mu = mu;
+  st = omc_ensure_bytes(ctx, (void**)&ctx->rww_a, &ctx->rww_a_bytes, (size_t)C * d * sizeof(double));
+  if (st != OMC_OK) return st;
+  double* a = ctx->rww_a;
+  if (fresh || !(state_is_current && ctx->rww_x == x && ctx->rww_ld == ld_x)) {  // a = L_Q'(x - mu)
+    st = omc_dgemm_small(ctx, (int)d, (int)C, Lt, d, x, ld_x, (int)d, nullptr, 0, nullptr, 0, 0, 1, negLtmu, a, d);
+    if (st != OMC_OK) return st;
+  }
+  double* Z = w.V;
+  double* WZ = w.XP;
+  hipLaunchKernelGGL(k_draw_normals, dim3(gx((d + 1) / 2) > 8 ? 8 : gx((d + 1) / 2), (unsigned)C), dim3(256), 0, s, d,
+                     ctx->chain_offset, omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), z_inject, ld_z, Z, d);
+  st = omc_dgemm_small(ctx, (int)d, (int)C, Lt, d, Z, d, (int)d, nullptr, 0, nullptr, 0, 0, 1, nullptr, WZ, d);
+  if (st != OMC_OK) return st;
+  hipLaunchKernelGGL(k_rw_white, dim3((unsigned)C), dim3(256), 0, s, d, ctx->chain_offset,
+                     omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), u_inject, sumlogLQ, step, Z, WZ, a, x, ld_x,
+                     (long long*)accept_count, (long long*)proposal_count);
+  OMC_HIP_CHECK(hipGetLastError());
+  ctx->rww_x = x; ctx->rww_ld = ld_x;
   return OMC_OK;
 }
 

@@ -381,6 +381,15 @@ class Engine:
                               int(draw_index), self._p(x, self.n_chains, d), x.stride(0), self._ip(accept_count),
                               self._ip(proposal_count)))
 
+    def rw_step_white(self, mu, LQ, sumlogLQ, step, x, state_is_current=False, z=None, u=None, draw_index=0,
+                      accept_count=None, proposal_count=None):
+        """omc_rw_step_white: the fused random-walk step with L_Q'(x - mu) carried from step to step."""
+        d = LQ.shape[0]
+        check(lib.omc_rw_step_white(self._ctx, d, self._vec(mu, d), self._p(LQ), self._p(sumlogLQ), float(step),
+                                    self._p(z, self.n_chains, d), 0 if z is None else z.stride(0), self._chain_scalar(u),
+                                    int(draw_index), self._p(x, self.n_chains, d), x.stride(0), int(bool(state_is_current)),
+                                    self._ip(accept_count), self._ip(proposal_count)))
+
     # ------------------------------------------------------------------ per-model constants
     def matrix_logdet(self, st):
         """Device scalar log det M of a Normal's unscaled precision (tridiagonal bands), cached."""

@@ -264,9 +264,12 @@ class RandomWalk(MetropolisHastings):
             LQ, sl = self._factor_plan(eng, current_state, Q, 1.0)  # chol(Q) for log p (gmrf.py:339)
             z = self.inject(self, self._sweep) if self.inject is not None else None
             u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
-            eng.rw_step(mu, LQ, sl, float(self.step.item()), self._x(current_state), z=z, u=u,
-                        draw_index=self._draw_index(), accept_count=self.accept_rate.accept,
-                        proposal_count=self.accept_rate.proposal)
+            x = self._x(current_state)
+            tag = (x.data_ptr(), x._version, LQ.data_ptr())  # see ManifoldMALA.sample: may the library reuse its L_Q'(x - mu)?
+            eng.rw_step_white(mu, LQ, sl, float(self.step.item()), x, state_is_current=getattr(self, "_white_tag", None) == tag,
+                              z=z, u=u, draw_index=self._draw_index(), accept_count=self.accept_rate.accept,
+                              proposal_count=self.accept_rate.proposal)
+            self._white_tag = tag
         else:
             current_state = self._generic_step(current_state)
         self._sweep += 1

@@ -299,3 +299,44 @@ def test_whitened_mala_step_matches_the_products_route(d, C):
     assert np.array_equal(out[0][1], out[1][1])
     assert relerr(out[0][0], out[1][0]) < 1e-10
     assert 0 < out[1][1].sum() < 8 * C
+
+
+@pytest.mark.parametrize("d,C", [(137, 70), (500, 33), (5, 3)])
+def test_whitened_rw_step_matches_the_products_route(d, C):
+    """omc_rw_step_white (L_Q'(x - mu) carried, one triangular product per step) against omc_rw_step on a target with a
+    non-zero mean and the same injected draws: decisions identical, states BIT-identical (x' = x + step z is formed the
+    same way in both), also across a write to x by someone else."""
+    import torch
+
+    rng = np.random.default_rng(d * 3 + C)
+    A = rng.standard_normal((d, 2 * d))
+    Qh = np.linalg.inv(A @ A.T / (2 * d))
+    Qh = (Qh + Qh.T) / 2
+    mu = rng.standard_normal(d)
+    x0 = mu + np.linalg.solve(np.linalg.cholesky(Qh).T, rng.standard_normal((d, C))).T
+    x_mid = mu + np.linalg.solve(np.linalg.cholesky(Qh).T, rng.standard_normal((d, C))).T
+    step = 0.05
+    zs, us = rng.standard_normal((8, C, d)), rng.random((8, C))
+    out = {}
+    for white in (0, 1):
+        eng = make_engine(C)
+        Q, dmu = eng.to_device(Qh), eng.to_device(mu)
+        L, sl = eng.dense_cholesky(Q, 1.0)
+        x = eng.to_device(x0)
+        acc = torch.zeros(C, dtype=torch.int64, device="cuda")
+        prop = torch.zeros(C, dtype=torch.int64, device="cuda")
+        for i in range(8):
+            if i == 5:
+                x.copy_(eng.to_device(x_mid))
+            z, u = eng.to_device(zs[i]), eng.to_device(us[i])
+            if white:
+                eng.rw_step_white(dmu, L, sl, step, x, state_is_current=i not in (0, 5), z=z, u=u, accept_count=acc,
+                                  proposal_count=prop)
+            else:
+                eng.rw_step(dmu, L, sl, step, x, z=z, u=u, accept_count=acc, proposal_count=prop)
+        eng.check_status()
+        out[white] = (x.cpu().numpy(), acc.cpu().numpy())
+        eng.close()
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][0], out[1][0])
+    assert 0 < out[1][1].sum() < 8 * C
