@@ -371,10 +371,14 @@ def main():
     trace = torch.stack([sweep.store_lam[: min(args.steps, n_store)], sweep.store_tau[: min(args.steps, n_store)]])
     if not on_gpu:
         trace = trace.cpu()
+    trace_error = None
     if dist is not None:
-        from openmcmc_amd.parallel import gather_chains
+        try:
+            from openmcmc_amd.parallel import gather_chains
 
-        trace = gather_chains(trace, chain_dim=2, dst=0)
+            trace = gather_chains(trace, chain_dim=2, dst=0)
+        except Exception as exc:  # the check value then covers rank 0's chains only; the headline stays
+            trace_error = repr(exc)
     lam_mean = trace[0].mean().item() if rank == 0 else None
 
     # ... and of the sample store itself: timed on a bounded part (the last <= 8 stored iterations of b,
@@ -440,7 +444,8 @@ def main():
                                    + "NormalNormal + 2x NormalGamma + store + log_post per step"
                                    + (" (one fused launch)" if not args.unfused else " (one launch per sampler)"),
                        "chains_total": total_chains, "chains_rank0": C, "nodes": n, "parallelism": f"chains sharded x{world}",
-                       "check": {"mean_lambda": lam_mean}, "store_gather": gather_info,
+                       "check": {"mean_lambda": lam_mean, **({"trace_gather_error": trace_error} if trace_error else {})},
+                       "store_gather": gather_info,
                        "repeats": m["spread"], "other_scaling": other},
         }
         if kern_ms is not None:

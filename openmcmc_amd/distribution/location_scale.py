@@ -218,6 +218,9 @@ class Normal(Distribution):
             x, m = self.chain_and_center(state)
             if m.shape[1] != 1 or x.shape[1] != 1:
                 raise NotImplementedError("replicated responses under a dense precision")
+            if is_chain(m):  # both sides sampled: the residual is formed on the device
+                r = engine.chain_lincomb(1.0, x.vector(), -1.0, m.vector())
+                return engine.dense_quadform(engine.shared(st.matrix), r)
             memo = self.__dict__.setdefault("_dense_memo", {})
             key = id(st.matrix)
             c_host = np.ascontiguousarray(m, dtype=np.float64).reshape(-1)

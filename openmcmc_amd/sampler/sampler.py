@@ -309,28 +309,39 @@ class NormalNormal(MCMCSampler):
         """Q_c = sum_k s_k[c] M_k with dense M_k: prior precision as is, a regression likelihood as the
         Gram matrix A' W A (one fp64 GEMM at plan time) -- sampler.py:185-192, location_scale.py:238-241."""
         eng = self.engine
-        self._no_chain_vectors(pieces, "dense")
-        terms, keys = [], []
+        terms, keys, chain_terms = [], [], []
         for pc in pieces:
-            if pc["offset"]:
-                raise NotImplementedError("per-chain offsets on the dense route")
             st, A = pc["st"], pc["design"]
             center = eng.to_device(pc["center"].reshape(-1))
+            per_chain = pc["offset"] or pc.get("chain_vec") is not None
             if A is None:
                 if st.n != n:
                     raise ValueError("precision / parameter size mismatch")
                 mat = None if (st.diag is None and st.off is None) else eng.shared(st.matrix)
                 rhs = center if mat is None else eng.design_rhs(mat, center)  # M' m = M m, once per model
+                op = mat
             else:
                 if st.diag is False or st.off is not None:
                     raise NotImplementedError("regression likelihood needs a diagonal response precision")
                 dA = eng.shared(A)
                 w = None if st.diag is None else eng.to_device(st.diag)
                 mat, rhs = eng.gram(dA, w), eng.design_rhs(dA, center, w)
+                op = None
+                if per_chain:  # A' W as a (p, n_obs) operator on per-chain vectors of the observation space
+                    Ad = A.toarray() if hasattr(A, "toarray") else np.asarray(A, dtype=np.float64)
+                    op = eng.to_device(np.ascontiguousarray((Ad if st.diag is None else Ad * np.asarray(st.diag).reshape(-1, 1)).T))
+            # what the right-hand side receives per chain and per sweep (sampler.py:181-192): the part of the mean carried by
+            # other sampled parameters (b_c -= s_c A'W d_c), a sampled prior mean (b_c += s_c M m_c), a sampled response
+            # (b_c += s_c W y_c) -- each one GEMM over all chains with the term's shared operator
+            if pc["offset"]:
+                chain_terms.append((("offset", pc["dist"]), st.scale_key, op))
+            if pc.get("chain_vec") is not None:
+                chain_terms.append((pc["chain_vec"], st.scale_key, op))
             scale = _as_chain_scalar(eng, state, st.scale_key) if st.scale_key is not None else None
             terms.append({"mat": mat, "rhs": rhs, "scale": None if scale is None else scale.scalar()})
             keys.append(pc["key"])
-        return {"kind": "dense", "n": n, "terms_list": terms, "terms": eng.dense_terms(terms, n), "keys": keys}
+        return {"kind": "dense", "n": n, "terms_list": terms, "terms": eng.dense_terms(terms, n), "keys": keys,
+                "chain_terms": chain_terms}
 
     spectral = True  # class-level switch: False keeps every dense draw on the per-chain factorisation
 
@@ -380,6 +391,17 @@ class NormalNormal(MCMCSampler):
                 rhs_chain = eng.tridiag_matvec_chain(n, cache["diag"], cache["off"], v, scale=scale)
             else:
                 eng.tridiag_matvec_chain(n, cache["diag"], cache["off"], v, scale=scale, out=rhs_chain, accumulate=True)
+        for (kind, what), scale_key, op in p.get("chain_terms", ()):  # dense route: the same three kinds, through `op`
+            scale = current_state[scale_key].scalar() if scale_key is not None else None
+            if kind == "offset":
+                v = what.mean.predictor_device(current_state, eng, exclude=self.param, alpha=-1.0, chain_scale=scale)
+            else:
+                v = what.mean.predictor_device(current_state, eng) if kind == "mean" and not isinstance(what.mean, Identity) else \
+                    current_state[what.mean.form if kind == "mean" else what].vector()
+                if scale is not None:
+                    v = v * scale.reshape(-1, 1)
+            t = v if op is None else eng.design_predict(op, v)
+            rhs_chain = t if rhs_chain is None else eng.chain_lincomb(1.0, rhs_chain, 1.0, t)
         if p["limits"] is not None:
             # truncated prior: the scan starts from the current value and `z` carries the injected UNIFORMS
             lower, upper = p["limits"]
@@ -394,16 +416,17 @@ class NormalNormal(MCMCSampler):
             # prior N(mean[alloc], diag(prec[alloc])^-1) (parameter.py:447,501): a per-chain diagonal on Q and
             # prec * mean on b (sampler.py:181-183), next to the shared likelihood terms
             _, pmean, pprec, _ = p["mixture_prior"].mixture_pieces(current_state, eng)
-            eng.dense_sample_canonical(n, p["terms"], x, z=z, rhs_chain=pprec * pmean, diag_chain=pprec,
-                                       draw_index=self._draw_index())
+            prior_rhs = pprec * pmean
+            eng.dense_sample_canonical(n, p["terms"], x, z=z, diag_chain=pprec, draw_index=self._draw_index(),
+                                       rhs_chain=prior_rhs if rhs_chain is None else eng.chain_lincomb(1.0, prior_rhs, 1.0, rhs_chain))
         elif z is None and self.spectral and self._spectral_plan(p) is not None:
             # Q_c = a_c I + b_c M with one shared M: the draw in M's eigenbasis -- two GEMMs over all chains instead of
             # one factorisation per chain.  Same conditional law and the reference's mean and log det; not its path-wise
             # image of the draws, so a replay with injected draws (z given) takes the factorisation below.
             k_mat, V, ev = self._spectral_plan(p)
-            eng.dense_spectral_sample(n, p["terms"], k_mat, V, ev, x, draw_index=self._draw_index())
+            eng.dense_spectral_sample(n, p["terms"], k_mat, V, ev, x, rhs_chain=rhs_chain, draw_index=self._draw_index())
         else:
-            eng.dense_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())
+            eng.dense_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
         current_state[self.param] = ChainArray(x)
         self._sweep += 1
         return current_state

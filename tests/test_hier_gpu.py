@@ -97,3 +97,49 @@ def test_tuple_max_variable_size_store_layout(golden):
     for c in range(C):
         assert relerr(out["b"][c, :n, 0, :], G[k + "store_b"]) < TOL
         assert np.isnan(out["b"][c, n:, :, :]).all() and np.isnan(out["b"][c, :, 1, :]).all()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_two_sampled_blocks_in_one_mean_replay_reference(golden, tag):
+    """y ~ N(X beta + Z gamma, (tau W)^-1) with NormalNormal on beta and on gamma: each dense conditional sees the other
+    block as a per-chain offset (sampler.py:185-192 -> parameter.py:162-197).  Variant b adds a weighted response and a sampled
+    prior mean of gamma under a dense prior precision (tests/golden/two_block.npz, recorded draws injected)."""
+    from openmcmc_amd.distribution.distribution import Gamma
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import LinearCombination, ScaledMatrix
+    from openmcmc_amd.sampler.sampler import NormalGamma, NormalNormal
+
+    G = golden("two_block")
+    k = tag + "_"
+    N, p, q, hier = int(G[k + "N"]), int(G[k + "p"]), int(G[k + "q"]), bool(G[k + "hier"])
+    dists = [
+        Normal("y", mean=LinearCombination(form={"beta": "X", "gamma": "Z"}), precision=ScaledMatrix(matrix="P_tau", scalar="tau")),
+        Normal("beta", mean="mu_b", precision=ScaledMatrix(matrix="P_lambda", scalar="lambda")),
+        Normal("gamma", mean="m" if hier else "mu_g", precision="P_g"),
+        Gamma("tau", shape="a_tau", rate="b_tau"),
+        Gamma("lambda", shape="a_lambda", rate="b_lambda"),
+    ]
+    if hier:
+        dists.append(Normal("m", mean="m0", precision="P_m"))
+    mdl = Model(dists, response={"y": "mean"})
+    state = {"y": G[k + "y"], "X": G[k + "X"], "Z": G[k + "Z"], "beta": np.zeros(p), "gamma": np.zeros(q), "mu_b": np.zeros(p),
+             "mu_g": np.zeros(q), "P_tau": sparse.csc_matrix(np.diag(G[k + "w"])), "tau": 1, "P_lambda": sparse.csc_matrix(np.eye(p)),
+             "lambda": 0.1, "P_g": sparse.csc_matrix(G[k + "P_g"]), "a_tau": 1e-2, "b_tau": 1e-2, "a_lambda": 1e-2, "b_lambda": 1e-2,
+             "m": np.full(q, 0.5), "m0": np.zeros(q), "P_m": sparse.csc_matrix(0.7 * np.eye(q))}
+    normals = [NormalNormal("beta", mdl), NormalNormal("gamma", mdl)] + ([NormalNormal("m", mdl)] if hier else [])
+    gammas = [NormalGamma("tau", mdl), NormalGamma("lambda", mdl)]
+    C = 3
+    M = MCMC(state, normals + gammas, model=mdl, n_burn=int(G[k + "n_burn"]), n_iter=int(G[k + "n_iter"]), n_chains=C)
+    eng = M.engine
+    cuts = np.cumsum([0, p, q] + ([q] if hier else []))
+    for i, smp in enumerate(normals):
+        smp.inject = lambda s_, t, i=i: eng.to_device(np.tile(G[k + "z"][t, cuts[i]:cuts[i + 1]], (C, 1)))
+    for i, smp in enumerate(gammas):
+        smp.inject = lambda s_, t, i=i: eng.full((C,), G[k + "g"][t, i])
+    M.run_mcmc()
+    out = M.collect()
+    for c in range(C):
+        for key in ["beta", "gamma", "tau", "lambda", "log_post", "y"] + (["m"] if hier else []):
+            assert relerr(out[key][c], G[k + "store_" + key]) < 1e-9, (key, c)
