@@ -361,6 +361,11 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
  * Normal.log_p gmrf.py:343-344); band NULL with w = 0 is the identity, center NULL = 0.                      */
 omc_status omc_band_quadform(omc_ctx* ctx, int64_t n, int64_t w, const double* band, const double* center,
                              const double* x, int64_t ld, double* quad);
+/* out[c] (+)= scale[c] * M v_c for a shared band matrix and per-chain vectors: Q_rsp @ mean with a sampled prior mean
+ * (sampler.py:181-183) and W (y_c - d) with a sampled response (sampler.py:190-192) on the band route; band NULL with
+ * w = 0 is the identity, scale NULL = 1.                                                                          */
+omc_status omc_band_matvec_chain(omc_ctx* ctx, int64_t n, int64_t w, const double* band, const double* v, int64_t ld_v,
+                                 const double* scale, double* out, int64_t ld_out, int32_t accumulate);
 
 /* ---- truncated Gaussian full conditional ------------------------------------
  * gmrf.gibbs_canonical_truncated_normal (gmrf.py:201-266), the branch NormalNormal.sample takes when the

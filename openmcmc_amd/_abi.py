@@ -136,6 +136,7 @@ SIGNATURES = {
     "omc_band_sample_canonical": (
         i32, [C.c_void_p, i64, i64, C.POINTER(BandTerms), c_dp, i64, c_dp, i64, u64, c_dp, i64, c_dp, i64, c_dp]),
     "omc_band_quadform": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, i64, c_dp]),
+    "omc_band_matvec_chain": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, i64, c_dp, c_dp, i64, i32]),
     "omc_tridiag_gibbs_truncated": (
         i32, [C.c_void_p, i64, C.POINTER(TridiagTerms), c_dp, i64, c_dp, c_dp, c_dp, i64, u64, c_dp, i64]),
     "omc_dense_gibbs_truncated": (

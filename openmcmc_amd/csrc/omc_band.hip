@@ -907,6 +907,25 @@ __global__ void __launch_bounds__(256) k_band_quadform(int64_t C, int64_t n, int
   if (threadIdx.x == 0) quad[c] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// out[c][i] (+)= scale[c] * sum_j M[i][j] v_c[j] for a shared symmetric band matrix in lower band storage (row d = the d-th
+// sub-diagonal): the per-chain right-hand-side pieces of a hierarchical model on the band route (sampler.py:181-192)
+__global__ void __launch_bounds__(256) k_band_matvec_chain(int64_t n, int w, const double* __restrict__ band, const double* __restrict__ v,
+                                                           int64_t ld_v, const double* __restrict__ scale, double* __restrict__ out,
+                                                           int64_t ld_out, int accumulate) {
+  const int64_t c = blockIdx.y;
+  const double* vc = v + c * ld_v;
+  double* oc = out + c * ld_out;
+  const double s = scale ? scale[c] : 1.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double acc = (band ? band[i] : 1.0) * vc[i];
+    for (int d = 1; d <= w; ++d) {
+      if (i + d < n) acc = fma(band[(int64_t)d * n + i], vc[i + d], acc);      // M[i+d][i] below the diagonal = M[i][i+d]
+      if (i - d >= 0) acc = fma(band[(int64_t)d * n + i - d], vc[i - d], acc);  // M[i][i-d]
+    }
+    oc[i] = accumulate ? fma(s, acc, oc[i]) : s * acc;
+  }
+}
+
 extern "C" {
 
 omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const omc_band_terms* terms,
@@ -1026,6 +1045,18 @@ omc_status omc_band_quadform(omc_ctx* ctx, int64_t n, int64_t w, const double* b
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(k_band_quadform, dim3((unsigned)ctx->n_chains), dim3(256), 0, ctx->stream, ctx->n_chains, n, (int)w, band,
                      center, x, ld, quad);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_band_matvec_chain(omc_ctx* ctx, int64_t n, int64_t w, const double* band, const double* v, int64_t ld_v,
+                                 const double* scale, double* out, int64_t ld_out, int32_t accumulate) {
+  if (!ctx || n < 1 || w < 0 || (w > 0 && !band) || !v || !out || ld_v < n || ld_out < n || v == out) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  int64_t gx_ = (n + 255) / 256;
+  if (gx_ > 64) gx_ = 64;
+  hipLaunchKernelGGL(k_band_matvec_chain, dim3((unsigned)gx_, (unsigned)ctx->n_chains), dim3(256), 0, ctx->stream, n, (int)w, band, v,
+                     ld_v, scale, out, ld_out, (int)accumulate);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

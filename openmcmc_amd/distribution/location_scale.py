@@ -234,6 +234,12 @@ class Normal(Distribution):
             x, m = self.chain_and_center(state)
             if m.shape[1] != 1 or x.shape[1] != 1:
                 raise NotImplementedError("replicated responses under a banded precision")
+            if is_chain(m):  # both sides sampled
+                r = engine.chain_lincomb(1.0, x.vector(), -1.0, m.vector())
+                cache = engine.band_cache(self, st, np.zeros((st.n, 1)))
+                quad = engine.empty(engine.n_chains)
+                engine.band_quadform(st.n, cache["band"], r, quad)
+                return quad
             cache = engine.band_cache(self, st, m)
             quad = engine.empty(engine.n_chains)
             engine.band_quadform(st.n, cache["band"], x.vector(), quad, center=cache["center"])

@@ -566,6 +566,14 @@ class Engine:
                                     x.stride(0), self._chain_scalar(quad_out)))
         return quad_out
 
+    def band_matvec_chain(self, n, band, v, scale=None, out=None, accumulate=False):
+        """out[c] (+)= scale[c] * M v_c for a shared band matrix (band rows as in band_terms; None = identity)."""
+        out = self.empty(self.n_chains, n) if out is None else out
+        w = 0 if band is None else band.shape[0] - 1
+        check(lib.omc_band_matvec_chain(self._ctx, n, w, self._p(band), self._p(v, self.n_chains, n), v.stride(0),
+                                        self._chain_scalar(scale), self._p(out, self.n_chains, n), out.stride(0), int(accumulate)))
+        return out
+
     # ------------------------------------------------------------------ truncated Gaussian conditional
     def band_gibbs_truncated(self, n, terms, x, lower=None, upper=None, u=None, rhs_chain=None, draw_index=0):
         """One scan of single-site truncated updates under a banded precision (omc_band_gibbs_truncated); x in place."""

@@ -281,20 +281,14 @@ class NormalNormal(MCMCSampler):
             raise NotImplementedError("ragged NormalNormal: exactly one likelihood term")
         return {"kind": "ragged", "n": n_max, "like": likes[0], "terms_list": [], "keys": [], "limits": None}
 
-    @staticmethod
-    def _no_chain_vectors(pieces, route):
-        if any(pc.get("chain_vec") is not None for pc in pieces):
-            raise NotImplementedError(f"per-chain prior mean / per-chain response on the {route} route")
-
     def _band_plan(self, state, n, pieces):
-        self._no_chain_vectors(pieces, "band")
         """Q_c = sum_k s_k[c] M_k with banded M_k wider than tridiagonal (RW2, seasonal, lattice GMRFs): natural-order
         band Cholesky per chain (omc_band_sample_canonical)."""
         eng = self.engine
-        terms, keys = [], []
+        terms, keys, chain_terms = [], [], []
         for pc in pieces:
-            if pc["offset"] or pc.get("replicated"):
-                raise NotImplementedError("per-chain offsets / replicated responses on the band route")
+            if pc.get("replicated"):
+                raise NotImplementedError("replicated responses on the band route")
             st = pc["st"]
             cache = eng.band_cache(pc["dist"], st, pc["center"])
             scale = _as_chain_scalar(eng, state, st.scale_key) if st.scale_key is not None else None
@@ -303,7 +297,13 @@ class NormalNormal(MCMCSampler):
                 rhs = cache["center"]  # identity matrix: M m = m
             terms.append({"band": cache["band"], "rhs": rhs, "scale": None if scale is None else scale.scalar()})
             keys.append(pc["key"])
-        return {"kind": "band", "n": n, "terms_list": terms, "terms": eng.band_terms(terms, n), "keys": keys}
+            op = None if cache["band"] is None else ("band", cache["band"])  # per-chain vectors go through M as a band product
+            if pc["offset"]:
+                chain_terms.append((("offset", pc["dist"]), st.scale_key, op))
+            if pc.get("chain_vec") is not None:
+                chain_terms.append((pc["chain_vec"], st.scale_key, op))
+        return {"kind": "band", "n": n, "terms_list": terms, "terms": eng.band_terms(terms, n), "keys": keys,
+                "chain_terms": chain_terms}
 
     def _dense_plan(self, state, n, pieces):
         """Q_c = sum_k s_k[c] M_k with dense M_k: prior precision as is, a regression likelihood as the
@@ -391,7 +391,7 @@ class NormalNormal(MCMCSampler):
                 rhs_chain = eng.tridiag_matvec_chain(n, cache["diag"], cache["off"], v, scale=scale)
             else:
                 eng.tridiag_matvec_chain(n, cache["diag"], cache["off"], v, scale=scale, out=rhs_chain, accumulate=True)
-        for (kind, what), scale_key, op in p.get("chain_terms", ()):  # dense route: the same three kinds, through `op`
+        for (kind, what), scale_key, op in p.get("chain_terms", ()):  # dense and band routes: the same three kinds, through `op`
             scale = current_state[scale_key].scalar() if scale_key is not None else None
             if kind == "offset":
                 v = what.mean.predictor_device(current_state, eng, exclude=self.param, alpha=-1.0, chain_scale=scale)
@@ -400,7 +400,12 @@ class NormalNormal(MCMCSampler):
                     current_state[what.mean.form if kind == "mean" else what].vector()
                 if scale is not None:
                     v = v * scale.reshape(-1, 1)
-            t = v if op is None else eng.design_predict(op, v)
+            if op is None:
+                t = v
+            elif isinstance(op, tuple):
+                t = eng.band_matvec_chain(n, op[1], v)
+            else:
+                t = eng.design_predict(op, v)
             rhs_chain = t if rhs_chain is None else eng.chain_lincomb(1.0, rhs_chain, 1.0, t)
         if p["limits"] is not None:
             # truncated prior: the scan starts from the current value and `z` carries the injected UNIFORMS
@@ -411,7 +416,7 @@ class NormalNormal(MCMCSampler):
         elif p["kind"] == "tridiag":
             eng.tridiag_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
         elif p["kind"] == "band":
-            eng.band_sample_canonical(n, p["terms"], x, z=z, draw_index=self._draw_index())
+            eng.band_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
         elif p.get("mixture_prior") is not None:
             # prior N(mean[alloc], diag(prec[alloc])^-1) (parameter.py:447,501): a per-chain diagonal on Q and
             # prec * mean on b (sampler.py:181-183), next to the shared likelihood terms

@@ -182,3 +182,54 @@ def test_rw2_smoother_replays_reference(golden):
             ref = G["store_" + key]
             err = np.max(np.abs(got[key][c] - ref) / np.maximum(1.0, np.abs(ref)))
             assert err < 1e-9, (key, err)  # D2'D2 + 1e-3 I at n = 45 has condition number ~ 4e7
+
+
+@pytest.mark.parametrize("tag", ["h", "o"])
+def test_rw2_per_chain_rhs_pieces_replay_reference(golden, tag):
+    """Band route with per-chain right-hand-side pieces (tests/golden/band_hier.npz): "h" a sampled prior mean, a sampled
+    response under a scaled pentadiagonal precision and a residual with both sides sampled; "o" a smoother next to a regression
+    block, each conditional seeing the other as an offset (sampler.py:181-192)."""
+    from openmcmc_amd.distribution.distribution import Gamma
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import LinearCombination, ScaledMatrix
+    from openmcmc_amd.sampler.sampler import NormalGamma, NormalNormal
+
+    G = golden("band_hier")
+    n, k = int(G["n"]), tag + "_"
+    if tag == "h":
+        mdl = Model([
+            Normal("y", mean="b", precision=ScaledMatrix(matrix="P_tau", scalar="tau")),
+            Normal("b", mean="m", precision=ScaledMatrix(matrix="P_lambda", scalar="lambda")),
+            Normal("m", mean="m0", precision="P_m"),
+            Gamma("lambda", shape="a_lam", rate="b_lam"), Gamma("tau", shape="a_tau", rate="b_tau")])
+        normals, keys, cuts = [NormalNormal("b", mdl), NormalNormal("m", mdl)], ("b", "m", "lambda", "tau", "log_post"), [0, n, 2 * n]
+    else:
+        mdl = Model([
+            Normal("y", mean=LinearCombination(form={"b": "A", "beta": "X"}), precision=ScaledMatrix(matrix="P_tau", scalar="tau")),
+            Normal("b", mean="mu", precision=ScaledMatrix(matrix="P_lambda", scalar="lambda")),
+            Normal("beta", mean="mu_beta", precision="P_beta"),
+            Gamma("lambda", shape="a_lam", rate="b_lam"), Gamma("tau", shape="a_tau", rate="b_tau")])
+        normals, keys, cuts = [NormalNormal("b", mdl), NormalNormal("beta", mdl)], ("b", "beta", "lambda", "tau", "log_post"), [0, n, n + 3]
+    gammas = [NormalGamma("lambda", mdl), NormalGamma("tau", mdl)]
+    y = G["y"]
+    state = {"y": y.copy(), "b": y.copy(), "m": np.full(n, 1.0), "m0": np.zeros(n), "P_m": sparse.csc_matrix(0.5 * np.eye(n)),
+             "mu": np.zeros(n), "lambda": 20, "P_lambda": sparse.csc_matrix(G["P"]), "a_lam": 10, "b_lam": 1, "tau": 1,
+             "P_tau": sparse.csc_matrix(np.eye(n)), "a_tau": 1, "b_tau": 1, "A": sparse.identity(n, format="csc"), "X": G["X"],
+             "beta": np.zeros(3), "mu_beta": np.zeros(3), "P_beta": sparse.csc_matrix(np.diag([0.1, 0.2, 0.3]))}
+    C = 3
+    M = MCMC(state, normals + gammas, model=mdl, n_burn=int(G["n_burn"]), n_iter=int(G["n_iter"]), n_chains=C)
+    eng = M.engine
+    assert normals[0].plan(M.state)["kind"] == "band"
+    for i, smp in enumerate(normals):
+        smp.inject = lambda s_, t, i=i: eng.to_device(np.tile(G[k + "z"][t, cuts[i]:cuts[i + 1]], (C, 1)))
+    for i, smp in enumerate(gammas):
+        smp.inject = lambda s_, t, i=i: eng.full((C,), G[k + "g"][t, i])
+    M.run_mcmc()
+    got = M.collect()
+    for c in range(C):
+        for key in keys:
+            ref = G[k + "store_" + key]
+            err = np.max(np.abs(got[key][c] - ref) / np.maximum(1.0, np.abs(ref)))
+            assert err < 1e-9, (key, c, err)
