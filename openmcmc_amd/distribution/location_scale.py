@@ -342,6 +342,11 @@ class Normal(Distribution):
                                                     "scale": scale}], x, draw_index=draw_index)
         return ChainArray(x)
 
+    def constant_hessian(self, param: str) -> bool:
+        """Is this distribution Gaussian in `param` (Hessian independent of it: branches (i) and (ii) of
+        location_scale.py:190-250)?  Then ManifoldMALA may take the dense route built on grad_terms."""
+        return param == self.response or (param in self.mean.get_grad_param_list() and param not in self.precision.get_grad_param_list())
+
     def grad_terms(self, state: dict, param: str, engine):
         """This distribution's share of the gradient and Hessian w.r.t. a per-chain (p, 1) parameter, in the form the
         dense route consumes: (grad (C, p) tensor, [{"mat": shared host matrix or None = identity, "scale": (C,) tensor or
@@ -466,6 +471,9 @@ class NullDistribution(Normal):
     def grad_terms(self, state: dict, param: str, engine):
         return None
 
+    def constant_hessian(self, param: str) -> bool:
+        return True  # zero
+
     def grad_log_p(self, state: dict, param: str, hessian_required: bool = True, engine=None):
         raise NotImplementedError("NullDistribution.grad_log_p: use grad_log_p_diag / grad_terms (zero contribution)")
 
@@ -475,8 +483,8 @@ class NullDistribution(Normal):
 
 @dataclass
 class LogNormal(Normal):
-    """Multivariate log-normal (location_scale.py:275-418): log(response) ~ Normal(mean, precision).  log_p and rvs are
-    built; the analytic gradient / Hessian (location_scale.py:302-402) are not (random-walk samplers do not need them)."""
+    """Multivariate log-normal (location_scale.py:275-418): log(response) ~ Normal(mean, precision): log_p, rvs and
+    the analytic gradient / Hessian."""
 
     def log_p(self, state: dict, by_observation: bool = False, engine=None, out=None, accumulate=False):
         """location_scale.py:279-300: the Normal log-density at log(response) minus sum log(response)."""
@@ -511,6 +519,46 @@ class LogNormal(Normal):
         draw = Normal.rvs(self, state, n=n, engine=engine, draw_index=draw_index)
         return ChainArray(draw.data.exp())
 
+    def constant_hessian(self, param: str) -> bool:
+        return param != self.response and Normal.constant_hessian(self, param)  # as a response: H depends on x
+
+    def grad_terms(self, state: dict, param: str, engine):
+        if param == self.response:
+            raise NotImplementedError("log-normal response: parameter-dependent Hessian (generic ManifoldMALA route)")
+        return Normal.grad_terms(self, state, param, engine)
+
     def grad_log_p(self, state: dict, param: str, hessian_required: bool = True, engine=None):
-        """The reference's analytic forms (location_scale.py:302-402) are not restated: central differences of log_p."""
+        """location_scale.py:302-402, the reference's three branches for a per-chain parameter:
+          (i)   `param` is the response x (shared mean mu, shared matrix precision Q): with r = log x - mu,
+                grad = -(1 + Q r) / x and (negative second derivatives) H = diag(1/x) Q diag(1/x) - diag((1 + Q r) / x^2),
+                one (d, d) matrix per chain;
+          (ii)  `param` enters the mean only: the Normal's branch (ii) at log(response);
+          (iii) anything else: central differences of log_p."""
+        if engine is None:
+            raise RuntimeError("LogNormal.grad_log_p needs the engine")
+        import torch
+
+        from openmcmc_amd.chains import ChainArray
+
+        x = state.get(param)
+        if param == self.response and isinstance(self.precision, Identity) and is_chain(x):
+            Q, mu = state[self.precision.form], self.mean.predictor(state)
+            if is_chain(Q) or is_chain(mu) or x.shape[1] != 1:
+                raise NotImplementedError("grad_log_p of a log-normal response needs a shared mean and precision and a (d, 1) response")
+            dQ = engine.shared(Q)
+            xv = x.vector()
+            lx, _ = engine.log_transform(xv)
+            r = lx - engine.to_device(np.asarray(mu, dtype=np.float64).reshape(1, -1))
+            inv = 1.0 / xv
+            t = inv * (1.0 + engine.design_predict(dQ, r))  # Q symmetric: Q r for every chain
+            grad = ChainArray(-t)
+            if not hessian_required:
+                return grad
+            return grad, inv.unsqueeze(2) * dQ.unsqueeze(0) * inv.unsqueeze(1) - torch.diag_embed(inv * t)
+        in_mean = param in self.mean.get_grad_param_list() and param not in self.precision.get_grad_param_list()
+        resp = state[self.response]
+        if in_mean and param != self.response and is_chain(x) and not self.is_mixture and not is_chain(resp):
+            logged = dict(state)
+            logged[self.response] = np.log(np.asarray(resp, dtype=np.float64))
+            return Normal.grad_log_p(self, logged, param, hessian_required=hessian_required, engine=engine)
         return Distribution.grad_log_p(self, state, param, hessian_required=hessian_required, engine=engine)

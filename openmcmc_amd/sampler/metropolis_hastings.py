@@ -66,6 +66,7 @@ class MetropolisHastings(MCMCSampler):
         super().__post_init__()
         self.step = np.array(self.step, ndmin=2)
         self.inject_uniform = None  # test hook like `inject`, for the accept/reject uniforms
+        self.trace = None  # test hook: a dict that receives the internals of the last proposal / decision
 
     def bind(self, engine, position=0, n_samplers=1):
         super().bind(engine, position, n_samplers)
@@ -547,7 +548,8 @@ class ManifoldMALA(MetropolisHastings):
             if diag_only:
                 current_state = self._diag_step(current_state)
             else:
-                structured = all(hasattr(d, "grad_terms") for d in self.model.values() if self.param in d.param_list)
+                structured = all(hasattr(d, "grad_terms") and d.constant_hessian(self.param)
+                                 for d in self.model.values() if self.param in d.param_list)
                 current_state = self._dense_step(current_state) if structured else self._general_step(current_state)
             self._sweep += 1
             return current_state
