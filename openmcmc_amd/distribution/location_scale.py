@@ -192,6 +192,13 @@ class Normal(Distribution):
             return resp, mean  # hierarchical: both sides sampled; the callers form the residual on the device
         raise NotImplementedError("Normal with response and mean both shared on the GPU path")
 
+    @staticmethod
+    def _replicate_split(st, m):
+        """sum_r (y_r - x)'M(y_r - x) = n_rep (x - ybar)'M(x - ybar) + sum_r (y_r - ybar)'M(y_r - ybar): (ybar, the constant)."""
+        ybar = m.mean(axis=1, keepdims=True)
+        dev = m - ybar
+        return ybar, float(np.sum(dev * np.asarray(st.matrix @ dev)))
+
     def residual_quad(self, state, engine, st=None, replicates=False):
         """(C,) tensor r' M r with r = response - mean, M the unscaled precision matrix: the sufficient
         statistic of NormalGamma.sample (sampler.py:276,284) and of log_p (gmrf.py:343-344)."""
@@ -216,11 +223,18 @@ class Normal(Distribution):
         if st.diag is False and st.band is None:
             # dense shared precision: r'Mr through one GEMM over all chains
             x, m = self.chain_and_center(state)
-            if m.shape[1] != 1 or x.shape[1] != 1:
-                raise NotImplementedError("replicated responses under a dense precision")
+            if x.shape[1] != 1:
+                raise NotImplementedError("replicated per-chain side of a Normal")
             if is_chain(m):  # both sides sampled: the residual is formed on the device
+                if m.shape[1] != 1:
+                    raise NotImplementedError("replicated per-chain side of a Normal")
                 r = engine.chain_lincomb(1.0, x.vector(), -1.0, m.vector())
                 return engine.dense_quadform(engine.shared(st.matrix), r)
+            n_rep, const = m.shape[1], 0.0
+            if n_rep != 1:
+                if not replicates:
+                    raise NotImplementedError("replicated responses")
+                m, const = self._replicate_split(st, m)
             memo = self.__dict__.setdefault("_dense_memo", {})
             key = id(st.matrix)
             c_host = np.ascontiguousarray(m, dtype=np.float64).reshape(-1)
@@ -229,21 +243,29 @@ class Normal(Distribution):
                 Mm = np.asarray(st.matrix @ c_host).reshape(-1)
                 hit = memo[key] = (c_host, engine.to_device(c_host) if c_host.any() else None,
                                    engine.to_device(Mm) if c_host.any() else None)
-            return engine.dense_quadform(engine.shared(st.matrix), x.vector(), center=hit[1], M_center=hit[2])
+            quad = engine.dense_quadform(engine.shared(st.matrix), x.vector(), center=hit[1], M_center=hit[2])
+            return quad if n_rep == 1 else quad * float(n_rep) + const
         if st.diag is False:
             x, m = self.chain_and_center(state)
-            if m.shape[1] != 1 or x.shape[1] != 1:
-                raise NotImplementedError("replicated responses under a banded precision")
+            if x.shape[1] != 1:
+                raise NotImplementedError("replicated per-chain side of a Normal")
             if is_chain(m):  # both sides sampled
+                if m.shape[1] != 1:
+                    raise NotImplementedError("replicated per-chain side of a Normal")
                 r = engine.chain_lincomb(1.0, x.vector(), -1.0, m.vector())
                 cache = engine.band_cache(self, st, np.zeros((st.n, 1)))
                 quad = engine.empty(engine.n_chains)
                 engine.band_quadform(st.n, cache["band"], r, quad)
                 return quad
+            n_rep, const = m.shape[1], 0.0
+            if n_rep != 1:
+                if not replicates:
+                    raise NotImplementedError("replicated responses")
+                m, const = self._replicate_split(st, m)
             cache = engine.band_cache(self, st, m)
             quad = engine.empty(engine.n_chains)
             engine.band_quadform(st.n, cache["band"], x.vector(), quad, center=cache["center"])
-            return quad
+            return quad if n_rep == 1 else quad * float(n_rep) + const
         x, m = self.chain_and_center(state)
         if x.shape[1] != 1:
             raise NotImplementedError("replicated per-chain side of a Normal")
@@ -262,11 +284,7 @@ class Normal(Distribution):
             raise NotImplementedError("replicated responses")
         const = 0.0
         if n_rep != 1:
-            # sum_r (y_r - x)'M(y_r - x) = n_rep (x - ybar)'M(x - ybar) + sum_r (y_r - ybar)'M(y_r - ybar)
-            ybar = m.mean(axis=1, keepdims=True)
-            dev = m - ybar
-            const = float(np.sum(dev * (st.matrix @ dev)))
-            m = ybar
+            m, const = self._replicate_split(st, m)
         cache = engine.model_cache(self, state, st, m)
         quad = engine.empty(1, engine.n_chains)
         engine.tridiag_quadform(st.n, cache["terms_unit"], x.vector(), quad)
@@ -278,11 +296,19 @@ class Normal(Distribution):
         if engine is None:
             raise RuntimeError("Normal.log_p needs the engine (use Model.log_p)")
         if by_observation:
+            if self._column_replicates(state):
+                return self._columns_log_p(state, engine)[1]  # (C, kmax): one value per live column, 0 beyond
             raise NotImplementedError("by_observation")
         if self.is_mixture:
             x, mean, prec, count = self.mixture_pieces(state, engine)
             out = engine.empty(engine.n_chains) if out is None else out
             engine.diag_gauss_logpdf(x, prec, out, mean=mean, count=count, accumulate=accumulate)
+            return out
+        if self._column_replicates(state):
+            lp = self._columns_log_p(state, engine)[0]
+            if out is None:
+                return lp
+            out.add_(lp) if accumulate else out.copy_(lp)
             return out
         st = self.structure(state)
         quad = self.residual_quad(state, engine, st, replicates=True)
@@ -311,15 +337,89 @@ class Normal(Distribution):
             memo[n] = (vec(self.domain_response_lower), vec(self.domain_response_upper))
         return memo[n]
 
-    def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):
+    # ------------------------------------------------------------------ a variable number of replicate columns
+    # The associated parameter of a reversible jump (theta (d, k): one column per knot, k per chain) under a Normal prior with
+    # shared mean and precision: the density is summed over the live columns (gmrf.py:346-348), a birth draws one new column
+    # from the prior and scores the LAST current one (reversible_jump.py:130-132,143).  d is small: plain tensor algebra.
+    def _column_replicates(self, state) -> bool:
+        x = state.get(self.response)  # (a prior draw is asked for when the state has no value yet)
+        return is_chain(x) and x.ragged is not None and x.ragged[1] == 1 and not self.is_mixture
+
+    def _columns_pieces(self, state, engine):
+        """(mu (d,) device, Q (d, d) device, log det Q, host Cholesky factor) of the shared prior; memoised on the matrix."""
+        if not isinstance(self.precision, Identity) or is_chain(state[self.precision.form]):
+            raise NotImplementedError("replicate columns need a shared matrix precision")
+        mean = self.mean.predictor(state)
+        if is_chain(mean):
+            raise NotImplementedError("replicate columns need a shared mean")
+        Q = state[self.precision.form]
+        memo = self.__dict__.setdefault("_columns_memo", {})
+        hit = memo.get(id(Q))
+        if hit is None or hit[0] is not Q:
+            Qd = Q.toarray() if sparse.issparse(Q) else np.array(Q, dtype=np.float64, ndmin=2)
+            L = np.linalg.cholesky(Qd)
+            hit = memo[id(Q)] = (Q, engine.to_device(Qd), 2.0 * float(np.sum(np.log(np.diag(L)))),
+                                 engine.to_device(np.linalg.inv(L)))
+        mu = engine.to_device(np.asarray(mean, dtype=np.float64).reshape(-1).copy())
+        return mu, hit[1], hit[2], hit[3]
+
+    def _columns_values(self, state, engine):
+        """(C, d, kmax) values the Gaussian density is evaluated at, the live-column mask and what is subtracted per live column
+        (0 here; sum of logs for the log-normal)."""
+        import torch
+
+        x = state[self.response]
+        k = torch.arange(x.data.shape[2], device=x.data.device).reshape(1, -1)
+        live = k < x.count(state).reshape(-1, 1)
+        return x.data, live, None
+
+    def _columns_log_p(self, state, engine):
+        """(log_p summed over the live columns (C,), per-column log densities (C, kmax), live mask)."""
+        import torch
+
+        mu, Qd, logdet, _ = self._columns_pieces(state, engine)
+        v, live, minus = self._columns_values(state, engine)
+        d = v.shape[1]
+        r = v - mu.reshape(1, d, 1)
+        q = (r * torch.einsum("ij,cjk->cik", Qd, r)).sum(dim=1)
+        per = 0.5 * logdet - 0.5 * d * float(np.log(2.0 * np.pi)) - 0.5 * q
+        if minus is not None:
+            per = per - minus
+        per = torch.where(live, per, torch.zeros_like(per))
+        return per.sum(dim=1), per, live
+
+    def log_p_last(self, state: dict, engine):
+        """log_p(state, by_observation=True)[-1] of every chain (reversible_jump.py:132,143): (C,) tensor."""
+        _, per, _ = self._columns_log_p(state, engine)
+        last = (state[self.response].count(state) - 1).clamp(min=0).to(per.device).long().reshape(-1, 1)
+        return per.gather(1, last).reshape(-1)
+
+    def _column_draw(self, state, engine, draw_index, sub, inject):
+        """mu + L^-T z for every chain (gmrf.py:29-61): (C, d) tensor; `inject` (C, d) standard normals."""
+        mu, _, _, Linv = self._columns_pieces(state, engine)
+        d = mu.numel()
+        if inject is None:
+            z = engine.fill_normal(d, draw_index=int(draw_index) + ((int(sub) & 0xF) << 44))
+        else:
+            z = inject.reshape(engine.n_chains, d)
+        return mu.reshape(1, d) + z @ Linv  # rows: (L^-T z)' = z' L^-1
+
+    def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0, sub=0, inject=None):
         """One draw per chain from N(mean, (scale * M)^-1) (location_scale.py:252-272 -> gmrf.py:29-61),
-        used by MCMC when the state has no initial value for a sampled parameter (mcmc.py:78-80)."""
+        used by MCMC when the state has no initial value for a sampled parameter (mcmc.py:78-80) and by a birth move for the
+        new column of an associated parameter (reversible_jump.py:130)."""
         if engine is None:
             raise RuntimeError("Normal.rvs needs the engine")
         if n != 1:
             raise NotImplementedError("replicated prior draws")
         if self.domain_response_lower is not None or self.domain_response_upper is not None:
             raise NotImplementedError("truncated prior draws (gmrf.sample_truncated_normal)")
+        if self._column_replicates(state):
+            from openmcmc_amd.chains import ChainArray
+
+            return ChainArray(self._column_draw(state, engine, draw_index, sub, inject).unsqueeze(2))
+        if inject is not None or sub:
+            raise NotImplementedError("injected draws / sub-streams for a fixed-size prior draw")
         st = self.structure(state)
         mean = self.mean.predictor(state)
         if is_chain(mean):
@@ -491,10 +591,18 @@ class LogNormal(Normal):
         if engine is None:
             raise RuntimeError("LogNormal.log_p needs the engine (use Model.log_p)")
         if by_observation:
+            if self._column_replicates(state):
+                return self._columns_log_p(state, engine)[1]
             raise NotImplementedError("by_observation")
         from openmcmc_amd.chains import ChainArray
 
         resp = state[self.response]
+        if self._column_replicates(state):
+            lp = self._columns_log_p(state, engine)[0]
+            if out is None:
+                return lp
+            out.add_(lp) if accumulate else out.copy_(lp)
+            return out
         logged = dict(state)
         if is_chain(resp):
             if resp.shape[1] != 1:
@@ -512,12 +620,20 @@ class LogNormal(Normal):
         out -= sumlog
         return out
 
-    def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):
+    def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0, sub=0, inject=None):
         """location_scale.py:404-418: exp of the Normal draw."""
         from openmcmc_amd.chains import ChainArray
 
-        draw = Normal.rvs(self, state, n=n, engine=engine, draw_index=draw_index)
+        draw = Normal.rvs(self, state, n=n, engine=engine, draw_index=draw_index, sub=sub, inject=inject)
         return ChainArray(draw.data.exp())
+
+    def _columns_values(self, state, engine):
+        """The Gaussian part is evaluated at log(x) and every live column pays its sum of logs (location_scale.py:296-299)."""
+        import torch
+
+        x, live, _ = Normal._columns_values(self, state, engine)
+        lx = torch.log(torch.where(live.unsqueeze(1), x, torch.ones_like(x)))  # padding is not data
+        return lx, live, lx.sum(dim=1)
 
     def constant_hessian(self, param: str) -> bool:
         return param != self.response and Normal.constant_hessian(self, param)  # as a response: H depends on x

@@ -27,6 +27,7 @@ import numpy as np
 
 from openmcmc_amd.chains import ChainArray, is_chain
 from openmcmc_amd.distribution.distribution import Gamma, Uniform
+from openmcmc_amd.distribution.location_scale import Normal
 from openmcmc_amd.sampler.metropolis_hastings import MetropolisHastings, _add_contribution
 
 # Philox sub-streams within one ReversibleJump.sample call (block numbers; omc_rj_move owns 0..63)
@@ -76,8 +77,8 @@ class ReversibleJump(MetropolisHastings):
             dist, cur = self.model[key], current_state[key]
             if not is_chain(cur) or cur.ragged is None or cur.ragged[0] != self.param:
                 raise NotImplementedError(f"associated parameter '{key}' must be a ragged ChainArray counted by '{self.param}'")
-            if not isinstance(dist, (Uniform, Gamma)):
-                raise NotImplementedError("associated parameters need a Uniform or Gamma prior")
+            if not isinstance(dist, (Uniform, Gamma, Normal)) or getattr(dist, "is_mixture", False):
+                raise NotImplementedError("associated parameters need a Uniform, Gamma, Normal or LogNormal prior")
             d = dist.log_p_last(current_state, eng)
             if hasattr(d, "data_ptr"):
                 dens_chain = d if dens_chain is None else dens_chain + d

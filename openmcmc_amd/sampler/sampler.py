@@ -188,9 +188,8 @@ class NormalNormal(MCMCSampler):
                     # replicated draws of the response (sampler.py:165-167, 187-188): b += W sum_r y_r and
                     # Q += n_rep * W  ==  one observation ybar under the precision n_rep * W
                     if not isinstance(dist.mean, Identity):
+                        # (the reference fails here too: b (p, 1) += A'W(y - d) of shape (p, n_rep), sampler.py:192)
                         raise NotImplementedError("replicated response under a LinearCombination mean")
-                    if st.diag is False:
-                        raise NotImplementedError("replicated response under a dense precision")
                     y = y.mean(axis=1, keepdims=True)
                     piece["st"] = st = self._replicated_structure(key, st, n_rep)
                     piece["replicated"] = True
@@ -234,10 +233,15 @@ class NormalNormal(MCMCSampler):
         memo = self.__dict__.setdefault("_rep_structs", {})
         hit = memo.get(key)
         if hit is None or hit[0] is not st.matrix or hit[1].n_pos != st.n_pos:
-            diag = np.full(st.n, float(n_rep)) if st.diag is None else st.diag * float(n_rep)
-            off = None if st.off is None else st.off * float(n_rep)
-            hit = memo[key] = (st.matrix, NormalStructure(n=st.n, matrix=st.matrix * float(n_rep), scale_key=st.scale_key,
-                                                          diag=diag, off=off, n_pos=st.n_pos))
+            if st.diag is False:  # dense or banded wider than tridiagonal
+                rep = NormalStructure(n=st.n, matrix=st.matrix * float(n_rep), scale_key=st.scale_key, diag=False, off=None,
+                                      n_pos=st.n_pos, band=None if st.band is None else st.band * float(n_rep))
+            else:
+                diag = np.full(st.n, float(n_rep)) if st.diag is None else st.diag * float(n_rep)
+                off = None if st.off is None else st.off * float(n_rep)
+                rep = NormalStructure(n=st.n, matrix=st.matrix * float(n_rep), scale_key=st.scale_key, diag=diag, off=off,
+                                      n_pos=st.n_pos)
+            hit = memo[key] = (st.matrix, rep)
         return hit[1]
 
     def _tridiag_plan(self, state, n, pieces):
@@ -287,8 +291,6 @@ class NormalNormal(MCMCSampler):
         eng = self.engine
         terms, keys, chain_terms = [], [], []
         for pc in pieces:
-            if pc.get("replicated"):
-                raise NotImplementedError("replicated responses on the band route")
             st = pc["st"]
             cache = eng.band_cache(pc["dist"], st, pc["center"])
             scale = _as_chain_scalar(eng, state, st.scale_key) if st.scale_key is not None else None

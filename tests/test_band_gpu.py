@@ -233,3 +233,32 @@ def test_rw2_per_chain_rhs_pieces_replay_reference(golden, tag):
             ref = G[k + "store_" + key]
             err = np.max(np.abs(got[key][c] - ref) / np.maximum(1.0, np.abs(ref)))
             assert err < 1e-9, (key, c, err)
+
+
+@pytest.mark.parametrize("tag", ["d", "w"])
+def test_replicated_response_under_dense_and_band_precision(golden, tag):
+    """n_rep columns of y under a response precision that is not diagonal (sampler.py:165-167,187-188; gmrf.py:346-348):
+    dense (n = 8) and pentadiagonal (n = 14, band route); NormalNormal(x) and the stored log_post replay the reference
+    (tests/golden/replicated_dense.npz)."""
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.sampler.sampler import NormalNormal
+
+    G = golden("replicated_dense")
+    k = tag + "_"
+    n, C = int(G[k + "n"]), 2
+    mdl = Model([Normal("y", mean="x", precision="Q_y"), Normal("x", mean="mu", precision="P_x")])
+    state = {"y": G[k + "y"].copy(), "x": np.zeros(n), "mu": np.full(n, 0.3), "Q_y": sparse.csc_matrix(G[k + "Q_y"]),
+             "P_x": sparse.csc_matrix(G[k + "P_x"])}
+    smp = NormalNormal("x", mdl)
+    M = MCMC(state, [smp], model=mdl, n_burn=0, n_iter=int(G[k + "n_iter"]), n_chains=C)
+    eng = M.engine
+    assert smp.plan(M.state)["kind"] == ("dense" if tag == "d" else "band")
+    smp.inject = lambda s_, t: eng.to_device(np.tile(G[k + "z"][t], (C, 1)))
+    M.run_mcmc()
+    got = M.collect()
+    for c in range(C):
+        for key in ("x", "log_post"):
+            ref = G[k + "store_" + key]
+            assert np.max(np.abs(got[key][c] - ref) / np.maximum(1.0, np.abs(ref))) < 1e-10, (key, c)

@@ -316,3 +316,64 @@ def test_prior_recovery_like_reference():
     mean, sd = nb_all.mean(), nb_all.std()
     print("n_basis mean", mean, "sd", sd, "chi-square p (100 samples)", p_val, [s.accept_rate.get_acceptance_rate() for s in samplers])
     assert abs(mean - 7.46) < 0.6 and 2.2 < sd < 3.4
+
+
+def test_jump_with_normal_and_lognormal_associated_priors(golden):
+    """ReversibleJump alone on n ~ Poisson with theta (2, n) under a bivariate Normal prior (dense precision) and omega (1, n)
+    under a LogNormal prior: births draw the new columns from the priors (model[key].rvs, reversible_jump.py:130) and score
+    the last current ones (:132,143); the model's log_p sums each prior over the live columns.  Two reference runs x 150
+    sweeps replayed with their draws (tests/golden/rj_normal_assoc.npz): counts and decisions identical."""
+    import torch
+
+    from openmcmc_amd.chains import ChainArray
+    from openmcmc_amd.distribution.distribution import Poisson
+    from openmcmc_amd.distribution.location_scale import LogNormal, Normal
+    from openmcmc_amd.engine import Engine
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.sampler.reversible_jump import ReversibleJump
+
+    G = golden("rj_normal_assoc")
+    n_max, n_iter = int(G["n_max"]), int(G["n_iter"])
+    k0 = G["init_k"]
+    C = k0.size
+    eng = Engine(C)
+    dev = eng.device
+
+    def t(a):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+
+    mdl = Model([Poisson("n", rate="rho"), Normal("theta", mean="mu_t", precision="P_t"), LogNormal("omega", mean="mu_o", precision="P_o")])
+    state = {"n": ChainArray(t(k0).reshape(C, 1, 1)),
+             "theta": ChainArray(t(np.nan_to_num(G["init_theta"])), ragged=("n", 1)),
+             "omega": ChainArray(t(np.nan_to_num(G["init_omega"])).reshape(C, 1, n_max), ragged=("n", 1)),
+             "rho": float(G["rho"]), "mu_t": G["mu_t"].reshape(2, 1), "P_t": G["P_t"], "mu_o": np.array([[float(G["mu_o"])]]),
+             "P_o": np.array([[float(G["P_o"])]])}
+    rj = ReversibleJump(param="n", model=mdl, associated_params=["theta", "omega"], n_max=n_max)
+    tape = {k[5:]: G[k] for k in G.files if k.startswith("tape_")}
+    rj.inject_move = lambda s, it: (t(tape["move_u"][:, it]), torch.as_tensor(np.maximum(tape["idx"][:, it], 0).astype(np.int64), device=dev))
+    rj.inject_associated = lambda s, it: {"theta": t(_nan0(tape["theta_z"][:, it], 0.0)), "omega": t(_nan0(tape["omega_z"][:, it], 0.0))}
+    rj.inject_uniform = lambda s, it: t(tape["acc_u"][:, it])
+    M = MCMC(state, [rj], model=mdl, n_burn=0, n_iter=n_iter, n_chains=C, engine=eng)
+    states = []
+    inner = rj.sample
+
+    def sample(st):
+        st = inner(st)
+        states.append((st["n"].scalar().cpu().numpy().copy(), st["theta"].data.cpu().numpy().copy(), st["omega"].data.cpu().numpy().copy()))
+        return st
+
+    rj.sample = sample
+    M.run_mcmc()
+    got = M.collect()
+    assert np.array_equal(got["n"], G["store_n"])
+    e = np.abs(got["log_post"] - G["store_log_post"]) / np.maximum(1.0, np.abs(G["store_log_post"]))
+    assert e.max() < 1e-10
+    for it, (k, th, om) in enumerate(states):
+        for c in range(C):
+            kc = int(k[c])
+            ref_t, ref_o = G["state_theta"][c, it], G["state_omega"][c, it]
+            assert np.isnan(ref_t[:, kc:]).all() and not np.isnan(ref_t[:, :kc]).any()
+            assert np.max(np.abs(th[c][:, :kc] - ref_t[:, :kc])) < 1e-10 and np.max(np.abs(om[c][0, :kc] - ref_o[:kc])) < 1e-10
+    assert np.array_equal(rj.accept_rate.accept.cpu().numpy(), G["accept"][:, 0].astype(np.int64))
+    assert np.array_equal(rj.accept_rate.proposal.cpu().numpy(), G["accept"][:, 1].astype(np.int64))
