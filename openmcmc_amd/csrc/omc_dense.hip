@@ -223,8 +223,16 @@ __global__ void __launch_bounds__(256) k_tri_solve_batched(int64_t p, const doub
     const int bs = (int)((p - k0) < OMC_TS_B ? (p - k0) : OMC_TS_B);
     if (wave == 0) {
       // stage the diagonal block: lane = row inside the block (rows are contiguous in memory)
-      for (int j = 0; j < bs; ++j)
-        blk[lane * (OMC_TS_B + 1) + j] = (lane < bs && j <= lane) ? L[(k0 + lane) + (k0 + j) * p] : 0.0;
+      if (bs == OMC_TS_B) {  // all 64 loads on the way before the first is stored (a rolled loop waits for each in turn)
+        double v[OMC_TS_B];
+#pragma unroll
+        for (int j = 0; j < OMC_TS_B; ++j) v[j] = (j <= lane) ? L[(k0 + lane) + (k0 + j) * p] : 0.0;
+#pragma unroll
+        for (int j = 0; j < OMC_TS_B; ++j) blk[lane * (OMC_TS_B + 1) + j] = v[j];
+      } else {
+        for (int j = 0; j < bs; ++j)
+          blk[lane * (OMC_TS_B + 1) + j] = (lane < bs && j <= lane) ? L[(k0 + lane) + (k0 + j) * p] : 0.0;
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -248,11 +256,21 @@ __global__ void __launch_bounds__(256) k_tri_solve_batched(int64_t p, const doub
     __syncthreads();
     if (!TRANS) {
       // x_i -= sum_j L[i, k0+j] x_{k0+j} for the rows below the block (thread per row, coalesced)
+      // (a full block: all 64 loads of a row in flight at once -- with eight, a workgroup keeps 16 KB on the way, a third of
+      // what its share of the memory bandwidth needs at 1.5 us latency)
       for (int64_t i = k0 + bs + tid; i < p; i += 256) {
         const double* lp = L + i + k0 * p;
         double acc = 0.0;
+        if (bs == OMC_TS_B) {
+          double v[OMC_TS_B];
+#pragma unroll
+          for (int j = 0; j < OMC_TS_B; ++j) v[j] = lp[(int64_t)j * p];
+#pragma unroll
+          for (int j = 0; j < OMC_TS_B; ++j) acc = fma(v[j], xs[k0 + j], acc);
+        } else {
 #pragma unroll 8
-        for (int j = 0; j < bs; ++j) acc = fma(lp[(int64_t)j * p], xs[k0 + j], acc);
+          for (int j = 0; j < bs; ++j) acc = fma(lp[(int64_t)j * p], xs[k0 + j], acc);
+        }
         xs[i] -= acc;
       }
     } else {
@@ -261,8 +279,16 @@ __global__ void __launch_bounds__(256) k_tri_solve_batched(int64_t p, const doub
       for (int64_t j = tid; j < k0; j += 256) {
         const double* lp = L + k0 + j * p;
         double acc = 0.0;
+        if (bs == OMC_TS_B) {
+          double v[OMC_TS_B];
+#pragma unroll
+          for (int i = 0; i < OMC_TS_B; ++i) v[i] = lp[i];
+#pragma unroll
+          for (int i = 0; i < OMC_TS_B; ++i) acc = fma(v[i], xs[k0 + i], acc);
+        } else {
 #pragma unroll 8
-        for (int i = 0; i < bs; ++i) acc = fma(lp[i], xs[k0 + i], acc);
+          for (int i = 0; i < bs; ++i) acc = fma(lp[i], xs[k0 + i], acc);
+        }
         xs[j] -= acc;
       }
     }
