@@ -25,6 +25,12 @@ struct omc_ctx {
   size_t workspace_bytes;
   // dense path (omc_dense.hip): rocBLAS handle and workspaces, created on first use
   void* blas;
+  // blocked dense factorisation: second half of the chains on a side stream (forked from / joined into `stream` by events),
+  // so that one half's panel kernel (one workgroup per chain, latency-bound) runs under the other half's update GEMM
+  void* blas_aux;
+  hipStream_t aux_stream;
+  hipEvent_t ev_fork, ev_join;
+  int dense_overlap;  // option "dense_overlap": 1 (default) = split the chains in two halves when there are >= 64; 0 = one batch
   double* dense_factor; size_t dense_factor_bytes;
   int* dense_info; size_t dense_info_bytes;
   double* dense_tmp; size_t dense_tmp_bytes;

@@ -52,6 +52,10 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->tridiag_newton_max = 4;
   c->tridiag_perturb_ppb = 0;
   c->stamps = nullptr;
+  c->blas_aux = nullptr;
+  c->aux_stream = nullptr;
+  c->ev_fork = c->ev_join = nullptr;
+  c->dense_overlap = 1;
   c->debug_zero_z = 0;
   c->dense_use_rocsolver = 0;
   c->gram_use_rocblas = 0;
@@ -229,6 +233,11 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   }
   if (!strcmp(name, "debug_zero_z")) {
     ctx->debug_zero_z = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "dense_overlap")) {
+    if (value != 0 && value != 1) return OMC_INVALID_ARG;
+    ctx->dense_overlap = (int)value;
     return OMC_OK;
   }
   if (!strcmp(name, "stamps_ptr")) {  // diagnostic: device buffer [n_chains][16][16] of uint64, 0 = off

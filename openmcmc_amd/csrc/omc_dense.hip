@@ -35,6 +35,20 @@ omc_status omc_ensure_blas(omc_ctx* ctx) {
   return OMC_OK;
 }
 
+// side stream, its BLAS handle and the fork / join events of the blocked factorisation (made on first use)
+static omc_status ensure_aux(omc_ctx* ctx) {
+  if (ctx->blas_aux) return OMC_OK;
+  OMC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+  OMC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  OMC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  rocblas_handle h;
+  OMC_BLAS_CHECK(rocblas_create_handle(&h));
+  OMC_BLAS_CHECK(rocblas_set_stream(h, ctx->aux_stream));
+  OMC_BLAS_CHECK(rocblas_set_pointer_mode(h, rocblas_pointer_mode_host));
+  ctx->blas_aux = (void*)h;
+  return OMC_OK;
+}
+
 omc_status omc_ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need) {
   if (*have >= need) return OMC_OK;
   OMC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -310,7 +324,7 @@ __device__ __forceinline__ void lds_barrier() {  // workgroup barrier that waits
 }
 
 __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int nb, double* Qall, int* info,
-                                                    long long* bad) {
+                                                    long long* bad, int64_t chain0) {
   __shared__ double D[CH_NB][CH_NB + 1];  // diagonal block, then its Cholesky factor (zero outside the live nb x nb)
   __shared__ double LiT[CH_NB][CH_NB];    // transposed inverse of the factor (row t: column t of L_JJ^-1)
   __shared__ double dinv[CH_NB], dsq[CH_NB];
@@ -378,7 +392,7 @@ __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int n
   }
   if (tid == 0 && failed) {
     info[c] = (int)j0 + 1;
-    atomicMin((unsigned long long*)bad, (unsigned long long)c);
+    atomicMin((unsigned long long*)bad, (unsigned long long)(chain0 + c));
   }
   // rows below the block:  X = A_panel L_JJ^-T, i.e. X[r][cc] = sum_{t <= cc} A[r][t] Linv[cc][t].  One thread per
   // row: 64 accumulators in registers (compile-time indices); the row is fetched eight entries at a time, the next
@@ -412,21 +426,42 @@ __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int n
   }
 }
 
-static omc_status potrf_blocked(omc_ctx* ctx, rocblas_handle h, int64_t p, double* Q, int64_t C) {
-  OMC_HIP_CHECK(hipMemsetAsync(ctx->dense_info, 0, (size_t)C * sizeof(int), ctx->stream));
+// block columns of the chains [c0, c0 + Cn) on one stream
+static omc_status potrf_blocked_part(omc_ctx* ctx, rocblas_handle h, hipStream_t stream, int64_t p, double* Q, int64_t c0, int64_t Cn) {
   const double minus_one = -1.0, one = 1.0;
+  double* Qp = Q + c0 * p * p;
   for (int64_t j0 = 0; j0 < p; j0 += CH_NB) {
     const int nb = (int)((p - j0 < CH_NB) ? p - j0 : CH_NB);
     if (j0 > 0)
       OMC_BLAS_CHECK(rocblas_dgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose,
                                                    (rocblas_int)(p - j0), (rocblas_int)nb, (rocblas_int)j0, &minus_one,
-                                                   Q + j0, (rocblas_int)p, (rocblas_stride)(p * p), Q + j0, (rocblas_int)p,
-                                                   (rocblas_stride)(p * p), &one, Q + j0 + j0 * p, (rocblas_int)p,
-                                                   (rocblas_stride)(p * p), (rocblas_int)C));
-    hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)C), dim3(256), 0, ctx->stream, p, j0, nb, Q, ctx->dense_info,
-                       ctx->d_bad_chain);
+                                                   Qp + j0, (rocblas_int)p, (rocblas_stride)(p * p), Qp + j0, (rocblas_int)p,
+                                                   (rocblas_stride)(p * p), &one, Qp + j0 + j0 * p, (rocblas_int)p,
+                                                   (rocblas_stride)(p * p), (rocblas_int)Cn));
+    hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)Cn), dim3(256), 0, stream, p, j0, nb, Qp, ctx->dense_info + c0,
+                       ctx->d_bad_chain, c0);
     OMC_HIP_CHECK(hipGetLastError());
   }
+  return OMC_OK;
+}
+
+static omc_status potrf_blocked(omc_ctx* ctx, rocblas_handle h, int64_t p, double* Q, int64_t C) {
+  OMC_HIP_CHECK(hipMemsetAsync(ctx->dense_info, 0, (size_t)C * sizeof(int), ctx->stream));
+  // The panel kernel is one latency-bound workgroup per chain and the update GEMM cannot start before it: in one batch the
+  // two alternate and each leaves most of the chip idle in turn.  Two halves of the chains on two streams (fork and join by
+  // events: the caller still sees one stream) let one half's panels run under the other half's GEMMs.
+  if (!ctx->dense_overlap || C < 64) return potrf_blocked_part(ctx, h, ctx->stream, p, Q, 0, C);
+  omc_status st = ensure_aux(ctx);
+  if (st != OMC_OK) return st;
+  const int64_t C0 = C / 2;
+  OMC_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+  OMC_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+  st = potrf_blocked_part(ctx, (rocblas_handle)ctx->blas_aux, ctx->aux_stream, p, Q, C0, C - C0);
+  if (st != OMC_OK) return st;
+  st = potrf_blocked_part(ctx, h, ctx->stream, p, Q, 0, C0);
+  if (st != OMC_OK) return st;
+  OMC_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+  OMC_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   return OMC_OK;
 }
 
@@ -456,6 +491,13 @@ static unsigned gx(int64_t n) {
 void omc_dense_release(omc_ctx* ctx) {
   if (ctx->blas) rocblas_destroy_handle((rocblas_handle)ctx->blas);
   ctx->blas = nullptr;
+  if (ctx->blas_aux) {
+    rocblas_destroy_handle((rocblas_handle)ctx->blas_aux);
+    hipEventDestroy(ctx->ev_fork);
+    hipEventDestroy(ctx->ev_join);
+    hipStreamDestroy(ctx->aux_stream);
+    ctx->blas_aux = nullptr;
+  }
 }
 
 extern "C" {

@@ -190,6 +190,46 @@ def test_blocked_cholesky_route(p):
     eng.close()
 
 
+@pytest.mark.parametrize("C", [64, 129])
+def test_blocked_cholesky_two_halves_on_two_streams(C):
+    """From 64 chains on, the blocked factorisation runs the two halves of the chains on two streams (one half's panel
+    kernels under the other half's update GEMMs, fork / join by events).  Same arithmetic per chain: draws, means and log
+    determinants are bit-identical to the one-batch run; a chain that is not positive definite in the SECOND half is reported
+    under its own index; and the caller's stream sees the result complete (the next launch on it reads x)."""
+    import torch
+
+    p = 320
+    rng = np.random.default_rng(C)
+    X = rng.standard_normal((2 * p, p))
+    G = X.T @ X / p
+    lam, tau = rng.random(C) + 0.5, rng.random(C) * 2 + 0.5
+    eng = make_engine(C, seed=4)
+    terms = eng.dense_terms([{"mat": None, "scale": eng.to_device(lam)},
+                             {"mat": eng.to_device(G), "rhs": eng.to_device(rng.standard_normal(p)), "scale": eng.to_device(tau)}], p)
+    out = {}
+    for overlap in (0, 1):
+        eng.set_option("dense_overlap", overlap)
+        x, mean, logdet = eng.empty(C, p), eng.empty(C, p), eng.empty(C)
+        eng.dense_sample_canonical(p, terms, x, draw_index=7, mean_out=mean, logdet_out=logdet)
+        total = x.sum()  # a torch kernel on the same stream right behind the library call
+        eng.check_status()
+        out[overlap] = (x.clone(), mean.clone(), logdet.clone(), total.item())
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert torch.equal(a, b)
+    assert out[0][3] == out[1][3]
+    # oracle on a chain of each half
+    for c in (0, C - 1):
+        Q = lam[c] * np.eye(p) + tau[c] * G
+        assert abs(out[1][2][c].item() - np.linalg.slogdet(Q)[1]) < 1e-10 * abs(np.linalg.slogdet(Q)[1])
+    sc = np.ones(C)
+    sc[C - 2] = -1.0
+    bad = eng.dense_terms([{"mat": eng.to_device(G), "scale": eng.to_device(sc)}], p)
+    eng.dense_sample_canonical(p, bad, eng.empty(C, p))
+    with pytest.raises(np.linalg.LinAlgError, match=f"chain {C - 2}"):
+        eng.check_status()
+    eng.close()
+
+
 # ---- spectral route: Q_c = a_c I + b_c M in M's eigenbasis (omc_dense_spectral_sample) ------------------------------
 @pytest.mark.parametrize("p,C", [(70, 5), (300, 4)])
 def test_spectral_route_mean_logdet_and_mahalanobis(p, C):
