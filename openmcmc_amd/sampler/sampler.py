@@ -400,12 +400,12 @@ class NormalNormal(MCMCSampler):
             else:
                 v = what.mean.predictor_device(current_state, eng) if kind == "mean" and not isinstance(what.mean, Identity) else \
                     current_state[what.mean.form if kind == "mean" else what].vector()
-                if scale is not None:
-                    v = v * scale.reshape(-1, 1)
+                if scale is not None and op is not None and not isinstance(op, tuple):
+                    v = eng.tridiag_matvec_chain(v.shape[1], None, None, v, scale=scale)  # s_c v_c (identity matrix)
             if op is None:
-                t = v
+                t = v if (scale is None or kind == "offset") else eng.tridiag_matvec_chain(n, None, None, v, scale=scale)
             elif isinstance(op, tuple):
-                t = eng.band_matvec_chain(n, op[1], v)
+                t = eng.band_matvec_chain(n, op[1], v, scale=None if kind == "offset" else scale)
             else:
                 t = eng.design_predict(op, v)
             rhs_chain = t if rhs_chain is None else eng.chain_lincomb(1.0, rhs_chain, 1.0, t)
