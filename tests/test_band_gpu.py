@@ -262,3 +262,31 @@ def test_replicated_response_under_dense_and_band_precision(golden, tag):
         for key in ("x", "log_post"):
             ref = G[k + "store_" + key]
             assert np.max(np.abs(got[key][c] - ref) / np.maximum(1.0, np.abs(ref))) < 1e-10, (key, c)
+
+
+@pytest.mark.parametrize("n,w", [(1, 0), (5, 0), (7, 2), (64, 3), (1000, 5), (257, 128)])
+def test_band_matvec_chain_against_numpy(n, w):
+    """omc_band_matvec_chain: out[c] (+)= scale[c] * M v_c for a shared symmetric band matrix in lower band storage, identity
+    when no band is given; with and without per-chain scale, overwrite and accumulate."""
+    from openmcmc_amd.engine import Engine
+
+    w = min(w, n - 1)
+    rng = np.random.default_rng(n + w)
+    C = 5
+    M = np.zeros((n, n))
+    band = np.zeros((w + 1, n))
+    for d in range(w + 1):
+        v = rng.standard_normal(n - d)
+        band[d, : n - d] = v
+        M += np.diag(v, -d) + (np.diag(v, d) if d else 0)
+    V, sc, base = rng.standard_normal((C, n)), rng.random(C) + 0.5, rng.standard_normal((C, n))
+    eng = Engine(C)
+    dB, dV = eng.to_device(band), eng.to_device(V)
+    got = eng.band_matvec_chain(n, dB, dV).cpu().numpy()
+    assert np.allclose(got, V @ M, rtol=1e-13, atol=1e-13)
+    out = eng.to_device(base.copy())
+    eng.band_matvec_chain(n, dB, dV, scale=eng.to_device(sc), out=out, accumulate=True)
+    assert np.allclose(out.cpu().numpy(), base + sc[:, None] * (V @ M), rtol=1e-13, atol=1e-13)
+    ident = eng.band_matvec_chain(n, None, dV, scale=eng.to_device(sc)).cpu().numpy()
+    assert np.allclose(ident, sc[:, None] * V, rtol=1e-15, atol=0)
+    eng.close()
