@@ -33,6 +33,7 @@ struct omc_ctx {
   int dense_overlap;  // option "dense_overlap": 1 (default) = split the chains in two halves when there are >= 64; 0 = one batch
   double* dense_factor; size_t dense_factor_bytes;
   int* dense_info; size_t dense_info_bytes;
+  double* slice_buf; size_t slice_buf_bytes;  // partial products of a sliced contraction (omc_design_predict) [S][C][n]
   double* dense_tmp; size_t dense_tmp_bytes;
   double* rj_tmp; size_t rj_tmp_bytes;   // omc_knot_loop: the proposals of all knots
   double* mh_work; size_t mh_work_bytes;  // omc_mala.hip

@@ -38,6 +38,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->blas = nullptr;
   c->dense_factor = nullptr; c->dense_factor_bytes = 0;
   c->dense_info = nullptr; c->dense_info_bytes = 0;
+  c->slice_buf = nullptr; c->slice_buf_bytes = 0;
   c->dense_tmp = nullptr; c->dense_tmp_bytes = 0;
   c->rj_tmp = nullptr; c->rj_tmp_bytes = 0;
   c->mh_work = nullptr; c->mh_work_bytes = 0;
@@ -87,6 +88,7 @@ omc_status omc_ctx_destroy(omc_ctx* ctx) {
   if (ctx->d_handoff) hipFree(ctx->d_handoff);
   if (ctx->dense_factor) hipFree(ctx->dense_factor);
   if (ctx->dense_info) hipFree(ctx->dense_info);
+  if (ctx->slice_buf) hipFree(ctx->slice_buf);
   if (ctx->dense_tmp) hipFree(ctx->dense_tmp);
   if (ctx->rj_tmp) hipFree(ctx->rj_tmp);
   if (ctx->mh_work) hipFree(ctx->mh_work);

@@ -290,3 +290,19 @@ def test_spectral_route_draws_have_the_right_law():
     cov, S = r.T @ r / C, np.linalg.inv(Q)
     assert np.max(np.abs(cov - S)) < 6 * np.max(np.abs(S)) / np.sqrt(C)
     eng.close()
+
+
+@pytest.mark.parametrize("n,p,C", [(1000, 10000, 7), (200, 4096, 256), (37, 5003, 3), (300, 4095, 5)])
+def test_design_predict_long_contraction(n, p, C):
+    """omc_design_predict with a short output under a long contraction (A'W applied to per-chain vectors of the observation
+    space: the per-chain offsets of the dense route) cuts the contraction into slices and adds them in order; against numpy,
+    including a slice count that does not divide the contraction and a size just below the switch."""
+    rng = np.random.default_rng(n + p)
+    X, B = rng.standard_normal((n, p)), rng.standard_normal((C, p))
+    eng = make_engine(C)
+    got = eng.design_predict(eng.to_device(X), eng.to_device(B)).cpu().numpy()
+    ref = B @ X.T
+    assert np.max(np.abs(got - ref)) < 1e-11 * np.abs(ref).max()
+    again = eng.design_predict(eng.to_device(X), eng.to_device(B)).cpu().numpy()
+    assert np.array_equal(got, again)
+    eng.close()
