@@ -264,7 +264,27 @@ struct BandLaneArgs {
   const double* rhs[OMC_MAX_TERMS];          // shared right-hand sides with their scales
   const double* s_rhs[OMC_MAX_TERMS];
   int n_rhs;
+  const double* rhs_t;     // per-chain right-hand side, transposed: element (column i, chain c) at rhs_t[i * ld_t + c], or NULL
+  int64_t ld_t;            // (a lane beyond the last chain repeats the last chain's work, right-hand side included: the
+                           //  duplicates write the same values to the same workspace slots)
 };
+
+// rhs_chain [C][ld] -> [n][ld_t] (chains contiguous: what a lane-per-chain kernel reads coalesced), 64 x 64 tiles through LDS
+__global__ void __launch_bounds__(256) k_band_rhs_transpose(int64_t C, int64_t n, const double* __restrict__ src, int64_t ld,
+                                                            double* __restrict__ dst, int64_t ld_t) {
+  __shared__ double tile[64][65];
+  const int64_t i0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t c = c0 + r, i = i0 + tx;
+    tile[r][tx] = (c < C && i < n) ? src[c * ld + i] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t i = i0 + r;
+    if (i < n) dst[i * ld_t + c0 + tx] = tile[tx][r];
+  }
+}
 
 template <int W>
 __global__ void __launch_bounds__(64) k_band_lane(int64_t C, int64_t chain_offset, int64_t n, BandLaneArgs P,
@@ -300,7 +320,7 @@ __global__ void __launch_bounds__(64) k_band_lane(int64_t C, int64_t chain_offse
 #pragma unroll
       for (int d = 0; d < W1; ++d) q[d] = brow[d] ? sb * brow[d][col] : 0.0;
       q[0] += sid;
-      double b = 0.0;
+      double b = P.rhs_t ? P.rhs_t[col * P.ld_t + cc] : 0.0;
 #pragma unroll
       for (int k = 0; k < OMC_MAX_TERMS; ++k)
         if (k < P.n_rhs) b = fma(sr[k], P.rhs[k][col], b);
@@ -466,6 +486,7 @@ __global__ void __launch_bounds__(64) k_band_lane(int64_t C, int64_t chain_offse
 // acknowledgement per step.  Natural-order Cholesky throughout: the factor, u = L^-1 b and x = L^-T (u + z) are
 // k_band_lane's to rounding (the updates of a column are added in another order).
 #define BSEG_MAX 128
+#define BSEG_RC 32  // columns per staged piece of a per-chain right-hand side
 template <int W, int PHASE>
 __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset, int64_t n, BandLaneArgs P, int nseg,
                                                  int64_t mseg, int ov, double tol, const double* z_in, int64_t ld_z,
@@ -479,6 +500,7 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
   constexpr int NS = 2 * NJ + NF + NB + 2;  // per (group, segment): start window, end window, G/g, H/h/hm, log-det part, fail
   constexpr int O_JS = 0, O_JE = NJ, O_F = 2 * NJ, O_B = 2 * NJ + NF, O_LD = 2 * NJ + NF + NB, O_FAIL = O_LD + 1;
   __shared__ double stage_all[2 * (W1 + OMC_MAX_TERMS) * 64];
+  __shared__ double rc_tile[PHASE == 0 ? BSEG_RC : 1][64];  // per-chain right-hand side of the current BSEG_RC columns
   const int lane = threadIdx.x, seg = blockIdx.x;
   const int64_t grp = blockIdx.y;
   // second attempt with a longer warm-up: only the groups whose joins did not close the first time (gate is what the
@@ -535,6 +557,27 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
       staged = ch;
       fetch_chunk(ch + 1);
     };
+    // A per-chain right-hand side (transposed: a lane's value of a column is one coalesced load) is staged the same way,
+    // BSEG_RC columns at a time: the piece after the current one waits in registers (fetched a whole piece ahead of its
+    // use) and goes to this wave's LDS tile when the recurrence reaches it.
+    double rcreg[BSEG_RC];
+    int64_t rc_staged = -1, rc_inreg = -1;
+    auto rc_fetch = [&](int64_t pc) {
+#pragma unroll
+      for (int t = 0; t < BSEG_RC; ++t) {
+        const int64_t col = pc * BSEG_RC + t;
+        rcreg[t] = (col < n) ? P.rhs_t[col * P.ld_t + cc] : 0.0;
+      }
+      rc_inreg = pc;
+    };
+    auto rc_need = [&](int64_t pc) {  // uniform over the wave; columns are asked for in ascending order
+      if (pc <= rc_staged) return;
+      if (rc_inreg != pc) rc_fetch(pc);
+#pragma unroll
+      for (int t = 0; t < BSEG_RC; ++t) rc_tile[t][lane] = rcreg[t];
+      rc_staged = pc;
+      rc_fetch(pc + 1);
+    };
     auto column = [&](int64_t col, double (&q)[W1], double& r) {
       if (col < n) {
         need_chunk(col >> 6);
@@ -543,6 +586,10 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
         for (int d = 0; d < W1; ++d) q[d] = sb * src[d * 64];
         q[0] += sid;
         double b = 0.0;
+        if (P.rhs_t) {
+          rc_need(col / BSEG_RC);
+          b = rc_tile[col % BSEG_RC][lane];
+        }
 #pragma unroll
         for (int k2 = 0; k2 < OMC_MAX_TERMS; ++k2)
           if (k2 < P.n_rhs) b = fma(sr[k2], src[(W1 + k2) * 64], b);
@@ -862,7 +909,7 @@ __global__ void __launch_bounds__(256) k_band_transpose(int64_t C, int64_t n, co
 
 // Does the term list fit k_band_lane (exactly one banded term, the others identities)?
 static bool band_lane_args(const BandTermsDev& T, BandLaneArgs* P) {
-  P->band = nullptr; P->bw = 0; P->s_band = nullptr; P->n_ident = 0; P->n_rhs = 0;
+  P->band = nullptr; P->bw = 0; P->s_band = nullptr; P->n_ident = 0; P->n_rhs = 0; P->rhs_t = nullptr; P->ld_t = 0;
   for (int k = 0; k < T.n_terms; ++k) {
     if (T.band[k]) {
       if (P->band) return false;
@@ -949,7 +996,7 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
   const int64_t Cn = ctx->n_chains;
   const int64_t groups = (Cn + 63) / 64;
   BandLaneArgs LP;
-  const bool lane_fits = w >= 1 && w <= 8 && !rhs_chain && ctx->band_algo != 2 && band_lane_args(T, &LP);
+  const bool lane_fits = w >= 1 && w <= 8 && ctx->band_algo != 2 && band_lane_args(T, &LP);
   // Segmented route: about a thousand waves in all, segments of at least 128 columns and at least half the warm-up
   const int ov = ctx->band_seg_overlap;
   int64_t min_seg = ov / 2 > 96 ? ov / 2 : 96;
@@ -960,8 +1007,18 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
   // factor, then per column the zero-state u and its w unit responses (segmented route) / u alone
   const size_t base_doubles = (size_t)Cn * n * (segmented ? 2 * (w + 1) : (w + 2));
   const size_t seg_doubles = segmented ? 2 * (size_t)Cn * n + (size_t)groups * nseg * 48 * 64 + 2 * (size_t)groups : 0;
-  omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->workspace, &ctx->workspace_bytes, (base_doubles + seg_doubles) * sizeof(double));
+  const size_t rt_doubles = (lane_fits && rhs_chain) ? (size_t)n * groups * 64 : 0;  // the per-chain right-hand side, transposed
+  omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->workspace, &ctx->workspace_bytes,
+                                   (base_doubles + seg_doubles + rt_doubles) * sizeof(double));
   if (st != OMC_OK) return st;
+  if (rt_doubles) {
+    double* rt = ctx->workspace + base_doubles + seg_doubles;
+    hipLaunchKernelGGL(k_band_rhs_transpose, dim3((unsigned)((n + 63) / 64), (unsigned)groups), dim3(256), 0, ctx->stream, Cn, n,
+                       rhs_chain, ld_rhs, rt, groups * 64);
+    OMC_HIP_CHECK(hipGetLastError());
+    LP.rhs_t = rt;
+    LP.ld_t = groups * 64;
+  }
   if (segmented) {
     const int64_t mseg = (n + nseg - 1) / nseg;
     while ((int64_t)(nseg - 1) * mseg >= n) --nseg;  // no empty segment

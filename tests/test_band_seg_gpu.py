@@ -103,3 +103,40 @@ def test_without_mean_output():
     xs, ms, ls, fb, _ = draw(5000, 66, 2, 100.0, 1.0, 0, want_mean=False)
     x1, _, l1, _, _ = draw(5000, 66, 2, 100.0, 1.0, 1, want_mean=False)
     assert ms is None and np.abs(xs - x1).max() < 1e-10 * np.abs(x1).max()
+
+
+@pytest.mark.parametrize("n,C,order,algo", [(6000, 70, 2, 0), (4099, 5, 3, 0), (2500, 130, 1, 0), (700, 9, 2, 1), (300, 66, 5, 1)])
+def test_per_chain_right_hand_side_on_the_lane_routes(n, C, order, algo):
+    """A per-chain right-hand side (the offsets / sampled means of a hierarchical model on the band route) on the segmented
+    route (algo 0 at these sizes) and on the one-piece lane kernel (algo 1, widths up to 8): transposed once so that a lane
+    reads its value of a column coalesced, staged through registers and LDS a piece ahead in the segmented kernel.  Against
+    the workgroup-per-chain kernel (band_algo = 2), which reads rhs_chain directly, and a dense solve for one chain."""
+    from openmcmc_amd.engine import Engine
+
+    rng = np.random.default_rng(n + C)
+    P, band = rw_band(n, order, 1e-2)
+    y = rng.standard_normal(n)
+    lam_c, tau_c = 50.0 * (0.5 + rng.random(C)), 0.5 + rng.random(C)
+    rc = rng.standard_normal((C, n + 3))[:, :n]  # a leading dimension that is not n
+    z = rng.standard_normal((C, n))
+    out = {}
+    for a in (algo, 2):
+        eng = Engine(C, seed=4)
+        eng.set_option("band_algo", a)
+        T = eng.band_terms([{"band": eng.to_device(band), "scale": eng.to_device(lam_c)},
+                            {"rhs": eng.to_device(y), "scale": eng.to_device(tau_c)}], n)
+        rcd = eng.to_device(np.pad(rc, ((0, 0), (0, 3))))[:, :n]
+        x, m, ld = eng.empty(C, n), eng.empty(C, n), eng.empty(C)
+        eng.band_sample_canonical(n, T, x, z=eng.to_device(z), rhs_chain=rcd, mean_out=m, logdet_out=ld)
+        eng.check_status()
+        assert eng.counter("band_join_fallbacks") == 0
+        out[a] = (x.cpu().numpy(), m.cpu().numpy(), ld.cpu().numpy())
+        eng.close()
+    scale = np.abs(out[2][0]).max()
+    assert np.abs(out[algo][0] - out[2][0]).max() < 1e-10 * scale
+    assert np.abs(out[algo][1] - out[2][1]).max() < 1e-10 * scale
+    assert np.abs(out[algo][2] - out[2][2]).max() < 1e-9 * np.abs(out[2][2]).max()
+    c = C - 1
+    Q = lam_c[c] * P.toarray() + tau_c[c] * np.eye(n)
+    mu = np.linalg.solve(Q, tau_c[c] * y + rc[c])
+    assert np.abs(out[algo][1][c] - mu).max() < 1e-8 * max(1.0, np.abs(mu).max())
