@@ -112,18 +112,26 @@ class LinearCombination(Parameter):
             cs = None if (alpha == 1.0 and chain_scale is None) else _scaled(engine, chain_scale, alpha)
             return engine.design_predict_batched(B.columns(), v.vector(), add_chain=ident[0] if ident else None,
                                                  add_shared=shared, chain_scale=cs, out=out)
-        fitted = None
+        # several terms: summed with the library's a x + b y (omc_chain_lincomb; the state's own vectors are never written)
+        fitted, own = None, False  # own: `fitted` is a buffer of this call, free to be overwritten
         for t in ident:
-            fitted = t if fitted is None else fitted + t
+            if fitted is None:
+                fitted = t
+            else:
+                fitted, own = engine.chain_lincomb(1.0, fitted, 1.0, t, out=fitted if own else None), True
         for A, v in dense:
             term = engine.design_predict(engine.shared(A), v.vector(), out if fitted is None else None)
-            fitted = term if fitted is None else fitted + term
+            if fitted is None:
+                fitted, own = term, True
+            else:
+                fitted, own = engine.chain_lincomb(1.0, term, 1.0, fitted, out=term), True
         for B, v in batched:
-            fitted = engine.design_predict_batched(B.columns(), v.vector(), add_chain=fitted)
+            fitted, own = engine.design_predict_batched(B.columns(), v.vector(), add_chain=fitted), True
         if shared is not None:
-            fitted = fitted + shared.reshape(1, -1)
+            fitted, own = engine.chain_lincomb(1.0, fitted, 1.0, shared, out=fitted if own else None), True
         if alpha != 1.0 or chain_scale is not None:
-            fitted = fitted * _scaled(engine, chain_scale, alpha).reshape(-1, 1)
+            # s_c * fitted_c: the identity-matrix case of the per-chain scaled product
+            fitted, own = engine.tridiag_matvec_chain(fitted.shape[1], None, None, fitted, scale=_scaled(engine, chain_scale, alpha)), True
         if out is not None and fitted.data_ptr() != out.data_ptr():
             out.copy_(fitted)
             fitted = out
