@@ -184,6 +184,10 @@ omc_status omc_tridiag_matvec_chain(omc_ctx* ctx, int64_t n, const double* diag,
                                     const double* scale, double* out, int64_t ld_out, int32_t accumulate);
 omc_status omc_chain_lincomb(omc_ctx* ctx, int64_t n, double a, const double* x, int64_t ld_x, double b, const double* y, int64_t ld_y,
                              double* out, int64_t ld_out);
+/* dst[c][0..n) = src[c][0..n) for every chain: the current value of a parameter into its slab of the sample store
+ * (sampler/sampler.py:89-118, `store[param][:, [iteration]] = state[param]`) -- a copy kernel on the context's stream (the
+ * runtime's device-to-device memcpy moved the 82 MB of a 10 000 x 1024 state at 0.26 TB/s).                        */
+omc_status omc_chain_copy(omc_ctx* ctx, int64_t n, const double* src, int64_t ld_src, double* dst, int64_t ld_dst);
 omc_status omc_tridiag_logdet(omc_ctx* ctx, int64_t n, const double* diag, const double* off,
                               double* logdet);
 

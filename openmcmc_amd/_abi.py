@@ -183,6 +183,7 @@ SIGNATURES = {
     "omc_band_gibbs_truncated": (i32, [C.c_void_p, i64, i64, C.POINTER(BandTerms), c_dp, i64, c_dp, c_dp, c_dp, i64, u64, c_dp, i64]),
     "omc_tridiag_matvec_chain": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, i64, c_dp, c_dp, i64, i32]),
     "omc_chain_lincomb": (i32, [C.c_void_p, i64, C.c_double, c_dp, i64, C.c_double, c_dp, i64, c_dp, i64]),
+    "omc_chain_copy": (i32, [C.c_void_p, i64, c_dp, i64, c_dp, i64]),
     "omc_dense_spectral_prepare": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp]),
     "omc_dense_spectral_sample": (i32, [C.c_void_p, i64, C.POINTER(DenseTerms), i32, c_dp, c_dp, c_dp, i64, c_dp, i64, u64,
                                         c_dp, i64, c_dp, i64, c_dp]),

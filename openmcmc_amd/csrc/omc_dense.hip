@@ -727,6 +727,17 @@ omc_status omc_design_predict(omc_ctx* ctx, int64_t n, int64_t p, const double* 
   return OMC_OK;
 }
 
+omc_status omc_chain_copy(omc_ctx* ctx, int64_t n, const double* src, int64_t ld_src, double* dst, int64_t ld_dst) {
+  if (!ctx || n < 1 || !src || !dst || ld_src < n || ld_dst < n) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  if (src == dst && ld_src == ld_dst) return OMC_OK;
+  unsigned g = gx(n);
+  if (g > 64) g = 64;
+  hipLaunchKernelGGL(k_copy_rows, dim3(g, (unsigned)ctx->n_chains), dim3(256), 0, ctx->stream, n, src, ld_src, dst, ld_dst);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
 omc_status omc_weighted_resid_sq(omc_ctx* ctx, int64_t n, const double* y, const double* fitted, int64_t ld_fitted,
                                  const double* w, double* out) {
   if (!ctx || n < 1 || !y || !fitted || ld_fitted < n || !out) return OMC_INVALID_ARG;

@@ -1059,7 +1059,13 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   int sw = 0;  // sweep of this workgroup inside the launch (omc_gmrf_run: blockIdx = sweep * C + chain)
   if (MULTI) {
     unsigned blk = blockIdx.x;
-    if (A.n_sweeps > 1) {
+    // (several sweeps per launch: the specialised instantiation only.  The sweep index picks the sweep's record out of the
+    // kernel arguments; in the generic instantiation that dynamic index made the compiler keep a private copy of the
+    // records -- 1.4 KB of scratch per lane, 500 instead of 160 us per sweep -- so there it is the constant 0 and
+    // omc_gmrf_run issues its sweeps one per launch.  Still open: the per-lane selections of a Normal-Gamma block in the
+    // draws, the epilogue and the log-posterior together make the compiler keep a private copy of the four blocks for
+    // M >= 10 (360 bytes per lane, stored by every wave at entry); without it the generic instantiation runs at 107 us.)
+    if (SIG == 1 && A.n_sweeps > 1) {
       sw = (int)(blk / (unsigned)A.C);
       blk -= (unsigned)sw * (unsigned)A.C;
     }
@@ -1090,7 +1096,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // Sweeps after the first of a launch take the scales their Normal-Gamma blocks redraw from the hand-over line of
   // the chain (written by the workgroup of the previous sweep, possibly on another XCD); the loads are issued here
   // and examined where the scales are first needed (`take_scales`), behind the first pair of draws.
-  const bool handed = MULTI && sw > 0;
+  const bool handed = MULTI && SIG == 1 && sw > 0;
   // a self-restarting workgroup takes them from its own LDS (written by its wave 0 a moment ago: a poll there costs a
   // hundred cycles, a poll of the global line a trip to L2)
   const bool hand_lds = SIG == 1 && A.reenter != 0;
@@ -1975,7 +1981,7 @@ static int64_t seg_max_n(int seg) {
 }
 
 template <int M>
-static void launch_seg(omc_ctx* ctx, const TriArgs& A_in) {
+static bool launch_seg(omc_ctx* ctx, const TriArgs& A_in) {
   TriArgs A = A_in;
   const int S = (int)((A.n + M - 1) / M);
   if (S <= 64) {
@@ -1991,6 +1997,7 @@ static void launch_seg(omc_ctx* ctx, const TriArgs& A_in) {
     // self-restarting workgroups: the specialised instantiation only (it keeps no private memory, so the three entry
     // registers are all a restart has to reproduce)
     if (!special) A.reenter = 0;
+    if (!special && A.n_sweeps > 1) return false;  // (omc_gmrf_run gives the generic instantiation one sweep per launch)
     // workgroup-per-chain form: one workgroup per (sweep, chain), or per chain when the workgroups restart themselves
     const unsigned wg_grid = (unsigned)(A.C * ((A.n_sweeps > 0 && !A.reenter) ? A.n_sweeps : 1));
     if (special)
@@ -2000,15 +2007,16 @@ static void launch_seg(omc_ctx* ctx, const TriArgs& A_in) {
       hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT>), dim3(wg_grid), dim3(threads), 0, ctx->stream,
                          A, threads);
   }
+  return true;
 }
 
 static bool launch_seg_any(omc_ctx* ctx, const TriArgs& A, int seg) {
   switch (seg) {
-    case 8: launch_seg<8>(ctx, A); return true;
-    case 10: launch_seg<10>(ctx, A); return true;
-    case 16: launch_seg<16>(ctx, A); return true;
-    case 20: launch_seg<20>(ctx, A); return true;
-    case 32: launch_seg<32>(ctx, A); return true;
+    case 8: return launch_seg<8>(ctx, A);
+    case 10: return launch_seg<10>(ctx, A);
+    case 16: return launch_seg<16>(ctx, A);
+    case 20: return launch_seg<20>(ctx, A);
+    case 32: return launch_seg<32>(ctx, A);
   }
   return false;
 }
@@ -2027,6 +2035,21 @@ static bool takes_wg_per_chain(const omc_ctx* ctx, int64_t n) {
   const int seg = ctx->tridiag_seg ? ctx->tridiag_seg : auto_seg(n);
   if (n > seg_max_n(seg)) return false;
   return (n + seg - 1) / seg > 64;
+}
+
+// true if launch_tridiag would pick the structure-specialised instantiation (the one that takes several sweeps per launch)
+static bool takes_specialised(const omc_ctx* ctx, const TermsDev& T, int64_t n) {
+  if (!takes_wg_per_chain(ctx, n) || ctx->tridiag_generic || !is_smoother(T) || n < 2) return false;
+  const int seg = ctx->tridiag_seg ? ctx->tridiag_seg : auto_seg(n);
+  const int threads = 64 * (int)(((n + seg - 1) / seg + 63) / 64);
+  switch (seg) {
+    case 8: return SegCfg<8>::SMOOTHER && 2 * threads > SegCfg<8>::MAXT;
+    case 10: return SegCfg<10>::SMOOTHER && 2 * threads > SegCfg<10>::MAXT;
+    case 16: return SegCfg<16>::SMOOTHER && 2 * threads > SegCfg<16>::MAXT;
+    case 20: return SegCfg<20>::SMOOTHER && 2 * threads > SegCfg<20>::MAXT;
+    case 32: return SegCfg<32>::SMOOTHER && 2 * threads > SegCfg<32>::MAXT;
+  }
+  return false;
 }
 
 static omc_status launch_tridiag(omc_ctx* ctx, TriArgs& A) {
@@ -2171,7 +2194,9 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
     A.ld_x = ld_x;
     A.zero_z = ctx->debug_zero_z;
     A.fused = 1;
-    const int per = ctx->run_sweeps_per_launch < OMC_RUN_MAX ? ctx->run_sweeps_per_launch : OMC_RUN_MAX;
+    // (the generic instantiation: one sweep per launch, see the kernel)
+    const int per = !takes_specialised(ctx, A.T, n) ? 1
+                    : (ctx->run_sweeps_per_launch < OMC_RUN_MAX ? ctx->run_sweeps_per_launch : OMC_RUN_MAX);
     for (int64_t t0 = 0; t0 < total; t0 += per) {
       const int k_sw = (int)(total - t0 < per ? total - t0 : per);
       for (int i = 0; i < k_sw; ++i) {

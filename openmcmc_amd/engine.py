@@ -244,6 +244,12 @@ class Engine:
                                     self._p(out, self.n_chains, n), out.stride(0)))
         return out
 
+    def chain_copy(self, src, dst):
+        """dst[c] = src[c] for (C, n) tensors with unit inner stride (omc_chain_copy: into a store slab)."""
+        n = src.shape[1]
+        check(lib.omc_chain_copy(self._ctx, n, self._p(src, self.n_chains, n), src.stride(0), self._p(dst, self.n_chains, n), dst.stride(0)))
+        return dst
+
     def tridiag_matvec(self, n, diag, off, v):
         out = self.empty(n)
         check(lib.omc_tridiag_matvec(self._ctx, n, self._vec(diag, n), self._vec(off, n - 1) if n > 1 else None,

@@ -199,7 +199,7 @@ class MCMC:
                         continue
                     fitted = par.predictor(self.state)
                     if is_chain(fitted):
-                        self.store[response][i_it].copy_(fitted.data.reshape(self.n_chains, -1))
+                        eng.chain_copy(fitted.data.reshape(self.n_chains, -1), self.store[response][i_it])
                     else:
                         self.store[response][i_it].copy_(eng.to_device(np.asarray(fitted).reshape(1, -1)).expand(self.n_chains, -1))
         eng.check_status()  # raises numpy.linalg.LinAlgError like gmrf.py:518 if a factorisation failed

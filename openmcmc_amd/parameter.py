@@ -133,7 +133,7 @@ class LinearCombination(Parameter):
             # s_c * fitted_c: the identity-matrix case of the per-chain scaled product
             fitted, own = engine.tridiag_matvec_chain(fitted.shape[1], None, None, fitted, scale=_scaled(engine, chain_scale, alpha)), True
         if out is not None and fitted.data_ptr() != out.data_ptr():
-            out.copy_(fitted)
+            engine.chain_copy(fitted, out) if (fitted.stride(1) == 1 and out.stride(1) == 1) else out.copy_(fitted)
             fitted = out
         return fitted
 

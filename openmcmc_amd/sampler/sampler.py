@@ -93,7 +93,10 @@ class MCMCSampler(ABC):
         flat = value.data.reshape(self.engine.n_chains, -1)
         slab = store[self.param][iteration]
         if value.ragged is None:
-            slab.copy_(flat)
+            if flat.stride(1) == 1 and slab.stride(1) == 1 and flat.shape == slab.shape:
+                self.engine.chain_copy(flat, slab)
+            else:
+                slab.copy_(flat)
         else:  # live entries, NaN beyond (the reference leaves its NaN fill there, sampler.py:116)
             self.engine.store_ragged(flat if flat.stride(1) == 1 else flat.contiguous(), value.count(current_state), slab)
         return store
@@ -412,7 +415,7 @@ class NormalNormal(MCMCSampler):
         if p["limits"] is not None:
             # truncated prior: the scan starts from the current value and `z` carries the injected UNIFORMS
             lower, upper = p["limits"]
-            x.copy_(current_state[self.param].vector())
+            eng.chain_copy(current_state[self.param].vector(), x)
             gibbs = {"tridiag": eng.tridiag_gibbs_truncated, "band": eng.band_gibbs_truncated}.get(p["kind"], eng.dense_gibbs_truncated)
             gibbs(n, p["terms"], x, lower=lower, upper=upper, u=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
         elif p["kind"] == "tridiag":
