@@ -16,6 +16,7 @@ struct omc_ctx {
   unsigned long long* d_fallbacks;  // device word behind d_bad_chain: chain-updates that took the sequential join fallback
                                     // (d_fallbacks + 1: hand-overs of a several-sweeps launch that never arrived; + 2: groups of the
                                     //  segmented band route handed to the one-piece kernel; + 3: groups that needed its second attempt)
+  void* d_gamma_tab;                // generic tridiagonal instantiation: device image of a launch's Normal-Gamma blocks and streams
   unsigned long long* d_handoff;    // omc_gmrf_run: [n_chains][16] hand-over lines, allocated on first use
   uint32_t run_epoch;               // tag counter of the hand-over lines
   int run_sweeps_per_launch;        // omc_gmrf_run: sweeps per launch (1 = one launch per sweep)

@@ -69,6 +69,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   } else {
     c->stream = (hipStream_t)stream;
   }
+  c->d_gamma_tab = nullptr;
   c->d_handoff = nullptr; c->run_epoch = 1; c->run_sweeps_per_launch = 32; c->run_reenter = 2; c->run_reenter_force = 0;
   hipError_t e = hipMalloc(&c->d_bad_chain, 8 * sizeof(long long));
   if (e != hipSuccess) { omc_set_error("hipMalloc", e); delete c; return OMC_HIP_ERROR; }
@@ -85,6 +86,7 @@ omc_status omc_ctx_destroy(omc_ctx* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (ctx->workspace) hipFree(ctx->workspace);
+  if (ctx->d_gamma_tab) hipFree(ctx->d_gamma_tab);
   if (ctx->d_handoff) hipFree(ctx->d_handoff);
   if (ctx->dense_factor) hipFree(ctx->dense_factor);
   if (ctx->dense_info) hipFree(ctx->dense_info);

@@ -86,6 +86,11 @@ struct TriArgs {
   unsigned long long* stamps;  // diagnostic: [chain][wave][16] s_memtime at phase boundaries, or NULL
   int fused;
   GammaDev gb[OMC_MAX_TERMS];
+  // generic workgroup-per-chain instantiation: the same blocks and streams in device memory, where wave 0's lanes index them
+  // by their term (indexing the ARGUMENT copy per lane makes the compiler keep a private image of all blocks: 360 bytes of
+  // scratch per lane stored by every wave at entry, 160 instead of 107 us per sweep)
+  const GammaDev* gb_dev;
+  const unsigned long long* gdraw_dev;
   double* log_post;
   // several sweeps per launch (n_sweeps > 0; workgroup-per-chain form only)
   int n_sweeps;
@@ -146,14 +151,20 @@ __device__ __forceinline__ double read_lane_d(double v, int l) {  // l wave-unif
 // log-posterior of one sweep from the per-term scales, quadratic forms and log-determinants: lanes 16 k (k = term)
 // hold s, qk, ldet of their term; lane 0 stores the sum (model.py:57-70 -> gmrf.py:321-348, distribution.py:241-261).
 // Split from the epilogue so that a self-restarting workgroup can leave it to a wave that has slack (see the kernel).
+template <bool DEV = false>
 __device__ __forceinline__ void sweep_log_post_wave(const TriArgs& A, int64_t c, int lane, double s, double qk, double ldet,
                                                     double* lp_out) {
   const int k = lane >> 4, j = lane & 15;
   const bool term_on = k < A.T.n_terms;
-  GammaDev g = A.gb[0];
+  GammaDev g;
+  if constexpr (DEV) {
+    g = A.gb_dev[k];
+  } else {
+    g = A.gb[0];
 #pragma unroll
-  for (int t = 1; t < OMC_MAX_TERMS; ++t) {
-    if (k == t) g = A.gb[t];
+    for (int t = 1; t < OMC_MAX_TERMS; ++t) {
+      if (k == t) g = A.gb[t];
+    }
   }
   double lp = 0.0;
   if (term_on && j == 0) {
@@ -180,14 +191,22 @@ __device__ __forceinline__ void sweep_log_post_wave(const TriArgs& A, int64_t c,
 // shadow of the first global loads; each lane evaluates one Marsaglia-Tsang attempt, the lowest
 // accepted attempt is the serial answer.  Part 2, `sweep_epilogue_wave`: scale by 1/b once the
 // quadratic forms are known, store, log_post.
+template <bool DEV = false>
 __device__ __forceinline__ double sweep_gamma_draws_wave(const TriArgs& A, int64_t c, int lane, bool* failed, int sw = 0) {
   const int k = lane >> 4, j = lane & 15;
   const bool term_on = k < A.T.n_terms;
-  GammaDev g = A.gb[0];
-  uint64_t gdr = A.gdraw[0];
+  GammaDev g;
+  uint64_t gdr;
+  if constexpr (DEV) {
+    g = A.gb_dev[k];
+    gdr = A.gdraw_dev[k];
+  } else {
+    g = A.gb[0];
+    gdr = A.gdraw[0];
 #pragma unroll
-  for (int t = 1; t < OMC_MAX_TERMS; ++t)
-    if (k == t) { g = A.gb[t]; gdr = A.gdraw[t]; }
+    for (int t = 1; t < OMC_MAX_TERMS; ++t)
+      if (k == t) { g = A.gb[t]; gdr = A.gdraw[t]; }
+  }
   g.key = sweep_gamma_key(A, sw, g, gdr);
   const bool draw = term_on && g.enabled;
   double gd = 0.0;
@@ -220,6 +239,7 @@ __device__ __forceinline__ double sweep_gamma_draws_wave(const TriArgs& A, int64
   return gd;
 }
 
+template <bool DEV = false>
 __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c, double q0, double q1, double q2, double q3,
                                                     double s_old, double ldet, double gd, bool failed, int lane, int sw = 0,
                                                     unsigned long long* lds_hand = nullptr, bool defer_lp = false,
@@ -228,11 +248,16 @@ __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c,
   const bool term_on = k < A.T.n_terms;
   // per-lane copy of this lane's term, selected with compile-time indices (a dynamically indexed
   // kernel-argument array would be spilled to scratch)
-  GammaDev g = A.gb[0];
+  GammaDev g;
   double s = s_old;  // this lane's term; scalars were loaded before the quad phase
+  if constexpr (DEV) {
+    g = A.gb_dev[k];
+  } else {
+    g = A.gb[0];
 #pragma unroll
-  for (int t = 1; t < OMC_MAX_TERMS; ++t) {
-    if (k == t) g = A.gb[t];
+    for (int t = 1; t < OMC_MAX_TERMS; ++t) {
+      if (k == t) g = A.gb[t];
+    }
   }
   const double qk = (k == 0) ? q0 : ((k == 1) ? q1 : ((k == 2) ? q2 : q3));
   if (!term_on) s = 1.0;
@@ -263,7 +288,7 @@ __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c,
       }
     }
   }
-  if (lp_out && !defer_lp) sweep_log_post_wave(A, c, lane, s, qk, ldet, lp_out);
+  if (lp_out && !defer_lp) sweep_log_post_wave<DEV>(A, c, lane, s, qk, ldet, lp_out);
   if (failed) atomicMin((unsigned long long*)A.bad, (unsigned long long)c);
 }
 
@@ -1204,7 +1229,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // wave 0's SIMD has issue slots to spare (the opening phase is bound by the vector ALU there).
   if (SIG != 1 && epi_wave && chain_ok) {
     bool f = false;
-    const double g = sweep_gamma_draws_wave(A, c, lane, &f, sw);
+    const double g = sweep_gamma_draws_wave<MULTI && SIG != 1>(A, c, lane, &f, sw);
     lds_g[lane] = f ? -g : g;  // a Gamma draw is positive; the sign flags a draw that did not terminate
   }
 
@@ -1618,7 +1643,13 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     if (epi_wave) {  // lane group k = lane >> 4 serves term k
       _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt && (lane >> 4) == k) {
         if (A.T.scale[k]) my_scale = handed ? sc[k] : A.T.scale[k][cc];
-        if (sweep_log_post(A, sw) && A.gb[k].logdet_unscaled) my_logdet = A.gb[k].logdet_unscaled[0];
+        if constexpr (SIG == 1) {
+          if (sweep_log_post(A, sw) && A.gb[k].logdet_unscaled) my_logdet = A.gb[k].logdet_unscaled[0];
+        }
+      }
+      if constexpr (SIG != 1) {  // (the blocks' device image: see TriArgs::gb_dev)
+        const double* const ldp = ((lane >> 4) < nt) ? A.gb_dev[lane >> 4].logdet_unscaled : nullptr;
+        if (sweep_log_post(A, sw) && ldp) my_logdet = ldp[0];
       }
     }
     if constexpr (SIG == 1) {
@@ -1781,7 +1812,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       // restart without a barrier: the log-posterior of this sweep is left to wave 1 of the next one (it has the slack
       // this wave does not: everyone waits for the wave that ran the epilogue at the next sweep's first barrier)
       const bool defer_lp = SIG == 1 && A.reenter == 2 && sw + 1 < A.n_sweeps && nw > 1 && any_handed_f();
-      sweep_epilogue_wave(A, c, qsum[0], qsum[1], qsum[2], qsum[3], my_scale, my_logdet, fabs(g), g < 0.0, lane, sw,
+      sweep_epilogue_wave<SIG != 1>(A, c, qsum[0], qsum[1], qsum[2], qsum[3], my_scale, my_logdet, fabs(g), g < 0.0, lane, sw,
                           (SIG == 1 && A.reenter) ? lds_hand : nullptr, defer_lp, lds_q);
     }
     // x leaves last: a load issued behind a store would have to wait for the store to be
@@ -1945,6 +1976,7 @@ static void args_defaults(omc_ctx* ctx, TriArgs* A, int64_t n) {
   A->fused = 0;
   A->stamps = ctx->stamps;
   A->log_post = nullptr;
+  A->gb_dev = nullptr; A->gdraw_dev = nullptr;
   A->n_sweeps = 0; A->reenter = 0; A->early_draws = 0; A->epoch = 0; A->seed = ctx->seed; A->handoff = nullptr; A->timeouts = ctx->d_fallbacks + 1;
   for (int k = 0; k < OMC_MAX_TERMS; ++k) A->gdraw[k] = 0;
   for (int i = 0; i < OMC_RUN_MAX; ++i) { A->rec[i].draw = 0; A->rec[i].x = nullptr; A->rec[i].log_post = nullptr; A->rec[i].slot_off = -1; }
@@ -1998,6 +2030,17 @@ static bool launch_seg(omc_ctx* ctx, const TriArgs& A_in) {
     // registers are all a restart has to reproduce)
     if (!special) A.reenter = 0;
     if (!special && A.n_sweeps > 1) return false;  // (omc_gmrf_run gives the generic instantiation one sweep per launch)
+    if (!special && A.fused) {
+      // the Normal-Gamma blocks in device memory for the generic instantiation (stream-ordered copy: the previous launch
+      // has read its image by the time this one is written)
+      const size_t gb_bytes = sizeof(A.gb), gd_bytes = sizeof(A.gdraw);
+      if (!ctx->d_gamma_tab && hipMalloc(&ctx->d_gamma_tab, gb_bytes + gd_bytes) != hipSuccess) return false;
+      if (hipMemcpyAsync(ctx->d_gamma_tab, A.gb, gb_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return false;
+      if (hipMemcpyAsync((char*)ctx->d_gamma_tab + gb_bytes, A.gdraw, gd_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return false;
+      A.gb_dev = (const GammaDev*)ctx->d_gamma_tab;
+      A.gdraw_dev = (const unsigned long long*)((char*)ctx->d_gamma_tab + gb_bytes);
+    }
     // workgroup-per-chain form: one workgroup per (sweep, chain), or per chain when the workgroups restart themselves
     const unsigned wg_grid = (unsigned)(A.C * ((A.n_sweeps > 0 && !A.reenter) ? A.n_sweeps : 1));
     if (special)
