@@ -213,9 +213,11 @@ class Normal(Distribution):
             if resp.shape[1] != 1:
                 raise NotImplementedError("replicated responses")
             w = None if st.diag is None else engine.shared(st.diag)
-            quad = self.mean.resid_sq_device(state, engine, engine.shared(resp).reshape(-1), w)
-            if quad is not None:
-                return quad
+            frozen = getattr(self.mean, "_frozen", None)
+            if not (frozen and "fitted" in frozen):  # (fitted values at hand for this state: the residual is one pass over them)
+                quad = self.mean.resid_sq_device(state, engine, engine.shared(resp).reshape(-1), w)
+                if quad is not None:
+                    return quad
             fitted = self.mean.predictor_device(state, engine)
             quad = engine.empty(engine.n_chains)
             engine.weighted_resid_sq(engine.shared(resp).reshape(-1), fitted, quad, w=w)

@@ -167,6 +167,33 @@ class MCMC:
         last = self.store[nn.param][self.n_iter - 1] if self.n_iter > 0 else self._scratch(n)
         self.state[nn.param] = ChainArray(last)
 
+    def _early_freeze_plan(self):
+        """{sampler index: [(response key, predictor parameter)]}: stored LinearCombination predictors that may be evaluated
+        right after that sampler because nothing later in the sweep changes their inputs.  Only when every later sampler is a
+        conjugate one (it replaces its own parameter and nothing else) whose parameter the predictor does not use."""
+        from openmcmc_amd.parameter import LinearCombination
+        from openmcmc_amd.sampler.sampler import MixtureAllocation, NormalGamma, NormalNormal
+
+        plan = {}
+        if self._fused is not None or self.model.response is None:
+            return plan
+        for response, predictor in self.model.response.items():
+            par = getattr(self.model[response], predictor)
+            if not isinstance(par, LinearCombination):
+                continue
+            used = set(par.form.keys()) | set(par.form.values())
+            touching = [k for k, s in enumerate(self.samplers)
+                        if s.param in used or not isinstance(s, (NormalNormal, NormalGamma, MixtureAllocation))]
+            if not touching:
+                continue
+            k = max(touching)
+            if k == len(self.samplers) - 1 or self.samplers[k].param not in used:
+                continue  # nothing to gain, or the last sampler that matters is one that may change anything
+            if not isinstance(self.samplers[k], (NormalNormal, NormalGamma, MixtureAllocation)):
+                continue
+            plan.setdefault(k, []).append((response, par))
+        return plan
+
     def run_mcmc(self):
         eng = self.engine
         self._check_stream()
@@ -175,6 +202,7 @@ class MCMC:
             self._run_fused_in_c()
             eng.check_status()
             return
+        early = self._early_freeze_plan()
         for i_it in range(-self.n_burn, self.n_iter):
             storing = i_it >= 0
             for i_thin in range(self.n_thin):
@@ -182,26 +210,44 @@ class MCMC:
                 if self._fused is not None:
                     self._fused_sweep(i_it if (storing and last) else None)
                 else:
-                    for sampler in self.samplers:
+                    for k, sampler in enumerate(self.samplers):
                         self.state = sampler.sample(self.state)
+                        if storing and last:
+                            # a stored predictor whose inputs no later sampler of the sweep touches: evaluated here, into
+                            # its store slab, and reused by the samplers that follow (a NormalGamma's residual), by the store
+                            # and by log_post
+                            for response, par in early.get(k, ()):
+                                par._frozen = {}
+                                par.predictor_device(self.state, eng, out=self.store[response][i_it])
             if not storing:
                 continue
             if self._fused is None:
                 for sampler in self.samplers:
                     self.store = sampler.store(current_state=self.state, store=self.store, iteration=i_it)
-            if self._fused is None or not self._fused["log_post"]:
-                self.model.log_p(self.state, engine=eng, out=self.store["log_post"][i_it])
+            # The state does not change any more in this sweep: the fitted values go straight into their store slab and
+            # log_post's residual reads them from there (mcmc.py:99-111 evaluates the predictor once for each; for cfg2 that
+            # is a 5 GFLOP product per evaluation)
+            frozen = []
             if self.model.response is not None:
                 for response, predictor in self.model.response.items():
                     par = getattr(self.model[response], predictor)
                     if hasattr(par, "predictor_device") and any(is_chain(self.state[k]) for k in par.form):
-                        par.predictor_device(self.state, eng, out=self.store[response][i_it])
+                        if getattr(par, "_frozen", None) is None:
+                            par._frozen = {}
+                        frozen.append(par)
+                        par.predictor_device(self.state, eng, out=self.store[response][i_it])  # (a no-op when evaluated early)
                         continue
                     fitted = par.predictor(self.state)
                     if is_chain(fitted):
                         eng.chain_copy(fitted.data.reshape(self.n_chains, -1), self.store[response][i_it])
                     else:
                         self.store[response][i_it].copy_(eng.to_device(np.asarray(fitted).reshape(1, -1)).expand(self.n_chains, -1))
+            try:
+                if self._fused is None or not self._fused["log_post"]:
+                    self.model.log_p(self.state, engine=eng, out=self.store["log_post"][i_it])
+            finally:
+                for par in frozen:
+                    par._frozen = None
         eng.check_status()  # raises numpy.linalg.LinAlgError like gmrf.py:518 if a factorisation failed
         from openmcmc_amd.sampler.metropolis_hastings import MetropolisHastings
 

@@ -85,6 +85,22 @@ class LinearCombination(Parameter):
         evaluated on the GPU and shared terms added once (parameter.py:162-197).  A design matrix may be shared
         (one GEMM over all chains), an identity, or itself per chain -- a ChainArray (n, k) basis that depends on
         per-chain knots, possibly ragged -- which goes to omc_design_predict_batched."""
+        # While the state is frozen (MCMC's bookkeeping at the end of a sweep: fitted-value store, then log_post) the full
+        # predictor is evaluated once: `_frozen` is a dict the MCMC loop hangs on the parameter for that stretch.
+        frozen = getattr(self, "_frozen", None)
+        plain = exclude is None and alpha == 1.0 and chain_scale is None
+        if frozen is not None and plain and "fitted" in frozen:
+            hit = frozen["fitted"]
+            if out is None or out.data_ptr() == hit.data_ptr():
+                return hit
+            out.copy_(hit)
+            return out
+        if frozen is not None and plain:
+            frozen["fitted"] = self._predictor_device(state, engine, out, None, 1.0, None)
+            return frozen["fitted"]
+        return self._predictor_device(state, engine, out, exclude, alpha, chain_scale)
+
+    def _predictor_device(self, state: dict, engine, out, exclude, alpha, chain_scale):
         skip = [] if exclude is None else ([exclude] if isinstance(exclude, str) else list(exclude))
         host_sum, ident, batched, dense = 0, [], [], []
         for prm, prefactor in self.form.items():
