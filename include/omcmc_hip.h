@@ -279,9 +279,12 @@ omc_status omc_mala_step(omc_ctx* ctx, int64_t d, const double* Q, const double*
  * orders.  The context keeps a for the state at x: state_is_current != 0 promises that x has not been written by anyone
  * else since this function last returned for the same x (otherwise a = L'(x - mu) is recomputed: one more product).
  * L and mu must stay unchanged while in use (omc_mh_invalidate drops what was derived from them).                */
+/* log_p_out (both whitened steps; NULL = not wanted): [C] the log density of the target at the state the step leaves behind
+ * -- what Model.log_p would evaluate for the one-Normal model of this route (mcmc.py:99-111), taken from the quantities the
+ * acceptance test has formed anyway.                                                                                  */
 omc_status omc_mala_step_white(omc_ctx* ctx, int64_t d, const double* mu, const double* L, const double* sumlogL, double step,
                                const double* z_inject, int64_t ld_z, const double* u_inject, uint64_t draw_index, double* x,
-                               int64_t ld_x, int32_t state_is_current, int64_t* accept_count, int64_t* proposal_count);
+                               int64_t ld_x, int32_t state_is_current, int64_t* accept_count, int64_t* proposal_count, double* log_p_out);
 omc_status omc_rw_step(omc_ctx* ctx, int64_t d, const double* mu, const double* LQ, const double* sumlogLQ,
                        double step, const double* z_inject, int64_t ld_z, const double* u_inject,
                        uint64_t draw_index, double* x, int64_t ld_x, int64_t* accept_count,
@@ -291,7 +294,7 @@ omc_status omc_rw_step(omc_ctx* ctx, int64_t d, const double* mu, const double* 
  * formed exactly as in omc_rw_step.  state_is_current as for omc_mala_step_white.                                  */
 omc_status omc_rw_step_white(omc_ctx* ctx, int64_t d, const double* mu, const double* LQ, const double* sumlogLQ, double step,
                              const double* z_inject, int64_t ld_z, const double* u_inject, uint64_t draw_index, double* x,
-                             int64_t ld_x, int32_t state_is_current, int64_t* accept_count, int64_t* proposal_count);
+                             int64_t ld_x, int32_t state_is_current, int64_t* accept_count, int64_t* proposal_count, double* log_p_out);
 /* omc_mh_invalidate: drops the matrices cached for the last (Q, L, step) / LQ.  The cache is keyed by device
  * addresses; call this whenever Q, L or LQ were rewritten in place or re-created (a new buffer may land on a recycled
  * address).  The reference has nothing to invalidate: it refactorises every step (metropolis_hastings.py:345-346). */

@@ -103,11 +103,11 @@ SIGNATURES = {
     "omc_dense_cholesky": (i32, [C.c_void_p, i64, c_dp, C.c_double, c_dp, c_dp]),
     "omc_rw_step_white": (
         i32,
-        [C.c_void_p, i64, c_dp, c_dp, c_dp, C.c_double, c_dp, i64, c_dp, u64, c_dp, i64, i32, c_dp, c_dp],
+        [C.c_void_p, i64, c_dp, c_dp, c_dp, C.c_double, c_dp, i64, c_dp, u64, c_dp, i64, i32, c_dp, c_dp, c_dp],
     ),
     "omc_mala_step_white": (
         i32,
-        [C.c_void_p, i64, c_dp, c_dp, c_dp, C.c_double, c_dp, i64, c_dp, u64, c_dp, i64, i32, c_dp, c_dp],
+        [C.c_void_p, i64, c_dp, c_dp, c_dp, C.c_double, c_dp, i64, c_dp, u64, c_dp, i64, i32, c_dp, c_dp, c_dp],
     ),
     "omc_mala_step": (
         i32,

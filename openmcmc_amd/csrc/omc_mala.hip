@@ -346,7 +346,8 @@ omc_status omc_mala_step(omc_ctx* ctx, int64_t d, const double* Q, const double*
 __global__ void __launch_bounds__(256) k_mala_white(int64_t d, int64_t chain_offset, omc_rng_key nkey, omc_rng_key ukey,
                                                     const double* zin, int64_t ld_z, const double* u_in, const double* sumlogL,
                                                     double log_step_term, double lp_scale, double kappa, double* a,
-                                                    double* a_prop, int* accept_out, long long* acc_cnt, long long* prop_cnt) {
+                                                    double* a_prop, int* accept_out, long long* acc_cnt, long long* prop_cnt,
+                                                    double* logp_out) {
   __shared__ double red[4][4];
   __shared__ int accept;
   const int64_t c = blockIdx.x;
@@ -404,6 +405,7 @@ __global__ void __launch_bounds__(256) k_mala_white(int64_t d, int64_t chain_off
     }
     const int ok = log(u) < log_alpha;
     accept = ok;
+    if (logp_out) logp_out[c] = ok ? lp_prop : lp_cur;  // log target of the state this step leaves behind
     accept_out[c] = ok;
     if (prop_cnt) prop_cnt[c] += 1;
     if (acc_cnt && ok) acc_cnt[c] += 1;
@@ -440,7 +442,7 @@ static omc_status white_prepare(omc_ctx* ctx, int64_t d, const double* L, const 
 
 omc_status omc_mala_step_white(omc_ctx* ctx, int64_t d, const double* mu, const double* L, const double* sumlogL, double step,
                                const double* z_inject, int64_t ld_z, const double* u_inject, uint64_t draw_index, double* x,
-                               int64_t ld_x, int32_t state_is_current, int64_t* accept_count, int64_t* proposal_count) {
+                               int64_t ld_x, int32_t state_is_current, int64_t* accept_count, int64_t* proposal_count, double* log_p_out) {
   if (!ctx || d < 1 || d > 46340 || !L || !sumlogL || !x || ld_x < d || (z_inject && ld_z < d) || !(step > 0.0))
     return OMC_INVALID_ARG;
   const int64_t C = ctx->n_chains;
@@ -466,7 +468,7 @@ omc_status omc_mala_step_white(omc_ctx* ctx, int64_t d, const double* mu, const 
   hipLaunchKernelGGL(k_mala_white, dim3((unsigned)C), dim3(256), 0, ctx->stream, d, ctx->chain_offset,
                      omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL), omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM),
                      z_inject, ld_z, u_inject, sumlogL, (double)d * log(step), step * step, 1.0 - 0.5 * step * step, a, w.XP,
-                     w.flag, (long long*)accept_count, (long long*)proposal_count);
+                     w.flag, (long long*)accept_count, (long long*)proposal_count, log_p_out);
   OMC_HIP_CHECK(hipGetLastError());
   // x = mu + L^{-T} a on the chains that accepted (the others keep their x bit for bit)
   st = omc_dgemm_small(ctx, (int)d, (int)C, LinvT, d, a, d, (int)d, nullptr, 0, nullptr, 0, 0, 1, mu, x, ld_x, w.flag);
@@ -528,7 +530,8 @@ omc_status omc_rw_step(omc_ctx* ctx, int64_t d, const double* mu, const double* 
 // same two-rounding x + step z as there, so for equal decisions the states are bit-identical.
 __global__ void __launch_bounds__(256) k_rw_white(int64_t d, int64_t chain_offset, omc_rng_key ukey, const double* u_in,
                                                   const double* sumlogL, double step, const double* z, const double* wz,
-                                                  double* a, double* x, int64_t ld_x, long long* acc_cnt, long long* prop_cnt) {
+                                                  double* a, double* x, int64_t ld_x, long long* acc_cnt, long long* prop_cnt,
+                                                  double* logp_out) {
   __shared__ double red[2][4];
   __shared__ int accept;
   const int64_t c = blockIdx.x;
@@ -558,6 +561,7 @@ __global__ void __launch_bounds__(256) k_rw_white(int64_t d, int64_t chain_offse
     }
     const int ok = log(u) < log_alpha;
     accept = ok;
+    if (logp_out) logp_out[c] = ok ? lp_prop : lp_cur;  // log target of the state this step leaves behind
     if (prop_cnt) prop_cnt[c] += 1;
     if (acc_cnt && ok) acc_cnt[c] += 1;
   }
@@ -577,7 +581,7 @@ __global__ void __launch_bounds__(256) k_rw_white(int64_t d, int64_t chain_offse
 
 omc_status omc_rw_step_white(omc_ctx* ctx, int64_t d, const double* mu, const double* LQ, const double* sumlogLQ, double step,
                              const double* z_inject, int64_t ld_z, const double* u_inject, uint64_t draw_index, double* x,
-                             int64_t ld_x, int32_t state_is_current, int64_t* accept_count, int64_t* proposal_count) {
+                             int64_t ld_x, int32_t state_is_current, int64_t* accept_count, int64_t* proposal_count, double* log_p_out) {
   if (!ctx || d < 1 || d > 46340 || !LQ || !sumlogLQ || !x || ld_x < d || (z_inject && ld_z < d) || !(step > 0.0))
     return OMC_INVALID_ARG;
   const int64_t C = ctx->n_chains;
@@ -628,7 +632,7 @@ omc_status omc_rw_step_white(omc_ctx* ctx, int64_t d, const double* mu, const do
   if (st != OMC_OK) return st;
   hipLaunchKernelGGL(k_rw_white, dim3((unsigned)C), dim3(256), 0, s, d, ctx->chain_offset,
                      omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), u_inject, sumlogLQ, step, Z, WZ, a, x, ld_x,
-                     (long long*)accept_count, (long long*)proposal_count);
+                     (long long*)accept_count, (long long*)proposal_count, log_p_out);
   OMC_HIP_CHECK(hipGetLastError());
   ctx->rww_x = x; ctx->rww_ld = ld_x;
   return OMC_OK;

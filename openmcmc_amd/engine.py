@@ -371,13 +371,14 @@ class Engine:
                                 self._ip(proposal_count)))
 
     def mala_step_white(self, mu, L, sumlogL, step, x, state_is_current=False, z=None, u=None, draw_index=0, accept_count=None,
-                        proposal_count=None):
-        """omc_mala_step_white: the ManifoldMALA step for L = chol(Q / step^2) in whitened coordinates."""
+                        proposal_count=None, log_p_out=None):
+        """omc_mala_step_white: the ManifoldMALA step for L = chol(Q / step^2) in whitened coordinates; log_p_out (C,) takes
+        the target's log density at the state the step leaves behind."""
         d = L.shape[0]
         check(lib.omc_mala_step_white(self._ctx, d, self._vec(mu, d), self._p(L), self._p(sumlogL), float(step),
                                       self._p(z, self.n_chains, d), 0 if z is None else z.stride(0), self._chain_scalar(u),
                                       int(draw_index), self._p(x, self.n_chains, d), x.stride(0), int(bool(state_is_current)),
-                                      self._ip(accept_count), self._ip(proposal_count)))
+                                      self._ip(accept_count), self._ip(proposal_count), self._chain_scalar(log_p_out)))
 
     def rw_step(self, mu, LQ, sumlogLQ, step, x, z=None, u=None, draw_index=0, accept_count=None,
                 proposal_count=None):
@@ -388,13 +389,13 @@ class Engine:
                               self._ip(proposal_count)))
 
     def rw_step_white(self, mu, LQ, sumlogLQ, step, x, state_is_current=False, z=None, u=None, draw_index=0,
-                      accept_count=None, proposal_count=None):
+                      accept_count=None, proposal_count=None, log_p_out=None):
         """omc_rw_step_white: the fused random-walk step with L_Q'(x - mu) carried from step to step."""
         d = LQ.shape[0]
         check(lib.omc_rw_step_white(self._ctx, d, self._vec(mu, d), self._p(LQ), self._p(sumlogLQ), float(step),
                                     self._p(z, self.n_chains, d), 0 if z is None else z.stride(0), self._chain_scalar(u),
                                     int(draw_index), self._p(x, self.n_chains, d), x.stride(0), int(bool(state_is_current)),
-                                    self._ip(accept_count), self._ip(proposal_count)))
+                                    self._ip(accept_count), self._ip(proposal_count), self._chain_scalar(log_p_out)))
 
     # ------------------------------------------------------------------ per-model constants
     def matrix_logdet(self, st):

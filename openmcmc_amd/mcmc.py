@@ -244,7 +244,14 @@ class MCMC:
                         self.store[response][i_it].copy_(eng.to_device(np.asarray(fitted).reshape(1, -1)).expand(self.n_chains, -1))
             try:
                 if self._fused is None or not self._fused["log_post"]:
-                    self.model.log_p(self.state, engine=eng, out=self.store["log_post"][i_it])
+                    # one sampler on a one-distribution model whose fused step has just left the target's log density of
+                    # this very state behind (the whitened MALA / random-walk steps): that IS the model's log_p
+                    lp = getattr(self.samplers[0], "last_log_p", None) if len(self.samplers) == 1 and len(self.model) == 1 else None
+                    cur = self.state.get(self.samplers[0].param) if lp is not None else None
+                    if lp is not None and is_chain(cur) and cur.data.data_ptr() == lp[1].data_ptr():
+                        self.store["log_post"][i_it].copy_(lp[0])
+                    else:
+                        self.model.log_p(self.state, engine=eng, out=self.store["log_post"][i_it])
             finally:
                 for par in frozen:
                     par._frozen = None

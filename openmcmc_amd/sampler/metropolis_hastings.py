@@ -73,6 +73,13 @@ class MetropolisHastings(MCMCSampler):
         self.accept_rate.attach(engine)
         return self
 
+    def _log_p_buffer(self, engine):
+        """(C,) device buffer the fused steps leave the target's log density in."""
+        buf = getattr(self, "_log_p_buf", None)
+        if buf is None or buf.shape[0] != engine.n_chains:
+            buf = self._log_p_buf = engine.empty(engine.n_chains)
+        return buf
+
     def _gaussian_target(self, state):
         """Does the fused route apply?  (one Normal with the parameter as response, shared mean and precision)"""
         if list(self.model.keys()) != [self.param] or np.size(self.step) != 1:
@@ -259,6 +266,7 @@ class RandomWalk(MetropolisHastings):
                                             lp_cur=lp_cur)
 
     def sample(self, current_state: dict) -> dict:
+        self.last_log_p = None  # set again by the fused whitened steps only
         eng = self._need_engine()
         if self.domain_limits is None and self.state_update_function is None and self._gaussian_target(current_state):
             Q, mu, d = self._target(current_state)
@@ -269,8 +277,9 @@ class RandomWalk(MetropolisHastings):
             tag = (x.data_ptr(), x._version, LQ.data_ptr())  # see ManifoldMALA.sample: may the library reuse its L_Q'(x - mu)?
             eng.rw_step_white(mu, LQ, sl, float(self.step.item()), x, state_is_current=getattr(self, "_white_tag", None) == tag,
                               z=z, u=u, draw_index=self._draw_index(), accept_count=self.accept_rate.accept,
-                              proposal_count=self.accept_rate.proposal)
+                              proposal_count=self.accept_rate.proposal, log_p_out=self._log_p_buffer(eng))
             self._white_tag = tag
+            self.last_log_p = (self._log_p_buf, x)  # the target's log density at the state just left in x (see MCMC.run_mcmc)
         else:
             current_state = self._generic_step(current_state)
         self._sweep += 1
@@ -377,6 +386,7 @@ class RandomWalkLoop(RandomWalk):
         return current_state
 
     def sample(self, current_state: dict) -> dict:
+        self.last_log_p = None  # set again by the fused whitened steps only
         plan = self._knot_plan(current_state) if self.fused else None
         if plan is not None:
             current_state = self._knot_loop(current_state, plan)
@@ -539,6 +549,7 @@ class ManifoldMALA(MetropolisHastings):
         return self._accept_reject_proposal(current_state, prop_state, lq_f, lq_r, u=u, sub=(d + 1) // 2 + 1)
 
     def sample(self, current_state: dict) -> dict:
+        self.last_log_p = None  # set again by the fused whitened steps only
         eng = self._need_engine()
         if not self._gaussian_target(current_state):
             x = current_state[self.param]
@@ -566,8 +577,9 @@ class ManifoldMALA(MetropolisHastings):
             tag = (x.data_ptr(), x._version, L.data_ptr())
             eng.mala_step_white(mu, L, sl, step, x, state_is_current=getattr(self, "_white_tag", None) == tag, z=z, u=u,
                                 draw_index=self._draw_index(), accept_count=self.accept_rate.accept,
-                                proposal_count=self.accept_rate.proposal)
+                                proposal_count=self.accept_rate.proposal, log_p_out=self._log_p_buffer(eng))
             self._white_tag = tag
+            self.last_log_p = (self._log_p_buf, x)  # the target's log density at the state just left in x (see MCMC.run_mcmc)
         else:
             eng.mala_step(Q, mu, L, sl, step, x, z=z, u=u, draw_index=self._draw_index(),
                           accept_count=self.accept_rate.accept, proposal_count=self.accept_rate.proposal)

@@ -494,3 +494,46 @@ def test_gradient_branches_match_reference(golden):
         assert abs(gp.chain(c).item() - float(G[f"c{c}_grad_tau_prior"])) < 1e-6 * max(1.0, abs(float(G[f"c{c}_grad_tau_prior"])))
         assert abs(hp[c, 0, 0].item() - float(G[f"c{c}_hess_tau_prior"])) < 1e-4 * abs(float(G[f"c{c}_hess_tau_prior"]))
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["mala", "rw"])
+def test_log_post_of_the_fused_mh_steps_is_the_models_log_p(kind):
+    """One MH sampler on a one-Normal model: the whitened steps leave the target's log density of the state they end in
+    (omc_*_step_white log_p_out) and MCMC.run_mcmc stores that instead of evaluating Model.log_p again (mcmc.py:99-111).
+    Checked against the density evaluated in numpy at every stored state, and against the generic evaluation."""
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.sampler.metropolis_hastings import ManifoldMALA, RandomWalk
+
+    d, C = 24, 5
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((d, 2 * d))
+    Q = np.linalg.inv(A @ A.T / (2 * d))
+    Q = (Q + Q.T) / 2
+    mu = rng.standard_normal((d, 1))
+    out = {}
+    for fused_lp in (True, False):
+        mdl = Model([Normal("x", mean="mu", precision="Q")])
+        cls = ManifoldMALA if kind == "mala" else RandomWalk
+        smp = cls("x", mdl, step=np.array([[0.6 if kind == "mala" else 0.2]]))
+        M = MCMC({"x": np.zeros(d), "mu": mu, "Q": Q}, [smp], model=mdl, n_burn=5, n_iter=40, n_chains=C, seed=11)
+        if not fused_lp:  # force the generic evaluation: hide the step's by-product
+            inner = smp.sample
+
+            def sample(state, inner=inner, smp=smp):
+                state = inner(state)
+                smp.last_log_p = None
+                return state
+
+            smp.sample = sample
+        M.run_mcmc()
+        out[fused_lp] = M.collect()
+    x, lp = out[True]["x"], out[True]["log_post"]
+    _, logdet = np.linalg.slogdet(Q)
+    for c in range(C):
+        r = x[c] - mu  # (d, n_iter)
+        ref = 0.5 * (logdet - d * np.log(2 * np.pi) - np.einsum("it,ij,jt->t", r, Q, r))
+        assert np.max(np.abs(lp[c].ravel() - ref)) < 1e-9 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(out[True]["x"], out[False]["x"])
+    assert np.max(np.abs(out[True]["log_post"] - out[False]["log_post"])) < 1e-9 * np.abs(out[False]["log_post"]).max()
