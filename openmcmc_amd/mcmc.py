@@ -131,7 +131,8 @@ class MCMC:
             specs.append(spec)
         x_out = self.store[nn.param][store_it] if store_it is not None else self._scratch(n)
         lp = self.store["log_post"][store_it] if (store_it is not None and f["log_post"]) else None
-        eng.gmrf_sweep(n, plan["terms"], specs, x_out, z=None, draw_index=t * ns, log_post_out=lp)
+        z = nn.inject(nn, nn._sweep) if getattr(nn, "inject", None) is not None else None  # (test hook set after construction)
+        eng.gmrf_sweep(n, plan["terms"], specs, x_out, z=z, draw_index=t * ns, log_post_out=lp)
         self.state[nn.param] = ChainArray(x_out)
         for s in self.samplers:
             s._sweep += 1

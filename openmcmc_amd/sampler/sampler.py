@@ -207,9 +207,10 @@ class NormalNormal(MCMCSampler):
         if mixture_prior:
             plan = self._dense_plan(state, n, pieces)
             plan["mixture_prior"] = prior
-        elif tridiagonal:
+        elif tridiagonal and n <= self.TRIDIAG_WG_MAX:
             plan = self._tridiag_plan(state, n, pieces)
-        elif banded:
+        elif banded:  # (long tridiagonal chains too: beyond one workgroup per chain the segmented lane kernels of the band
+            #            route, w = 1, are a hundred times faster than the one-lane-per-chain fallback of the tridiagonal one)
             plan = self._band_plan(state, n, pieces)
         else:
             plan = self._dense_plan(state, n, pieces)
@@ -352,6 +353,7 @@ class NormalNormal(MCMCSampler):
                 "chain_terms": chain_terms}
 
     spectral = True  # class-level switch: False keeps every dense draw on the per-chain factorisation
+    TRIDIAG_WG_MAX = 16384  # largest n the workgroup-per-chain tridiagonal kernel takes (omc_tridiag.hip: seg_max_n(32))
 
     def _spectral_plan(self, p):
         """(k_mat, V, ev) if the dense plan is `scaled identities + one shared matrix` (order >= 64), else None; the

@@ -290,3 +290,48 @@ def test_band_matvec_chain_against_numpy(n, w):
     ident = eng.band_matvec_chain(n, None, dV, scale=eng.to_device(sc)).cpu().numpy()
     assert np.allclose(ident, sc[:, None] * V, rtol=1e-15, atol=0)
     eng.close()
+
+
+def test_long_tridiagonal_chains_take_the_band_route():
+    """Beyond the 16 384 nodes one workgroup takes, NormalNormal plans the band route (w = 1: the segmented lane-per-chain
+    kernels) instead of the tridiagonal route's one-lane-per-chain fallback.  Same draws: three sweeps of the example-4 model
+    at n = 17 000 through MCMC.run_mcmc with injected draws, once on each route, agree to rounding (b, lambda, tau, log_post)."""
+    from openmcmc_amd.distribution.distribution import Gamma
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import LinearCombination, ScaledMatrix
+    from openmcmc_amd.sampler.sampler import NormalGamma, NormalNormal
+
+    n, C, sweeps = 17000, 3, 3
+    rng = np.random.default_rng(5)
+    t = np.arange(n) * 60.0 / 10000
+    y = np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + 0.3 * rng.standard_normal(n)
+    D = sparse.diags([-np.ones(n - 1), np.ones(n - 1)], offsets=[0, 1], shape=(n - 1, n))
+    P = (D.T @ D + 1e-3 * sparse.identity(n)).tocsc()
+    z, g = rng.standard_normal((sweeps, n)), 5.0 + rng.random((sweeps, 2))
+    out = {}
+    saved = NormalNormal.TRIDIAG_WG_MAX
+    try:
+        for route, limit in (("band", saved), ("tridiag", 10**9)):
+            NormalNormal.TRIDIAG_WG_MAX = limit
+            mdl = Model([Normal("y", mean=LinearCombination(form={"b": "A"}), precision=ScaledMatrix(matrix="P_tau", scalar="tau")),
+                         Normal("b", mean="mu", precision=ScaledMatrix(matrix="P_lambda", scalar="lambda")),
+                         Gamma("lambda", shape="a_lam", rate="b_lam"), Gamma("tau", shape="a_tau", rate="b_tau")])
+            state = {"y": y, "b": y.copy(), "mu": np.full(n, 0.3), "lambda": 50.0, "P_lambda": P, "a_lam": 10.0, "b_lam": 1.0,
+                     "tau": 1.0, "P_tau": sparse.identity(n, format="csc"), "a_tau": 1.0, "b_tau": 1.0,
+                     "A": sparse.identity(n, format="csc")}
+            samplers = [NormalNormal("b", mdl), NormalGamma("lambda", mdl), NormalGamma("tau", mdl)]
+            M = MCMC(state, samplers, model=mdl, n_burn=0, n_iter=sweeps, n_chains=C)
+            eng = M.engine
+            samplers[0].inject = lambda s_, it: eng.to_device(np.tile(z[it], (C, 1)))
+            samplers[1].inject = lambda s_, it: eng.full((C,), g[it, 0])
+            samplers[2].inject = lambda s_, it: eng.full((C,), g[it, 1])
+            assert samplers[0].plan(M.state)["kind"] == route
+            M.run_mcmc()
+            out[route] = M.collect()
+    finally:
+        NormalNormal.TRIDIAG_WG_MAX = saved
+    for key in ("b", "lambda", "tau", "log_post"):
+        a, b = out["band"][key], out["tridiag"][key]
+        assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-9, key
