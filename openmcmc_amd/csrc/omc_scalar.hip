@@ -287,20 +287,32 @@ omc_status omc_fill_philox_u32(omc_ctx* ctx, int64_t n_words, uint64_t draw_inde
 }  // extern "C"
 
 // ---- log-density pieces for ragged parameters ---------------------
-__global__ void k_diag_gauss_logpdf(int64_t C, int64_t kmax, const double* x, const double* mean, const double* prec,
-                                    const double* count, double* out, int accumulate) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// sum over a wave in a fixed order (butterfly): every lane ends with the total
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) v += __shfl_xor(v, sh, 64);
+  return v;
+}
+
+// one WAVE per chain (blockDim 256 = 4 chains): the lanes stride over the chain's elements, coalesced; with one thread per
+// chain a p = 500 coefficient vector cost 180 us of serial, strided loads and logs
+__global__ void __launch_bounds__(256) k_diag_gauss_logpdf(int64_t C, int64_t kmax, const double* x, const double* mean, const double* prec,
+                                                           const double* count, double* out, int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (c >= C) return;
   const int64_t k = count ? (int64_t)count[c] : kmax;
   double ld = 0.0, q = 0.0;
-  for (int64_t j = 0; j < k; ++j) {
+  for (int64_t j = lane; j < k; j += 64) {
     const double d = prec[c * kmax + j];
     const double r = x[c * kmax + j] - (mean ? mean[c * kmax + j] : 0.0);
     ld += log(d);
     q = fma(d * r, r, q);
   }
+  ld = wave_sum_d(ld);
+  q = wave_sum_d(q);
   const double lp = 0.5 * (ld - (double)k * 1.8378770664093453 - q);
-  out[c] = accumulate ? out[c] + lp : lp;
+  if (lane == 0) out[c] = accumulate ? out[c] + lp : lp;
 }
 
 __global__ void k_poisson_logpmf(int64_t C, const double* x, double rate, double* out, int accumulate) {
@@ -418,12 +430,13 @@ __global__ void k_mixture_allocation(int64_t C, int64_t chain_offset, int64_t p,
   alloc[t] = (double)pick;
 }
 
-__global__ void k_categorical_logpmf(int64_t C, int64_t p, int64_t K, const double* alloc, const double* prob,
-                                     int64_t prob_rows, double* out, int accumulate, long long* bad) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_categorical_logpmf(int64_t C, int64_t p, int64_t K, const double* alloc, const double* prob,
+                                                            int64_t prob_rows, double* out, int accumulate, long long* bad) {
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per chain
+  const int lane = threadIdx.x & 63;
   if (c >= C) return;
   double lp = 0.0;
-  for (int64_t i = 0; i < p; ++i) {
+  for (int64_t i = lane; i < p; i += 64) {
     const int64_t a = (int64_t)alloc[c * p + i];
     if (a < 0 || a >= K) {
       atomicMin((unsigned long long*)bad, (unsigned long long)c);
@@ -431,24 +444,29 @@ __global__ void k_categorical_logpmf(int64_t C, int64_t p, int64_t K, const doub
     }
     lp += log(prob[(prob_rows > 1 ? i * K : 0) + a]);
   }
-  out[c] = accumulate ? out[c] + lp : lp;
+  lp = wave_sum_d(lp);
+  if (lane == 0) out[c] = accumulate ? out[c] + lp : lp;
 }
 
-// NormalGamma.sample for a mixture precision: one thread per (chain, component)
-__global__ void k_mixture_normal_gamma(int64_t C, int64_t chain_offset, int64_t p, int64_t K, const double* resid,
-                                       const double* alloc, const double* a0, const double* b0, const double* g_in,
-                                       omc_rng_key key, double* out, long long* bad) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// NormalGamma.sample for a mixture precision: one wave per (chain, component); the lanes stride over the elements
+__global__ void __launch_bounds__(256) k_mixture_normal_gamma(int64_t C, int64_t chain_offset, int64_t p, int64_t K, const double* resid,
+                                                              const double* alloc, const double* a0, const double* b0, const double* g_in,
+                                                              omc_rng_key key, double* out, long long* bad) {
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (t >= C * K) return;
   const int64_t c = t / K, k = t % K;
   double cnt = 0.0, ss = 0.0;
-  for (int64_t i = 0; i < p; ++i) {
+  for (int64_t i = lane; i < p; i += 64) {
     if ((int64_t)alloc[c * p + i] == k) {
       const double r = resid[c * p + i];
       cnt += 1.0;
       ss = fma(r, r, ss);
     }
   }
+  cnt = wave_sum_d(cnt);
+  ss = wave_sum_d(ss);
+  if (lane != 0) return;
   const double a = a0[k] + 0.5 * cnt, b = b0[k] + 0.5 * ss;
   const double scale = (b == 0.0) ? INFINITY : 1.0 / b;
   bool failed = false;
@@ -543,7 +561,7 @@ omc_status omc_categorical_logpmf(omc_ctx* ctx, int64_t p, int64_t K, const doub
                                   int64_t prob_rows, double* out, int32_t accumulate) {
   if (!ctx || p < 1 || K < 1 || !alloc || !prob || (prob_rows != 1 && prob_rows != p) || !out) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_categorical_logpmf, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, p, K,
+  hipLaunchKernelGGL(k_categorical_logpmf, dim3(grid1(ctx->n_chains, 4)), dim3(256), 0, ctx->stream, ctx->n_chains, p, K,
                      alloc, prob, prob_rows, out, (int)accumulate, ctx->d_bad_chain);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
@@ -554,7 +572,7 @@ omc_status omc_mixture_normal_gamma(omc_ctx* ctx, int64_t p, int64_t K, const do
                                     double* out) {
   if (!ctx || p < 1 || K < 1 || K > 255 || !resid || !alloc || !a0 || !b0 || !out) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_mixture_normal_gamma, dim3(grid1(ctx->n_chains * K, 64)), dim3(64), 0, ctx->stream, ctx->n_chains,
+  hipLaunchKernelGGL(k_mixture_normal_gamma, dim3(grid1(ctx->n_chains * K, 4)), dim3(256), 0, ctx->stream, ctx->n_chains,
                      ctx->chain_offset, p, K, resid, alloc, a0, b0, g_inject,
                      omc_make_key(ctx->seed, draw_index, OMC_RNG_GAMMA), out, ctx->d_bad_chain);
   OMC_HIP_CHECK(hipGetLastError());
@@ -615,7 +633,7 @@ omc_status omc_diag_gauss_logpdf(omc_ctx* ctx, int64_t kmax, const double* x, co
                                  const double* count, double* out, int32_t accumulate) {
   if (!ctx || kmax < 1 || !x || !prec || !out) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_diag_gauss_logpdf, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, kmax,
+  hipLaunchKernelGGL(k_diag_gauss_logpdf, dim3(grid1(ctx->n_chains, 4)), dim3(256), 0, ctx->stream, ctx->n_chains, kmax,
                      x, mean, prec, count, out, (int)accumulate);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
