@@ -92,7 +92,8 @@ omc_status omc_ctx_synchronize(omc_ctx* ctx);
  * (8..65536, default 192: columns of warm-up before a segment of the segmented narrow-band route),
  * "dense_overlap" (0/1, default 1: the blocked dense factorisation runs the two halves of the chains on two streams,
  * forked from and joined into the context's stream by events; bit-identical results), "dense_use_rocsolver" (1: rocSOLVER's
- * potrf instead of the blocked route; cross-checks).
+ * potrf instead of the blocked route; cross-checks), "dense_blocked_min" (default 144: smallest order that takes the blocked
+ * factorisation; rocSOLVER's small kernels below).
  * Unknown name -> OMC_INVALID_ARG.                                                            */
 omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value);
 /* Diagnostic counters, by name (synchronises): "tridiag_join_fallbacks" = chain-updates of the segmented

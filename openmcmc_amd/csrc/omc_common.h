@@ -31,6 +31,7 @@ struct omc_ctx {
   void* blas_aux;
   hipStream_t aux_stream;
   hipEvent_t ev_fork, ev_join;
+  int dense_blocked_min;  // option "dense_blocked_min": smallest order that takes the blocked factorisation (rocSOLVER below)
   int dense_overlap;  // option "dense_overlap": 1 (default) = split the chains in two halves when there are >= 64; 0 = one batch
   double* dense_factor; size_t dense_factor_bytes;
   int* dense_info; size_t dense_info_bytes;

@@ -57,6 +57,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->aux_stream = nullptr;
   c->ev_fork = c->ev_join = nullptr;
   c->dense_overlap = 1;
+  c->dense_blocked_min = 144;  // measured crossover with rocSOLVER: even at 128, the blocked route 1.3-1.8x faster at 200
   c->debug_zero_z = 0;
   c->dense_use_rocsolver = 0;
   c->gram_use_rocblas = 0;
@@ -237,6 +238,11 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   }
   if (!strcmp(name, "debug_zero_z")) {
     ctx->debug_zero_z = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "dense_blocked_min")) {
+    if (value < 1 || value > 32768) return OMC_INVALID_ARG;
+    ctx->dense_blocked_min = (int)value;
     return OMC_OK;
   }
   if (!strcmp(name, "dense_overlap")) {

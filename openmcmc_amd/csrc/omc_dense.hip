@@ -531,7 +531,7 @@ omc_status omc_dense_sample_canonical(omc_ctx* ctx, int64_t p, const omc_dense_t
   double* Q = ctx->dense_factor;
   hipLaunchKernelGGL(k_dense_assemble, dim3(gx(p * p) > 64 ? 64 : gx(p * p), (unsigned)C), dim3(256), 0, ctx->stream, T, p, C, Q);
   OMC_HIP_CHECK(hipGetLastError());
-  if (p >= 256 && !ctx->dense_use_rocsolver) {
+  if (p >= ctx->dense_blocked_min && !ctx->dense_use_rocsolver) {
     st = potrf_blocked(ctx, h, p, Q, C);
     if (st != OMC_OK) return st;
   } else {
