@@ -13,10 +13,17 @@ bookkeeping of MCMC.run_mcmc (store of b/lambda/tau and log_post, mcmc.py:105-10
 from the in-kernel Philox stream; all inputs are resident in HBM before the timed region.
 
 Chains are independent, so ranks share nothing during sampling; the only collective is the gather of
-the per-chain traces and stores at the end, outside the timed region.  --scaling weak (default, the
-headline `value`): every GPU runs 1024 chains.  --scaling strong: 1024 chains in all, sharded evenly
-(BASELINE.md section 3).  For N > 1 the default run measures the other mode as well, after the headline,
-and reports it in the same JSON line (`other_scaling`).
+the per-chain traces and stores at the end, outside the timed region.  --scaling strong (default, the
+headline `value`; BASELINE.json's metric is "1024 chains ... at 1/2/4/8 GPUs", BASELINE.md section 3 "chains
+sharded evenly"): 1024 chains in all.  --scaling weak: every GPU runs 1024 chains.  For N > 1 the default run
+measures the other mode as well, after the headline, and reports it in the same JSON line (`other_scaling`).
+
+Every timed run explains itself (`config.diagnostics`): the library's launch log (host clock around every kernel
+launch of the run), the in-kernel sweep clock (entry and exit of every (sweep, chain) workgroup on the device's
+constant-rate counter) and the deltas of the slow-path counters, reduced to: when the host issued, when the device
+started, how long the sweeps took (median, maximum, which chain), whether slow sweeps were single chains or the whole
+device at once -- so a slow run says where its time went.  After the headline and its repeats the other BASELINE
+configs run for a bounded time each and are attached under `config.secondary` (never part of `value`).
 """
 
 import argparse
@@ -107,6 +114,8 @@ class GmrfSweep:
 
     def run_fused(self, k):
         """k sweeps issued by ONE call into the library (omc_gmrf_run): no host work between launches."""
+        if k <= 0:
+            return
         eng, n = self.eng, self.n
         blocks = [{"a0": self.A_LAM, "b0": self.B_LAM, "n_pos": n, "store": self.store_lam, "logdet": self.logdetP, "draw_index": 1},
                   {"a0": self.A_TAU, "b0": self.B_TAU, "n_pos": n, "store": self.store_tau, "logdet": self.logdetI, "draw_index": 2}]
@@ -186,6 +195,40 @@ def cpu_baseline(n, seconds_budget=12.0):
     }
 
 
+def secondary_lines(args):
+    """cfg2 / cfg4 / cfg5 (benchmarks/secondary.py) for about --secondary-ms each, reduced to {ms_per_step, value, frac,
+    check, cpu_baseline}; a config that fails reports its error and the headline line stays."""
+    import types
+
+    import torch
+
+    from benchmarks import secondary
+
+    out = {}
+    # steps per config from the rates of profiles/ (cfg2 0.23 ms, cfg4 0.02 ms, cfg5 0.9 ms per step): about secondary_ms each
+    plan = {"cfg2": (0.25, 5), "cfg4": (0.03, 20), "cfg5": (1.0, 3)}
+    for name, (ms_guess, warm) in plan.items():
+        steps = int(max(20, min(20000, args.secondary_ms / ms_guess)))
+        a = types.SimpleNamespace(steps=steps, warmup=warm, chains=None, no_cpu=args.no_cpu, mala_products=False, config=name,
+                                  condition_ms=min(200.0, args.secondary_ms / 4))
+        t0 = time.perf_counter()
+        try:
+            line = getattr(secondary, name)(a, torch)
+            roof = line.get("roofline") or {}
+            out[name] = {"metric": line["metric"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+                         "steps": steps, "warmup": warm, "workload": line["config"]["workload"], "check": line["config"].get("check"),
+                         "roofline": {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "note", "factorisation_route",
+                                                                "equivalent_tflops_on_reference_count")} if roof else None,
+                         "cpu_baseline": line.get("cpu_baseline"), "route": line["config"].get("route"),
+                         "seconds_spent": None}
+        except Exception as exc:  # noqa: BLE001 -- the headline must survive
+            out[name] = {"error": repr(exc)}
+        out[name]["seconds_spent"] = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,17 +237,23 @@ def main():
     ap.add_argument("--config", choices=["cfg3", "cfg2", "cfg4", "cfg5"], default="cfg3",
                     help="cfg3 (default): the headline GMRF smoother; the others: benchmarks/secondary.py, one GPU")
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (weak) / in all (strong); default: the config's")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: --chains per GPU; strong: --chains in all, sharded evenly over the GPUs")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default; BASELINE's metric): --chains in all, sharded evenly over the GPUs; weak: --chains per GPU")
     ap.add_argument("--one-mode", action="store_true", help="N > 1: do not measure the other scaling mode as well")
-    ap.add_argument("--condition-ms", type=float, default=300.0,
-                    help="untimed device conditioning before the W warm-up steps: the same sweep on the same chains for this long, "
-                         "so that a short run does not time the clock ramp out of the idle power state (first ~10 ms of load)")
+    ap.add_argument("--condition-sweeps", type=int, default=4096,
+                    help="untimed device conditioning before the W warm-up steps: this many sweeps of the same kernel on the same "
+                         "chains (a FIXED count: state, draw indices and check values are the same on every box), so that a short "
+                         "run does not time the clock ramp out of the idle power state (first ~10 ms of load); ends with a dress "
+                         "rehearsal of the timed run (event pair + K sweeps + read-back of the diagnostics)")
+    ap.add_argument("--secondary-ms", type=float, default=1000.0,
+                    help="N = 1: after the headline, run cfg2 / cfg4 / cfg5 for about this long each and attach them under "
+                         "config.secondary (0 = skip)")
     ap.add_argument("--repeat-ms", type=float, default=250.0,
                     help="after the headline, repeat the K-step run until this much time has been measured (spread report)")
     ap.add_argument("--nodes", type=int, default=N_NODES)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-sweep-clock", action="store_true", help="diagnostic: without the in-kernel sweep clock (one 16-byte store per workgroup and sweep)")
     ap.add_argument("--python-loop", action="store_true", help="issue every sweep from Python instead of omc_gmrf_run")
     ap.add_argument("--unfused", action="store_true", help="one launch per sampler instead of the fused sweep kernel")
     ap.add_argument("--zero-z", action="store_true", help="diagnostic what-if: no draw generation (results are not samples)")
@@ -276,10 +325,74 @@ def main():
         base, extra = divmod(args.chains, world)
         return base + (1 if rank < extra else 0), rank * base + min(rank, extra)
 
+    def diagnose(sweep, snap, t_host0, ev_ms, counters0, counters1, launches):
+        """Where did the time of one timed K-sweep run go?  From the library's launch log (host clock), the sweep clock
+        (device counter at entry / exit of every (sweep, chain) workgroup; `snap` = the run's records, copied on the device
+        right after the run) and the slow-path counters.  Called after ALL timed runs: a read-back and a few milliseconds
+        of numpy between two runs leave the device idle long enough for its clocks to drop (measured: the next run 13 %
+        slow, the ones after it recovering over ~10 runs)."""
+        eng = sweep.eng
+        d = {}
+        d["counters"] = {nm: counters1[nm] - counters0[nm] for nm in counters0}
+        n_launch, recs = launches
+        d["launches"] = n_launch
+        d["host_issue_ms"] = [[round(1e3 * (r["t_begin"] - t_host0), 4), round(1e3 * (r["t_end"] - t_host0), 4)] for r in recs[:8]]
+        d["launch_form"] = sorted({r["form"] for r in recs})
+        if snap is None:
+            return d
+        tk = snap.cpu().numpy()  # (k, C, 2) ticks
+        k = tk.shape[0]
+        khz = float(eng.counter("wall_clock_khz")) or 1e5
+        start, end = tk[:, :, 0].astype(np.float64), tk[:, :, 1].astype(np.float64)
+        dur = (end - start) / khz  # ms per (sweep, chain)
+        t_first = start.min()
+        d["device_span_ms"] = float((end.max() - t_first) / khz)
+        if ev_ms is not None:  # the part of the event interval in which no workgroup of the run was on the device
+            d["outside_kernels_ms"] = float(ev_ms - d["device_span_ms"])
+        med = float(np.median(dur))
+        i_max = np.unravel_index(int(np.argmax(dur)), dur.shape)
+        d["sweep_ms"] = {"median": med, "p99": float(np.percentile(dur, 99)), "max": float(dur.max()),
+                         "max_at": {"sweep": int(i_max[0]), "chain": int(i_max[1])}}
+        slow = dur > 3.0 * med
+        n_slow = int(slow.sum())
+        d["slow_sweeps"] = {"count": n_slow, "of": int(dur.size), "chains": int(slow.any(axis=0).sum())}
+        # gaps between a chain's consecutive sweeps (self-restarting workgroups: none) and between launches
+        if k > 1:
+            gap = (start[1:] - end[:-1]) / khz
+            d["gap_between_sweeps_ms"] = {"median": float(np.median(gap)), "max": float(gap.max())}
+        if n_slow:
+            # do the slow sweeps share an instant (a device-wide stall: every resident workgroup at once) or are they
+            # single chains (a slow path of the kernel)?
+            s_lo, s_hi = start[slow].max(), end[slow].min()
+            d["slow_sweeps"]["share_an_instant"] = bool(s_lo < s_hi)
+            d["slow_sweeps"]["window_ms"] = [float((start[slow].min() - t_first) / khz), float((end[slow].max() - t_first) / khz)]
+            ch = np.nonzero(slow.any(axis=0))[0]
+            d["slow_sweeps"]["first_chains"] = [int(c) for c in ch[:8]]
+        return d
+
+    def explain(d, ms_total, ms_typical):
+        """One sentence for a run that took much longer than the typical one."""
+        if ms_typical is None or ms_total < 1.5 * ms_typical:
+            return None
+        if d.get("host_issue_ms") and d["host_issue_ms"][0][0] > 0.5 * (ms_total - ms_typical):
+            return "the host issued the first launch late (host_issue_ms): time lost on the CPU side before the kernel was queued"
+        if "outside_kernels_ms" in d and d["outside_kernels_ms"] > 0.5 * (ms_total - ms_typical):
+            return ("the device ran the sweeps at normal speed but started late or sat idle between the events (outside_kernels_ms): "
+                    "queue or host, not the kernel")
+        sl = d.get("slow_sweeps", {})
+        if sl.get("count"):
+            if sl.get("share_an_instant") and sl["chains"] >= min(64, sl["of"]):
+                return ("every resident workgroup stalled over the same interval (slow_sweeps.window_ms): a device-wide stall from "
+                        "outside the kernel (preemption, clock or power event), not a slow path of a chain")
+            fb = d.get("counters", {}).get("tridiag_join_fallbacks", 0)
+            return (f"{sl['chains']} chain(s) ran long sweeps" + (f"; {fb} pivot-join fallbacks in the run" if fb else "")
+                    + ": a slow path of the kernel on those chains (slow_sweeps.first_chains)")
+        return "no single cause in the record: sweeps uniformly slower (clock) -- compare sweep_ms.median with the repeats"
+
     def measure(mode, diagnostics=False):
         """One measurement in the driver's contract: W untimed warm-up steps, then exactly K steps between
         barrier + synchronize on both sides, MAX over ranks; then the same K-step run repeated (untimed in the
-        headline) for the spread."""
+        headline) for the spread.  Every timed run leaves its diagnostics."""
         C, offset = shard(mode)
         n_store = max(1, min(args.steps, STORE_SLABS_MAX))
         sweep = GmrfSweep(n, C, seed=2025, chain_offset=offset, device=local, n_store=n_store,
@@ -297,6 +410,10 @@ def main():
             stamps = torch.zeros(C * 16 * 16, dtype=torch.int64, device="cuda")
             sweep.eng.set_option("stamps_ptr", stamps.data_ptr())
         c_loop = not (args.python_loop or args.unfused)
+        ring = None
+        if c_loop and not args.no_sweep_clock:
+            ring = sweep.eng.sweep_clock(max(64, 32 * ((args.steps + 31) // 32) + 32))
+        counter_names = ["tridiag_join_fallbacks", "run_handoff_timeouts"]
 
         def run_k(events):
             if c_loop:  # one library call issues all K launches; the events bracket them on the launch stream
@@ -309,16 +426,80 @@ def main():
                 for i in range(args.steps):
                     sweep.step(events[i] if events else None)
 
+        use_ev = not args.no_kernel_events
+        n_ev = 1 if c_loop else args.steps
+        # the timing events exist and have been recorded once before any timed window opens
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)] if use_ev else None
+        if events:
+            for a, b in events:
+                a.record()
+                b.record()
+            torch.cuda.synchronize()
+
+        ring_idx = None
+
+        def timed():
+            """-> (seconds, MAX over ranks; kernel ms per sweep from the events; raw material of the run's diagnostics)"""
+            nonlocal ring_idx
+            counters0 = {nm: sweep.eng.counter(nm) for nm in counter_names} if c_loop else {}
+            pos0 = sweep.eng.counter("sweep_times_pos") if ring is not None else 0
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_k(events)
+            torch.cuda.synchronize()
+            barrier()
+            dt = time.perf_counter() - t0
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+            if dist is not None:
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            ev_total = float(np.sum([a.elapsed_time(b) for a, b in events])) if use_ev else None
+            kern = ev_total / args.steps if use_ev else None
+            raw = {"t0": t0, "ev_ms": ev_total, "wall_ms": 1e3 * dt, "counters0": counters0}
+            if c_loop:  # nothing here waits for the device or keeps it idle for long: the analysis comes after all runs
+                raw["launches"] = sweep.eng.launch_log()
+                if ring is not None:
+                    if ring_idx is None or ring_idx[0] != pos0:  # (index vector, ring position of its first entry)
+                        ring_idx = [pos0, (torch.arange(args.steps, device="cuda") + pos0) % ring.shape[0]]
+                    raw["snap"] = ring[ring_idx[1]]  # device-side copy of the run's records
+                    ring_idx = [(pos0 + args.steps) % ring.shape[0], (ring_idx[1] + args.steps) % ring.shape[0]]
+            return tmax.item(), kern, raw
+
+        def finish(raws):
+            """the diagnostics of the runs, in order (a run's counter deltas end where the next run's start)"""
+            out = []
+            last = {nm: sweep.eng.counter(nm) for nm in counter_names} if c_loop else {}
+            for i, r in enumerate(raws):
+                c1 = raws[i + 1]["counters0"] if i + 1 < len(raws) else last
+                g = diagnose(sweep, r.get("snap"), r["t0"], r["ev_ms"], r["counters0"], c1, r["launches"]) if c_loop else {}
+                g["wall_ms"], g["events_ms"] = r["wall_ms"], r["ev_ms"]
+                out.append(g)
+            return out
+
         # Device conditioning (untimed, before the contract's W warm-up steps): an idle MI355X needs ~10 ms of load to
         # leave its low-power clocks (measured: the first 100 sweeps after setup run at 91.9 us, every later 100 at
         # 85.4 us, profiles/README.md r02a); a --steps 20 run would time nothing but that ramp.  The chains simply run
         # longer burn-in: same kernel, same buffers (the store ring is touched once through, like the reference's
-        # NaN-filled store arrays are before its loop, mcmc.py:88-95).
-        if c_loop and args.condition_ms > 0 and not (diagnostics and args.stamps):
-            t_c = time.perf_counter()
-            while time.perf_counter() - t_c < args.condition_ms * 1e-3:
-                sweep.run_fused(max(n_store, 64))
+        # NaN-filled store arrays are before its loop, mcmc.py:88-95).  A FIXED number of sweeps, so that the chains'
+        # state, every draw index and the check values are the same on every box and in every run; the last K of them
+        # are a dress rehearsal of the timed run (same call, same events, same read-back).
+        rehearsal = None
+        if c_loop and args.condition_sweeps > 0 and not (diagnostics and args.stamps):
+            # First everything the timed run's bookkeeping touches for the first time in this process (the events' first
+            # timed interval, the counters' copies, torch's index kernel for the sweep-clock snapshot: lazily loaded code
+            # objects cost milliseconds of host time with the device idle, and an idle device drops its clocks within
+            # milliseconds -- measured: a timed run that follows such a gap starts 12 % slow and recovers over ~20 ms).
+            # Then the conditioning proper, with no idle gap between it and the timed runs.
+            timed()
+            left = max(0, args.condition_sweeps - 2 * args.steps)
+            while left > 0:
+                k = min(left, 256)
+                sweep.run_fused(k)
+                left -= k
                 torch.cuda.synchronize()
+            _, rk, rd = timed()
+            rehearsal = {"kernel_ms": rk, "wall_ms": rd["wall_ms"]}
+            del rd
         if c_loop:
             sweep.run_fused(args.warmup)
         else:
@@ -326,43 +507,37 @@ def main():
                 sweep.step()
         sweep.eng.check_status()
 
-        use_ev = not args.no_kernel_events
-        n_ev = 1 if c_loop else args.steps
-
-        def new_events():
-            return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)] if use_ev else None
-
-        def timed():
-            ev = new_events()
-            barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run_k(ev)
-            torch.cuda.synchronize()
-            barrier()
-            dt = time.perf_counter() - t0
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-            if dist is not None:
-                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            kern = float(np.sum([a.elapsed_time(b) for a, b in ev])) / args.steps if use_ev else None
-            return tmax.item(), kern
-
-        dt, kern_ms = timed()
+        dt, kern_ms, raw0 = timed()
         sweep.eng.check_status()
         # spread: the same K-step run again (every rank the same count: the loop bound comes from rank-agreed dt)
         reps = int(min(20, max(0, np.ceil(args.repeat_ms * 1e-3 / max(dt, 1e-6)) - 1))) if not (diagnostics and args.stamps) else 0
-        rep_ms, rep_kern = [1e3 * dt / args.steps], [kern_ms]
+        rep_ms, rep_kern, raws = [1e3 * dt / args.steps], [kern_ms], [raw0]
         for _ in range(reps):
-            d, k = timed()
+            d, k, rw = timed()
             rep_ms.append(1e3 * d / args.steps)
             rep_kern.append(k)
+            raws.append(rw)
         sweep.eng.check_status()
+        rep_diag = finish(raws)
+        diag = rep_diag[0]
+        del raws, raw0
         spread = {"runs": len(rep_ms), "ms_per_step_min": min(rep_ms), "ms_per_step_median": float(np.median(rep_ms)),
                   "ms_per_step_max": max(rep_ms)}
         if use_ev:
             spread.update(kernel_ms_min=min(rep_kern), kernel_ms_median=float(np.median(rep_kern)), kernel_ms_max=max(rep_kern))
+        # every run against the typical one; a run that stands out carries its explanation
+        typical = float(np.median([g["wall_ms"] for g in rep_diag])) if len(rep_diag) > 1 else (rehearsal["wall_ms"] if rehearsal else None)
+        for g in rep_diag:
+            why = explain(g, g["wall_ms"], typical)
+            if why:
+                g["verdict"] = why
+        outliers = [dict(run=i, **g) for i, g in enumerate(rep_diag) if i > 0 and "verdict" in g]
+        report = {"headline_run": diag, "rehearsal": rehearsal, "typical_wall_ms": typical,
+                  "repeats_with_a_verdict": outliers[:4],
+                  "sweep_ms_median_per_run": [g.get("sweep_ms", {}).get("median") for g in rep_diag],
+                  "reenter_abi_ok": sweep.eng.counter("reenter_abi_ok") if c_loop else None}
         return {"mode": mode, "C": C, "dt": dt, "kern_ms": kern_ms, "sweep": sweep, "stamps": stamps, "spread": spread,
-                "n_store": n_store}
+                "n_store": n_store, "diagnostics": report}
 
     m = measure(args.scaling, diagnostics=True)
     sweep, C, dt, n_store, stamps = m["sweep"], m["C"], m["dt"], m["n_store"], m["stamps"]
@@ -372,11 +547,24 @@ def main():
     if not on_gpu:
         trace = trace.cpu()
     trace_error = None
+    comm, collective = None, None
     if dist is not None:
+        # the library's own collective (omc_gather_samples on RCCL: every peer sends point to point into the root) when the
+        # ranks have a GPU each; torch.distributed's gather on the group's backend otherwise (gloo rehearsals) or if the
+        # communicator cannot be made
+        collective = "torch.distributed.gather (" + dist.get_backend() + ")"
+        if on_gpu:
+            try:
+                from openmcmc_amd.parallel import make_communicator
+
+                comm = make_communicator(sweep.eng)
+                collective = "omc_gather_samples (RCCL send/recv into the root)"
+            except Exception as exc:
+                collective += "; omc_comm_create failed: " + repr(exc)
         try:
             from openmcmc_amd.parallel import gather_chains
 
-            trace = gather_chains(trace, chain_dim=2, dst=0)
+            trace = gather_chains(trace, chain_dim=2, dst=0, comm=comm)
         except Exception as exc:  # the check value then covers rank 0's chains only; the headline stays
             trace_error = repr(exc)
     lam_mean = trace[0].mean().item() if rank == 0 else None
@@ -395,11 +583,11 @@ def main():
             barrier()
             torch.cuda.synchronize()
             tg = time.perf_counter()
-            full = gather_chains(part, chain_dim=1, dst=0)
+            full = gather_chains(part, chain_dim=1, dst=0, comm=comm)
             torch.cuda.synchronize()
             tg = time.perf_counter() - tg
             nbytes = (full.numel() - part.numel()) * 8 if rank == 0 else 0
-            gather_info = {"iterations": k_it, "bytes_into_root": nbytes, "ms": 1e3 * tg,
+            gather_info = {"collective": collective, "iterations": k_it, "bytes_into_root": nbytes, "ms": 1e3 * tg,
                            "GBps_into_root": nbytes / tg / 1e9}
             del full
         except Exception as exc:  # the headline must survive a collective problem
@@ -419,6 +607,8 @@ def main():
 
     # N > 1: the other scaling mode as well (a second, separate measurement after the headline)
     other = None
+    if comm is not None:
+        comm.close()
     if world > 1 and not args.one_mode and not args.stamps:
         del sweep
         m["sweep"] = None
@@ -446,7 +636,8 @@ def main():
                        "chains_total": total_chains, "chains_rank0": C, "nodes": n, "parallelism": f"chains sharded x{world}",
                        "check": {"mean_lambda": lam_mean, **({"trace_gather_error": trace_error} if trace_error else {})},
                        "store_gather": gather_info,
-                       "repeats": m["spread"], "other_scaling": other},
+                       "repeats": m["spread"], "other_scaling": other,
+                       "diagnostics": m["diagnostics"]},
         }
         if kern_ms is not None:
             # One launch of omc_gmrf_run carries up to 32 sweeps (blocks = sweeps x chains): per launch the kernel
@@ -471,6 +662,12 @@ def main():
                                        "(profiles/traffic.json, per sweep x sweeps_per_launch)"}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(n)
+        if world == 1 and args.secondary_ms > 0 and not args.stamps:
+            # the other BASELINE configs, bounded, after everything the headline needs has been measured
+            m["sweep"] = None
+            del sweep
+            torch.cuda.empty_cache()
+            out["config"]["secondary"] = secondary_lines(args)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -103,7 +103,7 @@ def cfg2(args, torch):
         eng.gamma_logpdf(tau, 1e-3, 1e-3, lp, accumulate=True)
         eng.gamma_logpdf(lam, 1e-3, 1e-3, lp, accumulate=True)
 
-    dt = _timed(torch, sweep, args.steps, args.warmup)
+    dt = _timed(torch, sweep, args.steps, args.warmup, condition_ms=getattr(args, "condition_ms", 200.0))
     eng.check_status()
     route["spectral"] = False
     dt_chol = _timed(torch, sweep, max(5, args.steps // 20), 2, condition_ms=0.0)
@@ -165,7 +165,7 @@ def cfg4(args, torch):
                                 proposal_count=prop)
             seen.append(1)
 
-    dt = _timed(torch, one, args.steps, args.warmup)
+    dt = _timed(torch, one, args.steps, args.warmup, condition_ms=getattr(args, "condition_ms", 200.0))
     eng.check_status()
     ref_flop = 14.0 * d * d                              # the reference's algorithm per chain-update
     flop = 9.0 * d * d if products else 2.0 * d * d      # what this route puts on the matrix cores (triangular counted dense)
@@ -238,11 +238,41 @@ def cfg5(args, torch):
                  "chains_total": C, "check": {"n_basis_mean": float(nb.mean().item()), "accept_theta": samplers[4].accept_rate.acceptance_rate,
                                               "accept_n_basis": samplers[5].accept_rate.acceptance_rate}})
     out["roofline"] = None  # the RJ index logic is latency / host bound, not roofline-rated
-    out["cpu_baseline"] = {"value": 12.3, "unit": "chain-updates/s", "cores": 8, "kind": "reference",
-                           "sample": "the reference itself in the build container (BASELINE.md section 2: 81.5 ms per chain-update, 8 vCPU Xeon "
-                                     "2.10 GHz); not re-timed on this host -- its Python cannot travel to the GPU box"}
+    if not args.no_cpu:
+        out["cpu_baseline"] = cfg5_cpu_baseline(y, X, P.tocsc(), n_max, make_basis_host)
     eng.close()
     return out
+
+
+def cfg5_cpu_baseline(y, X, P, n_max, make_basis_host, seconds_budget=4.0):
+    """The oracle's restatement of the whole reversible-jump + GMRF sweep (oracle/rj_sweep_ref.py: the reference's call
+    pattern, SuperLU factor + solves for b, matched transitions, full-model log density per knot move) timed on THIS host for
+    one chain on a synthetic draw tape; the reference's own rate in the build container is quoted beside it."""
+    from oracle import rj_sweep_ref
+
+    n = y.size
+    rng = np.random.default_rng(5)
+
+    def tape(S):
+        return {"z_b": rng.standard_normal((S, n)), "z_beta": rng.standard_normal((S, n_max)),
+                "g": np.stack([rng.standard_gamma(10 + n / 2, size=S), rng.standard_gamma(1 + n / 2, size=S)], axis=1),
+                "rw_u": rng.random((S, n_max)), "rw_acc_u": rng.random((S, n_max)), "rj_move_u": rng.random(S),
+                "rj_theta_u": rng.random(S), "rj_beta_u": rng.random(S), "rj_acc_u": rng.random(S),
+                "rj_idx": rng.integers(0, 1 << 20, size=S).astype(float)}
+
+    model = rj_sweep_ref.RjGmrfModel(y, X, P, make_basis_host, n_max)
+    init = {"theta": rng.uniform(-10, 10, size=5), "beta": rng.standard_normal(5)}
+    t0 = time.perf_counter()
+    rj_sweep_ref.rj_gmrf_chain(model, init, tape(2), 2)
+    per = (time.perf_counter() - t0) / 2
+    S = int(max(3, min(200, seconds_budget / per)))
+    t0 = time.perf_counter()
+    rj_sweep_ref.rj_gmrf_chain(model, init, tape(S), S)
+    per = (time.perf_counter() - t0) / S
+    return {"value": 1.0 / per, "unit": "chain-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{S} sweeps of 1 chain (n = {n}, 5 knots at the start) of oracle/rj_sweep_ref.py on this host",
+            "reference_in_build_container": {"value": 12.3, "note": "BASELINE.md section 2: the reference itself, 81.5 ms per chain-update, "
+                                                                    "8 vCPU Xeon 2.10 GHz"}, **_host()}
 
 
 def _line(metric, value, dt, args, config):

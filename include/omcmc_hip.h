@@ -94,6 +94,11 @@ omc_status omc_ctx_synchronize(omc_ctx* ctx);
  * forked from and joined into the context's stream by events; bit-identical results), "dense_use_rocsolver" (1: rocSOLVER's
  * potrf instead of the blocked route; cross-checks), "dense_blocked_min" (default 144: smallest order that takes the blocked
  * factorisation; rocSOLVER's small kernels below).
+ * Diagnostics of omc_gmrf_run: "sweep_times_cap" then "sweep_times_ptr" = capacity (in sweeps, >= 64) and device address
+ * of a caller-owned ring [cap][C][2] of uint64: wave 0 of the workgroup of every (sweep, chain) leaves the device's
+ * constant-rate counter (s_memrealtime; rate: counter "wall_clock_khz") at its entry and at its exit in record
+ * (position + sweep) mod cap; the position restarts at 0 when either option is set and advances by the sweeps of every
+ * launch (counter "sweep_times_pos"); 0 = off (the default).  One 16-byte store per workgroup and sweep.
  * Unknown name -> OMC_INVALID_ARG.                                                            */
 omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value);
 /* Diagnostic counters, by name (synchronises): "tridiag_join_fallbacks" = chain-updates of the segmented
@@ -101,8 +106,25 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value);
  * made consistent by the sequential recurrence instead (same pivots as the serial kernel; slow, rare);
  * "band_join_retries" = groups of 64 chains of the segmented narrow-band route whose segment joins did not close
  * within the warm-up and were redone with four times the warm-up; "band_join_fallbacks" = those that did not close
- * then either and were factorised in one piece instead; "run_handoff_timeouts".                                 */
+ * then either and were factorised in one piece instead; "run_handoff_timeouts" = sweeps of a several-sweeps launch whose
+ * scales never arrived from the chain's previous sweep (that sweep and the chain's later ones then run on NaN scales, and
+ * omc_ctx_status reports the run as failed).  Not counters, no synchronisation: "wall_clock_khz" (rate of the sweep clock),
+ * "sweep_times_pos"; "reenter_abi_ok" = 1 if the kernel descriptors of the loaded code object ask the dispatcher for exactly the
+ * entry state a self-restarting workgroup reproduces (read back from the device on first use; 0 switches "run_reenter" off
+ * for the process).                                                                                             */
 omc_status omc_ctx_counter(omc_ctx* ctx, const char* name, int64_t* value);
+/* Launch log of the LAST omc_gmrf_run call on this context [host]: *n_launches = kernel launches it issued; for the first
+ * min(cap, 64) of them out[5 i .. 5 i + 4] = {host CLOCK_MONOTONIC seconds just before and just after the launch call,
+ * sweeps in the launch, launch form (0: one workgroup per (sweep, chain); 1, 2: self-restarting workgroups), ring position
+ * of the launch's first sweep in the sweep clock or -1}.  Together with the sweep clock it tells where the time of a slow
+ * run went: the host issuing late, the queue starting late, or sweeps that ran long (and which chains').          */
+omc_status omc_ctx_launch_log(omc_ctx* ctx, double* out, int64_t cap, int64_t* n_launches);
+/* [host, no GPU] The test behind "reenter_abi_ok", on three words of an AMDGPU kernel descriptor (bytes 4-7, 52-55 and
+ * 56-59: PRIVATE_SEGMENT_FIXED_SIZE, COMPUTE_PGM_RSRC2, kernel code properties | kernarg preload spec << 16): 1 if a
+ * workgroup of that kernel is handed exactly s[0:1] = kernel-argument pointer, s2 = workgroup id x, v0 = work-item id and
+ * has no private segment -- the entry state omc_gmrf_run's self-restarting workgroups reproduce by hand.  The build-time
+ * test (tests/test_kernel_resources.py) feeds it the descriptors of the compiled code object.                        */
+int32_t omc_reentry_descriptor_ok(uint32_t private_segment_fixed_size, uint32_t compute_pgm_rsrc2, uint32_t properties_and_preload);
 const char* omc_last_error(void);          /* [host] text of the last HIP failure, thread-local */
 int32_t omc_abi_version(void);
 
@@ -643,6 +665,14 @@ omc_status omc_comm_create(omc_ctx* ctx, int32_t world, int32_t rank, const char
 omc_status omc_comm_destroy(omc_comm* comm);
 omc_status omc_gather_samples(omc_ctx* ctx, omc_comm* comm, const double* send, int64_t n_outer, int64_t row,
                               const int64_t* counts, double* recv, int32_t root, int64_t staging_limit_bytes);
+/* The same gather with the peers' blocks already on this GPU: sends[r] = device pointer of rank r's [n_outer][counts[r]][row]
+ * block (r = 0..world-1; sends[root] is the root's own block), no communicator.  It runs the root's side of
+ * omc_gather_samples unchanged -- slab loop under the staging budget, staging offsets, direct placement for n_outer == 1,
+ * the interleave kernel -- with a device-to-device copy standing where ncclRecv stands: what a process that keeps several
+ * contexts (shards) on one GPU uses to join their stores, and what tests the root-side arithmetic without peers
+ * (tests/test_gather_gpu.py: world 2, 3, 8, even and uneven counts, several staging limits).                          */
+omc_status omc_gather_samples_local(omc_ctx* ctx, int32_t world, const double* const* sends, int64_t n_outer, int64_t row,
+                                    const int64_t* counts, double* recv, int32_t root, int64_t staging_limit_bytes);
 
 /* ---- raw random streams (tests, prior draws for missing state: mcmc.py:78-80) -------------- */
 omc_status omc_fill_normal(omc_ctx* ctx, int64_t n, uint64_t draw_index, double* out, int64_t ld);

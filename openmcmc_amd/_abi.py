@@ -82,6 +82,8 @@ SIGNATURES = {
     "omc_ctx_synchronize": (i32, [C.c_void_p]),
     "omc_ctx_set_option": (i32, [C.c_void_p, C.c_char_p, i64]),
     "omc_ctx_counter": (i32, [C.c_void_p, C.c_char_p, C.POINTER(i64)]),
+    "omc_ctx_launch_log": (i32, [C.c_void_p, C.POINTER(C.c_double), i64, C.POINTER(i64)]),
+    "omc_reentry_descriptor_ok": (i32, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "omc_last_error": (C.c_char_p, []),
     "omc_abi_version": (i32, []),
     "omc_tridiag_sample_canonical": (
@@ -192,6 +194,7 @@ SIGNATURES = {
     "omc_comm_create": (i32, [C.c_void_p, i32, i32, C.c_char_p, i64, C.POINTER(C.c_void_p)]),
     "omc_comm_destroy": (i32, [C.c_void_p]),
     "omc_gather_samples": (i32, [C.c_void_p, C.c_void_p, c_dp, i64, i64, C.POINTER(i64), c_dp, i32, i64]),
+    "omc_gather_samples_local": (i32, [C.c_void_p, i32, C.POINTER(C.c_void_p), i64, i64, C.POINTER(i64), c_dp, i32, i64]),
     "omc_fill_normal": (i32, [C.c_void_p, i64, u64, c_dp, i64]),
     "omc_fill_philox_u32": (i32, [C.c_void_p, i64, u64, c_dp, i64]),
 }

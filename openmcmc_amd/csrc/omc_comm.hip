@@ -88,10 +88,18 @@ omc_status omc_comm_destroy(omc_comm* comm) {
   return OMC_OK;
 }
 
-omc_status omc_gather_samples(omc_ctx* ctx, omc_comm* comm, const double* send, int64_t n_outer, int64_t row,
-                              const int64_t* counts, double* recv, int32_t root, int64_t staging_limit_bytes) {
-  if (!ctx || !comm || !counts || n_outer < 0 || row < 1 || root < 0 || root >= comm->world) return OMC_INVALID_ARG;
-  const int W = comm->world, me = comm->rank;
+// What moves a peer's block to the root: RCCL in production, device-to-device copies in the single-process stand-in.
+struct GatherTransport {
+  ncclComm_t comm;             // RCCL: the communicator; loopback: unused
+  const double* const* sends;  // loopback: the send buffer of every rank (device pointers, all on this GPU); RCCL: NULL
+};
+
+// The gather as rank `me` of W sees it (see the head of the file).  Root side: receive the peers' blocks of a slab of outer
+// indices -- straight into place when there is one outer index, else into the staging buffer in rank order -- then
+// interleave the staged blocks into recv[o][chain offset of the peer + c][e].
+static omc_status gather_core(omc_ctx* ctx, const GatherTransport& tr, int W, int me, int root, const double* send, int64_t n_outer,
+                              int64_t row, const int64_t* counts, double* recv, int64_t staging_limit_bytes, double** staging,
+                              size_t* staging_bytes) {
   int64_t total = 0, off_me = 0;
   for (int r = 0; r < W; ++r) {
     if (counts[r] < 0) return OMC_INVALID_ARG;
@@ -121,37 +129,43 @@ omc_status omc_gather_samples(omc_ctx* ctx, omc_comm* comm, const double* send, 
     if (slab > n_outer) slab = n_outer;
     if (me == root) {
       const size_t need = (size_t)slab * (size_t)per_outer;
-      if (comm->staging_bytes < need) {
+      if (*staging_bytes < need) {
         OMC_HIP_CHECK(hipStreamSynchronize(st));
-        if (comm->staging) OMC_HIP_CHECK(hipFree(comm->staging));
-        comm->staging = nullptr; comm->staging_bytes = 0;
-        OMC_HIP_CHECK(hipMalloc(&comm->staging, need));
-        comm->staging_bytes = need;
+        if (*staging) OMC_HIP_CHECK(hipFree(*staging));
+        *staging = nullptr; *staging_bytes = 0;
+        OMC_HIP_CHECK(hipMalloc(staging, need));
+        *staging_bytes = need;
       }
     }
   }
+  const bool rccl = tr.sends == nullptr;
   for (int64_t o0 = 0; o0 < n_outer; o0 += slab) {
     const int64_t k = (n_outer - o0 < slab) ? n_outer - o0 : slab;
-    OMC_NCCL_CHECK(ncclGroupStart());
+    if (rccl) OMC_NCCL_CHECK(ncclGroupStart());
     if (me == root) {
       int64_t soff = 0, coff = 0;
       for (int r = 0; r < W; ++r) {
         if (r != root && counts[r] > 0) {
-          double* dst = direct ? recv + coff * row : comm->staging + soff;
-          OMC_NCCL_CHECK(ncclRecv(dst, (size_t)(k * counts[r] * row), ncclDouble, r, comm->comm, st));
+          double* dst = direct ? recv + coff * row : *staging + soff;
+          const size_t cnt = (size_t)(k * counts[r] * row);
+          if (rccl) {
+            OMC_NCCL_CHECK(ncclRecv(dst, cnt, ncclDouble, r, tr.comm, st));
+          } else {  // what rank r's ncclSend below would have put on the wire
+            OMC_HIP_CHECK(hipMemcpyAsync(dst, tr.sends[r] + o0 * counts[r] * row, cnt * sizeof(double), hipMemcpyDeviceToDevice, st));
+          }
           soff += k * counts[r] * row;
         }
         coff += counts[r];
       }
-    } else if (counts[me] > 0) {
-      OMC_NCCL_CHECK(ncclSend(send + o0 * counts[me] * row, (size_t)(k * counts[me] * row), ncclDouble, root, comm->comm, st));
+    } else if (counts[me] > 0 && rccl) {
+      OMC_NCCL_CHECK(ncclSend(send + o0 * counts[me] * row, (size_t)(k * counts[me] * row), ncclDouble, root, tr.comm, st));
     }
-    OMC_NCCL_CHECK(ncclGroupEnd());
+    if (rccl) OMC_NCCL_CHECK(ncclGroupEnd());
     if (me == root && !direct) {
       int64_t soff = 0, coff = 0;
       for (int r = 0; r < W; ++r) {
         if (r != root && counts[r] > 0) {
-          launch_interleave(st, comm->staging + soff, recv + o0 * dst_stride, k, counts[r] * row, dst_stride, coff * row);
+          launch_interleave(st, *staging + soff, recv + o0 * dst_stride, k, counts[r] * row, dst_stride, coff * row);
           soff += k * counts[r] * row;
         }
         coff += counts[r];
@@ -160,6 +174,31 @@ omc_status omc_gather_samples(omc_ctx* ctx, omc_comm* comm, const double* send, 
   }
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
+}
+
+omc_status omc_gather_samples(omc_ctx* ctx, omc_comm* comm, const double* send, int64_t n_outer, int64_t row,
+                              const int64_t* counts, double* recv, int32_t root, int64_t staging_limit_bytes) {
+  if (!ctx || !comm || !counts || n_outer < 0 || row < 1 || root < 0 || root >= comm->world) return OMC_INVALID_ARG;
+  const GatherTransport tr{comm->comm, nullptr};
+  return gather_core(ctx, tr, comm->world, comm->rank, root, send, n_outer, row, counts, recv, staging_limit_bytes, &comm->staging,
+                     &comm->staging_bytes);
+}
+
+omc_status omc_gather_samples_local(omc_ctx* ctx, int32_t world, const double* const* sends, int64_t n_outer, int64_t row,
+                                    const int64_t* counts, double* recv, int32_t root, int64_t staging_limit_bytes) {
+  if (!ctx || !sends || !counts || world < 1 || n_outer < 0 || row < 1 || root < 0 || root >= world) return OMC_INVALID_ARG;
+  for (int r = 0; r < world; ++r)
+    if (counts[r] > 0 && !sends[r]) return OMC_INVALID_ARG;
+  const GatherTransport tr{nullptr, sends};
+  double* staging = nullptr;
+  size_t staging_bytes = 0;
+  omc_status st = gather_core(ctx, tr, world, root, root, sends[root], n_outer, row, counts, recv, staging_limit_bytes, &staging,
+                              &staging_bytes);
+  if (staging) {  // the stand-in owns its staging buffer for the length of the call
+    hipStreamSynchronize(ctx->stream);
+    hipFree(staging);
+  }
+  return st;
 }
 
 }  // extern "C"

@@ -5,6 +5,8 @@
 
 #include "omcmc_hip.h"
 
+#define OMC_LAUNCH_LOG_MAX 64
+#define OMC_SWEEP_RING_MIN 64  // >= 2 * OMC_RUN_MAX: a launch never laps its own records
 struct omc_ctx {
   int device;
   int64_t n_chains;
@@ -58,11 +60,20 @@ struct omc_ctx {
   int gram_use_rocblas;  // 1: X' diag(w) X through rocBLAS (scaled copy of X + DGEMM) instead of the own MFMA kernel (cross-checks)
   int dense_use_rocsolver;  // 1: factor dense precisions with rocSOLVER's batched potrf instead of the blocked route
   unsigned long long* stamps;  // diagnostic phase stamps of the segmented kernel (NULL = off)
+  // diagnostic sweep clock (options "sweep_times_ptr" / "sweep_times_cap"): the workgroup-per-chain tridiagonal kernel writes
+  // {s_memrealtime at entry, at exit} of every (sweep, chain) into a caller-owned ring [cap][n_chains][2] of uint64
+  unsigned long long* sweep_times;
+  int64_t sweep_times_cap, sweep_times_pos;
+  // launch log of the last omc_gmrf_run call (omc_ctx_launch_log): host clock around every kernel launch it issued
+  struct LaunchRec { double t_begin, t_end; int n_sweeps, form; int64_t ring_pos; };
+  LaunchRec launch_log[OMC_LAUNCH_LOG_MAX];
+  int launch_log_n, launch_log_total;
 };
 
 void omc_set_error(const char* what, hipError_t e);
 void omc_set_error_text(const char* text);  // any other library failure (RCCL) for omc_last_error()
 void omc_dense_release(omc_ctx* ctx);
+int omc_reentry_probe_result(omc_ctx* ctx);  // omc_tridiag.hip: 1 if the loaded kernel descriptors match what a self-restart reproduces
 // omc_gemm.hip: small-state fp64 MFMA GEMM, C = A0 B0 (+ A1 B1) (+ addv per column), column-major
 omc_status omc_dgemm_small(omc_ctx* ctx, int M, int N, const double* A0, int64_t lda0, const double* B0, int64_t ldb0, int K0,
                            const double* A1, int64_t lda1, const double* B1, int64_t ldb1, int K1, int tri, const double* addv,

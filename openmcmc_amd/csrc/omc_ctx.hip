@@ -53,6 +53,8 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->tridiag_newton_max = 4;
   c->tridiag_perturb_ppb = 0;
   c->stamps = nullptr;
+  c->sweep_times = nullptr; c->sweep_times_cap = 0; c->sweep_times_pos = 0;
+  c->launch_log_n = 0; c->launch_log_total = 0;
   c->blas_aux = nullptr;
   c->aux_stream = nullptr;
   c->ev_fork = c->ev_join = nullptr;
@@ -162,6 +164,21 @@ omc_status omc_ctx_counter(omc_ctx* ctx, const char* name, int64_t* value) {
     *value = (int64_t)v;
     return OMC_OK;
   }
+  if (!strcmp(name, "wall_clock_khz")) {  // rate of the s_memrealtime counter the sweep clock records (not a counter; no sync)
+    int khz = 0;
+    OMC_HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+    *value = khz;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "reenter_abi_ok")) {  // probes the loaded kernel descriptors on first use (synchronises then)
+    OMC_HIP_CHECK(hipSetDevice(ctx->device));
+    *value = omc_reentry_probe_result(ctx);
+    return OMC_OK;
+  }
+  if (!strcmp(name, "sweep_times_pos")) {  // ring index the next sweep of omc_gmrf_run will write (no sync)
+    *value = ctx->sweep_times_pos;
+    return OMC_OK;
+  }
   if (!strcmp(name, "tridiag_join_fallbacks")) {
     unsigned long long v = 0;
     OMC_HIP_CHECK(hipMemcpyAsync(&v, ctx->d_fallbacks, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
@@ -170,6 +187,18 @@ omc_status omc_ctx_counter(omc_ctx* ctx, const char* name, int64_t* value) {
     return OMC_OK;
   }
   return OMC_INVALID_ARG;
+}
+
+omc_status omc_ctx_launch_log(omc_ctx* ctx, double* out, int64_t cap, int64_t* n_launches) {
+  if (!ctx || !n_launches || cap < 0 || (cap > 0 && !out)) return OMC_INVALID_ARG;
+  *n_launches = ctx->launch_log_total;
+  const int64_t m = ctx->launch_log_n < cap ? ctx->launch_log_n : cap;
+  for (int64_t i = 0; i < m; ++i) {
+    const omc_ctx::LaunchRec& r = ctx->launch_log[i];
+    out[5 * i] = r.t_begin; out[5 * i + 1] = r.t_end; out[5 * i + 2] = (double)r.n_sweeps; out[5 * i + 3] = (double)r.form;
+    out[5 * i + 4] = (double)r.ring_pos;
+  }
+  return OMC_OK;
 }
 
 omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
@@ -248,6 +277,19 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "dense_overlap")) {
     if (value != 0 && value != 1) return OMC_INVALID_ARG;
     ctx->dense_overlap = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "sweep_times_ptr")) {  // diagnostic: device ring [cap][n_chains][2] of uint64, 0 = off (set the capacity first)
+    if (value != 0 && ctx->sweep_times_cap < OMC_SWEEP_RING_MIN) return OMC_INVALID_ARG;
+    ctx->sweep_times = (unsigned long long*)(uintptr_t)value;
+    ctx->sweep_times_pos = 0;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "sweep_times_cap")) {
+    if (value != 0 && value < OMC_SWEEP_RING_MIN) return OMC_INVALID_ARG;
+    ctx->sweep_times_cap = value;
+    ctx->sweep_times_pos = 0;
+    if (value == 0) ctx->sweep_times = nullptr;
     return OMC_OK;
   }
   if (!strcmp(name, "stamps_ptr")) {  // diagnostic: device buffer [n_chains][16][16] of uint64, 0 = off

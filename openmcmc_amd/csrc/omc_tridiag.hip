@@ -29,6 +29,7 @@
 //                      With gamma blocks attached the same launch also performs the
 //                      Normal-Gamma updates and log_post of the sweep (omc_gmrf_sweep).
 #include <math.h>
+#include <time.h>
 
 #include "omc_common.h"
 
@@ -101,6 +102,10 @@ struct TriArgs {
   uint64_t gdraw[OMC_MAX_TERMS];   // Gamma stream of term k = sweep's draw index + gdraw[k]
   unsigned long long* handoff;     // [C][OMC_HANDOFF_WORDS]
   unsigned long long* timeouts;    // counter: hand-overs that did not arrive (dispatch-order assumption broken)
+  // diagnostic sweep clock: wave 0 of a (sweep, chain) workgroup leaves {s_memrealtime at entry, at exit} in record
+  // (sweep_times_pos + sweep) mod sweep_times_cap of the ring [cap][C][2]; NULL = off
+  unsigned long long* sweep_times;
+  int64_t sweep_times_cap, sweep_times_pos;
   SweepRec rec[OMC_RUN_MAX];
 };
 
@@ -1157,6 +1162,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   };
   auto take_scales = [&]() {
     if (!handed) return;
+    bool lost = false;  // the hand-over never came (reported through `timeouts`): this sweep runs on NaN scales, so that
+                        // whatever it stores is recognisably not a sample
     const uint32_t want = A.epoch + (uint32_t)sw;
     auto tags_ok = [&]() {
       bool ok = true;
@@ -1180,6 +1187,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         if (tags_ok()) break;
         if (spin >= (1 << 22)) {
           if (threadIdx.x == 0 && chain_ok) atomicAdd(A.timeouts, 1ull);
+          lost = true;
           break;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -1191,6 +1199,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         if (tags_ok()) break;
         if (spin >= (1 << 19)) {
           if (threadIdx.x == 0 && chain_ok) atomicAdd(A.timeouts, 1ull);
+          lost = true;
           break;
         }
         __builtin_amdgcn_s_sleep(64);
@@ -1205,7 +1214,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     }
 #pragma unroll
     for (int k = 0; k < OMC_MAX_TERMS; ++k)
-      if (k < nt && A.T.scale[k] && A.gb[k].enabled) sc[k] = __hiloint2double((int)(uint32_t)hw[2 * k + 1], (int)(uint32_t)hw[2 * k]);
+      if (k < nt && A.T.scale[k] && A.gb[k].enabled)
+        sc[k] = lost ? __builtin_nan("") : __hiloint2double((int)(uint32_t)hw[2 * k + 1], (int)(uint32_t)hw[2 * k]);
   };
   // per-sweep arguments (draw stream, output slab)
   auto nkey_f = [&]() -> omc_rng_key { return (MULTI && run_mode(A)) ? omc_make_key(A.seed, A.rec[sw].draw, OMC_RNG_NORMAL) : A.key; };
@@ -1219,6 +1229,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   const double* const vIr = p_first ? A.T.rhs[1] : A.T.rhs[0];
   const double* const vIc = p_first ? A.T.center[1] : A.T.center[0];
 
+  // diagnostic sweep clock: the constant-rate counter at this wave's entry, kept in two scalar registers to its exit
+  unsigned long long t_enter = 0ull;
+  if (MULTI && A.sweep_times) t_enter = __builtin_amdgcn_s_memrealtime();
   double Y[M], W[M];
   OMC_STAMP(0);
   // Normal-Gamma standard draws, made up front (see sweep_gamma_draws_wave) by the chain's last wave: its
@@ -1426,15 +1439,22 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       // segment: weak coupling, or |l| > 1 on a stretch).  Nothing is left to chance from here: the joins are
       // made consistent by the sequential recurrence itself.  Every pass starts each segment from the TRUE end
       // value of its predecessor's last pass, so after pass k the first k+1 segments carry exactly the pivots of
-      // the serial kernel; the loop stops when no start value changes any more (bit for bit), at the latest
-      // after one pass per segment.  Slow (a few hundred cycles per pass) and rare; counted in `fallbacks`.
+      // the serial kernel, and where the recurrence contracts, the rest converges geometrically at the same time;
+      // the loop stops when every join meets the tolerance the Newton path accepts, at the latest after one pass per
+      // segment.  (It used to insist on bit-equal joins.  On a homogeneous chain -- every segment the same map, as in
+      // the headline model -- that is a worst case by construction: the map has two floating-point fixed points one
+      // ulp apart, the part of the chain that converged from the spoiled starts sits on the other one than the part
+      // propagated from the chain's head, and the border between them moves one segment per pass: all ~1000 passes,
+      // 1.4 ms per chain-update measured by benchmarks/join_fallback_cost.py, for a difference of one ulp.)
+      // About 1.4 us per pass; rare; counted in `fallbacks`.
       if (A.fallbacks && chain_ok && s == 0) atomicAdd(A.fallbacks, 1ull);
       const int S = MULTI ? (int)blockDim.x : Wd;
       for (int pass = 0; pass < S; ++pass) {
         double Dq = Dend, Jq = 0.0;
         if (MULTI) prev_lane2_wg(Dq, Jq, Dst, 0.0, lds_x[pass & 1], lane, wave, nw);
         else prev_lane2<false>(Dq, Jq, Dst, 0.0, pos, Wd, lds_x[0], wave);
-        const int moved = (joined && Dq != Dst && Dq == Dq) ? 1 : 0;  // a NaN pivot is `bad`, not a reason to go on
+        // (a NaN pivot compares false: it is `bad`, not a reason to go on)
+        const int moved = (joined && fabs(Dq - Dst) > OMC_NEWTON_TOL * fabs(Dst)) ? 1 : 0;
         const int some = MULTI ? __syncthreads_or(moved) : (__ballot(moved) != 0ull);
         if (!some) break;
         if (joined) Dst = Dq;
@@ -1840,6 +1860,16 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     sweep_epilogue(A, c, qsum);
   }
   OMC_STAMP(15);
+  if (MULTI && A.sweep_times && threadIdx.x == 0 && chain_ok) {
+    // wave 0 is the one that runs the epilogue: its exit is the end of the chain's sweep (self-restarting workgroups: its
+    // next entry follows at once, so consecutive records of a chain tile the launch)
+    const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime();
+    int64_t r = A.sweep_times_pos + sw;
+    if (r >= A.sweep_times_cap) r -= A.sweep_times_cap;
+    unsigned long long* const p = A.sweep_times + (r * A.C + c) * 2;
+    p[0] = t_enter;
+    p[1] = t_exit;
+  }
   if (MULTI && SIG == 1 && A.reenter && sw + 1 < A.n_sweeps) {
     // Restart as the workgroup of the chain's next sweep: same code from its first instruction, with the three
     // registers a fresh workgroup is handed (kernel-argument pointer, workgroup id, work-item id) set to what the
@@ -1866,6 +1896,64 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 #undef OMC_REENTER
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// Self-check of what the restart above takes for granted.  `s_setpc_b64` to the kernel's first instruction reproduces a
+// fresh workgroup only if the kernel descriptor asks the dispatcher for exactly the three registers the restart sets:
+// two user SGPRs (the kernel-argument pointer, nothing else: no dispatch / queue pointer, no dispatch id, no flat-scratch
+// init, no preloaded kernel arguments), workgroup id x as the only system SGPR, the packed work-item id in v0, and no
+// private segment.  The descriptors of the re-entered instantiations are read HERE, from the code object the runtime
+// actually loaded (their `.kd` linker symbols), and compared on the host before the first restarting launch; a mismatch
+// (another compiler, another flag) switches the restarting form off for the process instead of producing wrong chains.
+// tests/test_kernel_resources.py checks the same facts at build time without a GPU.
+#define OMC_KD_WORDS(Mv, MAXTv, SIGv, dst)                                                                               \
+  do {                                                                                                                    \
+    uint64_t kd_;                                                                                                         \
+    asm volatile("s_getpc_b64 s[4:5]\n\t"                                                                                \
+                 "s_add_u32 s4, s4, _Z13k_tridiag_segILi" #Mv "ELb1ELi" #MAXTv "ELi" #SIGv "EEv7TriArgsi.kd@rel32@lo+4\n\t"  \
+                 "s_addc_u32 s5, s5, _Z13k_tridiag_segILi" #Mv "ELb1ELi" #MAXTv "ELi" #SIGv "EEv7TriArgsi.kd@rel32@hi+12\n\t" \
+                 "s_mov_b64 %0, s[4:5]"                                                                                   \
+                 : "=s"(kd_)::"s4", "s5");                                                                               \
+    const uint32_t* w_ = (const uint32_t*)kd_;                                                                            \
+    (dst)[0] = w_[1];  /* PRIVATE_SEGMENT_FIXED_SIZE */                                                                    \
+    (dst)[1] = w_[13]; /* COMPUTE_PGM_RSRC2 */                                                                             \
+    (dst)[2] = w_[14]; /* kernel code properties (low half), kernarg preload spec (high half) */                           \
+  } while (0)
+
+__global__ void k_reentry_probe(uint32_t* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  OMC_KD_WORDS(8, 1024, 1, out);
+  OMC_KD_WORDS(10, 1024, 1, out + 3);
+}
+
+// the expectation, on the three descriptor words the probe returns (LLVM AMDGPUUsage, "Kernel Descriptor")
+static bool reentry_descriptor_ok(uint32_t private_size, uint32_t rsrc2, uint32_t props_preload) {
+  const uint32_t props = props_preload & 0xffffu, preload = props_preload >> 16;
+  const bool user_sgprs = ((rsrc2 >> 1) & 0x1fu) == 2u && (props & 0x7fu) == 0x08u;  // kernarg segment pointer only
+  const bool system_sgprs = ((rsrc2 >> 7) & 0xfu) == 0x1u;                           // workgroup id x; no y, z, info
+  const bool no_private = private_size == 0u && (rsrc2 & 1u) == 0u && (props & (1u << 11)) == 0u;
+  const bool wave64 = (props & (1u << 10)) == 0u;
+  return user_sgprs && system_sgprs && no_private && wave64 && preload == 0u;
+}
+
+static int g_reentry_ok = -1;  // -1: not probed yet (process-wide: one code object)
+static bool reentry_abi_ok(omc_ctx* ctx) {
+  if (g_reentry_ok >= 0) return g_reentry_ok != 0;
+  uint32_t* d = nullptr;
+  uint32_t h[6] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
+  bool ok = hipMalloc(&d, sizeof(h)) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(k_reentry_probe, dim3(1), dim3(64), 0, ctx->stream, d);
+    ok = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+         hipStreamSynchronize(ctx->stream) == hipSuccess;
+    hipFree(d);
+  }
+  ok = ok && reentry_descriptor_ok(h[0], h[1], h[2]) && reentry_descriptor_ok(h[3], h[4], h[5]);
+  g_reentry_ok = ok ? 1 : 0;
+  if (!ok) omc_set_error_text("omc_gmrf_run: the kernel descriptor does not match the restart's entry state; self-restarting workgroups are off");
+  return ok;
+}
+int omc_reentry_probe_result(omc_ctx* ctx) { return reentry_abi_ok(ctx) ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------
 // small helpers
@@ -1975,6 +2063,7 @@ static void args_defaults(omc_ctx* ctx, TriArgs* A, int64_t n) {
   A->work = nullptr;
   A->fused = 0;
   A->stamps = ctx->stamps;
+  A->sweep_times = nullptr; A->sweep_times_cap = 0; A->sweep_times_pos = 0;  // (omc_gmrf_run switches the sweep clock on)
   A->log_post = nullptr;
   A->gb_dev = nullptr; A->gdraw_dev = nullptr;
   A->n_sweeps = 0; A->reenter = 0; A->early_draws = 0; A->epoch = 0; A->seed = ctx->seed; A->handoff = nullptr; A->timeouts = ctx->d_fallbacks + 1;
@@ -1985,6 +2074,14 @@ static void args_defaults(omc_ctx* ctx, TriArgs* A, int64_t n) {
     A->gb[k].g_inject = nullptr; A->gb[k].store = nullptr; A->gb[k].scale_out = nullptr;
     A->gb[k].logdet_unscaled = nullptr; A->gb[k].key = A->key;
   }
+}
+
+// CLOCK_MONOTONIC in seconds: the clock of Python's time.perf_counter on Linux, so a caller can place the launch log on
+// its own time axis
+static double omc_host_clock() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
 static int pow2_ceil(int v) {
@@ -2130,6 +2227,10 @@ static omc_status launch_tridiag(omc_ctx* ctx, TriArgs& A) {
 
 extern "C" {
 
+int32_t omc_reentry_descriptor_ok(uint32_t private_segment_fixed_size, uint32_t compute_pgm_rsrc2, uint32_t properties_and_preload) {
+  return reentry_descriptor_ok(private_segment_fixed_size, compute_pgm_rsrc2, properties_and_preload) ? 1 : 0;
+}
+
 omc_status omc_tridiag_sample_canonical(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
                                         const double* rhs_chain, int64_t ld_rhs, const double* z_inject,
                                         int64_t ld_z, uint64_t draw_index, double* x_out, int64_t ld_x,
@@ -2240,8 +2341,32 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
     // (the generic instantiation: one sweep per launch, see the kernel)
     const int per = !takes_specialised(ctx, A.T, n) ? 1
                     : (ctx->run_sweeps_per_launch < OMC_RUN_MAX ? ctx->run_sweeps_per_launch : OMC_RUN_MAX);
-    for (int64_t t0 = 0; t0 < total; t0 += per) {
-      const int k_sw = (int)(total - t0 < per ? total - t0 : per);
+    // Which form of the launch: one self-restarting workgroup per chain (a chain's sweeps stay on one CU: no dispatch
+    // gaps, restart under the epilogue) pays when the chains fill the CUs in whole rounds; otherwise one workgroup per
+    // (sweep, chain) -- the dispatcher then balances the CUs sweep by sweep, and with fewer chains than CUs the next
+    // sweep of a chain starts on an idle CU under the tail of the previous one (384 chains: 31.4 against 39.2 us per
+    // sweep, 128 chains: 19.0 against 19.9; 256 and 1024 chains: the restarting form by 6 % and 3 %).
+    int dev_cus = 256;
+    hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const int64_t rounds = (C + dev_cus - 1) / dev_cus;
+    const bool whole_rounds = C >= dev_cus && (double)C >= 0.95 * (double)(rounds * dev_cus);
+    A.reenter = (whole_rounds || ctx->run_reenter_force) ? ctx->run_reenter : 0;
+    if (A.reenter && per > 1 && !reentry_abi_ok(ctx)) A.reenter = 0;  // (see k_reentry_probe)
+    A.early_draws = (A.reenter == 0 && 2 * C <= dev_cus) ? 1 : 0;  // a waiting workgroup per chain has a CU to itself
+    // (sweep, chain) grid: two sweeps of one launch must not write the same store slot -- their workgroups are not ordered
+    // against each other (the self-restarting form walks a chain's sweeps in order and may lap the ring)
+    const int64_t stored_per_launch_max = (A.reenter == 0 && n_slots < per) ? n_slots : per;
+    ctx->launch_log_n = 0; ctx->launch_log_total = 0;
+    const bool clock_on = ctx->sweep_times && ctx->sweep_times_cap >= OMC_SWEEP_RING_MIN;
+    for (int64_t t0 = 0; t0 < total;) {
+      int k_sw = (int)(total - t0 < per ? total - t0 : per);
+      if (stored_per_launch_max < per) {  // end the launch before a store slot would repeat inside it
+        int64_t stored_seen = 0;
+        for (int i = 0; i < k_sw; ++i) {
+          const int64_t t = t0 + i;
+          if (t >= burn && ((t - burn + 1) % n_thin == 0) && ++stored_seen > stored_per_launch_max) { k_sw = i; break; }
+        }
+      }
       for (int i = 0; i < k_sw; ++i) {
         const int64_t t = t0 + i;
         const bool stored = t >= burn && ((t - burn + 1) % n_thin == 0);
@@ -2255,30 +2380,30 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
         A.rec[i].slot_off = stored ? slot * C : -1;
       }
       A.n_sweeps = k_sw;
-      // Which form of the launch: one self-restarting workgroup per chain (a chain's sweeps stay on one CU: no dispatch
-      // gaps, restart under the epilogue) pays when the chains fill the CUs in whole rounds; otherwise one workgroup per
-      // (sweep, chain) -- the dispatcher then balances the CUs sweep by sweep, and with fewer chains than CUs the next
-      // sweep of a chain starts on an idle CU under the tail of the previous one (384 chains: 31.4 against 39.2 us per
-      // sweep, 128 chains: 19.0 against 19.9; 256 and 1024 chains: the restarting form by 6 % and 3 %).
-      {
-        int dev_cus = 256;
-        hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        const int64_t rounds = (C + dev_cus - 1) / dev_cus;
-        const bool whole_rounds = C >= dev_cus && (double)C >= 0.95 * (double)(rounds * dev_cus);
-        A.reenter = (whole_rounds || ctx->run_reenter_force) ? ctx->run_reenter : 0;
-        A.early_draws = (A.reenter == 0 && 2 * C <= dev_cus) ? 1 : 0;  // a waiting workgroup per chain has a CU to itself
-      }
       A.epoch = ctx->run_epoch;
       ctx->run_epoch += (uint32_t)k_sw;
       // the non-specialised paths still read these
       A.key = omc_make_key(ctx->seed, A.rec[0].draw, OMC_RNG_NORMAL);
       A.x = A.rec[0].x;
       A.log_post = A.rec[0].log_post;
+      if (clock_on) {
+        A.sweep_times = ctx->sweep_times; A.sweep_times_cap = ctx->sweep_times_cap; A.sweep_times_pos = ctx->sweep_times_pos;
+      }
+      const double t_begin = omc_host_clock();
       omc_status st = launch_tridiag(ctx, A);
       if (st != OMC_OK) return st;
+      if (ctx->launch_log_n < OMC_LAUNCH_LOG_MAX) {
+        omc_ctx::LaunchRec& r = ctx->launch_log[ctx->launch_log_n++];
+        r.t_begin = t_begin; r.t_end = omc_host_clock(); r.n_sweeps = k_sw; r.form = A.reenter;
+        r.ring_pos = clock_on ? ctx->sweep_times_pos : -1;
+      }
+      ctx->launch_log_total++;
+      if (clock_on) ctx->sweep_times_pos = (ctx->sweep_times_pos + k_sw) % ctx->sweep_times_cap;
+      t0 += k_sw;
     }
     return OMC_OK;
   }
+  ctx->launch_log_n = 0; ctx->launch_log_total = 0;
   for (int64_t t = 0; t < total; ++t) {
     const bool stored = t >= burn && ((t - burn + 1) % n_thin == 0);
     const int64_t i = stored ? (t - burn + 1) / n_thin - 1 : 0;
@@ -2289,10 +2414,16 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
       b[k].draw_index = base + blocks[k].draw_index;
       b[k].store = (stored && blocks[k].store) ? blocks[k].store + slot * C : nullptr;
     }
+    const double t_begin = omc_host_clock();
     omc_status st = omc_gmrf_sweep(ctx, n, terms, b, nullptr, 0, nullptr, 0, base,
                                    stored ? x_store + slot * x_slot_stride : scratch_x, ld_x,
                                    (stored && log_post_store) ? log_post_store + slot * C : nullptr);
     if (st != OMC_OK) return st;
+    if (ctx->launch_log_n < OMC_LAUNCH_LOG_MAX) {
+      omc_ctx::LaunchRec& r = ctx->launch_log[ctx->launch_log_n++];
+      r.t_begin = t_begin; r.t_end = omc_host_clock(); r.n_sweeps = 1; r.form = 0; r.ring_pos = -1;
+    }
+    ctx->launch_log_total++;
   }
   return OMC_OK;
 }

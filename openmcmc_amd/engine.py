@@ -125,6 +125,33 @@ class Engine:
     def set_option(self, name, value):
         check(lib.omc_ctx_set_option(self._ctx, name.encode(), int(value)))
 
+    # ------------------------------------------------------------------ diagnostics of omc_gmrf_run
+    def sweep_clock(self, capacity):
+        """Switch on the sweep clock: a device ring [capacity][C][2] of int64 into which the workgroup of every (sweep, chain)
+        of omc_gmrf_run leaves the device's constant-rate counter at its entry and exit.  Returns the ring (a tensor the
+        caller keeps); capacity 0 switches it off."""
+        if capacity <= 0:
+            self.set_option("sweep_times_cap", 0)
+            self._sweep_ring = None
+            return None
+        torch = _torch()
+        ring = torch.zeros((int(capacity), self.n_chains, 2), dtype=torch.int64, device=self.device)
+        self.set_option("sweep_times_cap", int(capacity))
+        self.set_option("sweep_times_ptr", ring.data_ptr())
+        self._sweep_ring = ring
+        return ring
+
+    def launch_log(self):
+        """Launches of the last gmrf_run call: (total, [dict(t_begin, t_end, n_sweeps, form, ring_pos)]) with the host
+        times on time.perf_counter's clock (CLOCK_MONOTONIC)."""
+        cap = 64
+        buf = (C.c_double * (5 * cap))()
+        n = C.c_int64(0)
+        check(lib.omc_ctx_launch_log(self._ctx, buf, cap, C.byref(n)))
+        recs = [dict(t_begin=buf[5 * i], t_end=buf[5 * i + 1], n_sweeps=int(buf[5 * i + 2]), form=int(buf[5 * i + 3]),
+                     ring_pos=int(buf[5 * i + 4])) for i in range(min(cap, n.value))]
+        return int(n.value), recs
+
     # ------------------------------------------------------------------ tridiagonal GMRF
     def tridiag_terms(self, terms, n):
         """terms: list of dicts with optional keys diag, off, rhs, center (shared, length n / n-1)
@@ -964,6 +991,26 @@ class Engine:
         out = torch.empty(self.n_chains, n_words, dtype=torch.int32, device=self.device)
         check(lib.omc_fill_philox_u32(self._ctx, n_words, int(draw_index), C.c_void_p(out.data_ptr()), n_words))
         return out
+
+
+def gather_local(engine, blocks, root=0, staging_limit_bytes=0):
+    """omc_gather_samples_local: the blocks of several shards that live on THIS GPU, blocks[r] = (n_outer, counts[r], ...),
+    joined into (n_outer, sum(counts), ...) in rank order -- the root's side of omc_gather_samples with device-to-device
+    copies where the RCCL receives stand."""
+    blocks = [b.contiguous() for b in blocks]
+    world = len(blocks)
+    n_outer = int(blocks[0].shape[0])
+    tail = tuple(blocks[0].shape[2:])
+    if any(b.dim() < 2 or int(b.shape[0]) != n_outer or tuple(b.shape[2:]) != tail for b in blocks):
+        raise ValueError("blocks must be (n_outer, counts[r], ...) with equal outer and trailing dimensions")
+    counts = [int(b.shape[1]) for b in blocks]
+    row = int(np.prod(tail)) if tail else 1
+    out = engine.empty(n_outer, sum(counts), *tail)
+    ptrs = (C.c_void_p * world)(*[(engine._p(b) if b.numel() else None) for b in blocks])
+    arr = (C.c_int64 * world)(*counts)
+    check(lib.omc_gather_samples_local(engine._ctx, world, ptrs, n_outer, row, arr, engine._p(out) if out.numel() else None,
+                                       int(root), int(staging_limit_bytes)))
+    return out
 
 
 def new_unique_id():

@@ -73,3 +73,120 @@ def test_sharding_invariance_of_a_several_sweeps_run():
     a, b = run(10000, 3, 16, 2, 4, 1, C_all=6), run(10000, 3, 16, 2, 4, 1, chain_offset=3, C_all=6)
     for k in range(4):
         assert np.array_equal(full[k][:, :3], a[k]) and np.array_equal(full[k][:, 3:], b[k])
+
+
+def test_restart_entry_state_matches_the_loaded_kernel_descriptors():
+    """The library reads the kernel descriptors of the re-entered instantiations back from the device (the code object
+    the runtime actually loaded) before its first self-restarting launch; on this build they ask for exactly the entry
+    state a restart sets (tests/test_kernel_resources.py checks the same at build time without a GPU)."""
+    from openmcmc_amd.engine import Engine
+
+    eng = Engine(4, seed=1)
+    assert eng.counter("reenter_abi_ok") == 1
+    eng.close()
+
+
+@pytest.mark.parametrize("C,reenter", [(300, 2), (300, 0), (40, 0), (520, 2)])
+def test_sweep_clock_and_launch_log(C, reenter):
+    """The diagnostics of omc_gmrf_run: every (sweep, chain) leaves entry and exit of its workgroup on the device's
+    constant-rate counter, the library logs the host clock around every launch -- and switching them on changes no bit."""
+    import time
+
+    from openmcmc_amd.engine import Engine
+
+    n, K = 10000, 41
+    ref = run(n, C, 32, 0, 6, 1, reenter=reenter)
+    eng = Engine(C, seed=11)
+    eng.set_option("run_sweeps_per_launch", 32)
+    eng.set_option("run_reenter", reenter)
+    ring = eng.sweep_clock(96)
+    rng = np.random.default_rng(0)
+    t = np.arange(n) * 60.0 / n
+    y = np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + rng.standard_normal(n)
+    d = np.full(n, 2.0)
+    d[0] = d[-1] = 1.0
+    d[0] += 1e-3
+    d_y, d_d, d_off = eng.to_device(y), eng.to_device(d), eng.to_device(-np.ones(n - 1))
+    lam, tau = eng.to_device(80.0 + 40 * rng.random(C)), eng.to_device(0.5 + rng.random(C))
+    terms = eng.tridiag_terms([{"diag": d_d, "off": d_off, "scale": lam}, {"rhs": d_y, "center": d_y, "scale": tau}], n)
+    logdetP, logdetI = eng.tridiag_logdet(n, d_d, d_off), eng.zeros(1)
+    store_b, store_lam, store_tau, store_lp = eng.empty(6, C, n), eng.empty(6, C), eng.empty(6, C), eng.empty(6, C)
+    scratch = eng.empty(C, n)
+    blocks = [{"a0": 10.0, "b0": 1.0, "n_pos": n, "store": store_lam, "logdet": logdetP, "draw_index": 1},
+              {"a0": 1.0, "b0": 1.0, "n_pos": n, "store": store_tau, "logdet": logdetI, "draw_index": 2}]
+    # the same 6 stored sweeps as `run` (clock on) ...
+    eng.gmrf_run(n, terms, blocks, 0, 6, 1, store_b, scratch, draw_index0=7, draws_per_sweep=3, log_post_store=store_lp)
+    eng.check_status()
+    for a, b in zip(ref[:4], (store_b, store_lam, store_tau, store_lp)):
+        assert np.array_equal(a, b.cpu().numpy())
+    assert eng.counter("sweep_times_pos") == 6
+    # ... then a longer burn-in run: two launches (32 + 9 sweeps), ring positions 6 .. 46
+    t0 = time.perf_counter()
+    eng.gmrf_run(n, terms, blocks, K, 0, 1, store_b, scratch, draw_index0=100, draws_per_sweep=3, log_post_store=store_lp)
+    eng.check_status()
+    t1 = time.perf_counter()
+    total, recs = eng.launch_log()
+    assert total == 2 and [r["n_sweeps"] for r in recs] == [32, 9] and [r["ring_pos"] for r in recs] == [6, 38]
+    assert all(r["form"] == reenter for r in recs)
+    assert t0 <= recs[0]["t_begin"] <= recs[0]["t_end"] <= recs[1]["t_begin"] <= recs[1]["t_end"] <= t1
+    assert eng.counter("sweep_times_pos") == 47
+    khz = eng.counter("wall_clock_khz")
+    assert 1_000 <= khz <= 10_000_000
+    tk = ring[6:47].cpu().numpy()
+    start, end = tk[:, :, 0], tk[:, :, 1]
+    assert np.all(start > 0) and np.all(end > start)
+    dur_us = (end - start) / khz * 1e3
+    assert 3.0 < np.median(dur_us) < 500.0, np.median(dur_us)  # a sweep of a 10 000-node chain: tens of microseconds
+    # a chain's sweeps end in order (each needs the scales of the one before), and the second launch starts after the
+    # first has ended
+    assert np.all(end[1:] > end[:-1])
+    assert start[32:].min() >= end[:32].max()
+    if reenter:  # self-restarting workgroups: a chain's next sweep follows its previous one at once
+        assert np.all(start[1:32] >= end[0:31])
+        gap_us = (start[1:32] - end[0:31]) / khz * 1e3
+        assert np.median(gap_us) < 5.0
+    assert (time.perf_counter() - t0) > (end.max() - start.min()) / khz * 1e-3  # the device span fits inside the host interval
+    assert np.all(ring[47:].cpu().numpy() == 0)  # nothing beyond the run's records
+    eng.sweep_clock(0)
+    eng.close()
+
+
+@pytest.mark.parametrize("C,reenter", [(40, 0), (300, 2)])
+def test_store_ring_shorter_than_a_launch(C, reenter):
+    """Fewer store slots than sweeps per launch (a ring that the run laps): in the (sweep, chain) grid a launch ends before
+    a slot repeats inside it (its workgroups are not ordered against each other); the self-restarting form walks a chain's
+    sweeps in order.  Either way the ring ends up holding the run's last sweeps, as with one launch per sweep."""
+    from openmcmc_amd.engine import Engine
+
+    n, n_slots, K = 5000, 3, 11
+
+    def go(per):
+        eng = Engine(C, seed=5)
+        eng.set_option("run_sweeps_per_launch", per)
+        eng.set_option("run_reenter", reenter)
+        rng = np.random.default_rng(0)
+        y = rng.standard_normal(n) + 2
+        d = np.full(n, 2.0)
+        d[0] = d[-1] = 1.0
+        d[0] += 1e-3
+        d_y, d_d, d_off = eng.to_device(y), eng.to_device(d), eng.to_device(-np.ones(n - 1))
+        lam, tau = eng.full((C,), 100.0), eng.full((C,), 1.0)
+        terms = eng.tridiag_terms([{"diag": d_d, "off": d_off, "scale": lam}, {"rhs": d_y, "center": d_y, "scale": tau}], n)
+        logdetP, logdetI = eng.tridiag_logdet(n, d_d, d_off), eng.zeros(1)
+        sb, sl, st, lp = eng.zeros(n_slots, C, n), eng.zeros(n_slots, C), eng.zeros(n_slots, C), eng.zeros(n_slots, C)
+        blocks = [{"a0": 10.0, "b0": 1.0, "n_pos": n, "store": sl, "logdet": logdetP, "draw_index": 1},
+                  {"a0": 1.0, "b0": 1.0, "n_pos": n, "store": st, "logdet": logdetI, "draw_index": 2}]
+        eng.gmrf_run(n, terms, blocks, 0, K, 1, sb, eng.empty(C, n), draw_index0=3, draws_per_sweep=3, first_slot=1,
+                     log_post_store=lp)
+        eng.check_status()
+        n_launch, _ = eng.launch_log()
+        out = [t.cpu().numpy() for t in (sb, sl, st, lp, lam, tau)]
+        eng.close()
+        return out, n_launch
+
+    ref, n1 = go(1)
+    got, n32 = go(32)
+    assert n1 == K
+    assert n32 == (1 if reenter else 4)  # 3 + 3 + 3 + 2 sweeps per launch in the grid form
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
