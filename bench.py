@@ -265,6 +265,8 @@ def main():
     ap.add_argument("--reenter", type=int, default=None, choices=[0, 1, 2],
                     help="omc_gmrf_run: 1 = workgroups restart themselves for the next sweep of a launch (default: the library's)")
     ap.add_argument("--sweeps-per-launch", type=int, default=0, help="omc_gmrf_run: sweeps per launch (0 = library default, 32)")
+    ap.add_argument("--block-sweeps", type=int, default=None,
+                    help="omc_gmrf_run: sweeps a self-restarting workgroup walks before a fresh one takes its chain over (0 = the whole launch)")
     args = ap.parse_args()
 
     if args.config != "cfg3":
@@ -405,6 +407,8 @@ def main():
             sweep.eng.set_option("run_sweeps_per_launch", args.sweeps_per_launch)
         if args.reenter is not None:
             sweep.eng.set_option("run_reenter", args.reenter)
+        if args.block_sweeps is not None:
+            sweep.eng.set_option("run_block_sweeps", args.block_sweeps)
         stamps = None
         if diagnostics and args.stamps:
             stamps = torch.zeros(C * 16 * 16, dtype=torch.int64, device="cuda")

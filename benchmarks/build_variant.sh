@@ -6,7 +6,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; flags=$2
 mkdir -p $root/build/ab
 make -s -C $root/openmcmc_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -I$root/include -Wall -Wno-unused-result -Wno-unused-value $flags \
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -I$root/include -Wall -Wno-unused-result -Wno-unused-value -mllvm -instcombine-max-copied-from-constant-users=100000 $flags \
   -c $root/openmcmc_amd/csrc/omc_tridiag.hip -o $root/build/ab/omc_tridiag_$name.o
 objs=$(ls $root/openmcmc_amd/csrc/*.o | grep -v omc_tridiag.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $root/build/ab/omc_tridiag_$name.o -o $root/build/ab/libomcmc_hip_$name.so -L/opt/rocm/lib -lrocblas -lrocsolver -lrccl

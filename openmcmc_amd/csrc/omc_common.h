@@ -23,6 +23,7 @@ struct omc_ctx {
   uint32_t run_epoch;               // tag counter of the hand-over lines
   int run_sweeps_per_launch;        // omc_gmrf_run: sweeps per launch (1 = one launch per sweep)
   int run_reenter;                  // omc_gmrf_run: 1, 2 = a chain's workgroup restarts itself for the next sweep of the launch
+  int run_block_sweeps;             // omc_gmrf_run: sweeps a self-restarting workgroup walks before a fresh one takes over (0: the whole launch)
   int run_reenter_force;            // 1: take that form whatever the chain count (tests); 0: only when the chains fill the CUs in whole rounds
   double* workspace;       // scratch for the serial kernel (l vectors), grown on demand
   size_t workspace_bytes;

@@ -73,7 +73,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
     c->stream = (hipStream_t)stream;
   }
   c->d_gamma_tab = nullptr;
-  c->d_handoff = nullptr; c->run_epoch = 1; c->run_sweeps_per_launch = 32; c->run_reenter = 2; c->run_reenter_force = 0;
+  c->d_handoff = nullptr; c->run_epoch = 1; c->run_sweeps_per_launch = 32; c->run_reenter = 2; c->run_reenter_force = 0; c->run_block_sweeps = 0;
   hipError_t e = hipMalloc(&c->d_bad_chain, 8 * sizeof(long long));
   if (e != hipSuccess) { omc_set_error("hipMalloc", e); delete c; return OMC_HIP_ERROR; }
   c->d_fallbacks = (unsigned long long*)(c->d_bad_chain + 1);
@@ -216,6 +216,11 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "run_sweeps_per_launch")) {
     if (value < 1 || value > 32) return OMC_INVALID_ARG;
     ctx->run_sweeps_per_launch = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "run_block_sweeps")) {
+    if (value < 0 || value > 32) return OMC_INVALID_ARG;
+    ctx->run_block_sweeps = (int)value;
     return OMC_OK;
   }
   if (!strcmp(name, "run_reenter")) {

@@ -95,7 +95,9 @@ struct TriArgs {
   double* log_post;
   // several sweeps per launch (n_sweeps > 0; workgroup-per-chain form only)
   int n_sweeps;
-  int reenter;                     // 1, 2: the grid is C workgroups and each restarts itself as its chain's next sweep
+  int reenter;                     // 1, 2: a workgroup restarts itself as its chain's next sweep
+  int block_sweeps;                // ... for this many sweeps in a row; then a fresh workgroup (block index + C) takes the chain
+                                   // over through the global hand-over line.  n_sweeps: one workgroup per chain for the launch
   int early_draws;                 // 1: all buffered pairs of draws are made before the scales are waited for (see the kernel)
   uint32_t epoch;                  // tag of sweep 0's inputs + 1 = tag its outputs carry; unique per context over launches
   uint64_t seed;
@@ -1087,17 +1089,33 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   Geom<M, MULTI> geo;
   geo.lane = lane; geo.wave = wave; geo.G = G;
   int sw = 0;  // sweep of this workgroup inside the launch (omc_gmrf_run: blockIdx = sweep * C + chain)
+  bool restarted = false;  // this workgroup came here by its own restart (its predecessor sweep ran in this very workgroup)
+  int left = 0;            // sweeps this workgroup will still restart itself for
+  unsigned c_blk = 0;
   if (MULTI) {
     unsigned blk = blockIdx.x;
-    // (several sweeps per launch: the specialised instantiation only.  The sweep index picks the sweep's record out of the
-    // kernel arguments; in the generic instantiation that dynamic index made the compiler keep a private copy of the
-    // records -- 1.4 KB of scratch per lane, 500 instead of 160 us per sweep -- so there it is the constant 0 and
-    // omc_gmrf_run issues its sweeps one per launch.  Still open: the per-lane selections of a Normal-Gamma block in the
-    // draws, the epilogue and the log-posterior together make the compiler keep a private copy of the four blocks for
-    // M >= 10 (360 bytes per lane, stored by every wave at entry); without it the generic instantiation runs at 107 us.)
-    if (SIG == 1 && A.n_sweeps > 1) {
-      sw = (int)(blk / (unsigned)A.C);
-      blk -= (unsigned)sw * (unsigned)A.C;
+    // (Several sweeps per launch: the sweep index picks the sweep's record out of the kernel arguments.  Round 2 saw
+    // "private copies" of the argument struct appear in the generic instantiation whenever such an index was added and blamed
+    // the dynamic index; the cause was LLVM's limit of 300 users in the transform that forwards reads of a by-value kernel
+    // argument to the kernel-argument segment -- see the note in the Makefile.  With the limit raised every instantiation
+    // takes the sweep index, and none uses scratch.)
+    if (A.n_sweeps > 1) {
+      // A fresh workgroup: block index = (block of sweeps) * C + chain, and it starts at the block's first sweep.  A restarted
+      // one carries what the restart put into the workgroup-id register: bit 31, the sweeps still to follow in its block
+      // (bits 30:26) and the virtual index sweep * C + chain (OMC_REENTER at the end of the kernel).
+      restarted = (blk >> 31) != 0u;
+      const unsigned vblk = restarted ? (blk & 0x03ffffffu) : blk;
+      const unsigned q = vblk / (unsigned)A.C;
+      c_blk = vblk - q * (unsigned)A.C;
+      if (restarted) {
+        sw = (int)q;
+        left = (int)((blk >> 26) & 31u);
+      } else {
+        const int g = (A.reenter && A.block_sweeps > 0) ? A.block_sweeps : 1;
+        sw = (int)q * g;
+        left = (A.n_sweeps - sw < g ? A.n_sweeps - sw : g) - 1;
+      }
+      blk = c_blk;
     }
     c = blk;
     s = threadIdx.x;
@@ -1126,14 +1144,14 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // Sweeps after the first of a launch take the scales their Normal-Gamma blocks redraw from the hand-over line of
   // the chain (written by the workgroup of the previous sweep, possibly on another XCD); the loads are issued here
   // and examined where the scales are first needed (`take_scales`), behind the first pair of draws.
-  const bool handed = MULTI && SIG == 1 && sw > 0;
+  const bool handed = MULTI && sw > 0;
   // a self-restarting workgroup takes them from its own LDS (written by its wave 0 a moment ago: a poll there costs a
   // hundred cycles, a poll of the global line a trip to L2)
-  const bool hand_lds = SIG == 1 && A.reenter != 0;
+  const bool hand_lds = SIG == 1 && A.reenter != 0 && restarted;
   // LDS comes as the previous workgroup on this CU left it -- possibly this very kernel under another context, whose
   // tags count from 1 like ours: the launch's first sweep wipes the granules (tag 0 is never waited for) long before
   // its epilogue writes them and the second sweep looks
-  if (hand_lds && sw == 0 && threadIdx.x < 2 * OMC_MAX_TERMS)
+  if (SIG == 1 && A.reenter != 0 && !restarted && threadIdx.x < 2 * OMC_MAX_TERMS)
     __hip_atomic_store(lds_hand + threadIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   unsigned long long hw[2 * OMC_MAX_TERMS];
 #pragma unroll
@@ -1299,7 +1317,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       const double bm1_raw = vPo[(i0 > 0 && i0 < n) ? i0 - 1 : 0];
       vec_and_draws(po, vPo + wbase, nvo, 0);
       take_scales();
-      if (SIG == 1 && A.reenter == 2 && handed && wave_u == 1 && chain_ok && any_handed_f()) {
+      if (SIG == 1 && A.reenter == 2 && handed && hand_lds && wave_u == 1 && chain_ok && any_handed_f()) {
         // the previous sweep's log-posterior, left here by its epilogue (scales: just taken; quadratic forms: LDS)
         double* const lp_prev = A.rec[sw - 1].log_post;
         if (lp_prev) {
@@ -1831,7 +1849,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       const double g = lds_g[lane];
       // restart without a barrier: the log-posterior of this sweep is left to wave 1 of the next one (it has the slack
       // this wave does not: everyone waits for the wave that ran the epilogue at the next sweep's first barrier)
-      const bool defer_lp = SIG == 1 && A.reenter == 2 && sw + 1 < A.n_sweeps && nw > 1 && any_handed_f();
+      const bool defer_lp = SIG == 1 && A.reenter == 2 && left > 0 && nw > 1 && any_handed_f();
       sweep_epilogue_wave<SIG != 1>(A, c, qsum[0], qsum[1], qsum[2], qsum[3], my_scale, my_logdet, fabs(g), g < 0.0, lane, sw,
                           (SIG == 1 && A.reenter) ? lds_hand : nullptr, defer_lp, lds_q);
     }
@@ -1870,7 +1888,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     p[0] = t_enter;
     p[1] = t_exit;
   }
-  if (MULTI && SIG == 1 && A.reenter && sw + 1 < A.n_sweeps) {
+  if (MULTI && SIG == 1 && A.reenter && left > 0) {
     // Restart as the workgroup of the chain's next sweep: same code from its first instruction, with the three
     // registers a fresh workgroup is handed (kernel-argument pointer, workgroup id, work-item id) set to what the
     // dispatcher would have put there for block index + C.  Nothing else is live at a kernel's entry.  What this
@@ -1881,7 +1899,8 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     const uint64_t kptr = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
     const uint64_t kargs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kptr) |
                            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(kptr >> 32)) << 32);
-    const uint32_t next_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x + (uint32_t)A.C));
+    const uint32_t next_blk = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(0x80000000u | ((uint32_t)(left - 1) << 26) | ((uint32_t)(sw + 1) * (uint32_t)A.C + c_blk)));
     const uint32_t tid = threadIdx.x;
     // (device code may not name a kernel, so the entry point is reached through its linker symbol: a name that does
     // not match an instantiation fails the link, not the run)
@@ -2066,7 +2085,7 @@ static void args_defaults(omc_ctx* ctx, TriArgs* A, int64_t n) {
   A->sweep_times = nullptr; A->sweep_times_cap = 0; A->sweep_times_pos = 0;  // (omc_gmrf_run switches the sweep clock on)
   A->log_post = nullptr;
   A->gb_dev = nullptr; A->gdraw_dev = nullptr;
-  A->n_sweeps = 0; A->reenter = 0; A->early_draws = 0; A->epoch = 0; A->seed = ctx->seed; A->handoff = nullptr; A->timeouts = ctx->d_fallbacks + 1;
+  A->n_sweeps = 0; A->reenter = 0; A->block_sweeps = 0; A->early_draws = 0; A->epoch = 0; A->seed = ctx->seed; A->handoff = nullptr; A->timeouts = ctx->d_fallbacks + 1;
   for (int k = 0; k < OMC_MAX_TERMS; ++k) A->gdraw[k] = 0;
   for (int i = 0; i < OMC_RUN_MAX; ++i) { A->rec[i].draw = 0; A->rec[i].x = nullptr; A->rec[i].log_post = nullptr; A->rec[i].slot_off = -1; }
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
@@ -2126,7 +2145,6 @@ static bool launch_seg(omc_ctx* ctx, const TriArgs& A_in) {
     // self-restarting workgroups: the specialised instantiation only (it keeps no private memory, so the three entry
     // registers are all a restart has to reproduce)
     if (!special) A.reenter = 0;
-    if (!special && A.n_sweeps > 1) return false;  // (omc_gmrf_run gives the generic instantiation one sweep per launch)
     if (!special && A.fused) {
       // the Normal-Gamma blocks in device memory for the generic instantiation (stream-ordered copy: the previous launch
       // has read its image by the time this one is written)
@@ -2139,7 +2157,8 @@ static bool launch_seg(omc_ctx* ctx, const TriArgs& A_in) {
       A.gdraw_dev = (const unsigned long long*)((char*)ctx->d_gamma_tab + gb_bytes);
     }
     // workgroup-per-chain form: one workgroup per (sweep, chain), or per chain when the workgroups restart themselves
-    const unsigned wg_grid = (unsigned)(A.C * ((A.n_sweeps > 0 && !A.reenter) ? A.n_sweeps : 1));
+    const int64_t wg_per_chain = A.n_sweeps <= 0 ? 1 : (!A.reenter ? A.n_sweeps : (A.block_sweeps > 0 ? (A.n_sweeps + A.block_sweeps - 1) / A.block_sweeps : 1));
+    const unsigned wg_grid = (unsigned)(A.C * wg_per_chain);
     if (special)
       hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT, SegCfg<M>::SMOOTHER>), dim3(wg_grid), dim3(threads), 0,
                          ctx->stream, A, threads);
@@ -2339,8 +2358,7 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
     A.zero_z = ctx->debug_zero_z;
     A.fused = 1;
     // (the generic instantiation: one sweep per launch, see the kernel)
-    const int per = !takes_specialised(ctx, A.T, n) ? 1
-                    : (ctx->run_sweeps_per_launch < OMC_RUN_MAX ? ctx->run_sweeps_per_launch : OMC_RUN_MAX);
+    const int per = ctx->run_sweeps_per_launch < OMC_RUN_MAX ? ctx->run_sweeps_per_launch : OMC_RUN_MAX;
     // Which form of the launch: one self-restarting workgroup per chain (a chain's sweeps stay on one CU: no dispatch
     // gaps, restart under the epilogue) pays when the chains fill the CUs in whole rounds; otherwise one workgroup per
     // (sweep, chain) -- the dispatcher then balances the CUs sweep by sweep, and with fewer chains than CUs the next
@@ -2351,7 +2369,9 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
     const int64_t rounds = (C + dev_cus - 1) / dev_cus;
     const bool whole_rounds = C >= dev_cus && (double)C >= 0.95 * (double)(rounds * dev_cus);
     A.reenter = (whole_rounds || ctx->run_reenter_force) ? ctx->run_reenter : 0;
+    if (!takes_specialised(ctx, A.T, n)) A.reenter = 0;  // the generic instantiation: one workgroup per (sweep, chain)
     if (A.reenter && per > 1 && !reentry_abi_ok(ctx)) A.reenter = 0;  // (see k_reentry_probe)
+    if (A.reenter && C * (int64_t)per >= ((int64_t)1 << 26)) A.reenter = 0;  // (a restart's register carries sweep * C + chain in 26 bits)
     A.early_draws = (A.reenter == 0 && 2 * C <= dev_cus) ? 1 : 0;  // a waiting workgroup per chain has a CU to itself
     // (sweep, chain) grid: two sweeps of one launch must not write the same store slot -- their workgroups are not ordered
     // against each other (the self-restarting form walks a chain's sweeps in order and may lap the ring)
@@ -2380,6 +2400,12 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
         A.rec[i].slot_off = stored ? slot * C : -1;
       }
       A.n_sweeps = k_sw;
+      // Self-restarting workgroups in blocks: a workgroup walks `block_sweeps` sweeps of its chain, then a fresh one (block
+      // index + C, dispatched when a CU falls free) takes the chain over through the global hand-over line.  One block
+      // per launch ties a chain to one CU for the whole launch and the launch ends with its slowest CU (four rounds of
+      // 20 sweeps: a tail of ~60 us measured by the sweep clock); shorter blocks let the dispatcher level the CUs.
+      A.block_sweeps = k_sw;
+      if (A.reenter && ctx->run_block_sweeps > 0 && ctx->run_block_sweeps < k_sw) A.block_sweeps = ctx->run_block_sweeps;
       A.epoch = ctx->run_epoch;
       ctx->run_epoch += (uint32_t)k_sw;
       // the non-specialised paths still read these

@@ -33,7 +33,9 @@ def compiled(tmp_path_factory):
     """omc_tridiag.hip compiled once: (resource-usage remarks, path of the unbundled gfx950 code object)"""
     d = tmp_path_factory.mktemp("tridiag")
     obj = str(d / "omc_tridiag.o")
-    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", f"-I{ROOT}/include", "-c",
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", f"-I{ROOT}/include",
+           "-mllvm", "-instcombine-max-copied-from-constant-users=100000",  # as openmcmc_amd/csrc/Makefile (see the note there)
+           "-c",
            f"{ROOT}/openmcmc_amd/csrc/omc_tridiag.hip", "-o", obj, "-Rpass-analysis=kernel-resource-usage"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -9,13 +9,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def run(n, C, per_launch, n_burn, n_iter, n_thin, generic=False, seed=11, chain_offset=0, C_all=None, reenter=None):
+def run(n, C, per_launch, n_burn, n_iter, n_thin, generic=False, seed=11, chain_offset=0, C_all=None, reenter=None, block=None):
     from openmcmc_amd.engine import Engine
 
     eng = Engine(C, seed=seed, chain_id_offset=chain_offset)
     eng.set_option("run_sweeps_per_launch", per_launch)
     if reenter is not None:
         eng.set_option("run_reenter", reenter)
+    if block is not None:
+        eng.set_option("run_block_sweeps", block)
     if generic:
         eng.set_option("tridiag_generic", 1)
     rng = np.random.default_rng(0)
@@ -66,6 +68,17 @@ def test_self_restarting_workgroups_do_not_change_a_bit(n, C):
         got = run(n, C, per, 3, 9, 2, reenter=reenter)
         for a, b in zip(ref, got):
             assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("n,C", [(10000, 300), (10000, 1100), (5000, 40), (9999, 7)])
+def test_blocks_of_self_restarting_sweeps_do_not_change_a_bit(n, C):
+    """run_block_sweeps: a workgroup restarts itself for a block of sweeps, then a fresh workgroup takes the chain over
+    through the global hand-over line (the dispatcher levels the CUs between blocks)."""
+    ref = run(n, C, 1, 3, 9, 2, reenter=0)
+    for per, reenter, block in ((32, 2, 5), (32, 2, 1), (32, 1, 4), (21, 2, 7), (32, 2, 20), (32, 2, 32), (7, 2, 3)):
+        got = run(n, C, per, 3, 9, 2, reenter=reenter, block=block)  # 21 sweeps in all: 5+5+5+5+1, 7+7+7, ...
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b, equal_nan=True), (per, reenter, block)
 
 
 def test_sharding_invariance_of_a_several_sweeps_run():
