@@ -202,7 +202,7 @@ omc_status omc_tridiag_matvec(omc_ctx* ctx, int64_t n, const double* diag, const
  *   omc_tridiag_matvec_chain: out[c] (+)= scale[c] * M v_c -- the term Q_rsp @ mean of sampler.py:181-183 when the mean is
  *     itself per chain, and W (y_c - d) of sampler.py:190-192 when the response is (M tridiagonal; NULL diag = identity);
  *   omc_chain_lincomb: out[c] = a x_c + b y_c (y per chain, or shared with ld_y = 0): the residual of location_scale.py:
- *     153-160 when both sides of a Normal are per chain.                                                       */
+ *     153-160 when both sides of a Normal are per chain; b == 0 means y is not read (an inf or NaN there does not reach out). */
 omc_status omc_tridiag_matvec_chain(omc_ctx* ctx, int64_t n, const double* diag, const double* off, const double* v, int64_t ld_v,
                                     const double* scale, double* out, int64_t ld_out, int32_t accumulate);
 omc_status omc_chain_lincomb(omc_ctx* ctx, int64_t n, double a, const double* x, int64_t ld_x, double b, const double* y, int64_t ld_y,
@@ -589,6 +589,13 @@ omc_status omc_log_transform(omc_ctx* ctx, int64_t n, const double* x, int64_t l
 omc_status omc_centered_rowdot(omc_ctx* ctx, int64_t n, const double* a, int64_t ld_a, const double* center_a,
                                const double* b, int64_t ld_b, const double* center_b, double* out);
 
+/* Poisson.rvs for every chain (distribution.py:508-523: scipy.stats.poisson.rvs, i.e. NumPy's legacy generator -- multiplication
+ * method below rate 10, PTRS transformed rejection from 10 on): out[c] = one Poisson(rate[c * rate_stride]) count as a double
+ * (rate_stride 0: one shared rate).  u_inject [C][ld_u]: the uniforms the draw consumes, in order, NaN-padded (the parity tests
+ * replay the reference's generator through it; running off the tape latches the chain in omc_ctx_status); NULL: the chain's
+ * Philox stream at draw_index.  Used for the prior draw of a jump parameter without an initial value (mcmc.py:78-85).  */
+omc_status omc_poisson_draw(omc_ctx* ctx, const double* rate, int64_t rate_stride, const double* u_inject, int64_t ld_u,
+                            uint64_t draw_index, double* out);
 /* Uniform.rvs (distribution.py:444-458): out[c][e] = lower[e] + range[e] * U(0,1], e < p (lower/range device [p]);
  * u_inject [C][p]; in-kernel uniforms come from Philox blocks sub, sub+1, ... (two per block).               */
 omc_status omc_uniform_draw(omc_ctx* ctx, int64_t p, const double* lower, const double* range, const double* u_inject,

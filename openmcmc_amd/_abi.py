@@ -82,6 +82,7 @@ SIGNATURES = {
     "omc_ctx_synchronize": (i32, [C.c_void_p]),
     "omc_ctx_set_option": (i32, [C.c_void_p, C.c_char_p, i64]),
     "omc_ctx_counter": (i32, [C.c_void_p, C.c_char_p, C.POINTER(i64)]),
+    "omc_poisson_draw": (i32, [C.c_void_p, c_dp, i64, c_dp, i64, u64, c_dp]),
     "omc_ctx_launch_log": (i32, [C.c_void_p, C.POINTER(C.c_double), i64, C.POINTER(i64)]),
     "omc_reentry_descriptor_ok": (i32, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "omc_last_error": (C.c_char_p, []),

@@ -531,7 +531,96 @@ __global__ void k_uniform_draw(int64_t C, int64_t chain_offset, int64_t p, const
   }
 }
 
+// Poisson.rvs (distribution.py:508-523 -> scipy.stats.poisson.rvs = NumPy's legacy generator, third-party arithmetic:
+// random_poisson_mult below rate 10, Hoermann's PTRS transformed rejection with NumPy's own random_loggam from 10 on;
+// restated in oracle/prior_draws_ref.py and pinned by tests/golden/prior_draws.npz).  One lane per chain; the uniforms come
+// from the injected tape u_in[c * ld_u + 0 ..] (NaN-padded; a draw that runs off its tape is reported through `bad`) or from
+// the chain's Philox stream, two per block.
+__device__ __forceinline__ double poisson_loggam(double x) {
+  const double a[10] = {8.333333333333333e-02, -2.777777777777778e-03, 7.936507936507937e-04, -5.952380952380952e-04,
+                        8.417508417508418e-04, -1.917526917526918e-03, 6.410256410256410e-03, -2.955065359477124e-02,
+                        1.796443723688307e-01, -1.39243221690590e+00};
+  if (x == 1.0 || x == 2.0) return 0.0;
+  const int n = (x < 7.0) ? (int)(7.0 - x) : 0;
+  double x0 = x + (double)n;
+  const double x2 = (1.0 / x0) * (1.0 / x0);
+  double gl0 = a[9];
+  for (int k = 8; k >= 0; --k) gl0 = gl0 * x2 + a[k];
+  double gl = gl0 / x0 + 0.5 * 1.8378770664093453 + (x0 - 0.5) * log(x0) - x0;
+  for (int k = 0; k < n; ++k) {
+    gl -= log(x0 - 1.0);
+    x0 -= 1.0;
+  }
+  return gl;
+}
+
+__global__ void k_poisson_draw(int64_t C, int64_t chain_offset, const double* rate, int64_t rate_stride, const double* u_in,
+                               int64_t ld_u, omc_rng_key key, double* out, long long* bad) {
+#pragma clang fp contract(off)
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double lam = rate[c * rate_stride];
+  uint32_t used = 0;
+  bool exhausted = false;
+  uint4 w = {0u, 0u, 0u, 0u};
+  auto next = [&]() -> double {
+    double u;
+    if (u_in) {
+      u = ((int64_t)used < ld_u) ? u_in[c * ld_u + used] : __builtin_nan("");
+      if (!(u == u)) { exhausted = true; u = 0.0; }  // off the tape: 0 ends both loops
+    } else {
+      if ((used & 1u) == 0u) w = omc_rng_block(key, chain_offset + c, used >> 1);
+      u = (used & 1u) ? omc_u53(w.z, w.w) : omc_u53(w.x, w.y);
+    }
+    ++used;
+    return u;
+  };
+  double k = 0.0;
+  if (!(lam >= 0.0)) {
+    k = __builtin_nan("");
+    exhausted = true;
+  } else if (lam == 0.0) {
+    k = 0.0;
+  } else if (lam < 10.0) {
+    const double enlam = exp(-lam);
+    double prod = 1.0;
+    for (;;) {
+      prod *= next();
+      if (prod > enlam) k += 1.0;
+      else break;
+    }
+  } else {
+    const double slam = sqrt(lam), loglam = log(lam);
+    const double b = 0.931 + 2.53 * slam;
+    const double a = -0.059 + 0.02483 * b;
+    const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+    const double vr = 0.9277 - 3.6224 / (b - 2);
+    for (int guard = 0; guard < 100000; ++guard) {
+      const double U = next() - 0.5;
+      const double V = next();
+      if (exhausted) break;
+      const double us = 0.5 - fabs(U);
+      k = floor((2 * a / us + b) * U + lam + 0.43);
+      if (us >= 0.07 && V <= vr) break;
+      if (k < 0.0 || (us < 0.013 && V > us)) continue;
+      if ((log(V) + log(invalpha) - log(a / (us * us) + b)) <= (-lam + k * loglam - poisson_loggam(k + 1.0))) break;
+    }
+  }
+  out[c] = k;
+  if (exhausted) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+}
+
 extern "C" {
+
+omc_status omc_poisson_draw(omc_ctx* ctx, const double* rate, int64_t rate_stride, const double* u_inject, int64_t ld_u,
+                            uint64_t draw_index, double* out) {
+  if (!ctx || !rate || !out || rate_stride < 0 || (u_inject && ld_u < 1)) return OMC_INVALID_ARG;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_poisson_draw, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, ctx->chain_offset, rate,
+                     rate_stride, u_inject, ld_u, omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), out, ctx->d_bad_chain);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
 
 omc_status omc_uniform_draw(omc_ctx* ctx, int64_t p, const double* lower, const double* range, const double* u_inject,
                             uint64_t draw_index, uint32_t sub, double* out) {

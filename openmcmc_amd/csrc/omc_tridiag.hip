@@ -2008,6 +2008,13 @@ __global__ void __launch_bounds__(256) k_tridiag_matvec_chain(int64_t n, const d
 __global__ void __launch_bounds__(256) k_chain_lincomb(int64_t n, double a, const double* x, int64_t ld_x, double b, const double* y,
                                                        int64_t ld_y, double* out, int64_t ld_o) {
   const int64_t c = blockIdx.y;
+  // b == 0: y is not read at all (the BLAS convention: 0 * inf or 0 * NaN in y must not reach the result -- a scale of
+  // +inf is what the Normal-Gamma update's zero-rate guard produces, sampler.py:285-286)
+  if (b == 0.0) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+      out[c * ld_o + i] = a * x[c * ld_x + i];
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[c * ld_o + i] = fma(a, x[c * ld_x + i], b * y[c * ld_y + i]);
 }

@@ -280,8 +280,25 @@ class Poisson(Distribution):
         engine.poisson_logpmf(x.scalar(), rate, out, accumulate=accumulate)
         return out
 
-    def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0):
-        raise NotImplementedError("Poisson prior draws on the device: give the jump parameter an initial value")
+    def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0, inject=None):
+        """One Poisson count per chain (distribution.py:508-523 -> scipy.stats.poisson.rvs, i.e. NumPy's legacy generator;
+        omc_poisson_draw follows its algorithm draw for draw): the prior draw of a jump parameter without an initial value
+        (mcmc.py:78-85).  `inject` (C, K): the uniforms each chain's draw consumes, NaN-padded (parity tests)."""
+        if engine is None:
+            raise RuntimeError("Poisson.rvs needs the engine")
+        if n != 1:
+            raise NotImplementedError("replicated prior draws")
+        rate = self.rate.predictor(state)
+        if is_chain(rate):
+            if rate.size != 1:
+                raise NotImplementedError("vector-valued Poisson response")
+            rate = rate.scalar()
+        elif np.size(rate) != 1:
+            raise NotImplementedError("vector-valued Poisson response")
+        else:
+            rate = float(np.asarray(rate).item())
+        u = None if inject is None else engine.to_device(inject).reshape(engine.n_chains, -1).contiguous()
+        return ChainArray(engine.poisson_draw(rate, u=u, draw_index=draw_index).reshape(engine.n_chains, 1, 1))
 
 
 @dataclass

@@ -409,19 +409,62 @@ class Normal(Distribution):
     def rvs(self, state: dict, n: int = 1, engine=None, draw_index=0, sub=0, inject=None):
         """One draw per chain from N(mean, (scale * M)^-1) (location_scale.py:252-272 -> gmrf.py:29-61),
         used by MCMC when the state has no initial value for a sampled parameter (mcmc.py:78-80) and by a birth move for the
-        new column of an associated parameter (reversible_jump.py:130)."""
+        new column of an associated parameter (reversible_jump.py:130).  With domain limits: gmrf.sample_truncated_normal for
+        one replicate (gmrf.py:64-164), i.e. rejection on the whole vector -- every chain redraws until all of its elements lie
+        inside; `inject` is then (attempts, C, d): the standard normals of attempt 0, 1, ... of every chain."""
         if engine is None:
             raise RuntimeError("Normal.rvs needs the engine")
         if n != 1:
             raise NotImplementedError("replicated prior draws")
-        if self.domain_response_lower is not None or self.domain_response_upper is not None:
-            raise NotImplementedError("truncated prior draws (gmrf.sample_truncated_normal)")
-        if self._column_replicates(state):
-            from openmcmc_amd.chains import ChainArray
+        limited = self.domain_response_lower is not None or self.domain_response_upper is not None
+        columns = self._column_replicates(state)
+        if columns:
+            d = self._columns_pieces(state, engine)[0].numel()
 
-            return ChainArray(self._column_draw(state, engine, draw_index, sub, inject).unsqueeze(2))
-        if inject is not None or sub:
-            raise NotImplementedError("injected draws / sub-streams for a fixed-size prior draw")
+            def draw(attempt, z):
+                return self._column_draw(state, engine, int(draw_index) + (attempt << 24), sub, z)
+        else:
+            if sub:
+                raise NotImplementedError("sub-streams for a fixed-size prior draw")
+            d = self.structure(state).n
+
+            def draw(attempt, z):
+                return self._fixed_draw(state, engine, int(draw_index) + (attempt << 24), z)
+        from openmcmc_amd.chains import ChainArray
+
+        if not limited:
+            x = draw(0, None if inject is None else engine.to_device(inject).reshape(engine.n_chains, d))
+            return ChainArray(x.unsqueeze(2)) if columns else ChainArray(x)
+        import torch
+
+        lo = np.full(d, -np.inf) if self.domain_response_lower is None else np.broadcast_to(
+            np.asarray(self.domain_response_lower, dtype=np.float64).reshape(-1), (d,))
+        hi = np.full(d, np.inf) if self.domain_response_upper is None else np.broadcast_to(
+            np.asarray(self.domain_response_upper, dtype=np.float64).reshape(-1), (d,))
+        if np.any(lo >= hi):
+            raise ValueError("Error lower bound must be strictly less than upper bound")  # gmrf.py:149-150
+        lo_d, hi_d = engine.to_device(lo.copy()), engine.to_device(hi.copy())
+        tape = None if inject is None else engine.to_device(inject).reshape(-1, engine.n_chains, d)
+        x = engine.empty(engine.n_chains, d)
+        bad = torch.ones(engine.n_chains, dtype=torch.bool, device=x.device)
+        pen = engine.empty(engine.n_chains)
+        attempts = 100000 if tape is None else tape.shape[0]
+        for a in range(attempts):
+            cand = draw(a, None if tape is None else tape[a].contiguous()).contiguous()
+            pen.zero_()
+            engine.domain_penalty(cand, pen, lo_d, hi_d)  # -inf for a chain with an element outside
+            ok = (pen == 0) & bad                          # every chain keeps the first attempt that lies inside
+            engine.chain_select(ok.to(torch.int32), cand, x)
+            bad &= ~ok
+            if not bool(bad.any().item()):
+                break
+        else:
+            raise RuntimeError("truncated prior draw: some chains found no vector inside the domain limits"
+                               + ("" if tape is None else " on the injected tape"))
+        return ChainArray(x.unsqueeze(2)) if columns else ChainArray(x)
+
+    def _fixed_draw(self, state, engine, draw_index, z):
+        """mu + L^-T z for every chain on the structure's own route (gmrf.py:29-61); z: (C, n) injected standard normals."""
         st = self.structure(state)
         mean = self.mean.predictor(state)
         if is_chain(mean):
@@ -431,18 +474,16 @@ class Normal(Distribution):
         if st.scale_key is not None:
             sv = state[st.scale_key]
             scale = sv.scalar() if is_chain(sv) else engine.full((engine.n_chains,), float(np.asarray(sv).item()))
-        from openmcmc_amd.chains import ChainArray
-
         x = engine.empty(engine.n_chains, st.n)
         if st.diag is False:  # dense precision: x = Q^-1 (Q mean) + L^-T z
             M = engine.shared(st.matrix)
             rhs = engine.design_rhs(M, engine.to_device(mean)) if mean.any() else None
-            engine.dense_sample_canonical(st.n, [{"mat": M, "rhs": rhs, "scale": scale}], x, draw_index=draw_index)
+            engine.dense_sample_canonical(st.n, [{"mat": M, "rhs": rhs, "scale": scale}], x, z=z, draw_index=draw_index)
         else:
             cache = engine.model_cache(self, state, st, mean)
             engine.tridiag_sample_canonical(st.n, [{"diag": cache["diag"], "off": cache["off"], "rhs": cache["rhs"],
-                                                    "scale": scale}], x, draw_index=draw_index)
-        return ChainArray(x)
+                                                    "scale": scale}], x, z=z, draw_index=draw_index)
+        return x
 
     def constant_hessian(self, param: str) -> bool:
         """Is this distribution Gaussian in `param` (Hessian independent of it: branches (i) and (ii) of

@@ -44,6 +44,9 @@ class Engine:
                                  C.c_void_p(self._stream.cuda_stream), 0, C.byref(ctx)))
         self._ctx = ctx
         self._keep = []
+        # library writes into caller tensors that torch's version counter does not see (see note_write)
+        self._write_serial = 0
+        self._written = {}
 
     # ------------------------------------------------------------------ memory helpers
     def empty(self, *shape):
@@ -91,6 +94,21 @@ class Engine:
         if t.numel() != self.n_chains:
             raise ValueError(f"per-chain scalar must have {self.n_chains} entries, got {t.numel()}")
         return self._p(t)
+
+    # ------------------------------------------------------------------ who wrote what
+    def note_write(self, *tensors):
+        """Record that the library wrote into these tensors.  torch's version counter sees every write but the library's
+        own; a sampler that caches something derived from a state tensor (the whitened state of the fused
+        Metropolis-Hastings steps) asks `written_since` before it trusts the cache."""
+        self._write_serial += 1
+        for t in tensors:
+            if t is not None:
+                self._written[t.untyped_storage().data_ptr()] = self._write_serial
+        return self._write_serial
+
+    def written_since(self, t, serial):
+        """Has the library written into t's storage after write number `serial` (a value note_write returned)?"""
+        return self._written.get(t.untyped_storage().data_ptr(), 0) > serial
 
     # ------------------------------------------------------------------ context
     def close(self):
@@ -721,6 +739,7 @@ class Engine:
                 widths[e] = src.numel() // n
                 srcs[e], dsts[e] = self._p(src.view(n, -1)), self._p(dst.view(n, -1))
             check(lib.omc_chain_select_multi(self._ctx, self._i32(accept), m, widths, srcs, dsts))
+        self.note_write(*[d for _, d in pairs])
 
     def ragged_resize(self, src, count, birth, del_index, axis, new_vals=None, physical_transposed=False):
         """np.concatenate / np.delete along the ragged axis of a (C, p, n_rep) tensor for every chain.
@@ -903,6 +922,16 @@ class Engine:
                                 float(step), int(propose), self._p(z), int(draw_index), int(sub), self._p(out), self._p(lq)))
         return (out, lq) if propose else lq
 
+    def poisson_draw(self, rate, u=None, draw_index=0):
+        """One Poisson(rate) count per chain as a (C,) float64 tensor (omc_poisson_draw); rate: float or (C,) tensor;
+        u: (C, K) injected uniforms, NaN-padded."""
+        shared = not hasattr(rate, "data_ptr")
+        r = self.full((1,), float(rate)) if shared else rate
+        out = self.empty(self.n_chains)
+        check(lib.omc_poisson_draw(self._ctx, self._p(r), 0 if shared else 1, self._p(u, self.n_chains, 1) if u is not None else None,
+                                   0 if u is None else u.stride(0), int(draw_index), self._p(out)))
+        return out
+
     def poisson_logpmf(self, x, rate, out, accumulate=False):
         check(lib.omc_poisson_logpmf(self._ctx, self._chain_scalar(x), float(rate), self._chain_scalar(out), int(accumulate)))
 
@@ -991,6 +1020,42 @@ class Engine:
         out = torch.empty(self.n_chains, n_words, dtype=torch.int32, device=self.device)
         check(lib.omc_fill_philox_u32(self._ctx, n_words, int(draw_index), C.c_void_p(out.data_ptr()), n_words))
         return out
+
+
+# Engine methods that write into tensors the caller hands in (parameter names): the calls are recorded (Engine.note_write) so that
+# a cache derived from a state tensor can tell whether the library has touched that tensor since.  (Methods that return fresh
+# tensors need no entry; the whitened Metropolis-Hastings steps are the cache's owners and record nothing.)
+_WRITES = {
+    "tridiag_sample_canonical": ("x_out", "mean_out"), "gmrf_sweep": ("x_out",), "dense_sample_canonical": ("x_out", "mean_out"),
+    "dense_spectral_sample": ("x_out", "mean_out"), "band_sample_canonical": ("x_out", "mean_out"),
+    "band_gibbs_truncated": ("x",), "tridiag_gibbs_truncated": ("x",), "dense_gibbs_truncated": ("x",),
+    "chain_lincomb": ("out",), "chain_copy": ("dst",), "chain_select": ("dst",), "mala_step": ("x",), "rw_step": ("x",),
+    "tridiag_matvec_chain": ("out",), "band_matvec_chain": ("out",), "design_predict": ("fitted",),
+    "design_predict_batched": ("out",), "knot_loop": ("B", "beta", "theta"), "gaussian_basis": ("out",), "mala_diag": ("x",),
+}
+
+
+def _recording(fn, written):
+    import inspect
+
+    names = list(inspect.signature(fn).parameters)  # includes self
+    spec = tuple((names.index(w), w) for w in written)
+
+    def wrapper(self, *args, **kwargs):
+        out = fn(self, *args, **kwargs)
+        self._write_serial += 1
+        for pos, name in spec:
+            t = args[pos - 1] if pos - 1 < len(args) else kwargs.get(name)
+            if t is not None:
+                self._written[t.untyped_storage().data_ptr()] = self._write_serial
+        return out
+
+    wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+    return wrapper
+
+
+for _name, _written in _WRITES.items():
+    setattr(Engine, _name, _recording(getattr(Engine, _name), _written))
 
 
 def gather_local(engine, blocks, root=0, staging_limit_bytes=0):

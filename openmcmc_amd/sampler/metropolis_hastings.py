@@ -71,7 +71,19 @@ class MetropolisHastings(MCMCSampler):
     def bind(self, engine, position=0, n_samplers=1):
         super().bind(engine, position, n_samplers)
         self.accept_rate.attach(engine)
+        self._white_tag, self._white_serial = None, 0  # a sampler object taken into another run starts without a cached state
         return self
+
+    def _white_state_tag(self, state, x, L, mu):
+        """What the library's cached whitened state a = L'(x - mu) of the fused steps belongs to: this state entry (the object,
+        not only its address -- a fresh tensor can land on a recycled address with the same version), its contents as far as
+        torch sees them (version counter), the factor and the mean."""
+        return (id(state[self.param]), x.data_ptr(), x._version, L.data_ptr(), L._version,
+                None if mu is None else (mu.data_ptr(), mu._version))
+
+    def _white_state_is_current(self, engine, x, tag):
+        """... and as far as the library's own writes go, which torch's version counter does not see (Engine.note_write)."""
+        return getattr(self, "_white_tag", None) == tag and not engine.written_since(x, getattr(self, "_white_serial", 0))
 
     def _log_p_buffer(self, engine):
         """(C,) device buffer the fused steps leave the target's log density in."""
@@ -274,11 +286,11 @@ class RandomWalk(MetropolisHastings):
             z = self.inject(self, self._sweep) if self.inject is not None else None
             u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
             x = self._x(current_state)
-            tag = (x.data_ptr(), x._version, LQ.data_ptr())  # see ManifoldMALA.sample: may the library reuse its L_Q'(x - mu)?
-            eng.rw_step_white(mu, LQ, sl, float(self.step.item()), x, state_is_current=getattr(self, "_white_tag", None) == tag,
+            tag = self._white_state_tag(current_state, x, LQ, mu)  # see ManifoldMALA.sample: may the library reuse its L_Q'(x - mu)?
+            eng.rw_step_white(mu, LQ, sl, float(self.step.item()), x, state_is_current=self._white_state_is_current(eng, x, tag),
                               z=z, u=u, draw_index=self._draw_index(), accept_count=self.accept_rate.accept,
                               proposal_count=self.accept_rate.proposal, log_p_out=self._log_p_buffer(eng))
-            self._white_tag = tag
+            self._white_tag, self._white_serial = tag, eng._write_serial
             self.last_log_p = (self._log_p_buf, x)  # the target's log density at the state just left in x (see MCMC.run_mcmc)
         else:
             current_state = self._generic_step(current_state)
@@ -574,11 +586,11 @@ class ManifoldMALA(MetropolisHastings):
             # L = chol(Q / step^2): the step is element-wise in a = L'(x - mu) (omc_mala_step_white).  The library keeps a
             # for the x it wrote last; it may be reused if nobody else has written x since (torch's version counter sees
             # every write but the library's own).
-            tag = (x.data_ptr(), x._version, L.data_ptr())
-            eng.mala_step_white(mu, L, sl, step, x, state_is_current=getattr(self, "_white_tag", None) == tag, z=z, u=u,
+            tag = self._white_state_tag(current_state, x, L, mu)
+            eng.mala_step_white(mu, L, sl, step, x, state_is_current=self._white_state_is_current(eng, x, tag), z=z, u=u,
                                 draw_index=self._draw_index(), accept_count=self.accept_rate.accept,
                                 proposal_count=self.accept_rate.proposal, log_p_out=self._log_p_buffer(eng))
-            self._white_tag = tag
+            self._white_tag, self._white_serial = tag, eng._write_serial
             self.last_log_p = (self._log_p_buf, x)  # the target's log density at the state just left in x (see MCMC.run_mcmc)
         else:
             eng.mala_step(Q, mu, L, sl, step, x, z=z, u=u, draw_index=self._draw_index(),

@@ -389,3 +389,95 @@ def test_manifold_mala_through_lognormal_gradients(golden, case):
     for c in range(C):
         assert np.array_equal(flags[:, c], G[k + "accept"])
     eng.close()
+
+
+def test_whitened_mala_at_the_cfg4_size():
+    """BASELINE configs[3] at its per-GPU size: d = 500, 512 chains, step 0.5, the whitened step with in-kernel draws and its
+    cached whitened state carried: the acceptance rate of this target at stationarity (41 000 proposals here: 0.727 +- 0.003;
+    the CPU oracle's single chain gives 0.72 +- 0.02 over 400 steps; SURVEY.md 3.4 quotes ~68 % from a short reference run)
+    and the chains stay in the target, E|L_Q'(x - mu)|^2 = d, with a non-zero mean."""
+    import torch
+
+    d, C = 500, 512
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((d, 2 * d))
+    Qh = np.linalg.inv(A @ A.T / (2 * d))
+    Qh = (Qh + Qh.T) / 2
+    mu = rng.standard_normal(d)
+    eng = make_engine(C, seed=11)
+    Q, dmu = eng.to_device(Qh), eng.to_device(mu)
+    step = 0.5
+    L, sl = eng.dense_cholesky(Q, 1.0 / step**2)
+    x = eng.to_device(mu + np.linalg.solve(np.linalg.cholesky(Qh).T, rng.standard_normal((d, C))).T)  # draws from the target
+    acc = torch.zeros(C, dtype=torch.int64, device="cuda")
+    prop = torch.zeros(C, dtype=torch.int64, device="cuda")
+    lp = eng.empty(C)
+    n_steps = 80
+    for it in range(n_steps):
+        eng.mala_step_white(dmu, L, sl, step, x, state_is_current=it > 0, draw_index=it, accept_count=acc, proposal_count=prop,
+                            log_p_out=lp)
+    eng.check_status()
+    assert np.array_equal(prop.cpu().numpy(), np.full(C, n_steps))
+    rate = acc.sum().item() / prop.sum().item()
+    assert 0.705 < rate < 0.75, rate
+    r = x.cpu().numpy() - mu
+    maha = np.einsum("ci,ij,cj->c", r, Qh, r)
+    assert abs(maha.mean() / d - 1) < 0.015
+    # the log density the step hands out is the target's at the state it left (gmrf.py:321-348)
+    want = 0.5 * (np.linalg.slogdet(Qh)[1] - d * np.log(2 * np.pi) - maha)
+    assert np.max(np.abs(lp.cpu().numpy() - want)) < 1e-8 * d
+    eng.close()
+
+
+@pytest.mark.parametrize("cls_name", ["ManifoldMALA", "RandomWalk"])
+def test_cached_whitened_state_notices_library_writes(cls_name):
+    """The fused steps cache a = L'(x - mu) for the state they wrote last.  A write into the state by the LIBRARY (here
+    omc_chain_copy, which torch's version counter does not see), a fresh state tensor, and a sampler object taken into another
+    run must all be noticed: the whitened sampler has to stay equal to the route that recomputes everything."""
+    from openmcmc_amd.chains import ChainArray
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.sampler import metropolis_hastings as mh
+
+    d, C, steps = 24, 6, 9
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((d, 2 * d))
+    Qh = np.linalg.inv(A @ A.T / (2 * d))
+    Qh = (Qh + Qh.T) / 2
+    mu = rng.standard_normal((d, 1))
+    x0 = rng.standard_normal((C, d, 1))
+    other = rng.standard_normal((C, d))
+    zs, us = rng.standard_normal((steps, C, d)), rng.random((steps, C))
+    outs = []
+    for trust_cache in (False, True):
+        eng = make_engine(C, seed=2)
+        mdl = Model([Normal("x", mean="mu", precision="Q")])
+        smp = getattr(mh, cls_name)("x", mdl, step=np.array([[0.5 if cls_name == "ManifoldMALA" else 0.1]]))
+        smp.bind(eng)
+        smp.inject = lambda s, sweep, *a: eng.to_device(zs[sweep])
+        smp.inject_uniform = lambda s, sweep, *a: eng.to_device(us[sweep])
+        state = {"x": ChainArray(eng.to_device(x0)), "mu": mu, "Q": Qh}
+        used_cache = 0
+        for i in range(steps):
+            if i == 3:  # the library itself overwrites the state in place
+                eng.chain_copy(eng.to_device(other), state["x"].vector())
+            if i == 6:  # a fresh state entry (possibly on a recycled address, version 0 again)
+                state["x"] = ChainArray(eng.to_device(x0))
+            if not trust_cache:
+                smp._white_tag = None  # the reference: a = L'(x - mu) recomputed from x in every step
+            else:
+                x = state["x"].vector()
+                LQ = smp._plan[0] if smp._plan is not None else None
+                if LQ is not None:
+                    tag = smp._white_state_tag(state, x, LQ, eng.shared(mu).reshape(-1))
+                    current = smp._white_state_is_current(eng, x, tag)
+                    assert current == (i not in (0, 3, 6)), i
+                    used_cache += int(current)
+            state = smp.sample(state)
+        eng.check_status()
+        if trust_cache:
+            assert used_cache == steps - 3
+        outs.append((state["x"].data.cpu().numpy().copy(), smp.accept_rate.accept.cpu().numpy().copy()))
+        eng.close()
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert relerr(outs[1][0], outs[0][0]) < 1e-10
