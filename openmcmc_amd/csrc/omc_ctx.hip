@@ -34,6 +34,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->chain_offset = chain_id_offset;
   c->own_stream = (create_stream != 0);
   c->workspace = nullptr;
+  c->long_band = nullptr; c->long_band_bytes = 0; c->long_quad = nullptr; c->long_quad_bytes = 0;
   c->workspace_bytes = 0;
   c->blas = nullptr;
   c->dense_factor = nullptr; c->dense_factor_bytes = 0;
@@ -89,6 +90,8 @@ omc_status omc_ctx_destroy(omc_ctx* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (ctx->workspace) hipFree(ctx->workspace);
+  if (ctx->long_band) hipFree(ctx->long_band);
+  if (ctx->long_quad) hipFree(ctx->long_quad);
   if (ctx->d_gamma_tab) hipFree(ctx->d_gamma_tab);
   if (ctx->d_handoff) hipFree(ctx->d_handoff);
   if (ctx->dense_factor) hipFree(ctx->dense_factor);

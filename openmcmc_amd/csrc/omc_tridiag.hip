@@ -2251,6 +2251,51 @@ static omc_status launch_tridiag(omc_ctx* ctx, TriArgs& A) {
   return OMC_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Chains too long for one workgroup (n > 16 384).  The one-lane-per-chain kernel is a cliff there (28 ms per sweep at
+// n = 20 000 x 1024 chains); the segmented kernels of the band route (omc_band.hip, bandwidth 1) take any n at 2-5 ms.
+// The tridiagonal terms are put into that route's band storage (a stream-ordered device copy of 2 n doubles per term into
+// a context buffer), the draw is omc_band_sample_canonical -- same natural-order factor, same draw streams, equal to the
+// tridiagonal kernels' result to rounding -- and what the fused sweep adds (quadratic forms, Normal-Gamma updates, log
+// posterior) follows as the library's own separate launches.
+__global__ void __launch_bounds__(256) k_band_from_tridiag(int64_t n, const double* diag, const double* off, double* band) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    band[i] = diag ? diag[i] : 1.0;
+    band[n + i] = (off && i < n - 1) ? off[i] : 0.0;
+  }
+}
+
+static bool long_chain_route(const omc_ctx* ctx, int64_t n) { return ctx->tridiag_algo == 0 && n > seg_max_n(32); }
+
+static omc_status long_chain_draw(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* t, const double* rhs_chain, int64_t ld_rhs,
+                                  const double* z, int64_t ld_z, uint64_t draw_index, double* x, int64_t ld_x, double* mean,
+                                  int64_t ld_mean, double* logdet) {
+  omc_band_terms bt;
+  bt.n_terms = t->n_terms;
+  const size_t per = 2 * (size_t)n * sizeof(double);
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  {
+    const omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->long_band, &ctx->long_band_bytes, per * OMC_MAX_TERMS);
+    if (st != OMC_OK) return st;
+  }
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+    bt.band[k] = nullptr; bt.bw[k] = 0; bt.rhs[k] = nullptr; bt.scale[k] = nullptr;
+    if (k >= t->n_terms) continue;
+    bt.rhs[k] = t->rhs[k];
+    bt.scale[k] = t->scale[k];
+    if (t->diag[k] || t->off[k]) {
+      double* b = ctx->long_band + (size_t)k * 2 * (size_t)n;
+      int64_t grid = (n + 255) / 256;
+      if (grid > 1024) grid = 1024;
+      hipLaunchKernelGGL(k_band_from_tridiag, dim3((unsigned)grid), dim3(256), 0, ctx->stream, n, t->diag[k], t->off[k], b);
+      bt.band[k] = b;
+      bt.bw[k] = t->off[k] ? 1 : 0;
+    }
+  }
+  OMC_HIP_CHECK(hipGetLastError());
+  return omc_band_sample_canonical(ctx, n, 1, &bt, rhs_chain, ld_rhs, z, ld_z, draw_index, x, ld_x, mean, ld_mean, logdet);
+}
+
 extern "C" {
 
 int32_t omc_reentry_descriptor_ok(uint32_t private_segment_fixed_size, uint32_t compute_pgm_rsrc2, uint32_t properties_and_preload) {
@@ -2267,6 +2312,12 @@ omc_status omc_tridiag_sample_canonical(omc_ctx* ctx, int64_t n, const omc_tridi
   args_defaults(ctx, &A, n);
   if (!terms_to_dev(terms, &A.T)) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  if (long_chain_route(ctx, n)) {
+    omc_status st = long_chain_draw(ctx, n, terms, rhs_chain, ld_rhs, z_inject, ld_z, draw_index, x_out, ld_x, mean_out, ld_mean,
+                                    logdet_out);
+    if (st != OMC_OK || !quad_out) return st;
+    return omc_tridiag_quadform(ctx, n, terms, x_out, ld_x, quad_out);
+  }
   A.rhs_chain = rhs_chain; A.ld_rhs = ld_rhs;
   A.key = omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL);
   if (mean_out) {  // mu = Q^{-1} b is the same solve with z = 0 (gmrf.py:196)
@@ -2305,6 +2356,44 @@ omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* term
     g.key = omc_make_key(ctx->seed, b.draw_index, OMC_RNG_GAMMA);
   }
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  if (long_chain_route(ctx, n)) {
+    // the sweep as separate launches: draw, quadratic forms, Normal-Gamma updates, log posterior (model.py:57-70)
+    const int nt = terms->n_terms;
+    const int64_t C = ctx->n_chains;
+    {
+      const omc_status st0 = omc_ensure_bytes(ctx, (void**)&ctx->long_quad, &ctx->long_quad_bytes, (size_t)OMC_MAX_TERMS * C * sizeof(double));
+      if (st0 != OMC_OK) return st0;
+    }
+    omc_status st = long_chain_draw(ctx, n, terms, rhs_chain, ld_rhs, z_inject, ld_z, draw_index, x_out, ld_x, nullptr, 0, nullptr);
+    if (st != OMC_OK) return st;
+    st = omc_tridiag_quadform(ctx, n, terms, x_out, ld_x, ctx->long_quad);
+    if (st != OMC_OK) return st;
+    for (int k = 0; k < nt; ++k) {
+      const omc_gamma_block& b = blocks[k];
+      if (!b.enabled) continue;
+      double* const sc = const_cast<double*>(terms->scale[k]);
+      st = omc_normal_gamma_update(ctx, b.a0, b.b0, b.n_pos, ctx->long_quad + k * C, b.g_inject, b.draw_index, sc);
+      if (st != OMC_OK) return st;
+      if (b.store) {
+        st = omc_chain_copy(ctx, 1, sc, 1, b.store, 1);
+        if (st != OMC_OK) return st;
+      }
+    }
+    if (log_post_out) {
+      int first = 1;
+      for (int k = 0; k < nt; ++k) {
+        const omc_gamma_block& b = blocks[k];
+        st = omc_scaled_gauss_logpdf(ctx, n, terms->scale[k], b.logdet_unscaled, ctx->long_quad + k * C, log_post_out, first ? 0 : 1);
+        if (st != OMC_OK) return st;
+        first = 0;
+        if (b.enabled) {
+          st = omc_gamma_logpdf(ctx, terms->scale[k], b.a0, b.b0, log_post_out, 1);
+          if (st != OMC_OK) return st;
+        }
+      }
+    }
+    return OMC_OK;
+  }
   A.rhs_chain = rhs_chain; A.ld_rhs = ld_rhs;
   A.z = z_inject; A.ld_z = ld_z;
   A.key = omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL);

@@ -324,6 +324,8 @@ def test_long_tridiagonal_chains_take_the_band_route():
             samplers = [NormalNormal("b", mdl), NormalGamma("lambda", mdl), NormalGamma("tau", mdl)]
             M = MCMC(state, samplers, model=mdl, n_burn=0, n_iter=sweeps, n_chains=C)
             eng = M.engine
+            if route == "tridiag":  # the one-lane-per-chain kernel (since round 3 the C entry points reroute long chains as well)
+                eng.set_option("tridiag_algo", 1)
             samplers[0].inject = lambda s_, it: eng.to_device(np.tile(z[it], (C, 1)))
             samplers[1].inject = lambda s_, it: eng.full((C,), g[it, 0])
             samplers[2].inject = lambda s_, it: eng.full((C,), g[it, 1])

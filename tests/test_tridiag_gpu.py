@@ -514,3 +514,57 @@ def test_smoother_fused_specialised_equals_generic(torch, n, with_offsets, misal
     for a, b in zip(out[0], out[1]):
         assert np.all(np.isfinite(a))
         assert relerr(a, b) < 1e-10
+
+
+def test_c_entry_points_take_chains_beyond_one_workgroup():
+    """n > 16 384: omc_tridiag_sample_canonical, omc_gmrf_sweep and omc_gmrf_run no longer fall to the one-lane-per-chain
+    kernel (28 ms per sweep at n = 20 000 x 1024 chains) but take the segmented kernels of the band route internally.
+    Against the one-lane-per-chain kernel (tridiag_algo = 1) with the same injected draws / the same Philox streams: draw,
+    mean, log det, quadratic forms, the Normal-Gamma updates, the stores and log_post agree to rounding."""
+    from openmcmc_amd.engine import Engine
+
+    n, C, K = 20000, 40, 3
+    rng = np.random.default_rng(8)
+    t = np.arange(n) * 60.0 / 10000
+    y = np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + rng.standard_normal(n)
+    d = np.full(n, 2.0)
+    d[0] = d[-1] = 1.0
+    d[0] += 1e-3
+    off = -np.ones(n - 1)
+    lam0, tau0 = 80.0 + 40 * rng.random(C), 0.5 + rng.random(C)
+    z, g = rng.standard_normal((C, n)), 5000.0 + 50 * rng.random((2, C))
+    res = {}
+    for algo in (0, 1):
+        eng = Engine(C, seed=21)
+        eng.set_option("tridiag_algo", algo)
+        d_y, d_d, d_off = eng.to_device(y), eng.to_device(d), eng.to_device(off)
+        lam, tau = eng.to_device(lam0), eng.to_device(tau0)
+        terms = eng.tridiag_terms([{"diag": d_d, "off": d_off, "scale": lam}, {"rhs": d_y, "center": d_y, "scale": tau}], n)
+        x, mean, quad, ld = eng.empty(C, n), eng.empty(C, n), eng.empty(2, C), eng.empty(C)
+        eng.tridiag_sample_canonical(n, terms, x, z=eng.to_device(z), mean_out=mean, quad_out=quad, logdet_out=ld)
+        eng.check_status()
+        out = {"x": x.cpu().numpy(), "mean": mean.cpu().numpy(), "quad": quad.cpu().numpy(), "logdet": ld.cpu().numpy()}
+        # the fused sweep with injected draws
+        logdetP, logdetI = eng.full((1,), -3.7), eng.zeros(1)  # any constants: they enter log_post additively
+        s_lam, s_tau, lp, xs = eng.empty(C), eng.empty(C), eng.empty(C), eng.empty(C, n)
+        blocks = eng.gamma_blocks([{"a0": 10.0, "b0": 1.0, "n_pos": n, "g": eng.to_device(g[0]), "store": s_lam, "logdet": logdetP},
+                                   {"a0": 1.0, "b0": 1.0, "n_pos": n, "g": eng.to_device(g[1]), "store": s_tau, "logdet": logdetI}], 2)
+        eng.gmrf_sweep(n, terms, blocks, xs, z=eng.to_device(z), log_post_out=lp)
+        eng.check_status()
+        out.update(sweep_x=xs.cpu().numpy(), lam=lam.cpu().numpy().copy(), tau=tau.cpu().numpy().copy(), s_lam=s_lam.cpu().numpy(),
+                   s_tau=s_tau.cpu().numpy(), lp=lp.cpu().numpy())
+        # a short run on the Philox streams
+        sb, sl, st, slp = eng.empty(K, C, n), eng.empty(K, C), eng.empty(K, C), eng.empty(K, C)
+        blocks_run = [{"a0": 10.0, "b0": 1.0, "n_pos": n, "store": sl, "logdet": logdetP, "draw_index": 1},
+                      {"a0": 1.0, "b0": 1.0, "n_pos": n, "store": st, "logdet": logdetI, "draw_index": 2}]
+        eng.gmrf_run(n, terms, blocks_run, 1, K, 1, sb, eng.empty(C, n), draw_index0=9, draws_per_sweep=3, log_post_store=slp)
+        eng.check_status()
+        out.update(run_b=sb.cpu().numpy(), run_lam=sl.cpu().numpy(), run_tau=st.cpu().numpy(), run_lp=slp.cpu().numpy())
+        res[algo] = out
+        eng.close()
+    assert np.array_equal(res[0]["lam"], res[0]["s_lam"]) and np.array_equal(res[0]["tau"], res[0]["s_tau"])
+    for key in res[1]:
+        a, b = res[0][key], res[1][key]
+        assert np.all(np.isfinite(a)), key
+        err = np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+        assert err < (1e-8 if key.startswith("run_") else 1e-10), (key, err)
