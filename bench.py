@@ -599,6 +599,8 @@ def main():
 
     if stamps is not None and rank == 0:
         st = stamps.cpu().numpy().reshape(C, 16, 16).astype(np.float64)
+        if os.environ.get("OMC_STAMPS_DUMP"):  # raw [chain][wave][stamp] ticks for a timeline (benchmarks/stamp_timeline.py)
+            np.save(os.environ["OMC_STAMPS_DUMP"], st)
         nwv = int((st[0, :, 0] > 0).sum())
         d = np.diff(st[:, :nwv, :], axis=2)
         names = ["gamma draws", "fill b", "fill a", "moebius local", "moebius scan", "newton", "l", "fill rhs",

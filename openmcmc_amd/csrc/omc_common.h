@@ -119,22 +119,43 @@ __host__ __device__ inline omc_rng_key omc_make_key(uint64_t seed, uint64_t draw
   return k;
 }
 
-// one round, key schedule included
+// one round, key schedule included.  XOR3: hi ^ c ^ k as one v_bitop3_b32 (truth table 0x96 = three-input XOR, new on
+// gfx950) where the compiler's own selection leaves two v_xor_b32 -- 14 vector instructions per block.  Used from round 3
+// on, where all four words vary per lane in every kernel; in the workgroup-per-chain kernels only the block index differs
+// between the lanes at first, and the plain form lets the scalar unit do the wave-uniform part of rounds 0-2.
+template <bool XOR3>
 __device__ __forceinline__ void omc_philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t& k0,
                                                  uint32_t& k1) {
   constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
   const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
   const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
   const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-  const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+  uint32_t n0, n2;
+  if constexpr (XOR3) {
+    n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);
+    n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+  } else {
+    n0 = hi1 ^ c1 ^ k0;
+    n2 = hi0 ^ c3 ^ k1;
+  }
   c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
   k0 += W0; k1 += W1;
+}
+
+#ifndef OMC_XOR3_FROM
+#define OMC_XOR3_FROM 3  // first round that uses the three-input XOR (10 = never: A/B builds)
+#endif
+// round r of an unrolled loop (r folds to a constant there)
+__device__ __forceinline__ void omc_philox_round_r(int r, uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t& k0,
+                                                   uint32_t& k1) {
+  if (r >= OMC_XOR3_FROM) omc_philox_round<true>(c0, c1, c2, c3, k0, k1);
+  else omc_philox_round<false>(c0, c1, c2, c3, k0, k1);
 }
 
 __device__ __forceinline__ uint4 omc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                    uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) omc_philox_round(c0, c1, c2, c3, k0, k1);
+  for (int r = 0; r < 10; ++r) omc_philox_round_r(r, c0, c1, c2, c3, k0, k1);
   return make_uint4(c0, c1, c2, c3);
 }
 

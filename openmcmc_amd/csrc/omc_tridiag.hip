@@ -33,6 +33,10 @@
 
 #include "omc_common.h"
 
+#ifndef OMC_JOIN_OR_LIB
+#define OMC_JOIN_OR_LIB 0  // 1: the join test through __syncthreads_or (three barriers; A/B builds)
+#endif
+
 struct TermsDev {
   int n_terms;
   const double* diag[OMC_MAX_TERMS];
@@ -640,6 +644,19 @@ __device__ __forceinline__ double sum_wg(double v, double* lds, int lane, int wa
   return t;
 }
 
+// Workgroup-wide OR of a per-lane flag with ONE LDS barrier: every wave leaves its ballot in its own word of `slot`, all
+// read the row behind the barrier.  (`__syncthreads_or` is a library reduction of three `s_barrier`s -- clear, `ds_or`,
+// read -- and a full `__syncthreads` fence each; the join test sits on every chain-update's critical path.)  No trailing
+// barrier: the next call on the same `slot` must lie behind another barrier.
+__device__ __forceinline__ bool any_wg(int need, int* slot, int lane, int wave, int nw) {
+  const bool mine = __ballot(need) != 0ull;
+  if (nw <= 1) return mine;
+  if (lane == 0) slot[wave] = mine ? 1 : 0;
+  lds_barrier();
+  const int f = (lane < nw) ? slot[lane] : 0;
+  return __ballot(f) != 0ull;
+}
+
 // ------------------------------------------------------------------------------------------
 // Wave-private LDS tile: converts between "lane owns M consecutive nodes" (registers) and
 // "64 consecutive lanes touch 64 consecutive doubles" (global memory).  Tile element e
@@ -882,6 +899,9 @@ __device__ __forceinline__ double fast_sqrt(double r) {
 }
 
 // diagnostic phase stamps (guide section 7, in-kernel stamps): lane 0 of every wave, only when enabled
+#if OMC_NO_STAMPS
+#define OMC_STAMP(k) do { } while (0)
+#else
 #define OMC_STAMP(k)                                                                                  \
   do {                                                                                                \
     if (A.stamps) {                                                                                   \
@@ -891,6 +911,7 @@ __device__ __forceinline__ double fast_sqrt(double r) {
       __builtin_amdgcn_sched_barrier(0);                                                              \
     }                                                                                                 \
   } while (0)
+#endif
 
 // join residual (relative) below which the pivots are accepted: ~72 ulp; the Moebius start already
 // meets it for well-conditioned chains, weakly coupled ones take one or two Newton corrections
@@ -1048,7 +1069,7 @@ __device__ __forceinline__ void draws_over_load(const omc_rng_key& key, int64_t 
         v[t] = (FULLW || idx < nvalid) ? base[(unsigned)idx] : 0.0;
       }
     }
-    omc_philox_round(c0, c1, c2, c3, k0, k1);
+    omc_philox_round_r(r, c0, c1, c2, c3, k0, k1);
     __builtin_amdgcn_sched_barrier(0);
   }
   omc_normal_pair(make_uint4(c0, c1, c2, c3), z0, z1);
@@ -1069,6 +1090,12 @@ static bool is_smoother(const TermsDev& T) {
 template <int M, bool MULTI, int MAXT, int SIG = 0>
 __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   static_assert(SIG == 0 || MULTI, "specialised structures exist for the workgroup-per-chain form only");
+  // SIG 1, 2: the two-term smoother.  SIG 2 is its WAITING form -- the (sweep, chain) grid with at most half as many chains
+  // as CUs, in-kernel draws: the workgroup of a chain's next sweep sits on an idle CU until the previous sweep's scales
+  // arrive, so everything that does not depend on them is done up front (all three vector loads, the buffered draws, the
+  // Normal-Gamma standard draws), and the poll of the hand-over line is tight.  Never self-restarting.
+  constexpr bool SMO = SIG != 0;
+  constexpr bool EARLY = SIG == 2;
   using TM = TileMap<M>;
   constexpr int NWMAX = MAXT / 64;
   __shared__ double lds_tile[NWMAX][64 * (M + 1) + 2];  // + the successor slot of the last row (quad_wg)
@@ -1079,9 +1106,10 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   __shared__ Aff lds_aff[4][16];   // scans alternate buffers instead of paying a trailing barrier
   __shared__ double lds_x[2][32];  // neighbour exchange of the Newton passes (alternating)
   __shared__ double lds_d[6][16];  // reductions: one slot per call site
+  __shared__ int lds_any[16];      // any_wg of the join test
   // SIG 1: pairs of draws per lane made ahead of the forward pass (all but the last; at most 8: LDS)
-  constexpr int NZB = (SIG == 1) ? (M / 2 - 1 > 8 ? 8 : M / 2 - 1) : 0;
-  __shared__ double lds_z[SIG == 1 ? NWMAX : 1][NZB > 0 ? 2 * NZB : 1][64];
+  constexpr int NZB = (SMO) ? (M / 2 - 1 > 8 ? 8 : M / 2 - 1) : 0;
+  __shared__ double lds_z[SMO ? NWMAX : 1][NZB > 0 ? 2 * NZB : 1][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int Wd = MULTI ? 64 : G;
   int64_t c;
@@ -1135,7 +1163,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   const int64_t cc = chain_ok ? c : 0;
   const int64_t n = A.n;
   const int64_t i0 = (int64_t)s * M;
-  const int nt = (SIG == 1) ? 2 : A.T.n_terms;
+  const int nt = (SMO) ? 2 : A.T.n_terms;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int r0 = TM::lane_col(lane);
   double* tl = tile + lbase;
@@ -1215,12 +1243,14 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       // turns; it is bounded all the same (about a second), and a hand-over that never comes is reported.
       for (int spin = 0;; ++spin) {
         if (tags_ok()) break;
-        if (spin >= (1 << 19)) {
+        // (SIG 2: the consumer was on its CU long before the producer finished -- the poll interval is part of every
+        // chain-update's latency; 64 cycles instead of 4096 between looks, the bound scaled to the same ~1 s)
+        if (spin >= (EARLY ? (1 << 22) : (1 << 19))) {
           if (threadIdx.x == 0 && chain_ok) atomicAdd(A.timeouts, 1ull);
           lost = true;
           break;
         }
-        __builtin_amdgcn_s_sleep(64);
+        __builtin_amdgcn_s_sleep(EARLY ? 1 : 64);
 #pragma unroll
         for (int k = 0; k < OMC_MAX_TERMS; ++k)
           if (k < nt && A.T.scale[k] && A.gb[k].enabled) {
@@ -1239,7 +1269,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   auto nkey_f = [&]() -> omc_rng_key { return (MULTI && run_mode(A)) ? omc_make_key(A.seed, A.rec[sw].draw, OMC_RNG_NORMAL) : A.key; };
   auto x_out = [&]() -> double* { return (MULTI && run_mode(A)) ? A.rec[sw].x : A.x; };
   // SIG 1: which of the two terms is the tridiagonal one (wave-uniform; selects, not indexed kernel arguments)
-  const bool p_first = SIG == 1 && A.T.diag[0] != nullptr;
+  const bool p_first = SMO && A.T.diag[0] != nullptr;
   double sP = 1.0, sI = 1.0;  // the two scales by role; selected where first needed (a use up here would put the wait for
                               // the scalar loads in front of the first vector loads and draws)
   const double* const vPd = p_first ? A.T.diag[0] : A.T.diag[1];
@@ -1258,9 +1288,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // the draws are parked in LDS until the epilogue: two registers that would otherwise be live (or, as the
   // compiler prefers, spilled to scratch by every wave) across the whole kernel.  SIG 1 makes them later, where
   // wave 0's SIMD has issue slots to spare (the opening phase is bound by the vector ALU there).
-  if (SIG != 1 && epi_wave && chain_ok) {
+  if (!SMO && epi_wave && chain_ok) {
     bool f = false;
-    const double g = sweep_gamma_draws_wave<MULTI && SIG != 1>(A, c, lane, &f, sw);
+    const double g = sweep_gamma_draws_wave<MULTI && !SMO>(A, c, lane, &f, sw);
     lds_g[lane] = f ? -g : g;  // a Gamma draw is positive; the sign flags a draw that did not terminate
   }
 
@@ -1270,19 +1300,25 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   const uint32_t blk0 = (uint32_t)(i0 >> 1);
   const bool gen_z = !A.z && !A.zero_z;
   // SIG 1: may this wave's off-diagonal slice be parked in the draws' LDS slots (see the forward pass)?
-  const bool park_off = OMC_PARK_OFF && SIG == 1 && gen_z && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n - 1) == 64 * M &&
+  const bool park_off = OMC_PARK_OFF && SMO && gen_z && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n - 1) == 64 * M &&
                         (reinterpret_cast<uintptr_t>(vPo) & 15u) == 0;
-  const bool park_diag = OMC_PARK_DIAG && SIG == 1 && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n) == 64 * M &&
+  const bool park_diag = OMC_PARK_DIAG && SMO && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n) == 64 * M &&
                          (reinterpret_cast<uintptr_t>(vPd) & 15u) == 0;
 
   // Fewer chains than CUs ((sweep, chain) grid): this workgroup has been placed on an idle CU while the chain's previous
   // sweep is still running elsewhere, and all it can do until that sweep's scales arrive is what does not depend on them --
   // the loads and the draws.  Then ALL buffered pairs are made up here (nothing else is live yet), not spread over the
   // phases behind the hand-over where they would sit on the chain's critical path from sweep to sweep.
-  const bool early = SIG == 1 && gen_z && A.early_draws != 0;
-  const bool gen_late = gen_z && !early;
-  if constexpr (SIG == 1) {
-    if (early) {
+  // That is the SIG 2 instantiation (the host picks it for such launches): the three shared vectors are requested first
+  // (60 registers that nothing else wants yet), the draws are made while they travel, wave 0 adds the Normal-Gamma standard
+  // draws (functions of the priors only), and only then are the scales waited for -- with a tight poll: what follows the
+  // hand-over is the chain's critical path from sweep to sweep, and a poll interval is on it.
+  // (SIG 1 keeps the run-time form of the early draws: the host no longer asks for it, but without this block the
+  // register allocator spills three registers of the hot path)
+  const bool early1 = !EARLY && SMO && gen_z && A.early_draws != 0;
+  const bool gen_late = gen_z && !EARLY && !early1;
+  if constexpr (SMO && !EARLY) {
+    if (early1) {
 #pragma unroll
       for (int jb = 0; jb < NZB; ++jb) {
         double z0, z1;
@@ -1292,10 +1328,36 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       }
     }
   }
+  double pre[M];  // SIG 1, 2: the right-hand side vector
+  double epo[EARLY ? M : 1], epd[EARLY ? M : 1], ebm1_raw = 0.0;
+  if constexpr (EARLY) {
+    // draws first (light on registers), the loads behind them: the workgroup waits for its scales far longer than a load
+    // takes, so nothing has to travel under the draws -- and sixty registers of loads in flight beside them would spill
+    if (gen_z) {
+#pragma unroll
+      for (int jb = 0; jb < NZB; ++jb) {
+        double z0, z1;
+        omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + (uint32_t)jb), z0, z1);
+        lds_z[wave][2 * jb][lane] = z0;
+        lds_z[wave][2 * jb + 1][lane] = z1;
+      }
+    }
+    if (epi_wave && chain_ok) {
+      bool f = false;
+      const double g = sweep_gamma_draws_wave(A, c, lane, &f, sw);
+      lds_g[lane] = f ? -g : g;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int wbase = wave_u * 64 * M;
+    ebm1_raw = vPo[(i0 > 0 && i0 < n) ? i0 - 1 : 0];
+    coal_load<M>(epo, vPo + wbase, lane, wave_valid<M>(wave_u, (int)n - 1));
+    coal_load<M>(epd, vPd + wbase, lane, wave_valid<M>(wave_u, (int)n));
+    if (!(A.rhs_chain && chain_ok)) coal_load<M>(pre, vIr + wbase, lane, wave_valid<M>(wave_u, (int)n));
+    __builtin_amdgcn_sched_barrier(0);
+  }
   // ---- conditional precision: b -> Y (registers), a -> LDS tile ----
   double bm1 = 0.0;  // coupling b_{i0-1} into the segment
-  double pre[M];  // SIG 1: the right-hand side vector
-  if constexpr (SIG == 1) {
+  if constexpr (SMO) {
     const int wbase = wave_u * 64 * M;
     const int nv = wave_valid<M>(wave_u, (int)n), nvo = wave_valid<M>(wave_u, (int)n - 1);
     // one vector (20 registers) in flight beside the generation of one pair of draws: more than that spills
@@ -1313,9 +1375,16 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     };
     {
       double po[M];
-      // b_{i0-1}: only loaded here; any arithmetic on it would put a wait for all loads in front of the draws
-      const double bm1_raw = vPo[(i0 > 0 && i0 < n) ? i0 - 1 : 0];
-      vec_and_draws(po, vPo + wbase, nvo, 0);
+      double bm1_raw;
+      if constexpr (EARLY) {
+        bm1_raw = ebm1_raw;
+#pragma unroll
+        for (int t = 0; t < M; ++t) po[t] = epo[t];
+      } else {
+        // b_{i0-1}: only loaded here; any arithmetic on it would put a wait for all loads in front of the draws
+        bm1_raw = vPo[(i0 > 0 && i0 < n) ? i0 - 1 : 0];
+        vec_and_draws(po, vPo + wbase, nvo, 0);
+      }
       take_scales();
       if (SIG == 1 && A.reenter == 2 && handed && hand_lds && wave_u == 1 && chain_ok && any_handed_f()) {
         // the previous sweep's log-posterior, left here by its epilogue (scales: just taken; quadratic forms: LDS)
@@ -1340,7 +1409,12 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     }
     {
       double pd[M];
-      vec_and_draws(pd, vPd + wbase, nv, 1);
+      if constexpr (EARLY) {
+#pragma unroll
+        for (int t = 0; t < M; ++t) pd[t] = epd[t];
+      } else {
+        vec_and_draws(pd, vPd + wbase, nv, 1);
+      }
 #pragma unroll
       for (int j = 0; j < M; ++j) Y[j] = crow[j];
       OMC_STAMP(2);
@@ -1434,7 +1508,11 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   if (MULTI) {
     const bool has_next = i0 + M < n;
     const int need = (has_next && fabs(Dend - Dnext0) > OMC_NEWTON_TOL * fabs(Dnext0)) ? 1 : 0;  // false for NaN: -> `bad`
+#if OMC_JOIN_OR_LIB
     settled = !__syncthreads_or(need);
+#else
+    settled = !any_wg(need, lds_any, lane, wave, nw);
+#endif
   }
   for (int it = 0; !settled; ++it) {
     double J = lin * lin;  // d(last pivot)/d(start pivot) of this segment = prod of l^2 over it
@@ -1450,7 +1528,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     const double e = joined ? (Dp - Dst) : 0.0;
     if (!joined) Jp = 0.0;
     const int need = (fabs(e) > OMC_NEWTON_TOL * fabs(Dst)) ? 1 : 0;  // false for NaN: falls through to `bad`
-    const int any = MULTI ? __syncthreads_or(need) : (__ballot(need) != 0ull);
+    const int any = MULTI ? __syncthreads_or(need) : (__ballot(need) != 0ull);  // (rare path: any_wg here costs the hot path 3 spilled registers)
     if (!any) break;
     if (it >= A.newton_max) {
       // Newton has not brought every join below the tolerance (a recurrence that is not contractive over a
@@ -1503,10 +1581,10 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   OMC_STAMP(7);
   // ---- right-hand side -> tile; forward substitution (local affine map, scan, true pass) ----
   bool rhs_done = false;
-  if constexpr (SIG == 1) {
+  if constexpr (SMO) {
     // per-chain offsets (rhs_chain) go through the general fill below; the draws are made ahead in either case
     const bool with_offsets = A.rhs_chain && chain_ok;
-    if (!with_offsets) {
+    if (!with_offsets && !EARLY) {  // (SIG 2 asked for the vector at its start)
       const int nvr = wave_valid<M>(wave_u, (int)n);
       const double* base = vIr + wave_u * 64 * M;
       if (gen_late && NZB > 2) {
@@ -1568,10 +1646,15 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       if (zin) {
         if (i0 + j < n) z0 = zin[j];
         if (i0 + j + 1 < n) z1 = zin[j + 1];
-      } else if (SIG == 1 && (j >> 1) < NZB) {
+        // injected draws (tests): waited for HERE.  Left pending, these loads meet the in-kernel-draw path at the join below,
+        // and the compiler's wait-count pass -- which must assume either predecessor -- then puts an `s_waitcnt vmcnt(0)`
+        // into the shared code: behind the quadratic-form prefetches of SIG 1 that wait exposed the whole L2 latency of
+        // twelve loads on every sweep of the production path.
+        if (SMO) __builtin_amdgcn_s_waitcnt(0x0F70);
+      } else if (SMO && (j >> 1) < NZB) {
         if (gen_z) { z0 = lds_z[wave][j][lane]; z1 = lds_z[wave][j + 1][lane]; }
       } else if (!A.zero_z) {
-        if constexpr (SIG == 1) {
+        if constexpr (SMO) {
           // The parked draws have all been read: their LDS slots now take the first 128 NZB entries of this
           // wave's slice of the off-diagonal vector for the quadratic forms (LDS-DMA, no registers), under the
           // generation of the segment's last pair of draws.
@@ -1591,7 +1674,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       u = fma(-lp, u, crow[j + 1]);
       W[j + 1] = fma(u, W[j + 1], z1 * fast_sqrt(W[j + 1]));
       lp = Y[j + 1];
-      if (!(SIG == 1 && (j >> 1) < NZB - 1)) __builtin_amdgcn_sched_barrier(0);  // parked draws: let the pairs pipeline
+      if (!(SMO && (j >> 1) < NZB - 1)) __builtin_amdgcn_sched_barrier(0);  // parked draws: let the pairs pipeline
     }
   }
 
@@ -1601,7 +1684,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // the tridiagonal term's diagonal (LDS-DMA, contiguous image), which the back pass below reads in the row
   // mapping for the x' diag x part of the quadratic form -- one vector less to wait for afterwards
   double aPd = 0.0;
-  if constexpr (SIG == 1) {
+  if constexpr (SMO) {
     if (park_diag) {
       lds_reads_done();
 #pragma unroll
@@ -1615,7 +1698,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // pass (a tenth of the wave's lifetime, light on registers) cover its latency, the quadratic-form phase then reads
   // nothing from memory and its x stores start a load round trip earlier (OMC_PREFETCH_QUAD; measured on
   // benchmarks/ab_headline.py).
-  constexpr bool PFQ = SIG == 1 && OMC_PREFETCH_QUAD;
+  constexpr bool PFQ = SMO && OMC_PREFETCH_QUAD;
+  constexpr int PFQ_LOADS = M + (OMC_PREFETCH_QUAD > 1 ? M - 2 * NZB : 0);  // loads the prefetch puts behind the LDS-DMA
+  static_assert(!PFQ || PFQ_LOADS <= 15, "vmcnt immediate");
   double qcp[PFQ ? M : 1], qop[PFQ ? M : 1];
   bool pfq = false;
   if constexpr (PFQ) {
@@ -1645,8 +1730,11 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
                    : excl_scan<Aff, false>(f, Aff{0.0, 1.0}, pos, Wd, true, lds_aff[0], wave, nw)).p;
     double x = xnext;
     OMC_STAMP(11);
-    if (SIG == 1 && park_diag) {
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA has landed (the scan's barrier drained it already)
+    if (SMO && park_diag) {
+      // the LDS-DMA has landed: vector-memory operations retire in order, so it is enough that no more than the prefetch
+      // loads issued BEHIND it are still out (they are not needed before the quadratic forms)
+      if (PFQ && pfq) __builtin_amdgcn_s_waitcnt(0x0F70 | PFQ_LOADS);
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
       wave_lds_fence();
       const double* drow = tile + lane * M;  // contiguous image: no row padding
 #pragma unroll
@@ -1681,19 +1769,19 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     if (epi_wave) {  // lane group k = lane >> 4 serves term k
       _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt && (lane >> 4) == k) {
         if (A.T.scale[k]) my_scale = handed ? sc[k] : A.T.scale[k][cc];
-        if constexpr (SIG == 1) {
+        if constexpr (SMO) {
           if (sweep_log_post(A, sw) && A.gb[k].logdet_unscaled) my_logdet = A.gb[k].logdet_unscaled[0];
         }
       }
-      if constexpr (SIG != 1) {  // (the blocks' device image: see TriArgs::gb_dev)
+      if constexpr (!SMO) {  // (the blocks' device image: see TriArgs::gb_dev)
         const double* const ldp = ((lane >> 4) < nt) ? A.gb_dev[lane >> 4].logdet_unscaled : nullptr;
         if (sweep_log_post(A, sw) && ldp) my_logdet = ldp[0];
       }
     }
-    if constexpr (SIG == 1) {
+    if constexpr (SMO) {
       // Normal-Gamma standard draws (functions of the priors only): here, in front of the load-bound phase of
       // the quadratic forms, wave 0's delay costs nothing -- the other waves' loads keep the L2 path busy
-      if (epi_wave && chain_ok) {
+      if (!EARLY && epi_wave && chain_ok) {  // (SIG 2: made at the start, while the scales were waited for)
         bool f = false;
         const double g = sweep_gamma_draws_wave(A, c, lane, &f, sw);
         lds_g[lane] = f ? -g : g;
@@ -1850,14 +1938,14 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       // restart without a barrier: the log-posterior of this sweep is left to wave 1 of the next one (it has the slack
       // this wave does not: everyone waits for the wave that ran the epilogue at the next sweep's first barrier)
       const bool defer_lp = SIG == 1 && A.reenter == 2 && left > 0 && nw > 1 && any_handed_f();
-      sweep_epilogue_wave<SIG != 1>(A, c, qsum[0], qsum[1], qsum[2], qsum[3], my_scale, my_logdet, fabs(g), g < 0.0, lane, sw,
+      sweep_epilogue_wave<!SMO>(A, c, qsum[0], qsum[1], qsum[2], qsum[3], my_scale, my_logdet, fabs(g), g < 0.0, lane, sw,
                           (SIG == 1 && A.reenter) ? lds_hand : nullptr, defer_lp, lds_q);
     }
     // x leaves last: a load issued behind a store would have to wait for the store to be
     // acknowledged (vmcnt retires in order); this way nothing ever waits on the x stream.
     // (SIG 1 has stored it from its quadratic-form pass already.)
-    double* const xb = (SIG != 1) ? x_out() : nullptr;
-    if (SIG != 1 && xb && chain_ok) {
+    double* const xb = (!SMO) ? x_out() : nullptr;
+    if (!SMO && xb && chain_ok) {
       double* xo = xb + cc * A.ld_x + wave_u * 64 * M;
       const int nvalid = wave_valid<M>(wave_u, (int)n);
       {
@@ -2166,7 +2254,10 @@ static bool launch_seg(omc_ctx* ctx, const TriArgs& A_in) {
     // workgroup-per-chain form: one workgroup per (sweep, chain), or per chain when the workgroups restart themselves
     const int64_t wg_per_chain = A.n_sweeps <= 0 ? 1 : (!A.reenter ? A.n_sweeps : (A.block_sweeps > 0 ? (A.n_sweeps + A.block_sweeps - 1) / A.block_sweeps : 1));
     const unsigned wg_grid = (unsigned)(A.C * wg_per_chain);
-    if (special)
+    if (special && SegCfg<M>::SMOOTHER && A.early_draws && !A.reenter && !A.z && !A.zero_z)  // the waiting form (see the kernel)
+      hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT, 2 * SegCfg<M>::SMOOTHER>), dim3(wg_grid), dim3(threads), 0,
+                         ctx->stream, A, threads);
+    else if (special)
       hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT, SegCfg<M>::SMOOTHER>), dim3(wg_grid), dim3(threads), 0,
                          ctx->stream, A, threads);
     else

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(64) k_tridiag_gibbs_truncated(int64_t C, int64
 #pragma unroll
         for (int r = 0; r < 10; ++r)
 #pragma unroll
-          for (int b = 0; b < TG_U / 2; ++b) omc_philox_round(w0[b], w1[b], w2[b], w3[b], k0[b], k1[b]);
+          for (int b = 0; b < TG_U / 2; ++b) omc_philox_round_r(r, w0[b], w1[b], w2[b], w3[b], k0[b], k1[b]);
 #pragma unroll
         for (int b = 0; b < TG_U / 2; ++b) { u4[2 * b] = omc_u53(w0[b], w1[b]); u4[2 * b + 1] = omc_u53(w2[b], w3[b]); }
       }
