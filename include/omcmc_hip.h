@@ -61,6 +61,14 @@ typedef struct {
   const double* rhs[OMC_MAX_TERMS];     /* [n]   shared M_k m_k;  NULL = zeros               */
   const double* center[OMC_MAX_TERMS];  /* [n]   shared m_k;      NULL = zeros               */
   const double* scale[OMC_MAX_TERMS];   /* [C]   per-chain scalar; NULL = 1                  */
+  /* Per-chain part of a term's centre (ABI 2): a hierarchical model's prior mean that is itself sampled, or a
+   * sampled response whose mean is the parameter (sampler.py:181-192 with state[...] differing per chain).  Term k
+   * is then centred at center[k] + center_chain[k][c]:  rhs_c += scale[k][c] * M_k center_chain[k][c]  (formed
+   * inside the launch: no product vector travels through memory) and quad[k][c] is taken around that centre.
+   * NULL = none.  Taken by the workgroup-per-chain form of the draw (omc_tridiag_takes_center_chain) and by
+   * omc_tridiag_quadform; every other entry point returns OMC_UNSUPPORTED when one is set.               */
+  const double* center_chain[OMC_MAX_TERMS];  /* [C][ld_center_chain]                        */
+  int64_t ld_center_chain;
 } omc_tridiag_terms;
 
 /* ---- context ---------------------------------------------------------------------------- */
@@ -167,6 +175,10 @@ typedef struct {
   double* store;                  /* [C] optional copy of the new scale (store[param]), or NULL */
   const double* logdet_unscaled;  /* device scalar log det M_k; NULL allowed iff no log_post    */
 } omc_gamma_block;
+
+/* 1 if omc_tridiag_sample_canonical / omc_gmrf_sweep accept terms->center_chain for chains of n nodes under the
+ * context's current options (the workgroup-per-chain form of the kernel), else 0.                            */
+int32_t omc_tridiag_takes_center_chain(omc_ctx* ctx, int64_t n);
 
 omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
                           const omc_gamma_block* blocks /* [n_terms], host */,

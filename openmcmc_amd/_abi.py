@@ -32,6 +32,8 @@ class TridiagTerms(C.Structure):
         ("rhs", c_dp * OMC_MAX_TERMS),
         ("center", c_dp * OMC_MAX_TERMS),
         ("scale", c_dp * OMC_MAX_TERMS),
+        ("center_chain", c_dp * OMC_MAX_TERMS),
+        ("ld_center_chain", i64),
     ]
 
 
@@ -126,6 +128,7 @@ SIGNATURES = {
          i64, i64, c_dp, c_dp],
     ),
     "omc_tridiag_quadform": (i32, [C.c_void_p, i64, C.POINTER(TridiagTerms), c_dp, i64, c_dp]),
+    "omc_tridiag_takes_center_chain": (i32, [C.c_void_p, i64]),
     "omc_tridiag_matvec": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp]),
     "omc_tridiag_logdet": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp]),
     "omc_normal_gamma_update": (i32, [C.c_void_p, C.c_double, C.c_double, i64, c_dp, c_dp, u64, c_dp]),
@@ -220,6 +223,8 @@ def _load():
             C.CDLL(path, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("OMC_HIP_LIB") and not hasattr(lib, name):
+            continue  # an A/B build of an older revision (benchmarks/build_rev.sh): entry points added since are simply absent
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

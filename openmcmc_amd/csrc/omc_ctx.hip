@@ -17,7 +17,7 @@ extern "C" {
 
 const char* omc_last_error(void) { return g_last_error.c_str(); }
 
-int32_t omc_abi_version(void) { return 1; }
+int32_t omc_abi_version(void) { return 2; }
 
 omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64_t chain_id_offset,
                           void* stream, int32_t create_stream, omc_ctx** out) {

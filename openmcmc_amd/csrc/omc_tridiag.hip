@@ -45,6 +45,13 @@ struct TermsDev {
   const double* center[OMC_MAX_TERMS];
   const double* scale[OMC_MAX_TERMS];
 };
+// per-chain part of the terms' centres [C][ld] (omc_tridiag_terms::center_chain).  Its own struct, at the END of the kernel
+// arguments: the structure-specialised instantiation never reads it, and with the fields inside TermsDev the shifted
+// argument offsets alone cost that instantiation 1 us per sweep (same-box A/B).
+struct CentreChain {
+  const double* v[OMC_MAX_TERMS];
+  int64_t ld;
+};
 
 struct GammaDev {
   int enabled;
@@ -113,6 +120,7 @@ struct TriArgs {
   unsigned long long* sweep_times;
   int64_t sweep_times_cap, sweep_times_pos;
   SweepRec rec[OMC_RUN_MAX];
+  CentreChain cc;
 };
 
 __device__ __forceinline__ bool run_mode(const TriArgs& A) { return A.n_sweeps > 0; }
@@ -798,11 +806,56 @@ __device__ __forceinline__ int wave_valid(int wave_u, int lim) {
   return v < 0 ? 0 : (v > 64 * M ? 64 * M : v);
 }
 
+// Right-hand-side part of the terms with a per-chain centre (omc_tridiag_terms::center_chain): v_i += s_k (M_k c_k)_i with
+// c_k the chain's vector, in the coalesced mapping -- three predicated loads of c per node (the shifted ones come out of
+// the cache lines the first one brought), nothing staged.  Wave-uniform skip when no term has one.
+template <int M, int CH>
+__device__ __forceinline__ void rhs_center_chain(double (&v)[CH], const TriArgs& A, const double (&sc)[OMC_MAX_TERMS], bool chain_ok,
+                                                 int64_t cc, int wbase, int lane, int t0, int cnt, int nvalid) {
+  const int n = (int)A.n;
+#pragma unroll
+  for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+    if (k >= A.T.n_terms || !A.cc.v[k] || !chain_ok) continue;
+    const double* c = A.cc.v[k] + cc * A.cc.ld + wbase;
+    const double *dk = A.T.diag[k], *ok = A.T.off[k];
+    // all loads of the batch first, at clamped positions (no load sits behind a test of another one's result), then the
+    // arithmetic with the out-of-range neighbours masked
+    // (sub-batches of SB elements: six loads each in flight; the whole batch at once spills)
+    constexpr int SB = CH;
+#pragma unroll
+    for (int tb = 0; tb < CH; tb += SB) {
+      double c0[SB], cm[SB], cp[SB], dv[SB], om[SB], op[SB];
+      bool in[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int t = tb + u;
+        const int idx = lane + (t0 + t) * 64, i = wbase + idx;
+        in[u] = t < CH && t < cnt && idx < nvalid;
+        const bool has_m = in[u] && ok && i > 0, has_p = in[u] && ok && i + 1 < n;
+        const int j0 = in[u] ? idx : 0;  // (element 0 of the wave's slice exists whenever the wave has any node)
+        c0[u] = c[j0];
+        dv[u] = dk ? (dk + wbase)[j0] : 1.0;
+        cm[u] = c[has_m ? j0 - 1 : j0];
+        cp[u] = c[has_p ? j0 + 1 : j0];
+        om[u] = has_m ? (ok + wbase)[j0 - 1] : 0.0;
+        op[u] = has_p ? (ok + wbase)[j0] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int t = tb + u;
+        if (t >= CH) continue;
+        const double r = fma(op[u], cp[u], fma(om[u], cm[u], dv[u] * c0[u]));
+        v[t] = in[u] ? fma(sc[k], r, v[t]) : v[t];
+      }
+    }
+  }
+}
+
 // Per-chain combination of the shared term vectors, formed while the tile is filled.  All loads of a
 // batch are issued back to back (L2 latency is paid once per batch) and only then combined.  A batch
 // that lies wholly inside the vector takes the test-free path; the chain's last wave takes the
 // predicated one for its boundary batch and only writes fill values beyond it.
-template <int M, int WHICH>
+template <int M, int WHICH, bool CCH = false>
 __device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wave, int lbase, const TriArgs& A,
                                                   const double (&sc)[OMC_MAX_TERMS], bool chain_ok, int64_t cc) {
   using TM = TileMap<M>;
@@ -854,6 +907,7 @@ __device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wa
           for (int t = 0; t < CH; ++t)
             if (t < cnt) v[t] += ld[t];
         }
+        if (WHICH == COMB_RHS && CCH) rhs_center_chain<M, CH>(v, A, sc, chain_ok, cc, wbase, lane, t0, cnt, nvalid);
 #pragma unroll
         for (int t = 0; t < CH; ++t)
           if (t < cnt) *TM::elem(tl, r0, t0 + t) = v[t];
@@ -881,6 +935,12 @@ __device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wa
           const int idx = lane + (t0 + t) * TM::LU;
           if (t >= cnt) continue;
           if (WHICH == COMB_RHS && rc && idx < nvalid) v[t] += rc[(unsigned)idx];
+        }
+        if (WHICH == COMB_RHS && CCH) rhs_center_chain<M, CH>(v, A, sc, chain_ok, cc, wbase, lane, t0, cnt, nvalid);
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+          const int idx = lane + (t0 + t) * TM::LU;
+          if (t >= cnt) continue;
           if (idx < 64 * M) *TM::elem(tl, r0, t0 + t) = (idx < nvalid) ? v[t] : fillv;
         }
       }
@@ -943,7 +1003,7 @@ __device__ __forceinline__ double fast_sqrt(double r) {
 // first x of the next wave), the shared vectors straight from L2.
 template <int M>
 __device__ __forceinline__ void quad_wg(const double* tile, int lane, int wave_u, int lbase, const TriArgs& A,
-                                        double (&acc)[OMC_MAX_TERMS]) {
+                                        double (&acc)[OMC_MAX_TERMS], int64_t cc) {
   using TM = TileMap<M>;
   constexpr int CH = TM::CH;
   const int nt = A.T.n_terms, n32 = (int)A.n;
@@ -968,6 +1028,7 @@ __device__ __forceinline__ void quad_wg(const double* tile, int lane, int wave_u
         for (int k = 0; k < OMC_MAX_TERMS; ++k) {
           if (k >= nt) continue;
           const double *ck = A.T.center[k], *dk = A.T.diag[k], *ok = A.T.off[k];
+          const double* cck = A.cc.v[k] ? A.cc.v[k] + cc * A.cc.ld : nullptr;
           double ri[CH], rn[CH], dv[CH], ov[CH];
 #pragma unroll
           for (int t = 0; t < CH; ++t) {
@@ -975,6 +1036,10 @@ __device__ __forceinline__ void quad_wg(const double* tile, int lane, int wave_u
             const unsigned off = (unsigned)(lane + (t0 + t) * TM::LU);
             ri[t] = ck ? (ck + wbase)[off] : 0.0;
             rn[t] = (ck && ok) ? (ck + wbase)[off + 1u] : 0.0;
+            if (cck) {  // per-chain part of the centre
+              ri[t] += (cck + wbase)[off];
+              if (ok) rn[t] += (cck + wbase)[off + 1u];
+            }
             dv[t] = dk ? (dk + wbase)[off] : 1.0;
             ov[t] = ok ? (ok + wbase)[off] : 0.0;
           }
@@ -1005,8 +1070,10 @@ __device__ __forceinline__ void quad_wg(const double* tile, int lane, int wave_u
           for (int k = 0; k < OMC_MAX_TERMS; ++k) {
             if (k >= nt) continue;
             const double *ck = A.T.center[k], *dk = A.T.diag[k], *ok = A.T.off[k];
-            const double a = x0 - ((ck && in) ? (ck + wbase)[(unsigned)idx] : 0.0);
-            const double bnx = x1 - ((ck && ok && in1) ? (ck + wbase)[(unsigned)idx + 1u] : 0.0);
+            const double* cck = A.cc.v[k] ? A.cc.v[k] + cc * A.cc.ld : nullptr;
+            const double a = x0 - ((ck && in) ? (ck + wbase)[(unsigned)idx] : 0.0) - ((cck && in) ? (cck + wbase)[(unsigned)idx] : 0.0);
+            const double bnx = x1 - ((ck && ok && in1) ? (ck + wbase)[(unsigned)idx + 1u] : 0.0)
+                                  - ((cck && ok && in1) ? (cck + wbase)[(unsigned)idx + 1u] : 0.0);
             const double d = in ? (dk ? (dk + wbase)[(unsigned)idx] : 1.0) : 0.0;
             const double o = (ok && in1) ? (ok + wbase)[(unsigned)idx] : 0.0;
             acc[k] = fma(fma(2.0 * o, bnx, d * a), a, acc[k]);
@@ -1618,7 +1685,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   }
   if (rhs_done) {
   } else if (MULTI) {
-    tile_fill_comb_wg<M, COMB_RHS>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
+    tile_fill_comb_wg<M, COMB_RHS, !SMO>(tile, lane, wave, lbase, A, sc, chain_ok, cc);  // (per-chain centres: SIG 0 only)
   } else {
     tile_fill_comb<M, MULTI, COMB_RHS>(tile, geo, A, sc);
   }
@@ -1873,7 +1940,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       acc[0] = p_first ? aP : aI;
       acc[1] = p_first ? aI : aP;
     } else {
-      if (want_quad) quad_wg<M>(tile, lane, wave_u, lbase, A, acc);
+      if (want_quad) quad_wg<M>(tile, lane, wave_u, lbase, A, acc, cc);
     }
     OMC_STAMP(13);
     if (want_quad) {
@@ -2108,7 +2175,7 @@ __global__ void __launch_bounds__(256) k_chain_lincomb(int64_t n, double a, cons
 }
 
 // one workgroup per chain: quad[k][c] = (x-m_k)' M_k (x-m_k)
-__global__ void __launch_bounds__(256) k_tridiag_quadform(TermsDev T, int64_t n, int64_t C, const double* x,
+__global__ void __launch_bounds__(256) k_tridiag_quadform(TermsDev T, CentreChain CC, int64_t n, int64_t C, const double* x,
                                                          int64_t ld_x, double* quad) {
   __shared__ double red[4];
   const int64_t c = blockIdx.x;
@@ -2116,10 +2183,11 @@ __global__ void __launch_bounds__(256) k_tridiag_quadform(TermsDev T, int64_t n,
   for (int k = 0; k < T.n_terms; ++k) {
     double acc = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-      const double r = xc[i] - (T.center[k] ? T.center[k][i] : 0.0);
+      const double* cck = CC.v[k] ? CC.v[k] + c * CC.ld : nullptr;
+      const double r = xc[i] - (T.center[k] ? T.center[k][i] : 0.0) - (cck ? cck[i] : 0.0);
       acc = fma((T.diag[k] ? T.diag[k][i] : 1.0) * r, r, acc);
       if (T.off[k] && i < n - 1) {
-        const double rn = xc[i + 1] - (T.center[k] ? T.center[k][i + 1] : 0.0);
+        const double rn = xc[i + 1] - (T.center[k] ? T.center[k][i + 1] : 0.0) - (cck ? cck[i + 1] : 0.0);
         acc = fma(2.0 * T.off[k][i] * r, rn, acc);
       }
     }
@@ -2150,7 +2218,7 @@ __global__ void __launch_bounds__(64) k_tridiag_logdet_serial(int64_t n, const d
 
 // ------------------------------------------------------------------------------------------
 // host side
-static bool terms_to_dev(const omc_tridiag_terms* t, TermsDev* d) {
+static bool terms_to_dev(const omc_tridiag_terms* t, TermsDev* d, CentreChain* cc = nullptr) {
   if (!t || t->n_terms < 1 || t->n_terms > OMC_MAX_TERMS) return false;
   d->n_terms = t->n_terms;
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
@@ -2160,11 +2228,20 @@ static bool terms_to_dev(const omc_tridiag_terms* t, TermsDev* d) {
     d->rhs[k] = on ? t->rhs[k] : nullptr;
     d->center[k] = on ? t->center[k] : nullptr;
     d->scale[k] = on ? t->scale[k] : nullptr;
+    if (cc) cc->v[k] = on ? t->center_chain[k] : nullptr;
   }
+  if (cc) cc->ld = t->ld_center_chain;
   return true;
+}
+static bool has_center_chain(const CentreChain& cc) {
+  for (int k = 0; k < OMC_MAX_TERMS; ++k)
+    if (cc.v[k]) return true;
+  return false;
 }
 
 static void args_defaults(omc_ctx* ctx, TriArgs* A, int64_t n) {
+  A->T = TermsDev{};  // every pointer null, no terms: a caller that fills the terms by hand cannot leave a field behind
+  A->cc = CentreChain{};
   A->n = n; A->C = ctx->n_chains; A->chain_offset = ctx->chain_offset;
   A->rhs_chain = nullptr; A->ld_rhs = 0;
   A->z = nullptr; A->ld_z = 0; A->zero_z = 0;
@@ -2236,7 +2313,8 @@ static bool launch_seg(omc_ctx* ctx, const TriArgs& A_in) {
     const int threads = 64 * ((S + 63) / 64);
     // the specialised instantiation owns the CU (its LDS image is sized for a full workgroup); a short chain
     // leaves room for a second workgroup of the generic one, which then wins (n = 2000: 38 against 53 us)
-    const bool special = SegCfg<M>::SMOOTHER && !ctx->tridiag_generic && is_smoother(A.T) && A.n >= 2 && 2 * threads > SegCfg<M>::MAXT;
+    const bool special = SegCfg<M>::SMOOTHER && !ctx->tridiag_generic && is_smoother(A.T) && !has_center_chain(A.cc) && A.n >= 2 &&
+                         2 * threads > SegCfg<M>::MAXT;
     // self-restarting workgroups: the specialised instantiation only (it keeps no private memory, so the three entry
     // registers are all a restart has to reproduce)
     if (!special) A.reenter = 0;
@@ -2401,7 +2479,8 @@ omc_status omc_tridiag_sample_canonical(omc_ctx* ctx, int64_t n, const omc_tridi
   if ((rhs_chain && ld_rhs < n) || (z_inject && ld_z < n) || (mean_out && ld_mean < n)) return OMC_INVALID_ARG;
   TriArgs A;
   args_defaults(ctx, &A, n);
-  if (!terms_to_dev(terms, &A.T)) return OMC_INVALID_ARG;
+  if (!terms_to_dev(terms, &A.T, &A.cc)) return OMC_INVALID_ARG;
+  if (has_center_chain(A.cc) && (!takes_wg_per_chain(ctx, n) || A.cc.ld < n)) return OMC_UNSUPPORTED;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   if (long_chain_route(ctx, n)) {
     omc_status st = long_chain_draw(ctx, n, terms, rhs_chain, ld_rhs, z_inject, ld_z, draw_index, x_out, ld_x, mean_out, ld_mean,
@@ -2429,7 +2508,8 @@ omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* term
   if ((rhs_chain && ld_rhs < n) || (z_inject && ld_z < n)) return OMC_INVALID_ARG;
   TriArgs A;
   args_defaults(ctx, &A, n);
-  if (!terms_to_dev(terms, &A.T)) return OMC_INVALID_ARG;
+  if (!terms_to_dev(terms, &A.T, &A.cc)) return OMC_INVALID_ARG;
+  if (has_center_chain(A.cc) && (!takes_wg_per_chain(ctx, n) || A.cc.ld < n)) return OMC_UNSUPPORTED;
   for (int k = 0; k < A.T.n_terms; ++k) {
     const omc_gamma_block& b = blocks[k];
     GammaDev& g = A.gb[k];
@@ -2515,7 +2595,8 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
     // and boundary of a launch (7.4 us against 21 us per round of workgroups) are paid once per OMC_RUN_MAX sweeps.
     TriArgs A;
     args_defaults(ctx, &A, n);
-    if (!terms_to_dev(terms, &A.T)) return OMC_INVALID_ARG;
+    if (!terms_to_dev(terms, &A.T, &A.cc)) return OMC_INVALID_ARG;
+  if (has_center_chain(A.cc) && (!takes_wg_per_chain(ctx, n) || A.cc.ld < n)) return OMC_UNSUPPORTED;
     for (int k = 0; k < A.T.n_terms; ++k) {
       const omc_gamma_block& bk = blocks[k];
       GammaDev& g = A.gb[k];
@@ -2556,10 +2637,10 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
     const int64_t rounds = (C + dev_cus - 1) / dev_cus;
     const bool whole_rounds = C >= dev_cus && (double)C >= 0.95 * (double)(rounds * dev_cus);
     A.reenter = (whole_rounds || ctx->run_reenter_force) ? ctx->run_reenter : 0;
-    if (!takes_specialised(ctx, A.T, n)) A.reenter = 0;  // the generic instantiation: one workgroup per (sweep, chain)
+    if (!takes_specialised(ctx, A.T, n) || has_center_chain(A.cc)) A.reenter = 0;  // the generic instantiation: one workgroup per (sweep, chain)
     if (A.reenter && per > 1 && !reentry_abi_ok(ctx)) A.reenter = 0;  // (see k_reentry_probe)
     if (A.reenter && C * (int64_t)per >= ((int64_t)1 << 26)) A.reenter = 0;  // (a restart's register carries sweep * C + chain in 26 bits)
-    A.early_draws = (A.reenter == 0 && 2 * C <= dev_cus) ? 1 : 0;  // a waiting workgroup per chain has a CU to itself
+    A.early_draws = (A.reenter == 0 && 2 * C <= dev_cus && !has_center_chain(A.cc)) ? 1 : 0;  // a waiting workgroup per chain has a CU to itself
     // (sweep, chain) grid: two sweeps of one launch must not write the same store slot -- their workgroups are not ordered
     // against each other (the self-restarting form walks a chain's sweeps in order and may lap the ring)
     const int64_t stored_per_launch_max = (A.reenter == 0 && n_slots < per) ? n_slots : per;
@@ -2641,13 +2722,17 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
   return OMC_OK;
 }
 
+int32_t omc_tridiag_takes_center_chain(omc_ctx* ctx, int64_t n) { return (ctx && n >= 1 && takes_wg_per_chain(ctx, n)) ? 1 : 0; }
+
 omc_status omc_tridiag_quadform(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms, const double* x,
                                 int64_t ld_x, double* quad_out) {
   if (!ctx || n < 1 || !x || ld_x < n || !quad_out) return OMC_INVALID_ARG;
   TermsDev T;
-  if (!terms_to_dev(terms, &T)) return OMC_INVALID_ARG;
+  CentreChain CC;
+  if (!terms_to_dev(terms, &T, &CC)) return OMC_INVALID_ARG;
+  if (has_center_chain(CC) && CC.ld < n) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_tridiag_quadform, dim3((unsigned)ctx->n_chains), dim3(256), 0, ctx->stream, T, n,
+  hipLaunchKernelGGL(k_tridiag_quadform, dim3((unsigned)ctx->n_chains), dim3(256), 0, ctx->stream, T, CC, n,
                      ctx->n_chains, x, ld_x, quad_out);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
@@ -2698,9 +2783,7 @@ omc_status omc_tridiag_logdet(omc_ctx* ctx, int64_t n, const double* diag, const
   }
   TriArgs A;
   args_defaults(ctx, &A, n);
-  for (int k = 0; k < OMC_MAX_TERMS; ++k)
-    A.T.diag[k] = A.T.off[k] = A.T.rhs[k] = A.T.center[k] = A.T.scale[k] = nullptr;
-  A.T.n_terms = 1;
+  A.T.n_terms = 1;  // (args_defaults has cleared every pointer of the terms)
   A.T.diag[0] = diag;
   A.T.off[0] = off;
   A.C = 1; A.chain_offset = 0;

@@ -340,6 +340,8 @@ omc_status omc_tridiag_gibbs_truncated(omc_ctx* ctx, int64_t n, const omc_tridia
   if (!ctx || n < 1 || !terms || terms->n_terms < 1 || terms->n_terms > OMC_MAX_TERMS || !x || ld_x < n ||
       (rhs_chain && ld_rhs < n) || (u_inject && ld_u < n))
     return OMC_INVALID_ARG;
+  for (int k = 0; k < terms->n_terms; ++k)
+    if (terms->center_chain[k]) return OMC_UNSUPPORTED;  // (per-chain centres: the exact draw only)
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   TruncTerms T;
   T.n_terms = terms->n_terms;

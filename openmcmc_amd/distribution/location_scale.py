@@ -199,10 +199,18 @@ class Normal(Distribution):
         dev = m - ybar
         return ybar, float(np.sum(dev * np.asarray(st.matrix @ dev)))
 
+    def residual_inputs(self, state):
+        """Device tensors of the per-chain state entries the residual response - mean reads."""
+        keys = [self.response] + [k for k in self.mean.get_param_list() if k != self.response]
+        return [state[k].data for k in keys if k in state and is_chain(state[k])]
+
     def residual_quad(self, state, engine, st=None, replicates=False):
         """(C,) tensor r' M r with r = response - mean, M the unscaled precision matrix: the sufficient
         statistic of NormalGamma.sample (sampler.py:276,284) and of log_p (gmrf.py:343-344)."""
         st = self.structure(state) if st is None else st
+        hit = engine.quad_cache_get(self, self.residual_inputs(state))
+        if hit is not None:  # the draw that produced this state computed it (NormalNormal.sample)
+            return hit
         resp = state[self.response]
         dense_design = (isinstance(self.mean, LinearCombination) and not is_chain(resp)
                         and any(is_chain(state[k]) and not _is_identity(state[a], state[k].shape[0])
@@ -275,10 +283,18 @@ class Normal(Distribution):
             # both sides per chain (a sampled mean under a sampled response): r_c = x_c - m_c on the device, then r'Mr
             if m.shape[1] != 1:
                 raise NotImplementedError("replicated per-chain side of a Normal")
-            r = engine.chain_lincomb(1.0, x.vector(), -1.0, m.vector())
             cache = engine.model_cache(self, state, st, np.zeros((st.n, 1)))
             quad = engine.empty(1, engine.n_chains)
-            engine.tridiag_quadform(st.n, cache["terms_unit"], r, quad)
+            mv = m.vector()
+            if mv.stride(1) == 1:  # one launch: the quadratic form around the chain's own centre
+                engine.set_center_chain(cache["terms_unit"], [mv], st.n)
+                try:
+                    engine.tridiag_quadform(st.n, cache["terms_unit"], x.vector(), quad)
+                finally:
+                    engine.set_center_chain(cache["terms_unit"], [None], st.n)
+            else:
+                r = engine.chain_lincomb(1.0, x.vector(), -1.0, mv)
+                engine.tridiag_quadform(st.n, cache["terms_unit"], r, quad)
             return quad[0]
         n_rep = m.shape[1]
         if n_rep != 1 and not replicates:

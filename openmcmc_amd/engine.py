@@ -110,6 +110,24 @@ class Engine:
         """Has the library written into t's storage after write number `serial` (a value note_write returned)?"""
         return self._written.get(t.untyped_storage().data_ptr(), 0) > serial
 
+    # ------------------------------------------------------------------ quadratic forms a draw left behind
+    def quad_cache_put(self, dist, quad, inputs):
+        """The fused quadratic form of a draw IS the residual statistic r'Mr of `dist` for the state the draw leaves
+        (sampler.py:276,284; gmrf.py:343-344).  Kept with what it was computed from -- the device tensors of the state
+        entries the residual reads -- and handed out by `quad_cache_get` while none of them has been replaced or written."""
+        if not hasattr(self, "_quad_cache"):
+            self._quad_cache = {}
+        self._quad_cache[id(dist)] = (dist, quad, [(t, t.data_ptr(), t._version) for t in inputs], self._write_serial)
+
+    def quad_cache_get(self, dist, inputs):
+        hit = getattr(self, "_quad_cache", {}).get(id(dist))
+        if hit is None or hit[0] is not dist or len(hit[2]) != len(inputs):
+            return None
+        for (t0, ptr, ver), t in zip(hit[2], inputs):
+            if t.data_ptr() != ptr or t.shape != t0.shape or t._version != ver or self.written_since(t, hit[3]):
+                return None
+        return hit[1]
+
     # ------------------------------------------------------------------ context
     def close(self):
         if self._ctx is not None:
@@ -187,7 +205,29 @@ class Engine:
             T.scale[k] = self._chain_scalar(t.get("scale"))
             keep.append(dict(t))
         T._keep = keep
+        self.set_center_chain(T, [t.get("center_chain") for t in terms], n)
         return T
+
+    def set_center_chain(self, T, vectors, n):
+        """Per-chain part of the terms' centres (omc_tridiag_terms.center_chain): one (C, n) tensor or None per term, all with the
+        same row stride.  Patched into an existing struct: a sampled prior mean is a new tensor every sweep."""
+        ld = 0
+        held = []
+        for k in range(T.n_terms):
+            v = vectors[k] if k < len(vectors) else None
+            if v is None:
+                T.center_chain[k] = None
+                continue
+            if v.dim() != 2 or v.shape[0] != self.n_chains or v.shape[1] != n or v.stride(1) != 1 or (ld and v.stride(0) != ld):
+                raise ValueError("center_chain: (C, n) tensors of one row stride")
+            ld = v.stride(0)
+            T.center_chain[k] = v.data_ptr()
+            held.append(v)
+        T.ld_center_chain = ld
+        T._keep_cc = held
+
+    def tridiag_takes_center_chain(self, n):
+        return bool(lib.omc_tridiag_takes_center_chain(self._ctx, int(n)))
 
     def tridiag_sample_canonical(self, n, terms, x_out, z=None, rhs_chain=None, draw_index=0,
                                  mean_out=None, quad_out=None, logdet_out=None):

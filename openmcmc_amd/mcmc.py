@@ -137,6 +137,19 @@ class MCMC:
         for s in self.samplers:
             s._sweep += 1
 
+    def _direct_slab(self, sampler, i_it):
+        """The store slab of this iteration if `sampler` can draw straight into it (a fixed-size NormalNormal block whose
+        store is the plain (n_iter, C, n) tensor): the store step then has nothing to copy."""
+        if type(sampler) is not NormalNormal or sampler.max_variable_size is not None:
+            return None
+        if getattr(sampler.sample, "__func__", None) is not NormalNormal.sample:
+            return None  # a replaced sample method (tests count the calls): it gets the reference's signature
+        cur = self.state.get(sampler.param)
+        st = self.store.get(sampler.param)
+        if not is_chain(cur) or cur.ragged is not None or cur.shape[1] != 1 or st is None or st.dim() != 3 or st.shape[2] != cur.shape[0]:
+            return None
+        return st[i_it]
+
     def _scratch(self, n):
         if getattr(self, "_scratch_x", None) is None or self._scratch_x.shape[1] != n:
             self._scratch_x = self.engine.empty(self.n_chains, n)
@@ -212,7 +225,8 @@ class MCMC:
                     self._fused_sweep(i_it if (storing and last) else None)
                 else:
                     for k, sampler in enumerate(self.samplers):
-                        self.state = sampler.sample(self.state)
+                        slab = self._direct_slab(sampler, i_it) if (storing and last) else None
+                        self.state = sampler.sample(self.state) if slab is None else sampler.sample(self.state, out=slab)
                         if storing and last:
                             # a stored predictor whose inputs no later sampler of the sweep touches: evaluated here, into
                             # its store slab, and reused by the samplers that follow (a NormalGamma's residual), by the store

@@ -92,6 +92,8 @@ class MCMCSampler(ABC):
             return store
         flat = value.data.reshape(self.engine.n_chains, -1)
         slab = store[self.param][iteration]
+        if flat.data_ptr() == slab.data_ptr() and flat.shape == slab.shape and flat.stride() == slab.stride():
+            return store  # the draw was written into its slab directly (MCMC.run_mcmc hands the slab to NormalNormal.sample)
         if value.ragged is None:
             # big states through the library's copy kernel (the runtime's device-to-device memcpy moves 82 MB at 0.26 TB/s);
             # small ones stay with the tensor copy, whose host-side cost is a third of a ctypes call (cfg5's loop is bound
@@ -265,10 +267,19 @@ class NormalNormal(MCMCSampler):
             terms.append({"diag": cache["diag"], "off": cache["off"], "rhs": cache["rhs"], "center": cache["center"],
                           "scale": None if scale is None else scale.scalar()})
             keys.append(pc["key"])
+        # A term centred at a per-chain vector (sampled prior mean, sampled response): where the kernel takes it
+        # (omc_tridiag_terms.center_chain: the workgroup-per-chain form) the launch forms s_c M v_c itself and its fused
+        # quadratic form is the term's residual statistic; elsewhere the product vector is made by a launch of its own
+        # and fed in as a per-chain right-hand side.
+        in_launch = eng.tridiag_takes_center_chain(n)
         chain_rhs = [(pc["chain_vec"], pc["st"].scale_key, eng.model_cache(pc["dist"], state, pc["st"], pc["center"]))
-                     for pc in pieces if pc.get("chain_vec") is not None]
+                     for pc in pieces if pc.get("chain_vec") is not None and not in_launch]
+        center_chain = [(k, pc["chain_vec"]) for k, pc in enumerate(pieces) if pc.get("chain_vec") is not None and in_launch]
+        # terms whose fused quadratic form equals the distribution's residual statistic for the state the draw leaves
+        quad_ok = [not pc["offset"] and not pc.get("replicated") and (pc.get("chain_vec") is None or in_launch) for pc in pieces]
         return {"kind": "tridiag", "n": n, "terms_list": terms, "terms": eng.tridiag_terms(terms, n), "keys": keys,
-                "offsets": offsets, "replicated": any(pc.get("replicated") for pc in pieces), "chain_rhs": chain_rhs}
+                "offsets": offsets, "replicated": any(pc.get("replicated") for pc in pieces), "chain_rhs": chain_rhs,
+                "center_chain": center_chain, "quad_ok": quad_ok}
 
     def _ragged_plan(self, state, n_max):
         """Small variable-size parameter with a mixture prior (diagonal precision picked by an allocation) and
@@ -424,7 +435,22 @@ class NormalNormal(MCMCSampler):
             gibbs = {"tridiag": eng.tridiag_gibbs_truncated, "band": eng.band_gibbs_truncated}.get(p["kind"], eng.dense_gibbs_truncated)
             gibbs(n, p["terms"], x, lower=lower, upper=upper, u=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
         elif p["kind"] == "tridiag":
-            eng.tridiag_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
+            vecs = [None] * len(p["keys"])
+            for k, (kind, what) in p.get("center_chain", ()):
+                vecs[k] = what.mean.predictor_device(current_state, eng) if kind == "mean" and not isinstance(what.mean, Identity) else \
+                    current_state[what.mean.form if kind == "mean" else what].vector()
+            if p.get("center_chain"):
+                eng.set_center_chain(p["terms"], vecs, n)
+            quad = eng.empty(len(p["keys"]), eng.n_chains) if any(p.get("quad_ok", ())) else None
+            eng.tridiag_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index(), quad_out=quad)
+            if quad is not None:
+                # the quadratic forms of the launch are the residual statistics of these distributions for the new state:
+                # NormalGamma and log_p take them from here instead of a pass of their own over the state
+                new_state = dict(current_state)
+                new_state[self.param] = ChainArray(x)
+                for k, key in enumerate(p["keys"]):
+                    if p["quad_ok"][k]:
+                        eng.quad_cache_put(self.model[key], quad[k], self.model[key].residual_inputs(new_state))
         elif p["kind"] == "band":
             eng.band_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
         elif p.get("mixture_prior") is not None:

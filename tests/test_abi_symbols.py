@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_error_text_callable_without_gpu():
     from openmcmc_amd import _abi
 
-    assert _abi.lib.omc_abi_version() == 1
+    assert _abi.lib.omc_abi_version() == 2
     assert isinstance(_abi.lib.omc_last_error(), bytes)
 
 

@@ -143,3 +143,69 @@ def test_two_sampled_blocks_in_one_mean_replay_reference(golden, tag):
     for c in range(C):
         for key in ["beta", "gamma", "tau", "lambda", "log_post", "y"] + (["m"] if hier else []):
             assert relerr(out[key][c], G[k + "store_" + key]) < 1e-9, (key, c)
+
+
+def _synthetic(n, rng, n_burn=2, n_iter=4):
+    d = np.full(n, 2.0)
+    d[0] = d[-1] = 1.0
+    d[0] += 1e-3
+    t = np.arange(n) * 60.0 / n
+    return {"s_n": n, "s_kappa": 0.5, "s_P_diag": d, "s_P_off": -np.ones(n - 1),
+            "s_y": np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + 0.3 * rng.standard_normal(n), "s_n_burn": n_burn, "s_n_iter": n_iter}
+
+
+def _run_injected(G, C, z, g, option=None):
+    M, (nn_b, nn_m, g_lam, g_tau) = build(G, "s_", C)
+    eng = M.engine
+    if option:
+        eng.set_option(*option)
+    nn_b.inject = lambda smp, t: eng.to_device(z[t, 0])
+    nn_m.inject = lambda smp, t: eng.to_device(z[t, 1])
+    g_lam.inject = lambda smp, t: eng.to_device(g[t, 0])
+    g_tau.inject = lambda smp, t: eng.to_device(g[t, 1])
+    M.run_mcmc()
+    return M, M.collect()
+
+
+@pytest.mark.parametrize("n", [700, 2500])
+def test_centres_inside_the_launch_equal_the_separate_launches(n):
+    """Above 64 segments per chain the Normal-Normal blocks of a hierarchical model hand the kernel the other block's
+    state as a per-chain centre (omc_tridiag_terms.center_chain), the fused quadratic forms of the draw feed NormalGamma
+    and log_p (Engine.quad_cache_*), and the draws go straight into their store slabs.  Same injected draws through the
+    route all of that replaces (one-lane kernel: product vector, residual and quadratic forms as launches of their own):
+    every stored quantity agrees to rounding; and against the oracle's dense restatement for one chain."""
+    rng = np.random.default_rng(n)
+    C, sweeps = 4, 6
+    G = _synthetic(n, rng)
+    z = rng.standard_normal((sweeps, 2, C, n))
+    g = rng.standard_gamma(n / 2.0, size=(sweeps, 2, C))
+    M_new, new = _run_injected(G, C, z, g)
+    assert M_new.engine.tridiag_takes_center_chain(n)
+    M_old, old = _run_injected(G, C, z, g, option=("tridiag_algo", 1))
+    assert not M_old.engine.tridiag_takes_center_chain(n)
+    for key in ("b", "m", "lambda", "tau", "log_post"):
+        assert relerr(new[key], old[key]) < 1e-9, key
+    # the last stored state is the state (the draw went into its slab; nothing was copied)
+    assert M_new.state["b"].data.data_ptr() == M_new.store["b"][-1].data_ptr()
+
+
+def test_hierarchical_smoother_at_size_is_not_slow():
+    """A coarse clock on the two-block sweep at the headline size (n = 10 000, 1024 chains; 0.43 ms per sweep when this was
+    written, 0.74 before the centres moved into the launch): a regression by several times -- the generic kernel once
+    fell from 110 to 500 us per sweep without any test noticing -- fails here."""
+    import time
+
+    import torch
+
+    rng = np.random.default_rng(1)
+    G = _synthetic(10000, rng, n_burn=20, n_iter=30)
+    M, _ = build(G, "s_", 1024, seed=3)
+    M.run_mcmc()  # plans, caches, first-use costs
+    M.engine.check_status()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    M.run_mcmc()
+    torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / 50
+    M.engine.check_status()
+    assert per < 1.5e-3, f"{1e3 * per:.2f} ms per sweep"

@@ -203,3 +203,30 @@ def test_store_ring_shorter_than_a_launch(C, reenter):
     assert n32 == (1 if reenter else 4)  # 3 + 3 + 3 + 2 sweeps per launch in the grid form
     for a, b in zip(ref, got):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("generic,limit_us", [(0, 200.0), (1, 300.0)])
+def test_headline_sweep_is_not_slow(generic, limit_us):
+    """Coarse clock on the headline sweep (10 000 nodes, 1024 chains, omc_gmrf_run): 80 us per sweep on the specialised
+    instantiation, 110 on the generic one when this was written.  The generic instantiation once fell to 500 us
+    (private copies of kernel arguments) and only a benchmark noticed; a regression of that size fails here."""
+    import os
+    import sys
+    import time
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import GmrfSweep
+
+    sweep = GmrfSweep(10000, 1024, seed=7, chain_offset=0, device=0, n_store=8)
+    if generic:
+        sweep.eng.set_option("tridiag_generic", 1)
+    sweep.run_fused(64)  # first-use costs, clocks
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sweep.run_fused(128)
+    torch.cuda.synchronize()
+    per_us = 1e6 * (time.perf_counter() - t0) / 128
+    sweep.eng.check_status()
+    assert per_us < limit_us, f"{per_us:.1f} us per sweep"

@@ -568,3 +568,59 @@ def test_c_entry_points_take_chains_beyond_one_workgroup():
         assert np.all(np.isfinite(a)), key
         err = np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
         assert err < (1e-8 if key.startswith("run_") else 1e-10), (key, err)
+
+
+@pytest.mark.parametrize("n", [650, 1000, 3333, 10000])
+@pytest.mark.parametrize("kind", ["prior_mean", "response", "both"])
+def test_per_chain_centres_inside_the_launch(torch, n, kind):
+    """omc_tridiag_terms.center_chain (ABI 2): a term centred at a vector that differs per chain -- the prior mean of a
+    hierarchical model that is itself sampled (sampler.py:181-183) or a sampled response whose mean is the parameter
+    (sampler.py:185-192).  The launch forms s_k M_k c_k itself and takes the quadratic forms around c_k; checked against
+    the oracle's dense statement per chain, and against the route it replaces (product vector by omc_tridiag_matvec_chain
+    fed in as rhs_chain, residual by omc_chain_lincomb + omc_tridiag_quadform)."""
+    C = 5
+    rng = np.random.default_rng(n)
+    eng = make_engine(C, seed=5)
+    assert eng.tridiag_takes_center_chain(n)
+    pd, po = rw1(n)
+    y = rng.standard_normal(n) + 1.0
+    lam, tau = 20 + 50 * rng.random(C), 0.5 + rng.random(C)
+    m = 0.3 * rng.standard_normal((C, n)) + 1.0   # per-chain prior mean
+    yc = y + 0.2 * rng.standard_normal((C, n))    # per-chain response
+    z = rng.standard_normal((C, n))
+    d_pd, d_po, d_y = eng.to_device(pd), eng.to_device(po), eng.to_device(y)
+    d_m, d_yc = eng.to_device(m), eng.to_device(yc)
+    t_prior = {"diag": d_pd, "off": d_po, "scale": eng.to_device(lam)}
+    t_lik = {"scale": eng.to_device(tau)}
+    if kind in ("prior_mean", "both"):
+        t_prior["center_chain"] = d_m
+    if kind in ("response", "both"):
+        t_lik["center_chain"] = d_yc
+    else:
+        t_lik.update(rhs=d_y, center=d_y)
+    x, quad = eng.empty(C, n), eng.empty(2, C)
+    eng.tridiag_sample_canonical(n, [t_prior, t_lik], x, z=eng.to_device(z), quad_out=quad)
+    eng.check_status()
+    xh, qh = x.cpu().numpy(), quad.cpu().numpy()
+    for c in range(C):
+        mu = m[c] if kind in ("prior_mean", "both") else np.zeros(n)
+        yy = yc[c] if kind in ("response", "both") else y
+        xo, _, q, _ = oracle_draw(n, pd, po, lam[c], tau[c], yy, mu, z[c])
+        assert relerr(xh[c], np.asarray(xo).ravel()) < TOL
+        assert relerr(qh[:, c], q) < 1e-9
+    # the standalone quadratic form around the same centres
+    q2 = eng.empty(2, C)
+    eng.tridiag_quadform(n, [t_prior, t_lik], x, q2)
+    assert relerr(q2.cpu().numpy(), qh) < 1e-12
+    eng.close()
+
+
+def test_per_chain_centres_are_refused_where_no_kernel_takes_them(torch):
+    eng = make_engine(3, seed=1)
+    n = 40  # sub-wave form
+    assert not eng.tridiag_takes_center_chain(n)
+    pd, po = rw1(n)
+    terms = [{"diag": eng.to_device(pd), "off": eng.to_device(po), "center_chain": eng.zeros(3, n)}, {}]
+    with pytest.raises(NotImplementedError):
+        eng.tridiag_sample_canonical(n, terms, eng.empty(3, n), z=eng.zeros(3, n))
+    eng.close()
