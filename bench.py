@@ -250,6 +250,9 @@ def main():
                          "config.secondary (0 = skip)")
     ap.add_argument("--repeat-ms", type=float, default=250.0,
                     help="after the headline, repeat the K-step run until this much time has been measured (spread report)")
+    ap.add_argument("--collective-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the gathers and the second scaling mode may take after the headline before rank 0 prints "
+                         "the line without them and all ranks leave (0 = wait for ever)")
     ap.add_argument("--nodes", type=int, default=N_NODES)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -543,8 +546,70 @@ def main():
         return {"mode": mode, "C": C, "dt": dt, "kern_ms": kern_ms, "sweep": sweep, "stamps": stamps, "spread": spread,
                 "n_store": n_store, "diagnostics": report}
 
+    def make_line(lam_mean, trace_error, gather_info, other):
+        """the bench line of this run (rank 0), with whatever of the collective part is known"""
+        kern_ms = m["kern_ms"]
+        total_chains = args.chains * world if args.scaling == "weak" else args.chains
+        value = total_chains * args.steps / dt
+        out = {
+            "metric": "chain-updates/sec (1024 chains, 10k-node GMRF) at 1/2/4/8 GPUs vs CPU ref",
+            "value": value, "unit": "chain-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"GMRF smoother (examples/4): {n} nodes, RW1 precision, "
+                                   + (f"{args.chains} chains per GPU, " if args.scaling == "weak" else f"{args.chains} chains in all, sharded evenly, ")
+                                   + "NormalNormal + 2x NormalGamma + store + log_post per step"
+                                   + (" (one fused launch)" if not args.unfused else " (one launch per sampler)"),
+                       "chains_total": total_chains, "chains_rank0": C, "nodes": n, "parallelism": f"chains sharded x{world}",
+                       "check": {"mean_lambda": lam_mean, **({"trace_gather_error": trace_error} if trace_error else {})},
+                       "store_gather": gather_info,
+                       "repeats": m["spread"], "other_scaling": other,
+                       "diagnostics": m["diagnostics"]},
+        }
+        if kern_ms is not None:
+            # One launch of omc_gmrf_run carries up to 32 sweeps (blocks = sweeps x chains): per launch the kernel
+            # processes spl x C chain-updates.  `kernel_ms` stays the time per SWEEP (events around all launches of the
+            # timed region / K); the launch figures are those of a full launch.
+            spl = args.sweeps_per_launch or 32
+            spl = 1 if (args.python_loop or args.unfused) else min(spl, args.steps)
+            alg_sweep = ALG_BYTES_PER_CHAIN_UPDATE * (n / N_NODES) * C
+            achieved = alg_sweep / (kern_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                rec = json.load(open(tpath))
+                if rec.get("nodes") == n and rec.get("chains") == C:
+                    traffic = rec.get("hbm_bytes_per_sweep") * spl
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "kernel": "k_tridiag_seg", "kernel_ms": kern_ms,
+                               "sweeps_per_launch": spl, "launch_ms": kern_ms * spl,
+                               "alg_bytes_per_launch": alg_sweep * spl,
+                               "note": "achieved = alg_bytes_per_launch / launch_ms; traffic = PMC HBM bytes per launch "
+                                       "(profiles/traffic.json, per sweep x sweeps_per_launch)"}
+        return out
+
     m = measure(args.scaling, diagnostics=True)
     sweep, C, dt, n_store, stamps = m["sweep"], m["C"], m["dt"], m["n_store"], m["stamps"]
+
+    # The headline is measured.  What follows for N > 1 -- the library's own RCCL communicator, the gathers, the other scaling
+    # mode -- has never met real multi-GPU hardware in this repository (one-GPU boxes; gloo rehearsals only), and a collective
+    # that hangs would take the measured line with it.  A watchdog therefore holds the line as it stands now: if the rest
+    # is not through after --collective-timeout seconds, rank 0 prints it (saying so in config.store_gather) and every rank
+    # leaves; a rank stuck inside a native call cannot be interrupted any other way.
+    watchdog = None
+    fallback_line = {}
+    if dist is not None and args.collective_timeout > 0:
+        import threading
+
+        def give_up():
+            if rank == 0 and fallback_line:
+                fallback_line["config"]["store_gather"] = {"error": f"not finished after {args.collective_timeout:.0f} s: gave up (watchdog)"}
+                print(json.dumps(fallback_line), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.collective_timeout, give_up)
+        watchdog.daemon = True
 
     # the one collective of the path: gather of the per-chain traces (outside the timed region)
     trace = torch.stack([sweep.store_lam[: min(args.steps, n_store)], sweep.store_tau[: min(args.steps, n_store)]])
@@ -552,6 +617,10 @@ def main():
         trace = trace.cpu()
     trace_error = None
     comm, collective = None, None
+    if watchdog is not None:
+        if rank == 0:
+            fallback_line.update(make_line(trace[0].mean().item(), "traces of rank 0's chains only (watchdog line)", None, None))
+        watchdog.start()
     if dist is not None:
         # the library's own collective (omc_gather_samples on RCCL: every peer sends point to point into the root) when the
         # ranks have a GPU each; torch.distributed's gather on the group's backend otherwise (gloo rehearsals) or if the
@@ -626,46 +695,10 @@ def main():
                  "kernel_ms": o["kern_ms"], "repeats": o["spread"]}
         o["sweep"] = None
 
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        kern_ms = m["kern_ms"]
-        total_chains = args.chains * world if args.scaling == "weak" else args.chains
-        value = total_chains * args.steps / dt
-        out = {
-            "metric": "chain-updates/sec (1024 chains, 10k-node GMRF) at 1/2/4/8 GPUs vs CPU ref",
-            "value": value, "unit": "chain-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"GMRF smoother (examples/4): {n} nodes, RW1 precision, "
-                                   + (f"{args.chains} chains per GPU, " if args.scaling == "weak" else f"{args.chains} chains in all, sharded evenly, ")
-                                   + "NormalNormal + 2x NormalGamma + store + log_post per step"
-                                   + (" (one fused launch)" if not args.unfused else " (one launch per sampler)"),
-                       "chains_total": total_chains, "chains_rank0": C, "nodes": n, "parallelism": f"chains sharded x{world}",
-                       "check": {"mean_lambda": lam_mean, **({"trace_gather_error": trace_error} if trace_error else {})},
-                       "store_gather": gather_info,
-                       "repeats": m["spread"], "other_scaling": other,
-                       "diagnostics": m["diagnostics"]},
-        }
-        if kern_ms is not None:
-            # One launch of omc_gmrf_run carries up to 32 sweeps (blocks = sweeps x chains): per launch the kernel
-            # processes spl x C chain-updates.  `kernel_ms` stays the time per SWEEP (events around all launches of the
-            # timed region / K); the launch figures are those of a full launch.
-            spl = args.sweeps_per_launch or 32
-            spl = 1 if (args.python_loop or args.unfused) else min(spl, args.steps)
-            alg_sweep = ALG_BYTES_PER_CHAIN_UPDATE * (n / N_NODES) * C
-            achieved = alg_sweep / (kern_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                rec = json.load(open(tpath))
-                if rec.get("nodes") == n and rec.get("chains") == C:
-                    traffic = rec.get("hbm_bytes_per_sweep") * spl
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "k_tridiag_seg", "kernel_ms": kern_ms,
-                               "sweeps_per_launch": spl, "launch_ms": kern_ms * spl,
-                               "alg_bytes_per_launch": alg_sweep * spl,
-                               "note": "achieved = alg_bytes_per_launch / launch_ms; traffic = PMC HBM bytes per launch "
-                                       "(profiles/traffic.json, per sweep x sweeps_per_launch)"}
+        out = make_line(lam_mean, trace_error, gather_info, other)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(n)
         if world == 1 and args.secondary_ms > 0 and not args.stamps:
