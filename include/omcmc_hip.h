@@ -65,8 +65,9 @@ typedef struct {
    * sampled response whose mean is the parameter (sampler.py:181-192 with state[...] differing per chain).  Term k
    * is then centred at center[k] + center_chain[k][c]:  rhs_c += scale[k][c] * M_k center_chain[k][c]  (formed
    * inside the launch: no product vector travels through memory) and quad[k][c] is taken around that centre.
-   * NULL = none.  Taken by the workgroup-per-chain form of the draw (omc_tridiag_takes_center_chain) and by
-   * omc_tridiag_quadform; every other entry point returns OMC_UNSUPPORTED when one is set.               */
+   * NULL = none; at most ONE term of a call may have one.  Taken by the workgroup-per-chain form of the draw
+   * (omc_tridiag_takes_center_chain) and by omc_tridiag_quadform; every other entry point -- and a call with two
+   * such terms -- returns OMC_UNSUPPORTED.                                                                */
   const double* center_chain[OMC_MAX_TERMS];  /* [C][ld_center_chain]                        */
   int64_t ld_center_chain;
 } omc_tridiag_terms;

@@ -33,6 +33,9 @@
 
 #include "omc_common.h"
 
+#ifndef OMC_EARLY_LAST_PAIR
+#define OMC_EARLY_LAST_PAIR 0  // SIG 2: 1 = the last pair of draws made before the scales arrive too and kept in registers (measured: 68 spilled bytes, 16.0 against 14.6 us per sweep at 128 chains)
+#endif
 #ifndef OMC_JOIN_OR_LIB
 #define OMC_JOIN_OR_LIB 0  // 1: the join test through __syncthreads_or (three barriers; A/B builds)
 #endif
@@ -49,8 +52,10 @@ struct TermsDev {
 // arguments: the structure-specialised instantiation never reads it, and with the fields inside TermsDev the shifted
 // argument offsets alone cost that instantiation 1 us per sweep (same-box A/B).
 struct CentreChain {
-  const double* v[OMC_MAX_TERMS];
+  const double* v;  // the chains' vectors [C][ld], or NULL
   int64_t ld;
+  int k;            // the term it belongs to (ONE term per launch: with the code unrolled over all four terms the generic
+                    // instantiation spilled 100 bytes per lane)
 };
 
 struct GammaDev {
@@ -812,42 +817,26 @@ __device__ __forceinline__ int wave_valid(int wave_u, int lim) {
 template <int M, int CH>
 __device__ __forceinline__ void rhs_center_chain(double (&v)[CH], const TriArgs& A, const double (&sc)[OMC_MAX_TERMS], bool chain_ok,
                                                  int64_t cc, int wbase, int lane, int t0, int cnt, int nvalid) {
-  const int n = (int)A.n;
+  if (!A.cc.v || !chain_ok) return;  // wave-uniform
+  const int n = (int)A.n, kc = A.cc.k;
+  const double* c = A.cc.v + cc * A.cc.ld + wbase;
+  // the term's vectors and scale by wave-uniform selects (a dynamic index into the kernel arguments would cost a private copy)
+  const double* dk = kc == 0 ? A.T.diag[0] : (kc == 1 ? A.T.diag[1] : (kc == 2 ? A.T.diag[2] : A.T.diag[3]));
+  const double* ok = kc == 0 ? A.T.off[0] : (kc == 1 ? A.T.off[1] : (kc == 2 ? A.T.off[2] : A.T.off[3]));
+  const double sk = kc == 0 ? sc[0] : (kc == 1 ? sc[1] : (kc == 2 ? sc[2] : sc[3]));
+  // (plain predicated loads, element by element: batching them -- all loads of the batch first, at clamped positions -- was
+  // no faster and cost the generic instantiation 100 bytes of scratch per lane)
 #pragma unroll
-  for (int k = 0; k < OMC_MAX_TERMS; ++k) {
-    if (k >= A.T.n_terms || !A.cc.v[k] || !chain_ok) continue;
-    const double* c = A.cc.v[k] + cc * A.cc.ld + wbase;
-    const double *dk = A.T.diag[k], *ok = A.T.off[k];
-    // all loads of the batch first, at clamped positions (no load sits behind a test of another one's result), then the
-    // arithmetic with the out-of-range neighbours masked
-    // (sub-batches of SB elements: six loads each in flight; the whole batch at once spills)
-    constexpr int SB = CH;
-#pragma unroll
-    for (int tb = 0; tb < CH; tb += SB) {
-      double c0[SB], cm[SB], cp[SB], dv[SB], om[SB], op[SB];
-      bool in[SB];
-#pragma unroll
-      for (int u = 0; u < SB; ++u) {
-        const int t = tb + u;
-        const int idx = lane + (t0 + t) * 64, i = wbase + idx;
-        in[u] = t < CH && t < cnt && idx < nvalid;
-        const bool has_m = in[u] && ok && i > 0, has_p = in[u] && ok && i + 1 < n;
-        const int j0 = in[u] ? idx : 0;  // (element 0 of the wave's slice exists whenever the wave has any node)
-        c0[u] = c[j0];
-        dv[u] = dk ? (dk + wbase)[j0] : 1.0;
-        cm[u] = c[has_m ? j0 - 1 : j0];
-        cp[u] = c[has_p ? j0 + 1 : j0];
-        om[u] = has_m ? (ok + wbase)[j0 - 1] : 0.0;
-        op[u] = has_p ? (ok + wbase)[j0] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < SB; ++u) {
-        const int t = tb + u;
-        if (t >= CH) continue;
-        const double r = fma(op[u], cp[u], fma(om[u], cm[u], dv[u] * c0[u]));
-        v[t] = in[u] ? fma(sc[k], r, v[t]) : v[t];
-      }
+  for (int t = 0; t < CH; ++t) {
+    if (t >= cnt) continue;
+    const int idx = lane + (t0 + t) * 64, i = wbase + idx;
+    if (idx >= nvalid) continue;
+    double r = (dk ? (dk + wbase)[(unsigned)idx] : 1.0) * c[(unsigned)idx];
+    if (ok) {
+      if (i > 0) r = fma((ok + wbase)[idx - 1], c[idx - 1], r);
+      if (i + 1 < n) r = fma((ok + wbase)[(unsigned)idx], c[(unsigned)idx + 1u], r);
     }
+    v[t] = fma(sk, r, v[t]);
   }
 }
 
@@ -1028,7 +1017,7 @@ __device__ __forceinline__ void quad_wg(const double* tile, int lane, int wave_u
         for (int k = 0; k < OMC_MAX_TERMS; ++k) {
           if (k >= nt) continue;
           const double *ck = A.T.center[k], *dk = A.T.diag[k], *ok = A.T.off[k];
-          const double* cck = A.cc.v[k] ? A.cc.v[k] + cc * A.cc.ld : nullptr;
+          const double* cck = (A.cc.v && A.cc.k == k) ? A.cc.v + cc * A.cc.ld : nullptr;
           double ri[CH], rn[CH], dv[CH], ov[CH];
 #pragma unroll
           for (int t = 0; t < CH; ++t) {
@@ -1070,7 +1059,7 @@ __device__ __forceinline__ void quad_wg(const double* tile, int lane, int wave_u
           for (int k = 0; k < OMC_MAX_TERMS; ++k) {
             if (k >= nt) continue;
             const double *ck = A.T.center[k], *dk = A.T.diag[k], *ok = A.T.off[k];
-            const double* cck = A.cc.v[k] ? A.cc.v[k] + cc * A.cc.ld : nullptr;
+            const double* cck = (A.cc.v && A.cc.k == k) ? A.cc.v + cc * A.cc.ld : nullptr;
             const double a = x0 - ((ck && in) ? (ck + wbase)[(unsigned)idx] : 0.0) - ((cck && in) ? (cck + wbase)[(unsigned)idx] : 0.0);
             const double bnx = x1 - ((ck && ok && in1) ? (ck + wbase)[(unsigned)idx + 1u] : 0.0)
                                   - ((cck && ok && in1) ? (cck + wbase)[(unsigned)idx + 1u] : 0.0);
@@ -1396,7 +1385,12 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     }
   }
   double pre[M];  // SIG 1, 2: the right-hand side vector
-  double epo[EARLY ? M : 1], epd[EARLY ? M : 1], ebm1_raw = 0.0;
+  // SIG 2 stages the three vectors while it waits, UNSCALED, in the mapping the recurrences read them in: the off-diagonal
+  // slice in Y, the right-hand side in Rrow (both through the tile's transpose), the diagonal slice in the tile itself.
+  // When the scales arrive b = sP Y, a_j = sP tile_j + sI and r_j = sI Rrow_j are single operations at the places that read
+  // them -- the same values, bit for bit, as the scaled images the other forms write into the tile -- and the three tile
+  // fills (thirty LDS operations per wave, bound by the CU's LDS bandwidth: ~1 us) are off the chain's critical path.
+  double Rrow[EARLY ? M : 1], ebm1_raw = 0.0, ezl0 = 0.0, ezl1 = 0.0;
   if constexpr (EARLY) {
     // draws first (light on registers), the loads behind them: the workgroup waits for its scales far longer than a load
     // takes, so nothing has to travel under the draws -- and sixty registers of loads in flight beside them would spill
@@ -1414,12 +1408,28 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       const double g = sweep_gamma_draws_wave(A, c, lane, &f, sw);
       lds_g[lane] = f ? -g : g;
     }
+    if (OMC_EARLY_LAST_PAIR && gen_z) omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + (uint32_t)NZB), ezl0, ezl1);
     __builtin_amdgcn_sched_barrier(0);
     const int wbase = wave_u * 64 * M;
+    const int env = wave_valid<M>(wave_u, (int)n), envo = wave_valid<M>(wave_u, (int)n - 1);
     ebm1_raw = vPo[(i0 > 0 && i0 < n) ? i0 - 1 : 0];
-    coal_load<M>(epo, vPo + wbase, lane, wave_valid<M>(wave_u, (int)n - 1));
-    coal_load<M>(epd, vPd + wbase, lane, wave_valid<M>(wave_u, (int)n));
-    if (!(A.rhs_chain && chain_ok)) coal_load<M>(pre, vIr + wbase, lane, wave_valid<M>(wave_u, (int)n));
+    auto stage = [&](const double* base, int nvalid) {  // coalesced loads -> the wave's tile (zeros beyond the vector's end)
+      double tmp[M];
+      coal_load<M>(tmp, base, lane, nvalid);
+      wave_lds_fence();
+#pragma unroll
+      for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = tmp[t];
+      wave_lds_fence();
+    };
+    if (!(A.rhs_chain && chain_ok)) {
+      stage(vIr + wbase, env);
+#pragma unroll
+      for (int j = 0; j < M; ++j) Rrow[j] = crow[j];
+    }
+    stage(vPo + wbase, envo);
+#pragma unroll
+    for (int j = 0; j < M; ++j) Y[j] = crow[j];
+    stage(vPd + wbase, env);  // stays in the tile until the pivots are final
     __builtin_amdgcn_sched_barrier(0);
   }
   // ---- conditional precision: b -> Y (registers), a -> LDS tile ----
@@ -1445,8 +1455,6 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       double bm1_raw;
       if constexpr (EARLY) {
         bm1_raw = ebm1_raw;
-#pragma unroll
-        for (int t = 0; t < M; ++t) po[t] = epo[t];
       } else {
         // b_{i0-1}: only loaded here; any arithmetic on it would put a wait for all loads in front of the draws
         bm1_raw = vPo[(i0 > 0 && i0 < n) ? i0 - 1 : 0];
@@ -1468,20 +1476,26 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       }
       sP = p_first ? sc[0] : sc[1];
       sI = p_first ? sc[1] : sc[0];
-      wave_lds_fence();
-#pragma unroll
-      for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = sP * po[t];
-      wave_lds_fence();
-      bm1 = (i0 > 0 && i0 < n) ? sP * bm1_raw : 0.0;
-    }
-    {
-      double pd[M];
       if constexpr (EARLY) {
 #pragma unroll
-        for (int t = 0; t < M; ++t) pd[t] = epd[t];
+        for (int j = 0; j < M; ++j) Y[j] *= sP;
+        if (!(A.rhs_chain && chain_ok)) {  // r = sI rhs: scaled here, where nothing else is live yet
+#pragma unroll
+          for (int j = 0; j < M; ++j) Rrow[j] *= sI;
+        }
       } else {
-        vec_and_draws(pd, vPd + wbase, nv, 1);
+        wave_lds_fence();
+#pragma unroll
+        for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = sP * po[t];
+        wave_lds_fence();
       }
+      bm1 = (i0 > 0 && i0 < n) ? sP * bm1_raw : 0.0;
+    }
+    if constexpr (EARLY) {
+      OMC_STAMP(2);
+    } else {
+      double pd[M];
+      vec_and_draws(pd, vPd + wbase, nv, 1);
 #pragma unroll
       for (int j = 0; j < M; ++j) Y[j] = crow[j];
       OMC_STAMP(2);
@@ -1509,6 +1523,13 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     else tile_fill_comb<M, MULTI, COMB_DIAG>(tile, geo, A, sc);
   }
   const double* arow = crow;
+  // the combined diagonal as the recurrences read it (SIG 2: scaled on the way out of the tile, see above)
+  auto a_at = [&](int j) -> double {
+    // (beyond the chain's end the staged image is 0, so a = sI there instead of the other forms' 1: those nodes are
+    // decoupled from the chain -- b = 0 -- and take part in no result; any positive pivot serves)
+    if constexpr (EARLY) return fma(sP, arow[j], sI);
+    else return arow[j];
+  };
 
   OMC_STAMP(3);
   // ---- Moebius product of the segment, scan -> incoming pivot ----
@@ -1519,7 +1540,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     double bp = bm1;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      const double b2 = bp * bp, aj = arow[j];
+      const double b2 = bp * bp, aj = a_at(j);
       const double na = fma(aj, m.a, -b2 * m.c), nb = fma(aj, m.b, -b2 * m.d);
       m.c = m.a; m.d = m.b; m.a = na; m.b = nb;
       bp = Y[j];
@@ -1555,7 +1576,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     bool badp = false;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      const double D = fma(-lp, bprev, arow[j]);
+      const double D = fma(-lp, bprev, a_at(j));
       badp |= !(D > 0.0);
       const double r = fast_rcp(D);
       W[j] = r;
@@ -1676,26 +1697,36 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       }
     }
     if (!with_offsets) {
-      wave_lds_fence();
+      if constexpr (!EARLY) {  // (SIG 2: Rrow holds the scaled vector since the scales arrived)
+        wave_lds_fence();
 #pragma unroll
-      for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = sI * pre[t];
-      wave_lds_fence();
+        for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = sI * pre[t];
+        wave_lds_fence();
+      }
       rhs_done = true;
     }
   }
   if (rhs_done) {
   } else if (MULTI) {
     tile_fill_comb_wg<M, COMB_RHS, !SMO>(tile, lane, wave, lbase, A, sc, chain_ok, cc);  // (per-chain centres: SIG 0 only)
+    if constexpr (EARLY) {  // (per-chain offsets: the general fill above; read out once, like the staged vector)
+#pragma unroll
+      for (int j = 0; j < M; ++j) Rrow[j] = crow[j];
+    }
   } else {
     tile_fill_comb<M, MULTI, COMB_RHS>(tile, geo, A, sc);
   }
   OMC_STAMP(8);
+  auto r_at = [&](int j) -> double {  // the right-hand side as the forward substitution reads it
+    if constexpr (EARLY) return Rrow[j];
+    else return crow[j];
+  };
   {
     Aff f{0.0, 1.0};
     double lp = lin;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      f.p = fma(-lp, f.p, crow[j]);
+      f.p = fma(-lp, f.p, r_at(j));
       f.q = -lp * f.q;
       lp = Y[j];
     }
@@ -1733,12 +1764,16 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
                                                (__attribute__((address_space(3))) void*)&lds_z[wave][2 * k][0], 16, 0, 0);
           }
         }
-        omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + (uint32_t)(j >> 1)), z0, z1);
+        if constexpr (EARLY && OMC_EARLY_LAST_PAIR) {
+          z0 = ezl0; z1 = ezl1;  // (made while the scales were waited for: one pair of draws less on the critical path)
+        } else {
+          omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + (uint32_t)(j >> 1)), z0, z1);
+        }
       }
-      u = fma(-lp, u, crow[j]);
+      u = fma(-lp, u, r_at(j));
       W[j] = fma(u, W[j], z0 * fast_sqrt(W[j]));
       lp = Y[j];
-      u = fma(-lp, u, crow[j + 1]);
+      u = fma(-lp, u, r_at(j + 1));
       W[j + 1] = fma(u, W[j + 1], z1 * fast_sqrt(W[j + 1]));
       lp = Y[j + 1];
       if (!(SMO && (j >> 1) < NZB - 1)) __builtin_amdgcn_sched_barrier(0);  // parked draws: let the pairs pipeline
@@ -2183,7 +2218,7 @@ __global__ void __launch_bounds__(256) k_tridiag_quadform(TermsDev T, CentreChai
   for (int k = 0; k < T.n_terms; ++k) {
     double acc = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-      const double* cck = CC.v[k] ? CC.v[k] + c * CC.ld : nullptr;
+      const double* cck = (CC.v && CC.k == k) ? CC.v + c * CC.ld : nullptr;
       const double r = xc[i] - (T.center[k] ? T.center[k][i] : 0.0) - (cck ? cck[i] : 0.0);
       acc = fma((T.diag[k] ? T.diag[k][i] : 1.0) * r, r, acc);
       if (T.off[k] && i < n - 1) {
@@ -2228,16 +2263,19 @@ static bool terms_to_dev(const omc_tridiag_terms* t, TermsDev* d, CentreChain* c
     d->rhs[k] = on ? t->rhs[k] : nullptr;
     d->center[k] = on ? t->center[k] : nullptr;
     d->scale[k] = on ? t->scale[k] : nullptr;
-    if (cc) cc->v[k] = on ? t->center_chain[k] : nullptr;
   }
-  if (cc) cc->ld = t->ld_center_chain;
+  if (cc) {  // at most one term with a per-chain centre per call
+    *cc = CentreChain{};
+    for (int k = 0; k < t->n_terms; ++k)
+      if (t->center_chain[k]) {
+        cc->k = cc->v ? -1 : k;  // (-1: more than one -- the entry points answer OMC_UNSUPPORTED)
+        cc->v = t->center_chain[k];
+      }
+    cc->ld = t->ld_center_chain;
+  }
   return true;
 }
-static bool has_center_chain(const CentreChain& cc) {
-  for (int k = 0; k < OMC_MAX_TERMS; ++k)
-    if (cc.v[k]) return true;
-  return false;
-}
+static bool has_center_chain(const CentreChain& cc) { return cc.v != nullptr; }
 
 static void args_defaults(omc_ctx* ctx, TriArgs* A, int64_t n) {
   A->T = TermsDev{};  // every pointer null, no terms: a caller that fills the terms by hand cannot leave a field behind
@@ -2480,7 +2518,7 @@ omc_status omc_tridiag_sample_canonical(omc_ctx* ctx, int64_t n, const omc_tridi
   TriArgs A;
   args_defaults(ctx, &A, n);
   if (!terms_to_dev(terms, &A.T, &A.cc)) return OMC_INVALID_ARG;
-  if (has_center_chain(A.cc) && (!takes_wg_per_chain(ctx, n) || A.cc.ld < n)) return OMC_UNSUPPORTED;
+  if (has_center_chain(A.cc) && (A.cc.k < 0 || !takes_wg_per_chain(ctx, n) || A.cc.ld < n)) return OMC_UNSUPPORTED;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   if (long_chain_route(ctx, n)) {
     omc_status st = long_chain_draw(ctx, n, terms, rhs_chain, ld_rhs, z_inject, ld_z, draw_index, x_out, ld_x, mean_out, ld_mean,
@@ -2509,7 +2547,7 @@ omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* term
   TriArgs A;
   args_defaults(ctx, &A, n);
   if (!terms_to_dev(terms, &A.T, &A.cc)) return OMC_INVALID_ARG;
-  if (has_center_chain(A.cc) && (!takes_wg_per_chain(ctx, n) || A.cc.ld < n)) return OMC_UNSUPPORTED;
+  if (has_center_chain(A.cc) && (A.cc.k < 0 || !takes_wg_per_chain(ctx, n) || A.cc.ld < n)) return OMC_UNSUPPORTED;
   for (int k = 0; k < A.T.n_terms; ++k) {
     const omc_gamma_block& b = blocks[k];
     GammaDev& g = A.gb[k];
@@ -2596,7 +2634,7 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
     TriArgs A;
     args_defaults(ctx, &A, n);
     if (!terms_to_dev(terms, &A.T, &A.cc)) return OMC_INVALID_ARG;
-  if (has_center_chain(A.cc) && (!takes_wg_per_chain(ctx, n) || A.cc.ld < n)) return OMC_UNSUPPORTED;
+  if (has_center_chain(A.cc) && (A.cc.k < 0 || !takes_wg_per_chain(ctx, n) || A.cc.ld < n)) return OMC_UNSUPPORTED;
     for (int k = 0; k < A.T.n_terms; ++k) {
       const omc_gamma_block& bk = blocks[k];
       GammaDev& g = A.gb[k];
@@ -2730,6 +2768,7 @@ omc_status omc_tridiag_quadform(omc_ctx* ctx, int64_t n, const omc_tridiag_terms
   TermsDev T;
   CentreChain CC;
   if (!terms_to_dev(terms, &T, &CC)) return OMC_INVALID_ARG;
+  if (has_center_chain(CC) && CC.k < 0) return OMC_UNSUPPORTED;
   if (has_center_chain(CC) && CC.ld < n) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(k_tridiag_quadform, dim3((unsigned)ctx->n_chains), dim3(256), 0, ctx->stream, T, CC, n,

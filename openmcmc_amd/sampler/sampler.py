@@ -271,7 +271,7 @@ class NormalNormal(MCMCSampler):
         # (omc_tridiag_terms.center_chain: the workgroup-per-chain form) the launch forms s_c M v_c itself and its fused
         # quadratic form is the term's residual statistic; elsewhere the product vector is made by a launch of its own
         # and fed in as a per-chain right-hand side.
-        in_launch = eng.tridiag_takes_center_chain(n)
+        in_launch = eng.tridiag_takes_center_chain(n) and sum(pc.get("chain_vec") is not None for pc in pieces) == 1  # (one per launch)
         chain_rhs = [(pc["chain_vec"], pc["st"].scale_key, eng.model_cache(pc["dist"], state, pc["st"], pc["center"]))
                      for pc in pieces if pc.get("chain_vec") is not None and not in_launch]
         center_chain = [(k, pc["chain_vec"]) for k, pc in enumerate(pieces) if pc.get("chain_vec") is not None and in_launch]
