@@ -1360,6 +1360,17 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
                         (reinterpret_cast<uintptr_t>(vPo) & 15u) == 0;
   const bool park_diag = OMC_PARK_DIAG && SMO && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n) == 64 * M &&
                          (reinterpret_cast<uintptr_t>(vPd) & 15u) == 0;
+  // SIG 2, the chain's last (partly empty) wave.  It cannot take the LDS-DMA parking as it stands (the transfers would read
+  // past the end of the shared vectors) and used to fetch its three quadratic-form vectors inside the phase itself; with
+  // a CU to itself per chain every wave waits for that one at the reduction's barrier (the per-wave timeline: 2 000 cycles).
+  // Here it gets its own variant: the diagonal slice read back from the staged tile before x overwrites it, the
+  // off-diagonal slice parked by transfers whose source is clamped to the last whole 16-byte pair (the consumer masks by
+  // index; an odd last element comes from a scalar load), the centre vector prefetched with predicated loads.  The
+  // arithmetic and its order are those of the other forms: results stay bit-identical.
+  const int e_nv = EARLY ? wave_valid<M>(wave_u, (int)n) : 0, e_nvo = EARLY ? wave_valid<M>(wave_u, (int)n - 1) : 0;
+  const bool e_partial = EARLY && (A.quad || A.fused) && e_nv > 0 && e_nv < 64 * M && !(A.rhs_chain && chain_ok);
+  const bool park_off_p = OMC_PARK_OFF && e_partial && gen_z && e_nvo >= 2 && (reinterpret_cast<uintptr_t>(vPo) & 15u) == 0;
+  double e_edge_o = 0.0;
 
   // Fewer chains than CUs ((sweep, chain) grid): this workgroup has been placed on an idle CU while the chain's previous
   // sweep is still running elsewhere, and all it can do until that sweep's scales arrive is what does not depend on them --
@@ -1763,6 +1774,20 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
               __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vPo + wave_u * 64 * M + 128 * k + 2 * lane),
                                                (__attribute__((address_space(3))) void*)&lds_z[wave][2 * k][0], 16, 0, 0);
           }
+          if constexpr (EARLY) {
+            if (j == 2 * NZB && park_off_p) {  // (wave-uniform)
+              lds_reads_done();
+              const int last_pair = (e_nvo - 2) & ~1;
+#pragma unroll
+              for (int k = 0; k < NZB; ++k) {
+                const int e = 128 * k + 2 * lane;
+                const int ec = (e + 1 < e_nvo) ? e : last_pair;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vPo + wave_u * 64 * M + ec),
+                                                 (__attribute__((address_space(3))) void*)&lds_z[wave][2 * k][0], 16, 0, 0);
+              }
+              if (e_nvo & 1) e_edge_o = vPo[wave_u * 64 * M + e_nvo - 1];
+            }
+          }
         }
         if constexpr (EARLY && OMC_EARLY_LAST_PAIR) {
           z0 = ezl0; z1 = ezl1;  // (made while the scales were waited for: one pair of draws less on the critical path)
@@ -1786,8 +1811,12 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // the tridiagonal term's diagonal (LDS-DMA, contiguous image), which the back pass below reads in the row
   // mapping for the x' diag x part of the quadratic form -- one vector less to wait for afterwards
   double aPd = 0.0;
+  double eqd[EARLY ? M : 1];  // SIG 2, last wave: its diagonal slice in the coalesced mapping, taken before x overwrites the tile
+  // SIG 2 without per-chain offsets: the wave's diagonal slice has been sitting in the tile, unscaled, since the workgroup
+  // started (nothing wrote the tile after the pivots): no transfer, the back pass reads the staged rows
+  const bool diag_staged = EARLY && !(A.rhs_chain && chain_ok);
   if constexpr (SMO) {
-    if (park_diag) {
+    if (park_diag && !diag_staged) {
       lds_reads_done();
 #pragma unroll
       for (int k = 0; k < (64 * M) / 128; ++k)
@@ -1808,6 +1837,13 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   if constexpr (PFQ) {
     pfq = want_quad && park_off && wave_valid<M>(wave_u, (int)n) == 64 * M;  // wave-uniform; other waves load in the phase itself
     __builtin_amdgcn_sched_barrier(0);  // not into the forward pass: its registers are all taken
+    if constexpr (EARLY) {
+      if (e_partial) {  // (wave-uniform) the last wave's centre slice, predicated
+        const int wbase = wave_u * 64 * M;
+#pragma unroll
+        for (int t = 0; t < M; ++t) qcp[t] = (lane + 64 * t < e_nv) ? (vIc + wbase)[(unsigned)(lane + 64 * t)] : 0.0;
+      }
+    }
     if (pfq) {
       const int wbase = wave_u * 64 * M;
 #pragma unroll
@@ -1832,13 +1868,22 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
                    : excl_scan<Aff, false>(f, Aff{0.0, 1.0}, pos, Wd, true, lds_aff[0], wave, nw)).p;
     double x = xnext;
     OMC_STAMP(11);
+    if constexpr (EARLY) {
+      if (e_partial) {
+        wave_lds_fence();
+#pragma unroll
+        for (int t = 0; t < M; ++t) eqd[t] = *TM::elem(tl, r0, t);
+      }
+    }
     if (SMO && park_diag) {
       // the LDS-DMA has landed: vector-memory operations retire in order, so it is enough that no more than the prefetch
       // loads issued BEHIND it are still out (they are not needed before the quadratic forms)
-      if (PFQ && pfq) __builtin_amdgcn_s_waitcnt(0x0F70 | PFQ_LOADS);
-      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      if (!diag_staged) {
+        if (PFQ && pfq) __builtin_amdgcn_s_waitcnt(0x0F70 | PFQ_LOADS);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+      }
       wave_lds_fence();
-      const double* drow = tile + lane * M;  // contiguous image: no row padding
+      const double* drow = diag_staged ? crow : tile + lane * M;  // the staged rows (padded), or the transfer's contiguous image
 #pragma unroll
       for (int j = M - 1; j >= 0; --j) {
         x = fma(-Y[j], x, W[j]);
@@ -1907,11 +1952,26 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
               if constexpr (PFQ && OMC_PREFETCH_QUAD > 1) qo[t] = pfq ? qop[t] : (vPo + wbase)[(unsigned)(lane + 64 * t)];
               else qo[t] = OMC_WHATIF_NOQLOAD ? 0.25 : (vPo + wbase)[(unsigned)(lane + 64 * t)];
             }
+          } else if (EARLY && park_off_p) {
+            const double* zf = &lds_z[wave][0][0];
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // the transfers (and the centre prefetch behind them) have landed
+            wave_lds_fence();
+#pragma unroll
+            for (int t = 0; t < M; ++t) {
+              const int idx = lane + 64 * t;
+              double v = 0.0;
+              if (t < 2 * NZB) v = zf[idx];
+              else if (idx < nvo) v = (vPo + wbase)[(unsigned)idx];  // (a last wave of more than 512 nodes)
+              qo[t] = (idx < nvo) ? (((nvo & 1) && idx == nvo - 1) ? e_edge_o : v) : 0.0;
+            }
           } else {
             coal_load<M>(qo, vPo + wbase, lane, nvo);
           }
         }
-        if (park_diag) {
+        if (EARLY && e_partial) {
+#pragma unroll
+          for (int t = 0; t < M; ++t) qd[t] = eqd[t];
+        } else if (park_diag) {
 #pragma unroll
           for (int t = 0; t < M; ++t) qd[t] = 0.0;  // that part is in aPd already
         } else {
@@ -1920,7 +1980,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         if (OMC_WHATIF_NOQLOAD) {
 #pragma unroll
           for (int t = 0; t < M; ++t) qc[t] = 1.0;
-        } else if (PFQ && pfq) {
+        } else if (PFQ && (pfq || (EARLY && e_partial))) {
 #pragma unroll
           for (int t = 0; t < M; ++t) qc[t] = qcp[t];
         } else {
