@@ -36,6 +36,9 @@
 #ifndef OMC_EARLY_LAST_PAIR
 #define OMC_EARLY_LAST_PAIR 0  // SIG 2: 1 = the last pair of draws made before the scales arrive too and kept in registers (measured: 68 spilled bytes, 16.0 against 14.6 us per sweep at 128 chains)
 #endif
+#ifndef OMC_GENERIC_PARK
+#define OMC_GENERIC_PARK 1  // SIG 0, M <= 10: draws made under the loads of the tile fills and parked in LDS (0: all in the forward pass; A/B builds)
+#endif
 #ifndef OMC_JOIN_OR_LIB
 #define OMC_JOIN_OR_LIB 0  // 1: the join test through __syncthreads_or (three barriers; A/B builds)
 #endif
@@ -844,9 +847,13 @@ __device__ __forceinline__ void rhs_center_chain(double (&v)[CH], const TriArgs&
 // batch are issued back to back (L2 latency is paid once per batch) and only then combined.  A batch
 // that lies wholly inside the vector takes the test-free path; the chain's last wave takes the
 // predicated one for its boundary batch and only writes fill values beyond it.
-template <int M, int WHICH, bool CCH = false>
+struct omc_no_work { __device__ __forceinline__ void operator()(int) const {} };
+// `under_loads(b)`: work that depends on nothing, run once per batch b while that batch's first loads are in flight
+template <int M, int WHICH, bool CCH = false, class F = omc_no_work>
 __device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wave, int lbase, const TriArgs& A,
-                                                  const double (&sc)[OMC_MAX_TERMS], bool chain_ok, int64_t cc) {
+                                                  const double (&sc)[OMC_MAX_TERMS], bool chain_ok, int64_t cc,
+                                                  F under_loads = F()) {
+  constexpr bool OVL = !__is_same(F, omc_no_work);
   using TM = TileMap<M>;
   constexpr int CH = TM::CH;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -867,6 +874,25 @@ __device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wa
 #pragma unroll
       for (int t = 0; t < CH; ++t) v[t] = 0.0;
       if (TM::upto(t0 + cnt) <= nvalid) {  // wave-uniform: the whole batch is inside
+        // With work to overlap (OVL): the loads of the first two terms, then the work that depends on nothing, then their
+        // combination; further terms one by one.  Without: every term loads and combines in turn (fewest registers).
+        constexpr int KF = OVL ? 2 : 0;
+        double ldf[KF > 0 ? KF : 1][CH];
+        if constexpr (OVL) {
+#pragma unroll
+          for (int k = 0; k < KF; ++k) {
+            if (k >= nt) continue;
+            const double* src = (WHICH == COMB_DIAG) ? A.T.diag[k] : (WHICH == COMB_OFF ? A.T.off[k] : A.T.rhs[k]);
+            if (!src) continue;
+            const double* ps = src + wbase;
+#pragma unroll
+            for (int t = 0; t < CH; ++t)
+              if (t < cnt) ldf[k][t] = ps[(unsigned)(lane + (t0 + t) * TM::LU)];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          under_loads(t0 / CH);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int k = 0; k < OMC_MAX_TERMS; ++k) {
           if (k >= nt) continue;
@@ -878,14 +904,20 @@ __device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wa
             }
             continue;
           }
-          const double* ps = src + wbase;
-          double ld[CH];
+          if (k < KF) {
 #pragma unroll
-          for (int t = 0; t < CH; ++t)
-            if (t < cnt) ld[t] = ps[(unsigned)(lane + (t0 + t) * TM::LU)];
+            for (int t = 0; t < CH; ++t)
+              if (t < cnt) v[t] = fma(sc[k], ldf[k < KF ? k : 0][t], v[t]);
+          } else {
+            const double* ps = src + wbase;
+            double ld[CH];
 #pragma unroll
-          for (int t = 0; t < CH; ++t)
-            if (t < cnt) v[t] = fma(sc[k], ld[t], v[t]);
+            for (int t = 0; t < CH; ++t)
+              if (t < cnt) ld[t] = ps[(unsigned)(lane + (t0 + t) * TM::LU)];
+#pragma unroll
+            for (int t = 0; t < CH; ++t)
+              if (t < cnt) v[t] = fma(sc[k], ld[t], v[t]);
+          }
         }
         if (WHICH == COMB_RHS && rc) {
           double ld[CH];
@@ -901,6 +933,7 @@ __device__ __forceinline__ void tile_fill_comb_wg(double* tile, int lane, int wa
         for (int t = 0; t < CH; ++t)
           if (t < cnt) *TM::elem(tl, r0, t0 + t) = v[t];
       } else {
+        if constexpr (OVL) under_loads(t0 / CH);
 #pragma unroll
         for (int k = 0; k < OMC_MAX_TERMS; ++k) {
           if (k >= nt) continue;
@@ -1164,8 +1197,12 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   __shared__ double lds_d[6][16];  // reductions: one slot per call site
   __shared__ int lds_any[16];      // any_wg of the join test
   // SIG 1: pairs of draws per lane made ahead of the forward pass (all but the last; at most 8: LDS)
-  constexpr int NZB = (SMO) ? (M / 2 - 1 > 8 ? 8 : M / 2 - 1) : 0;
-  __shared__ double lds_z[SMO ? NWMAX : 1][NZB > 0 ? 2 * NZB : 1][64];
+  // SIG 0, M <= 10 (round 3): the generic instantiation parks the same pairs -- its LDS image leaves 66 KB free -- and makes
+  // them under the loads of its three tile fills (`fill_draws`), where the vector ALU used to idle; it generated all of a
+  // segment's draws inside the forward pass (10 000 cycles of pure vector-ALU time on the critical path).
+  constexpr bool PARKZ = SMO || (MULTI && M <= 10 && OMC_GENERIC_PARK);
+  constexpr int NZB = PARKZ ? (M / 2 - 1 > 8 ? 8 : M / 2 - 1) : 0;
+  __shared__ double lds_z[PARKZ ? NWMAX : 1][NZB > 0 ? 2 * NZB : 1][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int Wd = MULTI ? 64 : G;
   int64_t c;
@@ -1443,6 +1480,17 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     stage(vPd + wbase, env);  // stays in the tile until the pivots are final
     __builtin_amdgcn_sched_barrier(0);
   }
+  // SIG 0: one parked pair of draws, made under the loads of a tile fill (see PARKZ)
+  auto fill_draws = [&](int jb) {
+    if constexpr (PARKZ && !SMO) {
+      if (gen_z && jb < NZB) {
+        double z0, z1;
+        omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + (uint32_t)jb), z0, z1);
+        lds_z[wave][2 * jb][lane] = z0;
+        lds_z[wave][2 * jb + 1][lane] = z1;
+      }
+    }
+  };
   // ---- conditional precision: b -> Y (registers), a -> LDS tile ----
   double bm1 = 0.0;  // coupling b_{i0-1} into the segment
   if constexpr (SMO) {
@@ -1522,7 +1570,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     }
   } else {
     take_scales();
-    if (MULTI) tile_fill_comb_wg<M, COMB_OFF>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
+    if (MULTI) tile_fill_comb_wg<M, COMB_OFF>(tile, lane, wave, lbase, A, sc, chain_ok, cc, [&](int b) { if (b == 0) fill_draws(0); });
     else tile_fill_comb<M, MULTI, COMB_OFF>(tile, geo, A, sc);
 #pragma unroll
     for (int j = 0; j < M; ++j) Y[j] = crow[j];
@@ -1530,7 +1578,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) if (k < nt)
         if (A.T.off[k]) bm1 = fma(sc[k], A.T.off[k][i0 - 1], bm1);
     OMC_STAMP(2);
-    if (MULTI) tile_fill_comb_wg<M, COMB_DIAG>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
+    if (MULTI) tile_fill_comb_wg<M, COMB_DIAG>(tile, lane, wave, lbase, A, sc, chain_ok, cc, [&](int b) { if (b == 0) fill_draws(1); });
     else tile_fill_comb<M, MULTI, COMB_DIAG>(tile, geo, A, sc);
   }
   const double* arow = crow;
@@ -1719,7 +1767,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   }
   if (rhs_done) {
   } else if (MULTI) {
-    tile_fill_comb_wg<M, COMB_RHS, !SMO>(tile, lane, wave, lbase, A, sc, chain_ok, cc);  // (per-chain centres: SIG 0 only)
+    // (per-chain centres: SIG 0 only; SIG 0 makes two more pairs of draws under this fill's loads)
+    if constexpr (SMO) tile_fill_comb_wg<M, COMB_RHS, false>(tile, lane, wave, lbase, A, sc, chain_ok, cc);
+    else tile_fill_comb_wg<M, COMB_RHS, true>(tile, lane, wave, lbase, A, sc, chain_ok, cc, [&](int b) { fill_draws(2 + b); });
     if constexpr (EARLY) {  // (per-chain offsets: the general fill above; read out once, like the staged vector)
 #pragma unroll
       for (int j = 0; j < M; ++j) Rrow[j] = crow[j];
@@ -1760,7 +1810,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         // into the shared code: behind the quadratic-form prefetches of SIG 1 that wait exposed the whole L2 latency of
         // twelve loads on every sweep of the production path.
         if (SMO) __builtin_amdgcn_s_waitcnt(0x0F70);
-      } else if (SMO && (j >> 1) < NZB) {
+      } else if (PARKZ && (j >> 1) < NZB) {
         if (gen_z) { z0 = lds_z[wave][j][lane]; z1 = lds_z[wave][j + 1][lane]; }
       } else if (!A.zero_z) {
         if constexpr (SMO) {
@@ -1801,7 +1851,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       u = fma(-lp, u, r_at(j + 1));
       W[j + 1] = fma(u, W[j + 1], z1 * fast_sqrt(W[j + 1]));
       lp = Y[j + 1];
-      if (!(SMO && (j >> 1) < NZB - 1)) __builtin_amdgcn_sched_barrier(0);  // parked draws: let the pairs pipeline
+      if (!(PARKZ && (j >> 1) < NZB - 1)) __builtin_amdgcn_sched_barrier(0);  // parked draws: let the pairs pipeline
     }
   }
 
