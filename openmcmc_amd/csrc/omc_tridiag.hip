@@ -296,23 +296,24 @@ __device__ __forceinline__ void sweep_epilogue_wave(const TriArgs& A, int64_t c,
     const double b = g.b0 + 0.5 * qk;
     s = gd * ((b == 0.0) ? INFINITY : omc_rcp_nr(b));  // sampler.py:285-287
     if (j == 0) {
+      if (run_mode(A)) {  // hand the new scale to the workgroup of the chain's next sweep (same launch): FIRST -- a consumer
+                          // on another CU waits for exactly these stores, and vector-memory operations leave in order
+        const uint32_t tag = A.epoch + (uint32_t)sw + 1u;
+        unsigned long long* h = A.handoff + c * OMC_HANDOFF_WORDS + 2 * k;
+        const unsigned long long lo = ((unsigned long long)tag << 32) | (uint32_t)__double2loint(s);
+        const unsigned long long hi = ((unsigned long long)tag << 32) | (uint32_t)__double2hiint(s);
+        if (lds_hand) {  // self-restarting workgroup: the consumer is this workgroup -- the same granules through LDS
+          __hip_atomic_store(lds_hand + 2 * k, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(lds_hand + 2 * k + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __hip_atomic_store(h, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(h + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       // the caller's scale array: written by the launch's last sweep only (two XCDs' write-through stores to one
       // address within a launch have no defined order)
       if (!run_mode(A) || sw == A.n_sweeps - 1) g.scale_out[c] = s;
       double* const st = sweep_gamma_store(A, sw, g);
       if (st) st[c] = s;
-      if (run_mode(A)) {  // hand the new scale to the workgroup of the chain's next sweep (same launch)
-        const uint32_t tag = A.epoch + (uint32_t)sw + 1u;
-        unsigned long long* h = A.handoff + c * OMC_HANDOFF_WORDS + 2 * k;
-        const unsigned long long lo = ((unsigned long long)tag << 32) | (uint32_t)__double2loint(s);
-        const unsigned long long hi = ((unsigned long long)tag << 32) | (uint32_t)__double2hiint(s);
-        __hip_atomic_store(h, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(h + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lds_hand) {  // self-restarting workgroup: the consumer is this workgroup -- the same granules through LDS
-          __hip_atomic_store(lds_hand + 2 * k, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_store(lds_hand + 2 * k + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
     }
   }
   if (lp_out && !defer_lp) sweep_log_post_wave<DEV>(A, c, lane, s, qk, ldet, lp_out);
@@ -1343,7 +1344,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           lost = true;
           break;
         }
-        __builtin_amdgcn_s_sleep(EARLY ? 1 : 64);
+        if (!EARLY) __builtin_amdgcn_s_sleep(64);  // (SIG 2: back-to-back looks, a load round trip apart)
 #pragma unroll
         for (int k = 0; k < OMC_MAX_TERMS; ++k)
           if (k < nt && A.T.scale[k] && A.gb[k].enabled) {
