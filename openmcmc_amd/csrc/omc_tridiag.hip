@@ -34,7 +34,7 @@
 #include "omc_common.h"
 
 #ifndef OMC_EARLY_LAST_PAIR
-#define OMC_EARLY_LAST_PAIR 0  // SIG 2: 1 = the last pair of draws made before the scales arrive too and kept in registers (measured: 68 spilled bytes, 16.0 against 14.6 us per sweep at 128 chains)
+#define OMC_EARLY_LAST_PAIR 1  // SIG 2: the last pair of draws made before the scales arrive too (one value in the tile row's pad slot, one in registers; both in registers: 68 spilled bytes, 16.0 against 14.6 us per sweep at 128 chains)
 #endif
 #ifndef OMC_GENERIC_PARK
 #define OMC_GENERIC_PARK 1  // SIG 0, M <= 10: draws made under the loads of the tile fills and parked in LDS (0: all in the forward pass; A/B builds)
@@ -1457,7 +1457,13 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       const double g = sweep_gamma_draws_wave(A, c, lane, &f, sw);
       lds_g[lane] = f ? -g : g;
     }
-    if (OMC_EARLY_LAST_PAIR && gen_z) omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + (uint32_t)NZB), ezl0, ezl1);
+    if (OMC_EARLY_LAST_PAIR && gen_z) {
+      // the segment's last pair as well: one value goes into the pad slot of this lane's tile row (the slot that staggers
+      // the rows over the banks: no tile operation of this form touches it -- the one that would, the transfer of the
+      // diagonal slice, does not happen here), the other stays in a register pair
+      omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + (uint32_t)NZB), ezl0, ezl1);
+      crow[M] = ezl0;
+    }
     __builtin_amdgcn_sched_barrier(0);
     const int wbase = wave_u * 64 * M;
     const int env = wave_valid<M>(wave_u, (int)n), envo = wave_valid<M>(wave_u, (int)n - 1);
@@ -1841,7 +1847,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           }
         }
         if constexpr (EARLY && OMC_EARLY_LAST_PAIR) {
-          z0 = ezl0; z1 = ezl1;  // (made while the scales were waited for: one pair of draws less on the critical path)
+          z0 = crow[M]; z1 = ezl1;  // (made while the scales were waited for: one pair of draws less on the critical path)
         } else {
           omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + (uint32_t)(j >> 1)), z0, z1);
         }
