@@ -39,6 +39,12 @@
 #ifndef OMC_GENERIC_PARK
 #define OMC_GENERIC_PARK 1  // SIG 0, M <= 10: draws made under the loads of the tile fills and parked in LDS (0: all in the forward pass; A/B builds)
 #endif
+#ifndef OMC_EARLY_DEFER_STORE
+#define OMC_EARLY_DEFER_STORE 0  // SIG 2: 1 = x stored behind the hand-over instead of inside the quadratic-form pass (measured: 13.51 against 13.38 us per sweep at 128 chains)
+#endif
+#ifndef OMC_EARLY_ONE_POLLER
+#define OMC_EARLY_ONE_POLLER 1  // SIG 2: wave 0 polls the hand-over line in memory, the other waves poll its LDS copy
+#endif
 #ifndef OMC_JOIN_OR_LIB
 #define OMC_JOIN_OR_LIB 0  // 1: the join test through __syncthreads_or (three barriers; A/B builds)
 #endif
@@ -1313,7 +1319,22 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           ok = ok && (uint32_t)(hw[2 * k] >> 32) == want && (uint32_t)(hw[2 * k + 1] >> 32) == want;
       return __builtin_amdgcn_readfirstlane((int)ok) != 0;  // every lane loaded the same words
     };
-    if (hand_lds) {
+    if (EARLY && OMC_EARLY_ONE_POLLER && wave_u != 0) {
+      // SIG 2: wave 0 alone polls the chain's hand-over line in memory; the other waves wait at a BARRIER (no polling
+      // traffic of their own, released together the moment wave 0 arrives) and then read what wave 0 left in LDS.
+      // Sixteen waves polling back to back got in each other's way: the per-wave timeline showed the last wave seeing
+      // the scales 4 000 cycles after the first, and the first scan waits for the last wave.  The LDS words were wiped
+      // at the workgroup's start (behind a barrier): LDS arrives as the CU's previous workgroup left it, and that may have
+      // been another chain's sweep with exactly the tag waited for here.
+      lds_barrier();
+#pragma unroll
+      for (int k = 0; k < OMC_MAX_TERMS; ++k)
+        if (k < nt && A.T.scale[k] && A.gb[k].enabled) {
+          hw[2 * k] = __hip_atomic_load(lds_hand + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          hw[2 * k + 1] = __hip_atomic_load(lds_hand + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      lost = !tags_ok();  // (wave 0 passes NaN on under the right tag when the hand-over never came; this cannot fail)
+    } else if (hand_lds) {
       // The producer is this workgroup's wave 0, still in the previous sweep's epilogue if this wave is ahead of it: a
       // loop of LDS reads only (no vector-memory wait in it: the previous sweep's x stores are still draining).
       // Bounded; a hand-over that never comes is reported.
@@ -1358,6 +1379,16 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     for (int k = 0; k < OMC_MAX_TERMS; ++k)
       if (k < nt && A.T.scale[k] && A.gb[k].enabled)
         sc[k] = lost ? __builtin_nan("") : __hiloint2double((int)(uint32_t)hw[2 * k + 1], (int)(uint32_t)hw[2 * k]);
+    if (EARLY && OMC_EARLY_ONE_POLLER && wave_u == 0 && lane == 0) {  // pass the scales (or the NaN of a lost hand-over) on
+#pragma unroll
+      for (int k = 0; k < OMC_MAX_TERMS; ++k)
+        if (k < nt && A.T.scale[k] && A.gb[k].enabled) {
+          const unsigned long long tg = (unsigned long long)want << 32;
+          __hip_atomic_store(lds_hand + 2 * k, tg | (uint32_t)__double2loint(sc[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(lds_hand + 2 * k + 1, tg | (uint32_t)__double2hiint(sc[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    if (EARLY && OMC_EARLY_ONE_POLLER && wave_u == 0) lds_barrier();  // releases the fifteen waves waiting for these words
   };
   // per-sweep arguments (draw stream, output slab)
   auto nkey_f = [&]() -> omc_rng_key { return (MULTI && run_mode(A)) ? omc_make_key(A.seed, A.rec[sw].draw, OMC_RNG_NORMAL) : A.key; };
@@ -1486,6 +1517,10 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     for (int j = 0; j < M; ++j) Y[j] = crow[j];
     stage(vPd + wbase, env);  // stays in the tile until the pivots are final
     __builtin_amdgcn_sched_barrier(0);
+    if (OMC_EARLY_ONE_POLLER && handed) {  // (workgroup-uniform) the LDS hand-over words: wiped before anybody looks
+      if (threadIdx.x < 2 * OMC_MAX_TERMS) __hip_atomic_store(lds_hand + threadIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      lds_barrier();
+    }
   }
   // SIG 0: one parked pair of draws, made under the loads of a tile fill (see PARKZ)
   auto fill_draws = [&](int jb) {
@@ -2049,6 +2084,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       // x stream, and the 80 KB of stores drain under the reduction and the epilogue instead of after them)
       double* const xb = x_out();
       double* xo = (xb && chain_ok) ? xb + cc * A.ld_x + wave_u * 64 * M : nullptr;
+      // SIG 2: the stores wait until the quadratic forms are reduced and wave 0 has handed the new scales over (the block
+      // at the kernel's end): between two hand-overs nothing uses the memory pipeline that the next hand-over does not need
+      if (EARLY && OMC_EARLY_DEFER_STORE && want_quad) xo = nullptr;
       if (!want_quad) {
         if (xo) {
 #pragma unroll
@@ -2163,8 +2201,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     // x leaves last: a load issued behind a store would have to wait for the store to be
     // acknowledged (vmcnt retires in order); this way nothing ever waits on the x stream.
     // (SIG 1 has stored it from its quadratic-form pass already.)
-    double* const xb = (!SMO) ? x_out() : nullptr;
-    if (!SMO && xb && chain_ok) {
+    const bool store_here = !SMO || (EARLY && OMC_EARLY_DEFER_STORE && (A.quad || A.fused));
+    double* const xb = store_here ? x_out() : nullptr;
+    if (store_here && xb && chain_ok) {
       double* xo = xb + cc * A.ld_x + wave_u * 64 * M;
       const int nvalid = wave_valid<M>(wave_u, (int)n);
       {
