@@ -32,12 +32,33 @@ def test_abi_version_and_error_text_callable_without_gpu():
     assert isinstance(_abi.lib.omc_last_error(), bytes)
 
 
-def test_terms_struct_layout_matches_header():
+def test_terms_struct_layout_matches_header(tmp_path):
+    """ctypes' omc_tridiag_terms against the C compiler's view of include/omcmc_hip.h (ABI 2: center_chain, ld_center_chain)."""
+    import shutil
+    import subprocess
+
     from openmcmc_amd import _abi
 
-    # int32 + padding, then 5 arrays of 4 pointers
-    assert ctypes.sizeof(_abi.TridiagTerms) == 8 + 5 * 4 * 8
-    assert _abi.TridiagTerms.diag.offset == 8
+    T = _abi.TridiagTerms
+    # int32 + padding, 5 arrays of 4 pointers, the per-chain centres (4 pointers) and their row stride
+    assert ctypes.sizeof(T) == 8 + 5 * 4 * 8 + 4 * 8 + 8
+    assert T.diag.offset == 8 and T.center_chain.offset == 8 + 5 * 32 and T.ld_center_chain.offset == 8 + 6 * 32
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        return
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "omcmc_hip.h"\n'
+        'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(omc_tridiag_terms), offsetof(omc_tridiag_terms, diag),'
+        ' offsetof(omc_tridiag_terms, off), offsetof(omc_tridiag_terms, rhs), offsetof(omc_tridiag_terms, center),'
+        ' offsetof(omc_tridiag_terms, scale), offsetof(omc_tridiag_terms, center_chain), offsetof(omc_tridiag_terms, ld_center_chain));'
+        ' return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.run([cc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True, timeout=120)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True, timeout=30).stdout.split()]
+    want = [ctypes.sizeof(T), T.diag.offset, T.off.offset, T.rhs.offset, T.center.offset, T.scale.offset, T.center_chain.offset,
+            T.ld_center_chain.offset]
+    assert got == want, (got, want)
 
 
 def test_product_path_never_imports_the_oracle():
