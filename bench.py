@@ -117,10 +117,20 @@ class GmrfSweep:
         if k <= 0:
             return
         eng, n = self.eng, self.n
-        blocks = [{"a0": self.A_LAM, "b0": self.B_LAM, "n_pos": n, "store": self.store_lam, "logdet": self.logdetP, "draw_index": 1},
-                  {"a0": self.A_TAU, "b0": self.B_TAU, "n_pos": n, "store": self.store_tau, "logdet": self.logdetI, "draw_index": 2}]
-        eng.gmrf_run(n, self.terms, blocks, 0, k, 1, self.store_b, self.scratch, draw_index0=3 * self.it,
-                     draws_per_sweep=3, first_slot=self.it % self.n_store, log_post_store=self.store_lp)
+        if getattr(self, "_run_args", None) is None:
+            # the argument block of omc_gmrf_run, marshalled ONCE: a C caller passes these pointers as they are, and 35 us of
+            # Python in front of every call (a tenth of a 20-sweep run at 128 chains per GPU) are not part of a sweep
+            import ctypes as C
+
+            from openmcmc_amd import _abi
+
+            blocks = [{"a0": self.A_LAM, "b0": self.B_LAM, "n_pos": n, "store": self.store_lam, "logdet": self.logdetP, "draw_index": 1},
+                      {"a0": self.A_TAU, "b0": self.B_TAU, "n_pos": n, "store": self.store_tau, "logdet": self.logdetI, "draw_index": 2}]
+            B = eng._gamma_blocks_strided(blocks, self.terms.n_terms)
+            self._run_args = (_abi.lib.omc_gmrf_run, _abi.check, eng._ctx, C.byref(self.terms), B, eng._p(self.store_b),
+                              self.store_b.stride(1), self.store_b.stride(0), eng._p(self.store_lp), eng._p(self.scratch, self.C, n))
+        fn, check, ctx, T, B, xs, ld_x, slot_stride, lp, scratch = self._run_args
+        check(fn(ctx, n, T, B, 0, k, 1, 3 * self.it, 3, xs, ld_x, slot_stride, self.it % self.n_store, self.n_store, lp, scratch))
         self.it += k
 
     def step_fused(self, kernel_events=None):

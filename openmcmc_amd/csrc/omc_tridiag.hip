@@ -2826,8 +2826,13 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
     // (sweep, chain) -- the dispatcher then balances the CUs sweep by sweep, and with fewer chains than CUs the next
     // sweep of a chain starts on an idle CU under the tail of the previous one (384 chains: 31.4 against 39.2 us per
     // sweep, 128 chains: 19.0 against 19.9; 256 and 1024 chains: the restarting form by 6 % and 3 %).
-    int dev_cus = 256;
-    hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    static int cached_cus[64];  // (per device: the attribute query is a driver call on every omc_gmrf_run otherwise)
+    int dev_cus = (ctx->device >= 0 && ctx->device < 64) ? cached_cus[ctx->device] : 0;
+    if (dev_cus <= 0) {
+      dev_cus = 256;
+      hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+      if (ctx->device >= 0 && ctx->device < 64) cached_cus[ctx->device] = dev_cus;
+    }
     const int64_t rounds = (C + dev_cus - 1) / dev_cus;
     const bool whole_rounds = C >= dev_cus && (double)C >= 0.95 * (double)(rounds * dev_cus);
     A.reenter = (whole_rounds || ctx->run_reenter_force) ? ctx->run_reenter : 0;
