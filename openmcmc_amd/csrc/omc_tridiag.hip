@@ -45,6 +45,9 @@
 #ifndef OMC_EARLY_ONE_POLLER
 #define OMC_EARLY_ONE_POLLER 1  // SIG 2: wave 0 polls the hand-over line in memory, the other waves poll its LDS copy
 #endif
+#ifndef OMC_PAIR_IN_SCAN_WINDOW
+#define OMC_PAIR_IN_SCAN_WINDOW 0  // SIG 1: 1 = waves 1..15 make their last buffered pair of draws while wave 0 scans the Moebius wave totals (measured: 80.7 against 80.3 us per sweep)
+#endif
 #ifndef OMC_JOIN_OR_LIB
 #define OMC_JOIN_OR_LIB 0  // 1: the join test through __syncthreads_or (three barriers; A/B builds)
 #endif
@@ -561,8 +564,10 @@ __device__ __forceinline__ void lds_barrier() {
 // ONE_WAVE: the scan over the wave totals is done by wave 0 alone and handed out through `lds2` behind a second
 // barrier, instead of redundantly by every wave -- worth it for the Moebius elements, whose 16-lane row scan
 // is ~140 vector-ALU instructions per wave (x 16 waves on 4 SIMDs) against a few hundred cycles of one wave.
-template <class T, bool REV, bool ONE_WAVE = false>
-__device__ __forceinline__ T excl_scan_wg(T v, const T id, T* lds, int lane, int wave, int nw, T* lds2 = nullptr) {
+// `idle_work` (ONE_WAVE only): run by every wave but wave 0 while that one scans the totals and they would wait for it
+struct omc_no_idle_work { __device__ __forceinline__ void operator()() const {} };
+template <class T, bool REV, bool ONE_WAVE = false, class F = omc_no_idle_work>
+__device__ __forceinline__ T excl_scan_wg(T v, const T id, T* lds, int lane, int wave, int nw, T* lds2 = nullptr, F idle_work = F()) {
   v = row_scan<T, REV>(v, id);
   // row totals sit in the last (first) lane of each row; fold the preceding rows in
   const int row = lane >> 4;
@@ -591,6 +596,8 @@ __device__ __forceinline__ T excl_scan_wg(T v, const T id, T* lds, int lane, int
         T t = (lane < nw) ? renorm(lds[lane]) : id;
         t = row_scan<T, REV>(t, id);
         if (lane < nw) lds2[lane] = t;
+      } else {
+        idle_work();
       }
       lds_barrier();
       if (src >= 0 && src < nw) e = compose(e, lds2[src]);
@@ -1653,7 +1660,19 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     m = mob_norm(m);
     OMC_STAMP(4);
     const Mob idm{1.0, 0.0, 0.0, 1.0};
-    const Mob E = MULTI ? excl_scan_wg<Mob, false, true>(m, idm, lds_mob, lane, wave, nw, lds_mob2)
+    // SIG 1: waves 1..15 make their last buffered pair of draws while wave 0 scans the wave totals (2 000 cycles in which
+    // they would wait at the second barrier); wave 0 makes its own in the right-hand-side phase as before
+    auto pair_in_window = [&]() {
+      if constexpr (SIG == 1 && OMC_PAIR_IN_SCAN_WINDOW) {
+        if (gen_late && NZB > 3) {
+          double z0, z1;
+          omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + (uint32_t)(NZB - 1)), z0, z1);
+          lds_z[wave][2 * (NZB - 1)][lane] = z0;
+          lds_z[wave][2 * (NZB - 1) + 1][lane] = z1;
+        }
+      }
+    };
+    const Mob E = MULTI ? excl_scan_wg<Mob, false, true>(m, idm, lds_mob, lane, wave, nw, lds_mob2, pair_in_window)
                         : excl_scan<Mob, false>(m, idm, pos, Wd, false, lds_mob, wave, nw);
     Dst = (E.a + E.b) / (E.c + E.d);
     if (A.perturb_start != 0.0 && s > 0) Dst *= 1.0 + A.perturb_start;  // tests: a start the join test must reject
@@ -1791,6 +1810,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
 #pragma unroll
       for (int jb = 2; jb < NZB; ++jb) {
         if (jb == 2 && !with_offsets) continue;  // made under the load above
+        if (SIG == 1 && OMC_PAIR_IN_SCAN_WINDOW && NZB > 3 && jb == NZB - 1 && wave_u != 0) continue;  // made in the Moebius scan's window
         double z0, z1;
         omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + (uint32_t)jb), z0, z1);
         lds_z[wave][2 * jb][lane] = z0;
