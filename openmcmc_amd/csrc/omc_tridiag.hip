@@ -48,6 +48,9 @@
 #ifndef OMC_PAIR_IN_SCAN_WINDOW
 #define OMC_PAIR_IN_SCAN_WINDOW 0  // SIG 1: 1 = waves 1..15 make their last buffered pair of draws while wave 0 scans the Moebius wave totals (measured: 80.7 against 80.3 us per sweep)
 #endif
+#ifndef OMC_EARLY_PFQ_AHEAD
+#define OMC_EARLY_PFQ_AHEAD 0  // SIG 2: 1 = the quadratic forms prefetch issued before the forward substitution instead of before the reverse scan (measured: 13.4 against 12.7 us per sweep at 128 chains)
+#endif
 #ifndef OMC_JOIN_OR_LIB
 #define OMC_JOIN_OR_LIB 0  // 1: the join test through __syncthreads_or (three barriers; A/B builds)
 #endif
@@ -1839,7 +1842,37 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   } else {
     tile_fill_comb<M, MULTI, COMB_RHS>(tile, geo, A, sc);
   }
+  constexpr bool PFQ = SMO && OMC_PREFETCH_QUAD;
+  constexpr int PFQ_LOADS = M + (OMC_PREFETCH_QUAD > 1 ? M - 2 * NZB : 0);  // loads the prefetch puts behind the LDS-DMA
+  static_assert(!PFQ || PFQ_LOADS <= 15, "vmcnt immediate");
+  double qcp[PFQ ? M : 1], qop[PFQ ? M : 1];
+  bool pfq = false;
+  auto issue_pfq = [&]() {
+    if constexpr (PFQ) {
+      const bool wq = A.quad || A.fused;
+      pfq = wq && park_off && wave_valid<M>(wave_u, (int)n) == 64 * M;  // wave-uniform; other waves load in the phase itself
+      __builtin_amdgcn_sched_barrier(0);  // not into the forward pass: its registers are all taken
+      if constexpr (EARLY) {
+        if (e_partial) {  // (wave-uniform) the last wave's centre slice, predicated
+          const int wbase = wave_u * 64 * M;
+#pragma unroll
+          for (int t = 0; t < M; ++t) qcp[t] = (lane + 64 * t < e_nv) ? (vIc + wbase)[(unsigned)(lane + 64 * t)] : 0.0;
+        }
+      }
+      if (pfq) {
+        const int wbase = wave_u * 64 * M;
+#pragma unroll
+        for (int t = 0; t < M; ++t) qcp[t] = (vIc + wbase)[(unsigned)(lane + 64 * t)];
+        if (OMC_PREFETCH_QUAD > 1) {
+#pragma unroll
+          for (int t = 2 * NZB; t < M; ++t) qop[t] = (vPo + wbase)[(unsigned)(lane + 64 * t)];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   OMC_STAMP(8);
+  if (EARLY && OMC_EARLY_PFQ_AHEAD) issue_pfq();
   auto r_at = [&](int j) -> double {  // the right-hand side as the forward substitution reads it
     if constexpr (EARLY) return Rrow[j];
     else return crow[j];
@@ -1941,32 +1974,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // pass (a tenth of the wave's lifetime, light on registers) cover its latency, the quadratic-form phase then reads
   // nothing from memory and its x stores start a load round trip earlier (OMC_PREFETCH_QUAD; measured on
   // benchmarks/ab_headline.py).
-  constexpr bool PFQ = SMO && OMC_PREFETCH_QUAD;
-  constexpr int PFQ_LOADS = M + (OMC_PREFETCH_QUAD > 1 ? M - 2 * NZB : 0);  // loads the prefetch puts behind the LDS-DMA
-  static_assert(!PFQ || PFQ_LOADS <= 15, "vmcnt immediate");
-  double qcp[PFQ ? M : 1], qop[PFQ ? M : 1];
-  bool pfq = false;
-  if constexpr (PFQ) {
-    pfq = want_quad && park_off && wave_valid<M>(wave_u, (int)n) == 64 * M;  // wave-uniform; other waves load in the phase itself
-    __builtin_amdgcn_sched_barrier(0);  // not into the forward pass: its registers are all taken
-    if constexpr (EARLY) {
-      if (e_partial) {  // (wave-uniform) the last wave's centre slice, predicated
-        const int wbase = wave_u * 64 * M;
-#pragma unroll
-        for (int t = 0; t < M; ++t) qcp[t] = (lane + 64 * t < e_nv) ? (vIc + wbase)[(unsigned)(lane + 64 * t)] : 0.0;
-      }
-    }
-    if (pfq) {
-      const int wbase = wave_u * 64 * M;
-#pragma unroll
-      for (int t = 0; t < M; ++t) qcp[t] = (vIc + wbase)[(unsigned)(lane + 64 * t)];
-      if (OMC_PREFETCH_QUAD > 1) {
-#pragma unroll
-        for (int t = 2 * NZB; t < M; ++t) qop[t] = (vPo + wbase)[(unsigned)(lane + 64 * t)];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  // (SIG 2 has issued the prefetch before its forward substitution, which generates no draws there: the loads'
+  // issue overlaps arithmetic instead of holding up the reverse scan, see OMC_EARLY_PFQ_AHEAD)
+  if (!(EARLY && OMC_EARLY_PFQ_AHEAD)) issue_pfq();
   // ---- backward substitution: local affine map, reverse scan, true pass ----
   double xnext;
   {
@@ -1991,7 +2001,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       // the LDS-DMA has landed: vector-memory operations retire in order, so it is enough that no more than the prefetch
       // loads issued BEHIND it are still out (they are not needed before the quadratic forms)
       if (!diag_staged) {
-        if (PFQ && pfq) __builtin_amdgcn_s_waitcnt(0x0F70 | PFQ_LOADS);
+        if (PFQ && pfq && !(EARLY && OMC_EARLY_PFQ_AHEAD)) __builtin_amdgcn_s_waitcnt(0x0F70 | PFQ_LOADS);
         else __builtin_amdgcn_s_waitcnt(0x0F70);
       }
       wave_lds_fence();
