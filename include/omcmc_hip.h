@@ -89,7 +89,9 @@ omc_status omc_ctx_status(omc_ctx* ctx, int64_t* first_bad_chain);
 omc_status omc_ctx_synchronize(omc_ctx* ctx);
 /* Tuning knobs, by name: "tridiag_algo" (0 auto, 1 serial lane-per-chain, 2 segmented),
  * "tridiag_seg" (nodes per lane: 0 auto, 8, 10, 16, 20, 32), "tridiag_generic" (1: never use the
- * instantiation specialised for the two-term smoother structure; for cross-checks), "tridiag_newton_max" (0..64,
+ * instantiation specialised for the two-term smoother structure; for cross-checks), "tridiag_quad_skip" (bit k set: the generic
+ * workgroup-per-chain draw skips term k's fused quadratic form -- a hierarchical sweep knows which of them a later block will
+ * invalidate --, that quad_out entry is then meaningless), "tridiag_newton_max" (0..64,
  * default 4: Newton corrections of the segment joins before the sequential fallback takes over; 0 forces it),
  * "tridiag_perturb_ppb" (tests: relative error, in 1e-9, put on the segments' start pivots so that the join test must
  * reject them), "run_sweeps_per_launch" (1..32, default 32: sweeps omc_gmrf_run issues per launch), "run_reenter" (0..2, default 2:

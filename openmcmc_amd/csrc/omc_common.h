@@ -54,6 +54,7 @@ struct omc_ctx {
   int tridiag_seg;   // 0 auto, else nodes per lane
   int debug_zero_z;  // diagnostic: skip the draw generation (timing what-if only)
   int tridiag_newton_max;  // Newton join corrections before the sequential fallback (default OMC_NEWTON_MAX = 4; 0 forces the fallback: tests)
+  int tridiag_quad_skip;    // bit k: the generic tridiagonal draw does not take term k's fused quadratic form (its quad_out entry is left unwritten)
   int tridiag_perturb_ppb;  // tests only: relative error (parts per billion) put on the Moebius start values of the segment joins
   int tridiag_generic;  // 1: never take the structure-specialised instantiation of the segmented kernel (tests)
   int band_algo;  // 0 auto, 1 lane-per-chain in one piece (narrow bands), 2 workgroup-per-chain

@@ -53,6 +53,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->tridiag_generic = 0;
   c->tridiag_newton_max = 4;
   c->tridiag_perturb_ppb = 0;
+  c->tridiag_quad_skip = 0;
   c->stamps = nullptr;
   c->sweep_times = nullptr; c->sweep_times_cap = 0; c->sweep_times_pos = 0;
   c->launch_log_n = 0; c->launch_log_total = 0;
@@ -230,6 +231,11 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
     if (value < 0 || value > 2) return OMC_INVALID_ARG;
     ctx->run_reenter = (int)value;
     ctx->run_reenter_force = 1;  // an explicit choice holds for every chain count (tests, A/B runs)
+    return OMC_OK;
+  }
+  if (!strcmp(name, "tridiag_quad_skip")) {
+    if (value < 0 || value > 15) return OMC_INVALID_ARG;
+    ctx->tridiag_quad_skip = (int)value;
     return OMC_OK;
   }
   if (!strcmp(name, "tridiag_perturb_ppb")) {

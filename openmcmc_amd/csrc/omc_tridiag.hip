@@ -69,6 +69,7 @@ struct TermsDev {
 struct CentreChain {
   const double* v;  // the chains' vectors [C][ld], or NULL
   int64_t ld;
+  int quad_skip;    // bit k: term k's fused quadratic form is not wanted (generic instantiation; option "tridiag_quad_skip")
   int k;            // the term it belongs to (ONE term per launch: with the code unrolled over all four terms the generic
                     // instantiation spilled 100 bytes per lane)
 };
@@ -1065,7 +1066,7 @@ __device__ __forceinline__ void quad_wg(const double* tile, int lane, int wave_u
           }
 #pragma unroll
         for (int k = 0; k < OMC_MAX_TERMS; ++k) {
-          if (k >= nt) continue;
+          if (k >= nt || ((A.cc.quad_skip >> k) & 1)) continue;  // (wave-uniform)
           const double *ck = A.T.center[k], *dk = A.T.diag[k], *ok = A.T.off[k];
           const double* cck = (A.cc.v && A.cc.k == k) ? A.cc.v + cc * A.cc.ld : nullptr;
           double ri[CH], rn[CH], dv[CH], ov[CH];
@@ -1107,7 +1108,7 @@ __device__ __forceinline__ void quad_wg(const double* tile, int lane, int wave_u
           const double x0 = in ? *TM::elem(tl, r0, t0 + t) : 0.0, x1 = in1 ? *TM::succ(TM::elem(tl, r0, t0 + t), r0, t0 + t) : 0.0;
 #pragma unroll
           for (int k = 0; k < OMC_MAX_TERMS; ++k) {
-            if (k >= nt) continue;
+            if (k >= nt || ((A.cc.quad_skip >> k) & 1)) continue;
             const double *ck = A.T.center[k], *dk = A.T.diag[k], *ok = A.T.off[k];
             const double* cck = (A.cc.v && A.cc.k == k) ? A.cc.v + cc * A.cc.ld : nullptr;
             const double a = x0 - ((ck && in) ? (ck + wbase)[(unsigned)idx] : 0.0) - ((cck && in) ? (cck + wbase)[(unsigned)idx] : 0.0);
@@ -2722,6 +2723,7 @@ omc_status omc_tridiag_sample_canonical(omc_ctx* ctx, int64_t n, const omc_tridi
   }
   A.z = z_inject; A.ld_z = ld_z; A.zero_z = 0;
   A.x = x_out; A.ld_x = ld_x; A.quad = quad_out; A.logdet = logdet_out;
+  A.cc.quad_skip = quad_out ? ctx->tridiag_quad_skip : 0;  // (honoured by the generic workgroup-per-chain instantiation only)
   return launch_tridiag(ctx, A);
 }
 

@@ -54,6 +54,9 @@ class MCMC:
         ns = len(self.samplers)
         for pos, sampler in enumerate(self.samplers):
             sampler.bind(eng, pos, ns)
+            # what the rest of the sweep samples after this block (a Normal-Normal block does not take the fused quadratic
+            # form of a term whose other side is about to be replaced)
+            sampler._later_params = frozenset(s.param for s in self.samplers[pos + 1:])
             if sampler.param not in self.state:  # mcmc.py:79-80: draw the start from the prior
                 self.state[sampler.param] = sampler.model[sampler.param].rvs(
                     self.state, engine=eng, draw_index=(1 << 40) + pos)

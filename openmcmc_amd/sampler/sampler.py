@@ -277,6 +277,15 @@ class NormalNormal(MCMCSampler):
         center_chain = [(k, pc["chain_vec"]) for k, pc in enumerate(pieces) if pc.get("chain_vec") is not None and in_launch]
         # terms whose fused quadratic form equals the distribution's residual statistic for the state the draw leaves
         quad_ok = [not pc["offset"] and not pc.get("replicated") and (pc.get("chain_vec") is None or in_launch) for pc in pieces]
+        # ... and of those, the ones a LATER block of the same sweep invalidates before anybody could read them (the other
+        # side of the term is sampled after this block: MCMC tells the sampler which parameters follow it): not computed
+        later = getattr(self, "_later_params", frozenset())
+        for k, pc in enumerate(pieces):
+            cv = pc.get("chain_vec")
+            if quad_ok[k] and cv is not None:
+                other = cv[1].mean.get_param_list() if cv[0] == "mean" else [cv[1]]
+                if any(key in later for key in other):
+                    quad_ok[k] = False
         return {"kind": "tridiag", "n": n, "terms_list": terms, "terms": eng.tridiag_terms(terms, n), "keys": keys,
                 "offsets": offsets, "replicated": any(pc.get("replicated") for pc in pieces), "chain_rhs": chain_rhs,
                 "center_chain": center_chain, "quad_ok": quad_ok}
@@ -442,7 +451,14 @@ class NormalNormal(MCMCSampler):
             if p.get("center_chain"):
                 eng.set_center_chain(p["terms"], vecs, n)
             quad = eng.empty(len(p["keys"]), eng.n_chains) if any(p.get("quad_ok", ())) else None
-            eng.tridiag_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index(), quad_out=quad)
+            skip = sum(1 << k for k, ok in enumerate(p.get("quad_ok", ())) if not ok) if quad is not None else 0
+            if skip:
+                eng.set_option("tridiag_quad_skip", skip)
+            try:
+                eng.tridiag_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index(), quad_out=quad)
+            finally:
+                if skip:
+                    eng.set_option("tridiag_quad_skip", 0)
             if quad is not None:
                 # the quadratic forms of the launch are the residual statistics of these distributions for the new state:
                 # NormalGamma and log_p take them from here instead of a pass of their own over the state
