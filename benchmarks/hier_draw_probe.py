@@ -53,6 +53,10 @@ def main():
     print("per-chain centre inside the launch + quad  %7.1f us" % timed(lambda: eng.tridiag_sample_canonical(n, incl, x, draw_index=1, quad_out=quad)))
     print("per-chain centre inside the launch, no quad%7.1f us" % timed(lambda: eng.tridiag_sample_canonical(n, incl, x, draw_index=1)))
     print("the route it replaces (4 launches)         %7.1f us" % timed(old_route))
+    eng.set_option("tridiag_generic", 0)  # the shifted smoother (SIG 3) takes this structure
+    print("shifted smoother (SIG 3) + quad            %7.1f us" % timed(lambda: eng.tridiag_sample_canonical(n, incl, x, draw_index=1, quad_out=quad)))
+    print("shifted smoother (SIG 3), no quad          %7.1f us" % timed(lambda: eng.tridiag_sample_canonical(n, incl, x, draw_index=1)))
+    print("plain specialised draw (SIG 1) + quad      %7.1f us" % timed(lambda: eng.tridiag_sample_canonical(n, plain, x, draw_index=1, quad_out=quad)))
     eng.check_status()
 
 

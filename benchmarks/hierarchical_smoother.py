@@ -1,7 +1,8 @@
 """The hierarchical version of the headline model at the headline size: y ~ N(b, (tau I)^-1), b ~ N(m, (lambda P)^-1) with a
 first-order random-walk P, m ~ N(0, (kappa I)^-1); samplers [NormalNormal(b), NormalNormal(m), NormalGamma(lambda),
 NormalGamma(tau)], n = 10 000, 1024 chains, through MCMC.run_mcmc (two Normal-Normal blocks: the sweep is issued sampler by
-sampler, each tridiagonal draw with a per-chain right-hand side).  Prints the time per sweep."""
+sampler; each block's tridiagonal draw is centred at the other block's state, omc_tridiag_terms.center_chain).  Prints the
+time per sweep of the repeated run_mcmc calls (steady state) and of the first call (set-up included: what round 2 quoted)."""
 import os
 import sys
 import time
@@ -39,14 +40,26 @@ def main():
              "a_tau": 1.0, "b_tau": 1.0}
     samplers = [NormalNormal("b", mdl), NormalNormal("m", mdl), NormalGamma("lambda", mdl), NormalGamma("tau", mdl)]
     M = MCMC(state, samplers, model=mdl, n_burn=n_burn, n_iter=n_iter, n_chains=C, seed=3)
+    if os.environ.get("GENERIC"):  # A/B: the generic instantiation instead of the shifted smoother
+        M.engine.set_option("tridiag_generic", 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    M.run_mcmc()
+    M.run_mcmc()  # the first call of a fresh MCMC object: plans, device caches, first touch of the stores, clocks
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / (n_burn + n_iter)
+    first = (time.perf_counter() - t0) / (n_burn + n_iter)
+    M.engine.check_status()
+    best = float("inf")
+    for _ in range(int(os.environ.get("REPEATS", 3))):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        M.run_mcmc()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / (n_burn + n_iter))
+    dt = best
     M.engine.check_status()
     out = M.collect()
-    print(f"n={n} C={C}: {1e3 * dt:.2f} ms per sweep = {C / dt:.0f} chain-updates/s; all finite: "
+    print(f"n={n} C={C}: {1e3 * dt:.2f} ms per sweep = {C / dt:.0f} chain-updates/s (best of the repeated run_mcmc calls; the first call, "
+          f"set-up included, {1e3 * first:.2f} ms per sweep over its {n_burn + n_iter} sweeps); all finite: "
           f"{bool(np.isfinite(out['b']).all() and np.isfinite(out['m']).all())}; tau mean {out['tau'].mean():.2f}, lambda mean {out['lambda'].mean():.1f}")
 
 

@@ -51,6 +51,9 @@
 #ifndef OMC_EARLY_PFQ_AHEAD
 #define OMC_EARLY_PFQ_AHEAD 0  // SIG 2: 1 = the quadratic forms prefetch issued before the forward substitution instead of before the reverse scan (measured: 13.4 against 12.7 us per sweep at 128 chains)
 #endif
+#ifndef OMC_SHIFT_PREFETCH
+#define OMC_SHIFT_PREFETCH 0  // SIG 3: 1 = the chain's centre slice prefetched with the shared centre under the reverse scan (144 spilled bytes)
+#endif
 #ifndef OMC_JOIN_OR_LIB
 #define OMC_JOIN_OR_LIB 0  // 1: the join test through __syncthreads_or (three barriers; A/B builds)
 #endif
@@ -1192,6 +1195,15 @@ static bool is_smoother(const TermsDev& T) {
   return false;
 }
 
+// SIG 3: the smoother whose tridiagonal term carries the per-chain centre (and nothing else differs: no per-chain offsets,
+// identity term with or without a shared centre)
+static bool is_shifted_smoother(const TermsDev& T, const CentreChain& cc) {
+  if (T.n_terms != 2 || !cc.v || cc.k < 0) return false;
+  const int p = cc.k, i = 1 - cc.k;
+  return !T.diag[i] && !T.off[i] && ((T.rhs[i] != nullptr) == (T.center[i] != nullptr)) && T.diag[p] && T.off[p] && !T.rhs[p] &&
+         !T.center[p];
+}
+
 // Register plan per lane (M nodes): Y = b -> l ; W = 1/D -> g -> x (draws are consumed as they are made).
 // The combined diagonal a (then the right-hand side r) lives in the wave's LDS tile.
 template <int M, bool MULTI, int MAXT, int SIG = 0>
@@ -1201,8 +1213,18 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   // as CUs, in-kernel draws: the workgroup of a chain's next sweep sits on an idle CU until the previous sweep's scales
   // arrive, so everything that does not depend on them is done up front (all three vector loads, the buffered draws, the
   // Normal-Gamma standard draws), and the poll of the hand-over line is tight.  Never self-restarting.
+  // SIG 3 (round 3): the smoother whose tridiagonal term is centred at a PER-CHAIN vector c (a hierarchical model's sampled
+  // prior mean, or the sampled field a mean block is conditioned on: omc_tridiag_terms.center_chain on that term).
+  // Evaluated by a shift: x = c + e, where e is the plain smoother's draw for the identity term centred at ys - c --
+  //   Q e = sP P c + sI ys - Q c = sI (ys - c)   --
+  // so the stencil product P c is never formed and all the specialised kernel has to do differently is element-wise: the
+  // right-hand side sI (ys - c), the identity term's quadratic form around ys - c (= (x - ys)'(x - ys) of the shifted x), and
+  // x = c + e on the way out; the tridiagonal term's quadratic form e'Pe IS (x - c)'P(x - c), with the parking scheme intact.
+  // Same conditional law and the same draw for the same z up to rounding (the two right-hand sides are equal in exact
+  // arithmetic).  ys may be absent (zeros).
   constexpr bool SMO = SIG != 0;
   constexpr bool EARLY = SIG == 2;
+  constexpr bool SHIFT = SIG == 3;
   using TM = TileMap<M>;
   constexpr int NWMAX = MAXT / 64;
   __shared__ double lds_tile[NWMAX][64 * (M + 1) + 2];  // + the successor slot of the last row (quad_wg)
@@ -1412,6 +1434,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   const double* const vPo = p_first ? A.T.off[0] : A.T.off[1];
   const double* const vIr = p_first ? A.T.rhs[1] : A.T.rhs[0];
   const double* const vIc = p_first ? A.T.center[1] : A.T.center[0];
+  const double* const vSh = (SHIFT && A.cc.v) ? A.cc.v + cc * A.cc.ld : nullptr;  // SIG 3: this chain's centre vector c
 
   // diagnostic sweep clock: the constant-rate counter at this wave's entry, kept in two scalar registers to its exit
   unsigned long long t_enter = 0ull;
@@ -1796,7 +1819,16 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   if constexpr (SMO) {
     // per-chain offsets (rhs_chain) go through the general fill below; the draws are made ahead in either case
     const bool with_offsets = A.rhs_chain && chain_ok;
-    if (!with_offsets && !EARLY) {  // (SIG 2 asked for the vector at its start)
+    if (SHIFT && !with_offsets && !vIr) {  // SIG 3 without a shared centre: nothing to load, the pair is made plainly
+#pragma unroll
+      for (int t = 0; t < M; ++t) pre[t] = 0.0;
+      if (gen_late && NZB > 2) {
+        double z0, z1;
+        omc_normal_pair(omc_rng_block(nkey_f(), gc, blk0 + 2u), z0, z1);
+        lds_z[wave][4][lane] = z0;
+        lds_z[wave][5][lane] = z1;
+      }
+    } else if (!with_offsets && !EARLY) {  // (SIG 2 asked for the vector at its start)
       const int nvr = wave_valid<M>(wave_u, (int)n);
       const double* base = vIr + wave_u * 64 * M;
       if (gen_late && NZB > 2) {
@@ -1807,6 +1839,16 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         lds_z[wave][5][lane] = z1;
       } else {
         coal_load<M>(pre, base, lane, nvr);
+      }
+    }
+    double csh[SHIFT ? M : 1];  // SIG 3: the chain's centre slice, requested here so that it travels under the next pair of draws
+    if constexpr (SHIFT) {
+      if (!with_offsets) {
+        wave_lds_fence();
+#pragma unroll
+        for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = sI * pre[t];  // (frees `pre`: one vector in flight beside a pair of draws)
+        wave_lds_fence();
+        coal_load<M>(csh, vSh + wave_u * 64 * M, lane, wave_valid<M>(wave_u, (int)n));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1822,7 +1864,15 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       }
     }
     if (!with_offsets) {
-      if constexpr (!EARLY) {  // (SIG 2: Rrow holds the scaled vector since the scales arrived)
+      if constexpr (SHIFT) {  // r = sI (ys - c): the shared part is in the tile already
+        wave_lds_fence();
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+          double* pe = TM::elem(tl, r0, t);
+          *pe = fma(-sI, csh[t], *pe);
+        }
+        wave_lds_fence();
+      } else if constexpr (!EARLY) {  // (SIG 2: Rrow holds the scaled vector since the scales arrived)
         wave_lds_fence();
 #pragma unroll
         for (int t = 0; t < M; ++t) *TM::elem(tl, r0, t) = sI * pre[t];
@@ -1847,6 +1897,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   constexpr int PFQ_LOADS = M + (OMC_PREFETCH_QUAD > 1 ? M - 2 * NZB : 0);  // loads the prefetch puts behind the LDS-DMA
   static_assert(!PFQ || PFQ_LOADS <= 15, "vmcnt immediate");
   double qcp[PFQ ? M : 1], qop[PFQ ? M : 1];
+  double qcc[SHIFT ? M : 1];  // SIG 3: the chain's centre slice in the coalesced mapping (quadratic form's centre, x = c + e)
   bool pfq = false;
   auto issue_pfq = [&]() {
     if constexpr (PFQ) {
@@ -1862,8 +1913,17 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       }
       if (pfq) {
         const int wbase = wave_u * 64 * M;
+        if (!SHIFT || vIc) {
 #pragma unroll
-        for (int t = 0; t < M; ++t) qcp[t] = (vIc + wbase)[(unsigned)(lane + 64 * t)];
+          for (int t = 0; t < M; ++t) qcp[t] = (vIc + wbase)[(unsigned)(lane + 64 * t)];
+        } else {
+#pragma unroll
+          for (int t = 0; t < M; ++t) qcp[t] = 0.0;
+        }
+        if constexpr (SHIFT && OMC_SHIFT_PREFETCH) {
+#pragma unroll
+          for (int t = 0; t < M; ++t) qcc[t] = (vSh + wbase)[(unsigned)(lane + 64 * t)];
+        }
         if (OMC_PREFETCH_QUAD > 1) {
 #pragma unroll
           for (int t = 2 * NZB; t < M; ++t) qop[t] = (vPo + wbase)[(unsigned)(lane + 64 * t)];
@@ -2106,8 +2166,16 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         } else if (PFQ && (pfq || (EARLY && e_partial))) {
 #pragma unroll
           for (int t = 0; t < M; ++t) qc[t] = qcp[t];
+        } else if (SHIFT && !vIc) {
+#pragma unroll
+          for (int t = 0; t < M; ++t) qc[t] = 0.0;
         } else {
           coal_load<M>(qc, vIc + wbase, lane, nvq);
+        }
+        if constexpr (SHIFT) {
+          if (!(PFQ && pfq && OMC_SHIFT_PREFETCH)) coal_load<M>(qcc, vSh + wbase, lane, nv);
+#pragma unroll
+          for (int t = 0; t < M; ++t) qc[t] -= qcc[t];  // the identity term's centre in e-coordinates: ys - c
         }
       }
       double aI = 0.0, aP = aPd;
@@ -2122,7 +2190,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         if (xo) {
 #pragma unroll
           for (int t = 0; t < M; ++t)
-            if (lane + 64 * t < nv) xo[(unsigned)(lane + 64 * t)] = *TM::elem(tl, r0, t);
+            if (lane + 64 * t < nv) xo[(unsigned)(lane + 64 * t)] = SHIFT ? *TM::elem(tl, r0, t) + qcc[t] : *TM::elem(tl, r0, t);
         }
       } else if (nv == 64 * M && park_diag) {  // the diagonal part is in aPd already
 #pragma unroll
@@ -2132,8 +2200,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           aI = fma(a, a, aI);
           aP = fma(2.0 * qo[t] * xn, xv, aP);
           if (xo && !OMC_WHATIF_NOSTORE) {
-            if (OMC_STORE_NT) __builtin_nontemporal_store(xv, &xo[(unsigned)(lane + 64 * t)]);
-            else xo[(unsigned)(lane + 64 * t)] = xv;
+            const double xs = SHIFT ? xv + qcc[t] : xv;  // (SIG 3: x = c + e)
+            if (OMC_STORE_NT) __builtin_nontemporal_store(xs, &xo[(unsigned)(lane + 64 * t)]);
+            else xo[(unsigned)(lane + 64 * t)] = xs;
           }
         }
       } else if (nv == 64 * M) {
@@ -2144,8 +2213,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           aI = fma(a, a, aI);
           aP = fma(fma(2.0 * qo[t], xn, qd[t] * xv), xv, aP);
           if (xo && !OMC_WHATIF_NOSTORE) {
-            if (OMC_STORE_NT) __builtin_nontemporal_store(xv, &xo[(unsigned)(lane + 64 * t)]);
-            else xo[(unsigned)(lane + 64 * t)] = xv;
+            const double xs = SHIFT ? xv + qcc[t] : xv;  // (SIG 3: x = c + e)
+            if (OMC_STORE_NT) __builtin_nontemporal_store(xs, &xo[(unsigned)(lane + 64 * t)]);
+            else xo[(unsigned)(lane + 64 * t)] = xs;
           }
         }
       } else {  // the chain's last wave: nodes beyond n hold finite fill values, their vectors were loaded as 0
@@ -2155,7 +2225,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           const double xv = *pe, xn = *TM::succ(pe, r0, t), a = (lane + 64 * t < nv) ? xv - qc[t] : 0.0;
           aI = fma(a, a, aI);
           aP = fma(fma(2.0 * qo[t], xn, qd[t] * xv), xv, aP);
-          if (xo && lane + 64 * t < nv) xo[(unsigned)(lane + 64 * t)] = xv;
+          if (xo && lane + 64 * t < nv) xo[(unsigned)(lane + 64 * t)] = SHIFT ? xv + qcc[t] : xv;
         }
       }
       acc[0] = p_first ? aP : aI;
@@ -2557,7 +2627,14 @@ static bool launch_seg(omc_ctx* ctx, const TriArgs& A_in) {
     // workgroup-per-chain form: one workgroup per (sweep, chain), or per chain when the workgroups restart themselves
     const int64_t wg_per_chain = A.n_sweeps <= 0 ? 1 : (!A.reenter ? A.n_sweeps : (A.block_sweeps > 0 ? (A.n_sweeps + A.block_sweeps - 1) / A.block_sweeps : 1));
     const unsigned wg_grid = (unsigned)(A.C * wg_per_chain);
-    if (special && SegCfg<M>::SMOOTHER && A.early_draws && !A.reenter && !A.z && !A.zero_z)  // the waiting form (see the kernel)
+    // the shifted smoother (SIG 3): single-sweep launches without per-chain offsets (not the fused sweep: its epilogue's
+    // log-posterior would need the shared centre's terms spelled out for e-coordinates)
+    const bool shifted = SegCfg<M>::SMOOTHER && !ctx->tridiag_generic && is_shifted_smoother(A.T, A.cc) && !A.rhs_chain && !A.fused &&
+                         A.n_sweeps <= 0 && A.n >= 2 && 2 * threads > SegCfg<M>::MAXT;
+    if (shifted)
+      hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT, 3 * SegCfg<M>::SMOOTHER>), dim3(wg_grid), dim3(threads), 0,
+                         ctx->stream, A, threads);
+    else if (special && SegCfg<M>::SMOOTHER && A.early_draws && !A.reenter && !A.z && !A.zero_z)  // the waiting form (see the kernel)
       hipLaunchKernelGGL((k_tridiag_seg<M, true, SegCfg<M>::MAXT, 2 * SegCfg<M>::SMOOTHER>), dim3(wg_grid), dim3(threads), 0,
                          ctx->stream, A, threads);
     else if (special)

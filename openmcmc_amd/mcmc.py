@@ -96,7 +96,8 @@ class MCMC:
             plan = nn.plan(self.state)
         except NotImplementedError:
             return None
-        if plan["kind"] != "tridiag" or plan.get("offsets") or plan.get("chain_rhs") or plan.get("replicated") or plan.get("limits") is not None:
+        if plan["kind"] != "tridiag" or plan.get("offsets") or plan.get("chain_rhs") or plan.get("center_chain") or plan.get("replicated") \
+                or plan.get("limits") is not None:
             return None
         term_of = {}
         for k, key in enumerate(plan["keys"]):

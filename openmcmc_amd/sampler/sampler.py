@@ -286,9 +286,23 @@ class NormalNormal(MCMCSampler):
                 other = cv[1].mean.get_param_list() if cv[0] == "mean" else [cv[1]]
                 if any(key in later for key in other):
                     quad_ok[k] = False
+        # With a per-chain centre on the tridiagonal term the library has a specialised kernel for "that term + a scaled
+        # identity" (the shifted smoother, omc_tridiag.hip SIG 3).  An unscaled term with a CONSTANT diagonal d0 (a Normal prior
+        # N(m0, (d0 I)^-1), say) is that identity with the scalar d0: handed over in that form -- same precision, same right-hand
+        # side; its fused quadratic form then lacks the factor d0, which is put back where the form is cached.
+        quad_factor = [1.0] * len(pieces)
+        if center_chain and not offsets:
+            for k, pc in enumerate(pieces):
+                st = pc["st"]
+                if st.scale_key is None and st.off is None and st.diag is not None and pc.get("chain_vec") is None \
+                        and np.ptp(st.diag) == 0.0 and st.diag[0] > 0.0:
+                    d0 = float(st.diag[0])
+                    cvec = eng.model_cache(pc["dist"], state, st, pc["center"])["center"]
+                    terms[k] = {"diag": None, "off": None, "rhs": cvec, "center": cvec, "scale": eng.full((eng.n_chains,), d0)}
+                    quad_factor[k] = d0
         return {"kind": "tridiag", "n": n, "terms_list": terms, "terms": eng.tridiag_terms(terms, n), "keys": keys,
                 "offsets": offsets, "replicated": any(pc.get("replicated") for pc in pieces), "chain_rhs": chain_rhs,
-                "center_chain": center_chain, "quad_ok": quad_ok}
+                "center_chain": center_chain, "quad_ok": quad_ok, "quad_factor": quad_factor}
 
     def _ragged_plan(self, state, n_max):
         """Small variable-size parameter with a mixture prior (diagonal precision picked by an allocation) and
@@ -466,7 +480,8 @@ class NormalNormal(MCMCSampler):
                 new_state[self.param] = ChainArray(x)
                 for k, key in enumerate(p["keys"]):
                     if p["quad_ok"][k]:
-                        eng.quad_cache_put(self.model[key], quad[k], self.model[key].residual_inputs(new_state))
+                        f = p.get("quad_factor", (1.0,) * len(p["keys"]))[k]
+                        eng.quad_cache_put(self.model[key], quad[k] if f == 1.0 else quad[k] * f, self.model[key].residual_inputs(new_state))
         elif p["kind"] == "band":
             eng.band_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
         elif p.get("mixture_prior") is not None:
