@@ -183,6 +183,26 @@ typedef struct {
  * context's current options (the workgroup-per-chain form of the kernel), else 0.                            */
 int32_t omc_tridiag_takes_center_chain(omc_ctx* ctx, int64_t n);
 
+/* The log-posterior of a sweep in ONE launch: out[c] = host_const + sum over the pieces, in the order given, of
+ *   kind 0  0.5 (n log s_c + mult * logdet - n log 2 pi - s_c quad_c)      Normal.log_p with a scalar x shared-matrix precision
+ *           (location_scale.py:145-167 -> gmrf.py:321-348; quad from omc_*_quadform or a draw's fused form), s = 1 if scale NULL
+ *   kind 1  log Gamma(x_c; shape, rate)                                     Gamma.log_p (distribution.py:241-261)
+ * -- the same arithmetic, piece by piece and in the same order, as omc_scaled_gauss_logpdf / omc_gamma_logpdf called with
+ * accumulate (model.py:57-70 sums the members one after the other).  At most OMC_LOGP_MAX pieces.                          */
+#define OMC_LOGP_MAX 8
+typedef struct {
+  int32_t kind;
+  double n;                /* kind 0: dimension x replicates                       */
+  const double* scale;     /* kind 0: [C] or NULL                                  */
+  const double* logdet;    /* kind 0: device scalar log det M                      */
+  double logdet_mult;      /* kind 0: usually 1 (replicates: their number)         */
+  const double* quad;      /* kind 0: [C]                                          */
+  const double* x;         /* kind 1: [C]                                          */
+  double shape, rate;      /* kind 1                                               */
+} omc_logp_piece;
+omc_status omc_log_post_sum(omc_ctx* ctx, int32_t n_pieces, const omc_logp_piece* pieces /* host */, double host_const,
+                            double* out);
+
 omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
                           const omc_gamma_block* blocks /* [n_terms], host */,
                           const double* rhs_chain, int64_t ld_rhs,

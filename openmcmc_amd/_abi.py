@@ -37,6 +37,13 @@ class TridiagTerms(C.Structure):
     ]
 
 
+class LogpPiece(C.Structure):
+    """omc_logp_piece."""
+
+    _fields_ = [("kind", i32), ("n", C.c_double), ("scale", c_dp), ("logdet", c_dp), ("logdet_mult", C.c_double), ("quad", c_dp),
+                ("x", c_dp), ("shape", C.c_double), ("rate", C.c_double)]
+
+
 class DenseTerms(C.Structure):
     """omc_dense_terms."""
 
@@ -129,6 +136,7 @@ SIGNATURES = {
     ),
     "omc_tridiag_quadform": (i32, [C.c_void_p, i64, C.POINTER(TridiagTerms), c_dp, i64, c_dp]),
     "omc_tridiag_takes_center_chain": (i32, [C.c_void_p, i64]),
+    "omc_log_post_sum": (i32, [C.c_void_p, i32, C.POINTER(LogpPiece), C.c_double, c_dp]),
     "omc_tridiag_matvec": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp]),
     "omc_tridiag_logdet": (i32, [C.c_void_p, i64, c_dp, c_dp, c_dp]),
     "omc_normal_gamma_update": (i32, [C.c_void_p, C.c_double, C.c_double, i64, c_dp, c_dp, u64, c_dp]),

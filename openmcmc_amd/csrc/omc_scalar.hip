@@ -26,6 +26,35 @@ __global__ void k_scaled_gauss_logpdf(int64_t C, double n, const double* scale, 
   out[c] = accumulate ? out[c] + lp : lp;
 }
 
+// omc_log_post_sum: the pieces one after the other, each exactly as its own kernel computes it, summed in order
+struct LogpArgs {
+  int n;
+  omc_logp_piece p[OMC_LOGP_MAX];
+  double lnorm[OMC_LOGP_MAX];
+};
+__global__ void k_log_post_sum(int64_t C, LogpArgs P, double host_const, double* out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < OMC_LOGP_MAX; ++i) {
+    if (i >= P.n) break;
+    const omc_logp_piece& q = P.p[i];
+    double lp;
+    if (q.kind == 0) {
+      const double s = q.scale ? q.scale[c] : 1.0;
+      const double ld = (q.logdet_mult == 1.0) ? q.logdet[0] : q.logdet[0] * q.logdet_mult;
+      lp = 0.5 * (q.n * log(s) + ld - q.n * 1.8378770664093453 - s * q.quad[c]);
+    } else {
+      const double v = q.x[c];
+      lp = (v > 0.0) ? P.lnorm[i] + (q.shape - 1.0) * log(v) - q.rate * v : -INFINITY;
+      if (v == 0.0 && q.shape == 1.0) lp = P.lnorm[i];
+    }
+    acc = (i == 0) ? lp : acc + lp;
+  }
+  out[c] = (host_const != 0.0) ? acc + host_const : acc;
+}
+
 __global__ void k_gamma_logpdf(int64_t C, const double* x, double shape, double rate, double lnorm, double* out,
                                int accumulate) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -181,6 +210,28 @@ omc_status omc_scaled_gauss_logpdf(omc_ctx* ctx, int64_t n, const double* scale,
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(k_scaled_gauss_logpdf, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream,
                      ctx->n_chains, (double)n, scale, logdet_unscaled, quad, out, (int)accumulate);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
+omc_status omc_log_post_sum(omc_ctx* ctx, int32_t n_pieces, const omc_logp_piece* pieces, double host_const, double* out) {
+  if (!ctx || n_pieces < 1 || n_pieces > OMC_LOGP_MAX || !pieces || !out) return OMC_INVALID_ARG;
+  LogpArgs P;
+  P.n = n_pieces;
+  for (int i = 0; i < n_pieces; ++i) {
+    const omc_logp_piece& q = pieces[i];
+    P.p[i] = q;
+    if (q.kind == 0) {
+      if (!q.logdet || !q.quad) return OMC_INVALID_ARG;
+    } else if (q.kind == 1) {
+      if (!q.x || !(q.shape > 0.0) || !(q.rate > 0.0)) return OMC_INVALID_ARG;
+      P.lnorm[i] = q.shape * log(q.rate) - lgamma(q.shape);
+    } else {
+      return OMC_INVALID_ARG;
+    }
+  }
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_log_post_sum, dim3(grid1(ctx->n_chains, 64)), dim3(64), 0, ctx->stream, ctx->n_chains, P, host_const, out);
   OMC_HIP_CHECK(hipGetLastError());
   return OMC_OK;
 }

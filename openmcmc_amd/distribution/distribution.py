@@ -124,6 +124,16 @@ class Gamma(Distribution):
         bc = lambda v: np.broadcast_to(np.asarray(v, dtype=np.float64).reshape(-1), (K,)).copy()  # noqa: E731
         return bc(a), bc(b)
 
+    def log_p_piece(self, state, engine, dry=False):
+        """This distribution's term of Model.log_p as a piece of omc_log_post_sum (a per-chain scalar response), else None."""
+        x = state[self.response]
+        if type(self) is not Gamma or not is_chain(x) or x.size != 1 or x.ragged is not None:
+            return None
+        if dry:
+            return True
+        a, b = self.host_shape_rate(state)
+        return ("gamma", x.scalar(), float(a), float(b))
+
     def log_p(self, state: dict, by_observation: bool = False, engine=None, out=None, accumulate=False):
         """distribution.py:241-261.  Per-chain response -> (C,) tensor via omc_gamma_logpdf; a (1, k) response (ragged or
         not: e.g. the kernel widths of a reversible-jump basis) sums over its live entries."""

@@ -345,6 +345,24 @@ class Normal(Distribution):
             engine.domain_penalty(resp.vector(), out, lower=lo, upper=hi)
         return out
 
+    def log_p_piece(self, state, engine, dry=False):
+        """This distribution's term of Model.log_p as a piece of omc_log_post_sum, or None where log_p does more than the
+        scaled Gaussian formula (mixtures, replicate columns, domain limits on a per-chain response).  dry: only say whether."""
+        if type(self) is not Normal or self.is_mixture or self._column_replicates(state):
+            return None
+        resp = state[self.response]
+        if (self.domain_response_lower is not None or self.domain_response_upper is not None) and is_chain(resp):
+            return None
+        st = self.structure(state)
+        if st.scale_key is not None and not is_chain(state[st.scale_key]):
+            return None
+        if dry:
+            return True
+        quad = self.residual_quad(state, engine, st, replicates=True)
+        scale = state[st.scale_key].scalar() if st.scale_key is not None else None
+        n_rep = 1 if is_chain(resp) else resp.shape[1]
+        return ("gauss", st.n * n_rep, scale, engine.matrix_logdet(st), float(n_rep), quad)
+
     def _domain_device(self, engine, n):
         memo = self.__dict__.setdefault("_domain_memo", {})
         if n not in memo:

@@ -575,6 +575,18 @@ class Engine:
         check(lib.omc_scaled_gauss_logpdf(self._ctx, n, self._chain_scalar(scale), self._p(logdet_unscaled),
                                           self._chain_scalar(quad), self._chain_scalar(out), int(accumulate)))
 
+    def log_post_sum(self, pieces, host_const, out):
+        """omc_log_post_sum.  pieces: ("gauss", n, scale | None, logdet, mult, quad) or ("gamma", x, shape, rate), in order."""
+        arr = (_abi.LogpPiece * len(pieces))()
+        for i, pc in enumerate(pieces):
+            if pc[0] == "gauss":
+                arr[i].kind, arr[i].n = 0, float(pc[1])
+                arr[i].scale, arr[i].logdet, arr[i].logdet_mult = self._chain_scalar(pc[2]), self._p(pc[3]), float(pc[4])
+                arr[i].quad = self._chain_scalar(pc[5])
+            else:
+                arr[i].kind, arr[i].x, arr[i].shape, arr[i].rate = 1, self._chain_scalar(pc[1]), float(pc[2]), float(pc[3])
+        check(lib.omc_log_post_sum(self._ctx, len(pieces), arr, float(host_const), self._chain_scalar(out)))
+
     def gamma_logpdf(self, x, shape, rate, out, accumulate=False):
         check(lib.omc_gamma_logpdf(self._ctx, self._chain_scalar(x), float(shape), float(rate),
                                    self._chain_scalar(out), int(accumulate)))

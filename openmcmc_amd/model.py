@@ -26,6 +26,8 @@ class Model(dict):
         if engine is None:
             raise RuntimeError("Model.log_p needs the engine that holds the chains")
         out = engine.empty(engine.n_chains) if out is None else out
+        if self._log_p_in_one_launch(state, engine, out, members):
+            return out
         first = True
         host_sum = 0.0
         for key, dst in self.items():
@@ -45,6 +47,36 @@ class Model(dict):
             out += host_sum
         return out
 
+
+    def _log_p_in_one_launch(self, state, engine, out, members):
+        """The sum as ONE launch (omc_log_post_sum) when every member that reads per-chain state can hand over its piece -- a
+        Normal with a scalar x shared-matrix precision (its residual quadratic form cached by the draw or computed here), a Gamma
+        on a per-chain scalar -- in the members' order and with each piece's own arithmetic, so the value is the one the
+        member-by-member loop gives.  False: nothing was written, the loop takes over."""
+        import os
+
+        from openmcmc_amd.chains import is_chain
+
+        if os.environ.get("OMC_NO_FUSED_LOGP"):  # (A/B switch)
+            return False
+        device = [dst for key, dst in self.items() if (members is None or key in members)
+                  and any(is_chain(state.get(k)) for k in dst.param_list)]
+        # (one piece: the member's own kernel is the same single launch; eligibility first, before anything is computed)
+        try:
+            if not 2 <= len(device) <= 8 or not all(hasattr(d, "log_p_piece") and d.log_p_piece(state, engine, dry=True) for d in device):
+                return False
+        except NotImplementedError:  # (a structure the member-by-member loop reports in its own words)
+            return False
+        pieces, host_sum = [], 0.0
+        for key, dst in self.items():
+            if members is not None and key not in members:
+                continue
+            if not any(is_chain(state.get(k)) for k in dst.param_list):
+                host_sum += dst.log_p(state)
+            else:
+                pieces.append(dst.log_p_piece(state, engine))
+        engine.log_post_sum(pieces, host_sum, out)
+        return True
 
     def grad_terms(self, state: dict, param: str, engine):
         """(grad (C, p), terms, diag): the members' gradients summed and their Hessians collected as per-chain-scalar x

@@ -209,3 +209,27 @@ def test_hierarchical_smoother_at_size_is_not_slow():
     per = (time.perf_counter() - t0) / 50
     M.engine.check_status()
     assert per < 1.5e-3, f"{1e3 * per:.2f} ms per sweep"
+
+
+def test_log_post_in_one_launch_is_the_member_by_member_sum():
+    """Model.log_p as one launch (omc_log_post_sum: every member's term with its own arithmetic, summed in the members' order)
+    against the loop over the members' own kernels: bit for bit, with the quadratic forms cached by the draws and without."""
+    from openmcmc_amd.model import Model
+
+    rng = np.random.default_rng(3)
+    G = _synthetic(900, rng, n_burn=1, n_iter=2)
+    M, _ = build(G, "s_", 5, seed=2)
+    M.run_mcmc()
+    eng = M.engine
+    fused = M.model.log_p(M.state, engine=eng).cpu().numpy()            # quadratic forms from the draws' cache
+    eng._quad_cache = {}
+    fused_nocache = M.model.log_p(M.state, engine=eng).cpu().numpy()    # ... computed by their own launches
+    orig = Model._log_p_in_one_launch
+    Model._log_p_in_one_launch = lambda self, *a, **k: False
+    try:
+        loop = M.model.log_p(M.state, engine=eng).cpu().numpy()
+    finally:
+        Model._log_p_in_one_launch = orig
+    assert np.array_equal(fused_nocache, loop)
+    assert relerr(fused, loop) < 1e-12  # (the draws' fused forms agree with the stand-alone ones to rounding)
+    assert np.array_equal(M.store["log_post"][-1].cpu().numpy(), fused)
