@@ -54,6 +54,9 @@
 #ifndef OMC_SHIFT_PREFETCH
 #define OMC_SHIFT_PREFETCH 0  // SIG 3: 1 = the chain's centre slice prefetched with the shared centre under the reverse scan (144 spilled bytes)
 #endif
+#ifndef OMC_SHIFT_PARK_C
+#define OMC_SHIFT_PARK_C 1  // SIG 3: the draws' LDS slots take the chain's centre slice (HBM) instead of the off-diagonal slice (L2)
+#endif
 #ifndef OMC_JOIN_OR_LIB
 #define OMC_JOIN_OR_LIB 0  // 1: the join test through __syncthreads_or (three barriers; A/B builds)
 #endif
@@ -1459,8 +1462,11 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   const uint32_t blk0 = (uint32_t)(i0 >> 1);
   const bool gen_z = !A.z && !A.zero_z;
   // SIG 1: may this wave's off-diagonal slice be parked in the draws' LDS slots (see the forward pass)?
-  const bool park_off = OMC_PARK_OFF && SMO && gen_z && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n - 1) == 64 * M &&
-                        (reinterpret_cast<uintptr_t>(vPo) & 15u) == 0;
+  // (SIG 3 parks the chain's own centre slice there instead: that one comes from HBM, the off-diagonal slice from L2)
+  const double* const vPark = (SHIFT && OMC_SHIFT_PARK_C) ? vSh : vPo;
+  const bool park_off = OMC_PARK_OFF && SMO && gen_z && (A.quad || A.fused) &&
+                        wave_valid<M>(wave_u, (int)n - ((SHIFT && OMC_SHIFT_PARK_C) ? 0 : 1)) == 64 * M &&
+                        (reinterpret_cast<uintptr_t>(vPark) & 15u) == 0;
   const bool park_diag = OMC_PARK_DIAG && SMO && (A.quad || A.fused) && wave_valid<M>(wave_u, (int)n) == 64 * M &&
                          (reinterpret_cast<uintptr_t>(vPd) & 15u) == 0;
   // SIG 2, the chain's last (partly empty) wave.  It cannot take the LDS-DMA parking as it stands (the transfers would read
@@ -1926,7 +1932,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         }
         if (OMC_PREFETCH_QUAD > 1) {
 #pragma unroll
-          for (int t = 2 * NZB; t < M; ++t) qop[t] = (vPo + wbase)[(unsigned)(lane + 64 * t)];
+          for (int t = 2 * NZB; t < M; ++t) qop[t] = (vPark + wbase)[(unsigned)(lane + 64 * t)];
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1977,7 +1983,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
             lds_reads_done();
 #pragma unroll
             for (int k = 0; k < NZB; ++k)
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vPo + wave_u * 64 * M + 128 * k + 2 * lane),
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vPark + wave_u * 64 * M + 128 * k + 2 * lane),
                                                (__attribute__((address_space(3))) void*)&lds_z[wave][2 * k][0], 16, 0, 0);
           }
           if constexpr (EARLY) {
@@ -2122,7 +2128,21 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         const int wbase = wave_u * 64 * M;
         const int nvq = want_quad ? nv : 0, nvo = want_quad ? wave_valid<M>(wave_u, (int)n - 1) : 0;
         {
-          if (park_off) {
+          if (park_off && SHIFT && OMC_SHIFT_PARK_C) {  // the parked slice is the chain's centre; the off-diagonal comes from L2
+            const double* zf = &lds_z[wave][0][0];
+            coal_load<M>(qo, vPo + wbase, lane, nvo);
+            __builtin_amdgcn_s_waitcnt(0x0F70 | M);  // the transfers (older than these M loads) have landed
+            wave_lds_fence();
+#pragma unroll
+            for (int t = 0; t < M; ++t)
+              if (t < 2 * NZB) qcc[t] = zf[64 * t + lane];
+#pragma unroll
+            for (int t = 0; t < M; ++t) {
+              if (t < 2 * NZB) continue;
+              if constexpr (PFQ && OMC_PREFETCH_QUAD > 1) qcc[t] = pfq ? qop[t] : (vSh + wbase)[(unsigned)(lane + 64 * t)];
+              else qcc[t] = (vSh + wbase)[(unsigned)(lane + 64 * t)];
+            }
+          } else if (park_off) {
             const double* zf = &lds_z[wave][0][0];
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA has landed (the reverse scan's barrier drained it already)
             wave_lds_fence();
@@ -2173,7 +2193,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           coal_load<M>(qc, vIc + wbase, lane, nvq);
         }
         if constexpr (SHIFT) {
-          if (!(PFQ && pfq && OMC_SHIFT_PREFETCH)) coal_load<M>(qcc, vSh + wbase, lane, nv);
+          if (!(PFQ && pfq && OMC_SHIFT_PREFETCH) && !(park_off && OMC_SHIFT_PARK_C)) coal_load<M>(qcc, vSh + wbase, lane, nv);
 #pragma unroll
           for (int t = 0; t < M; ++t) qc[t] -= qcc[t];  // the identity term's centre in e-coordinates: ys - c
         }

@@ -190,7 +190,7 @@ def test_centres_inside_the_launch_equal_the_separate_launches(n):
 
 
 def test_hierarchical_smoother_at_size_is_not_slow():
-    """A coarse clock on the two-block sweep at the headline size (n = 10 000, 1024 chains; 0.43 ms per sweep when this was
+    """A coarse clock on the two-block sweep at the headline size (n = 10 000, 1024 chains; 0.27 ms per sweep when this was
     written, 0.74 before the centres moved into the launch): a regression by several times -- the generic kernel once
     fell from 110 to 500 us per sweep without any test noticing -- fails here."""
     import time
@@ -202,11 +202,13 @@ def test_hierarchical_smoother_at_size_is_not_slow():
     M, _ = build(G, "s_", 1024, seed=3)
     M.run_mcmc()  # plans, caches, first-use costs
     M.engine.check_status()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    M.run_mcmc()
-    torch.cuda.synchronize()
-    per = (time.perf_counter() - t0) / 50
+    per = float("inf")
+    for _ in range(3):  # (the best of three: a busy host must not fail the suite)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        M.run_mcmc()
+        torch.cuda.synchronize()
+        per = min(per, (time.perf_counter() - t0) / 50)
     M.engine.check_status()
     assert per < 1.5e-3, f"{1e3 * per:.2f} ms per sweep"
 

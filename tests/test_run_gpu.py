@@ -223,10 +223,12 @@ def test_headline_sweep_is_not_slow(generic, limit_us):
     if generic:
         sweep.eng.set_option("tridiag_generic", 1)
     sweep.run_fused(64)  # first-use costs, clocks
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sweep.run_fused(128)
-    torch.cuda.synchronize()
-    per_us = 1e6 * (time.perf_counter() - t0) / 128
+    per_us = float("inf")
+    for _ in range(3):  # (the best of three: a busy host must not fail the suite)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sweep.run_fused(128)
+        torch.cuda.synchronize()
+        per_us = min(per_us, 1e6 * (time.perf_counter() - t0) / 128)
     sweep.eng.check_status()
     assert per_us < limit_us, f"{per_us:.1f} us per sweep"
