@@ -806,72 +806,111 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
     const double* Up = U0 + (hi - 1) * (int64_t)W1 * C;
     double* Xp = Xws + (hi - 1) * C + cc;
     double* Mp = Mws ? Mws + (hi - 1) * C + cc : nullptr;
-    double lb[PD][W1], ub[PD];
+    // A slot keeps what it loaded as it came (combining the responses with the incoming state at the fetch would make the
+    // wave wait for the loads it has just issued) and an injected draw travels with its column's slot: as a load of its
+    // own next to the use it was the youngest load, and the wait the compiler has to put in front of the use -- on both
+    // sides of the branch -- emptied the queue at every column, the generated-draw case included: one memory latency per
+    // column, 2.7 us measured, with the other three columns' loads never in flight.
+    const bool inj = z_in != nullptr;  // uniform
+    double lb[PD][W1], ub[PD][W1], zb[PD];
     auto fetch = [&](int t, int64_t back) {  // column (hi - 1 - back) into slot t
 #pragma unroll
       for (int d = 0; d < W1; ++d) lb[t][d] = Lp[(d - back * W1) * C];
-      double u = Up[(0 - back * W1) * C];
 #pragma unroll
-      for (int k = 0; k < W; ++k) u = fma(Up[(k + 1 - back * W1) * C], din[k], u);  // u = zero-state u + responses . incoming
-      ub[t] = u;
+      for (int k = 0; k < W1; ++k) ub[t][k] = Up[(k - back * W1) * C];
+      if (inj) zb[t] = zrow[hi - 1 - back];
     };
+    const bool long_seg = hi - lo >= 2 * PD;  // uniform; (always, but for the last segment of a short chain)
+    if (long_seg) {
 #pragma unroll
-    for (int t = 0; t < PD; ++t) {
+      for (int t = 0; t < PD; ++t) fetch(t, t);
+    } else {
 #pragma unroll
-      for (int d = 0; d < W1; ++d) lb[t][d] = 0.0;
-      ub[t] = 0.0;
-      if (hi - 1 - t >= lo) fetch(t, t);
+      for (int t = 0; t < PD; ++t) {
+#pragma unroll
+        for (int d = 0; d < W1; ++d) { lb[t][d] = 0.0; ub[t][d] = 0.0; }
+        zb[t] = 0.0;
+        if (hi - 1 - t >= lo) fetch(t, t);
+      }
     }
     double z_even = 0.0;
     bool have_even = false;
     int64_t back0 = 0;
-    for (int64_t jt = hi - 1; jt >= lo; jt -= PD, back0 += PD) {
+    auto column = [&](int t, int64_t j) {  // column j from slot t
+      double u = ub[t][0];
+#pragma unroll
+      for (int k = 0; k < W; ++k) u = fma(ub[t][k + 1], din[k], u);  // u = zero-state u + responses . incoming
+      double z;
+      if (inj) {
+        z = zb[t];
+      } else if ((j & 1) || !have_even) {  // a Philox block gives the draws of columns 2q and 2q+1
+        double n0, n1;
+        omc_normal_pair(omc_rng_block(key, gc, (uint32_t)(j >> 1)), n0, n1);
+        z = (j & 1) ? n1 : n0;
+        z_even = n0;
+        have_even = (j & 1) != 0;
+      } else {
+        z = z_even;
+        have_even = false;
+      }
+      double ax = u + z, am = u, ak[W];
+#pragma unroll
+      for (int k2 = 0; k2 < W; ++k2) ak[k2] = 0.0;
+#pragma unroll
+      for (int d = 1; d < W1; ++d) {
+        ax = fma(-lb[t][d], xs[d], ax);
+        am = fma(-lb[t][d], ms[d], am);
+        if (PHASE == 1) {
+#pragma unroll
+          for (int k2 = 0; k2 < W; ++k2) ak[k2] = fma(-lb[t][d], Xk[k2][d], ak[k2]);
+        }
+      }
+      const double l0 = lb[t][0];
+      const double xv = ax * l0, mv = am * l0;
+#pragma unroll
+      for (int d = W; d > 1; --d) {
+        xs[d] = xs[d - 1]; ms[d] = ms[d - 1];
+#pragma unroll
+        for (int k2 = 0; k2 < W; ++k2) Xk[k2][d] = Xk[k2][d - 1];
+      }
+      xs[1] = xv; ms[1] = mv;
+#pragma unroll
+      for (int k2 = 0; k2 < W; ++k2) Xk[k2][1] = ak[k2] * l0;
+      if (PHASE == 2) {
+        Xp[-(back0 + t) * C] = fail_chain ? NAN : xv;
+        if (Mp) Mp[-(back0 + t) * C] = mv;
+      }
+    };
+    int64_t jt = hi - 1;
+    // whole groups whose columns and refills all lie inside the segment: nothing in the loop but the recurrence and its loads
+    // (the next group's loads go out first and land in a second set of registers, taken over when the group's own four
+    // columns are done: refilling a slot right after its column leaves the last slot's loads no time before the next
+    // group needs ... everything, since the compiler renames the slots by a copy at the loop's end)
+    for (; jt - (2 * PD - 1) >= lo; jt -= PD, back0 += PD) {
+      double lbn[PD][W1], ubn[PD][W1], zbn[PD];
+#pragma unroll
+      for (int t = 0; t < PD; ++t) {
+        const int64_t back = back0 + t + PD;
+#pragma unroll
+        for (int d = 0; d < W1; ++d) lbn[t][d] = Lp[(d - back * W1) * C];
+#pragma unroll
+        for (int k = 0; k < W1; ++k) ubn[t][k] = Up[(k - back * W1) * C];
+        zbn[t] = inj ? zrow[hi - 1 - back] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < PD; ++t) column(t, jt - t);
+#pragma unroll
+      for (int t = 0; t < PD; ++t) {
+#pragma unroll
+        for (int d = 0; d < W1; ++d) { lb[t][d] = lbn[t][d]; ub[t][d] = ubn[t][d]; }
+        zb[t] = zbn[t];
+      }
+    }
+    for (; jt >= lo; jt -= PD, back0 += PD) {
 #pragma unroll
       for (int t = 0; t < PD; ++t) {
         const int64_t j = jt - t;
-        if (j >= lo) {
-          const double u = ub[t];
-          double z;
-          if (zrow) {
-            z = zrow[j];
-          } else if ((j & 1) || !have_even) {  // a Philox block gives the draws of columns 2q and 2q+1
-            double n0, n1;
-            omc_normal_pair(omc_rng_block(key, gc, (uint32_t)(j >> 1)), n0, n1);
-            z = (j & 1) ? n1 : n0;
-            z_even = n0;
-            have_even = (j & 1) != 0;
-          } else {
-            z = z_even;
-            have_even = false;
-          }
-          double ax = u + z, am = u, ak[W];
-#pragma unroll
-          for (int k2 = 0; k2 < W; ++k2) ak[k2] = 0.0;
-#pragma unroll
-          for (int d = 1; d < W1; ++d) {
-            ax = fma(-lb[t][d], xs[d], ax);
-            am = fma(-lb[t][d], ms[d], am);
-            if (PHASE == 1) {
-#pragma unroll
-              for (int k2 = 0; k2 < W; ++k2) ak[k2] = fma(-lb[t][d], Xk[k2][d], ak[k2]);
-            }
-          }
-          const double l0 = lb[t][0];
-          const double xv = ax * l0, mv = am * l0;
-#pragma unroll
-          for (int d = W; d > 1; --d) {
-            xs[d] = xs[d - 1]; ms[d] = ms[d - 1];
-#pragma unroll
-            for (int k2 = 0; k2 < W; ++k2) Xk[k2][d] = Xk[k2][d - 1];
-          }
-          xs[1] = xv; ms[1] = mv;
-#pragma unroll
-          for (int k2 = 0; k2 < W; ++k2) Xk[k2][1] = ak[k2] * l0;
-          if (PHASE == 2) {
-            Xp[-(back0 + t) * C] = fail_chain ? NAN : xv;
-            if (Mp) Mp[-(back0 + t) * C] = mv;
-          }
-        }
+        if (j >= lo) column(t, j);
         if (j - PD >= lo) fetch(t, back0 + t + PD);
       }
     }
@@ -997,12 +1036,27 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
   const int64_t groups = (Cn + 63) / 64;
   BandLaneArgs LP;
   const bool lane_fits = w >= 1 && w <= 8 && ctx->band_algo != 2 && band_lane_args(T, &LP);
-  // Segmented route: about a thousand waves in all, segments of at least 128 columns and at least half the warm-up
+  // Segmented route: segments of at least 96 columns and at least half the warm-up, their number chosen for the SIMDs.
+  // The factor phase is bound by instruction issue, not by latency (measured: 0.5 us a column for a wave alone on its
+  // SIMD, 0.9-1.0 us when two share one), so what counts is (segment + warm-up) x the waves the fullest SIMD gets:
+  // 1664 waves on 1024 SIMDs took as long as 2048 would have.  A small charge per segment stands for what every wave
+  // does once per segment of its group (joins, composition of the incoming states).
   const int ov = ctx->band_seg_overlap;
   int64_t min_seg = ov / 2 > 96 ? ov / 2 : 96;
-  int nseg = (int)(2048 / groups);
-  if (nseg > BSEG_MAX) nseg = BSEG_MAX;
-  if ((int64_t)nseg * min_seg > n) nseg = (int)(n / min_seg);
+  int dev_cus = 256;
+  hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  const int64_t simds = 4 * (int64_t)(dev_cus > 0 ? dev_cus : 256);
+  int nseg = 0;
+  {
+    int64_t best = -1;
+    for (int cand = 2; cand <= BSEG_MAX; ++cand) {
+      const int64_t ms = (n + cand - 1) / cand;
+      if (ms < min_seg) break;
+      const int64_t rounds = (cand * groups + simds - 1) / simds;
+      const int64_t cost = 2 * (ms + ov) * rounds + cand;
+      if (best < 0 || cost < best) { best = cost; nseg = cand; }
+    }
+  }
   const bool segmented = lane_fits && w <= 3 && nseg >= 2 && ctx->band_algo != 1;
   // factor, then per column the zero-state u and its w unit responses (segmented route) / u alone
   const size_t base_doubles = (size_t)Cn * n * (segmented ? 2 * (w + 1) : (w + 2));
