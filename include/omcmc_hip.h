@@ -412,7 +412,9 @@ omc_status omc_store_ragged(omc_ctx* ctx, int64_t width, const double* src, int6
  *            M.diagonal(-d) padded to n); NULL = identity (bw 0);
  *   rhs[k]   [n] shared M_k m_k or NULL;  scale[k] [C] or NULL = 1;
  *   x = Q^{-1} b + L^{-T} z; mean (optional) = Q^{-1} b; logdet (optional) [C] = log det Q_c.
- * Uses a per-context workspace of C * n * (w+1) doubles for the factor.                                      */
+ * x, mean and z_inject are three different arrays (OMC_INVALID_ARG otherwise: the narrow-band route writes rows of
+ * x while other rows' draws are still being read).
+ * Uses a per-context workspace of C * n * (w+1) doubles for the factor (twice that on the segmented route).   */
 typedef struct {
   int32_t n_terms;
   const double* band[OMC_MAX_TERMS];

@@ -490,17 +490,24 @@ __global__ void __launch_bounds__(64) k_band_lane(int64_t C, int64_t chain_offse
 template <int W, int PHASE>
 __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset, int64_t n, BandLaneArgs P, int nseg,
                                                  int64_t mseg, int ov, double tol, const double* z_in, int64_t ld_z,
-                                                 omc_rng_key key, double* Lws, double* Xws, double* Mws, double* scratch,
+                                                 omc_rng_key key, double* Lws, double* x_out, int64_t ld_x, double* mean_out,
+                                                 int64_t ld_mean, double* scratch,
                                                  const int* gate, int* group_flag, double* logdet, long long* bad,
                                                  unsigned long long* n_fallback) {
   constexpr int W1 = W + 1;
   constexpr int NJ = W * (W + 1) / 2;  // window entries that carry eliminated columns' updates: A[b][d] with b + d < W
   constexpr int NF = W * W + W;        // forward map: G (W x W) and g (W)
   constexpr int NB = W * W + 2 * W;    // backward map: H, h (draw) and hm (mean)
-  constexpr int NS = 2 * NJ + NF + NB + 2;  // per (group, segment): start window, end window, G/g, H/h/hm, log-det part, fail
+  // per (group, segment): start window, end window, G/g, H/h/hm, log-det part, fail; then what PHASE 1 leaves for PHASE 2:
+  // the segment's true incoming forward state and (first segment's row only) whether the chain is positive definite
+  constexpr int NS = 2 * NJ + NF + NB + 2 + W + 1;
   constexpr int O_JS = 0, O_JE = NJ, O_F = 2 * NJ, O_B = 2 * NJ + NF, O_LD = 2 * NJ + NF + NB, O_FAIL = O_LD + 1;
+  constexpr int O_DIN = O_FAIL + 1, O_CF = O_DIN + W;
+  static_assert(NS <= 48, "scratch rows are allocated 48 entries long");
   __shared__ double stage_all[2 * (W1 + OMC_MAX_TERMS) * 64];
   __shared__ double rc_tile[PHASE == 0 ? BSEG_RC : 1][64];  // per-chain right-hand side of the current BSEG_RC columns
+  // PHASE 2: the results of 32 columns x 64 chains on their way to the caller's chain-major rows (256 B of a row at a time)
+  __shared__ double out_x[PHASE == 2 ? 32 : 1][65], out_m[PHASE == 2 ? 32 : 1][65];
   const int lane = threadIdx.x, seg = blockIdx.x;
   const int64_t grp = blockIdx.y;
   // second attempt with a longer warm-up: only the groups whose joins did not close the first time (gate is what the
@@ -713,55 +720,69 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
     sput(seg, O_FAIL, fail ? 1.0 : 0.0);
     return;
   } else {
-    // ---- joins of the whole group (every wave looks at all of them: the group goes to k_band_lane as a whole)
+    // ---- joins of the whole group: the first segment's wave of PHASE 1 looks at all of them and leaves the verdict (the
+    // group goes to a longer warm-up, then to k_band_lane, as a whole).  The other waves of PHASE 1 do not wait for it:
+    // what they compute for a group that is redone is simply not used, and PHASE 2 reads the verdict.  (Every wave of
+    // both phases used to repeat this loop -- 8 loads a segment, a third of the phases' time between them.)
     // (no short-circuits and a fixed unroll: the loads of eight segments go out together -- one at a time this loop is
     // 64 round trips to memory, longer than the segment's own work)
-    bool okj = true, failed = false;
-#pragma unroll 8
-    for (int sg = 0; sg < nseg; ++sg) {
-      failed |= sget(sg, O_FAIL) != 0.0;
-      const int nx = (sg + 1 < nseg) ? sg + 1 : sg;  // the last segment compares its own start with itself... skipped below
-      const double scale = fabs(sget(sg, O_JE));
-      bool good = true;
-#pragma unroll
-      for (int e = 0; e < NJ; ++e) good &= fabs(sget(nx, O_JS + e) - sget(sg, O_JE + e)) <= tol * scale;
-      okj &= good | (sg + 1 >= nseg);
-    }
-    const bool chain_bad = live && !failed && !okj;  // (a chain that is not positive definite is reported, not retried)
-    if (__builtin_amdgcn_readfirstlane((int)(__ballot(chain_bad) != 0ull))) {
-      if (PHASE == 1 && seg == 0 && lane == 0) {
-        group_flag[grp] = 1;
-        atomicAdd(n_fallback, 1ull);  // first attempt: a retry; second attempt: a group handed to k_band_lane
-      }
-      return;
-    }
-    if (PHASE == 1 && seg == 0) {
-      if (lane == 0) group_flag[grp] = 0;
-      if (live) {
-        if (logdet) {
-          double t = 0.0;
-          for (int sg = 0; sg < nseg; ++sg) t += sget(sg, O_LD);
-          logdet[c] = t;
-        }
-        if (failed) atomicMin((unsigned long long*)bad, (unsigned long long)c);
-      }
-    }
-    // ---- the segment's true incoming forward state
+    bool failed = false;
     double din[W];
 #pragma unroll
     for (int b = 0; b < W; ++b) din[b] = 0.0;
+    if (PHASE == 1) {
+      if (seg == 0) {
+        bool okj = true;
 #pragma unroll 8
-    for (int sg = 0; sg < seg; ++sg) {
-      double nx[W];
+        for (int sg = 0; sg < nseg; ++sg) {
+          failed |= sget(sg, O_FAIL) != 0.0;
+          const int nx = (sg + 1 < nseg) ? sg + 1 : sg;  // the last segment compares its own start with itself... skipped below
+          const double scale = fabs(sget(sg, O_JE));
+          bool good = true;
 #pragma unroll
-      for (int b = 0; b < W; ++b) {
-        double a = sget(sg, O_F + W * W + b);
+          for (int e = 0; e < NJ; ++e) good &= fabs(sget(nx, O_JS + e) - sget(sg, O_JE + e)) <= tol * scale;
+          okj &= good | (sg + 1 >= nseg);
+        }
+        const bool chain_bad = live && !failed && !okj;  // (a chain that is not positive definite is reported, not retried)
+        if (__builtin_amdgcn_readfirstlane((int)(__ballot(chain_bad) != 0ull))) {
+          if (lane == 0) {
+            group_flag[grp] = 1;
+            atomicAdd(n_fallback, 1ull);  // first attempt: a retry; second attempt: a group handed to k_band_lane
+          }
+          return;
+        }
+        if (lane == 0) group_flag[grp] = 0;
+        sput(0, O_CF, failed ? 1.0 : 0.0);
+        if (live) {
+          if (logdet) {
+            double t = 0.0;
+            for (int sg = 0; sg < nseg; ++sg) t += sget(sg, O_LD);
+            logdet[c] = t;
+          }
+          if (failed) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+        }
+      }
+      // ---- the segment's true incoming forward state (kept for PHASE 2)
+#pragma unroll 8
+      for (int sg = 0; sg < seg; ++sg) {
+        double nx[W];
 #pragma unroll
-        for (int k = 0; k < W; ++k) a = fma(sget(sg, O_F + k * W + b), din[k], a);
-        nx[b] = a;
+        for (int b = 0; b < W; ++b) {
+          double a = sget(sg, O_F + W * W + b);
+#pragma unroll
+          for (int k = 0; k < W; ++k) a = fma(sget(sg, O_F + k * W + b), din[k], a);
+          nx[b] = a;
+        }
+#pragma unroll
+        for (int b = 0; b < W; ++b) din[b] = nx[b];
       }
 #pragma unroll
-      for (int b = 0; b < W; ++b) din[b] = nx[b];
+      for (int b = 0; b < W; ++b) sput(seg, O_DIN + b, din[b]);
+    } else {
+      if (group_flag[grp]) return;
+      failed = sget(0, O_CF) != 0.0;
+#pragma unroll
+      for (int b = 0; b < W; ++b) din[b] = sget(seg, O_DIN + b);
     }
     // ---- its incoming backward state (PHASE 2): composed from the last segment down
     const bool last = seg == nseg - 1;
@@ -804,8 +825,28 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
     const double* zrow = z_in ? z_in + cc * ld_z : nullptr;
     const double* Lp = L0 + (hi - 1) * (int64_t)W1 * C;
     const double* Up = U0 + (hi - 1) * (int64_t)W1 * C;
-    double* Xp = Xws + (hi - 1) * C + cc;
-    double* Mp = Mws ? Mws + (hi - 1) * C + cc : nullptr;
+    // (PHASE 2 writes the caller's rows itself: a column's 64 results go to an LDS tile, and a tile of 32 columns -- aligned
+    // in the row, so that neighbouring segments share no 128-byte line but the one their border cuts -- leaves as 64
+    // pieces of 256 B.  The [column][chain] copy and its transpose launch, 82 MB each way per array, are gone.)
+    int64_t out_blk = (hi - 1) >> 5;
+    auto flush_tile = [&](int64_t blk) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int64_t col = blk * 32 + (lane & 31);
+      const bool col_ok = col >= lo && col < hi;
+#pragma unroll 4
+      for (int it = 0; it < 32; ++it) {
+        const int r = 2 * it + (lane >> 5);
+        if (col_ok && c0 + r < C) {
+          x_out[(c0 + r) * ld_x + col] = out_x[lane & 31][r];
+          if (mean_out) mean_out[(c0 + r) * ld_mean + col] = out_m[lane & 31][r];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     // A slot keeps what it loaded as it came (combining the responses with the incoming state at the fetch would make the
     // wave wait for the loads it has just issued) and an injected draw travels with its column's slot: as a load of its
     // own next to the use it was the youngest load, and the wait the compiler has to put in front of the use -- on both
@@ -877,8 +918,12 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
 #pragma unroll
       for (int k2 = 0; k2 < W; ++k2) Xk[k2][1] = ak[k2] * l0;
       if (PHASE == 2) {
-        Xp[-(back0 + t) * C] = fail_chain ? NAN : xv;
-        if (Mp) Mp[-(back0 + t) * C] = mv;
+        if ((j >> 5) != out_blk) {  // uniform
+          flush_tile(out_blk);
+          out_blk = j >> 5;
+        }
+        out_x[j & 31][lane] = fail_chain ? NAN : xv;
+        if (mean_out) out_m[j & 31][lane] = mv;
       }
     };
     int64_t jt = hi - 1;
@@ -914,6 +959,7 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
         if (j - PD >= lo) fetch(t, back0 + t + PD);
       }
     }
+    if (PHASE == 2) flush_tile(out_blk);
     if (PHASE == 1) {
       int e = 0;
 #pragma unroll
@@ -925,24 +971,6 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
 #pragma unroll
       for (int b = 0; b < W; ++b) sput(seg, O_B + e++, ms[b + 1]);
     }
-  }
-}
-
-// [column][chain] -> the caller's chain-major rows
-__global__ void __launch_bounds__(256) k_band_transpose(int64_t C, int64_t n, const double* src, double* dst, int64_t ld,
-                                                        const int* group_flag) {
-  __shared__ double tile[64][65];
-  if (group_flag && group_flag[blockIdx.y]) return;  // this group's rows were written by k_band_lane
-  const int64_t j0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int r = ty; r < 64; r += 4) {
-    const int64_t j = j0 + r, c = c0 + tx;
-    tile[r][tx] = (j < n && c < C) ? src[j * C + c] : 0.0;
-  }
-  __syncthreads();
-  for (int r = ty; r < 64; r += 4) {
-    const int64_t c = c0 + r, j = j0 + tx;
-    if (c < C && j < n) dst[c * ld + j] = tile[tx][r];
   }
 }
 
@@ -1060,7 +1088,7 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
   const bool segmented = lane_fits && w <= 3 && nseg >= 2 && ctx->band_algo != 1;
   // factor, then per column the zero-state u and its w unit responses (segmented route) / u alone
   const size_t base_doubles = (size_t)Cn * n * (segmented ? 2 * (w + 1) : (w + 2));
-  const size_t seg_doubles = segmented ? 2 * (size_t)Cn * n + (size_t)groups * nseg * 48 * 64 + 2 * (size_t)groups : 0;
+  const size_t seg_doubles = segmented ? (size_t)groups * nseg * 48 * 64 + 2 * (size_t)groups : 0;
   const size_t rt_doubles = (lane_fits && rhs_chain) ? (size_t)n * groups * 64 : 0;  // the per-chain right-hand side, transposed
   omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->workspace, &ctx->workspace_bytes,
                                    (base_doubles + seg_doubles + rt_doubles) * sizeof(double));
@@ -1077,9 +1105,7 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
     const int64_t mseg = (n + nseg - 1) / nseg;
     while ((int64_t)(nseg - 1) * mseg >= n) --nseg;  // no empty segment
     double* Lws = ctx->workspace;
-    double* Xws = ctx->workspace + base_doubles;
-    double* Mws = mean ? Xws + (size_t)Cn * n : nullptr;
-    double* scratch = Xws + 2 * (size_t)Cn * n;
+    double* scratch = ctx->workspace + base_doubles;
     int* flags = (int*)(scratch + (size_t)groups * nseg * 48 * 64);
     const omc_rng_key lane_key = omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL);
     const double tol = 1e-13;
@@ -1090,7 +1116,8 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
     const int ov2 = 4 * ov;  // second attempt for the groups whose joins did not close (a long-memory prior): 4 x the warm-up
 #define OMC_BSEG(Wv, PH, OV, GATE, FLAG, CNT)                                                                                     \
   hipLaunchKernelGGL((k_band_seg<Wv, PH>), sg, dim3(64), 0, ctx->stream, Cn, ctx->chain_offset, n, LP, nseg, mseg, OV, tol,       \
-                     z_inject, ld_z, lane_key, Lws, Xws, Mws, scratch, (const int*)(GATE), FLAG, logdet, ctx->d_bad_chain, CNT)
+                     z_inject, ld_z, lane_key, Lws, x, ld_x, mean, ld_mean, scratch, (const int*)(GATE), FLAG, logdet,           \
+                     ctx->d_bad_chain, CNT)
 #define OMC_BSEG_ALL(Wv)                                                                                                          \
   do {                                                                                                                            \
     OMC_BSEG(Wv, 0, ov, nullptr, flag1, ctx->d_fallbacks + 3);                                                                    \
@@ -1104,9 +1131,6 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
 #undef OMC_BSEG_ALL
 #undef OMC_BSEG
     flags = flag2;
-    const dim3 tg((unsigned)((n + 63) / 64), (unsigned)groups);
-    hipLaunchKernelGGL(k_band_transpose, tg, dim3(256), 0, ctx->stream, Cn, n, Xws, x, ld_x, flags);
-    if (mean) hipLaunchKernelGGL(k_band_transpose, tg, dim3(256), 0, ctx->stream, Cn, n, Mws, mean, ld_mean, flags);
     // groups whose joins did not close: in one piece (the kernel returns at once for the others)
     if (w == 1) launch_band_lane<1>(ctx, n, LP, z_inject, ld_z, lane_key, x, ld_x, mean, ld_mean, logdet, flags);
     else if (w == 2) launch_band_lane<2>(ctx, n, LP, z_inject, ld_z, lane_key, x, ld_x, mean, ld_mean, logdet, flags);
