@@ -733,9 +733,11 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
     if (PHASE == 1) {
       if (seg == 0) {
         bool okj = true;
+        double ld_sum = 0.0;  // (summed in this loop: a loop of its own was 64 round trips to memory one after the other)
 #pragma unroll 8
         for (int sg = 0; sg < nseg; ++sg) {
           failed |= sget(sg, O_FAIL) != 0.0;
+          ld_sum += sget(sg, O_LD);
           const int nx = (sg + 1 < nseg) ? sg + 1 : sg;  // the last segment compares its own start with itself... skipped below
           const double scale = fabs(sget(sg, O_JE));
           bool good = true;
@@ -754,11 +756,7 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
         if (lane == 0) group_flag[grp] = 0;
         sput(0, O_CF, failed ? 1.0 : 0.0);
         if (live) {
-          if (logdet) {
-            double t = 0.0;
-            for (int sg = 0; sg < nseg; ++sg) t += sget(sg, O_LD);
-            logdet[c] = t;
-          }
+          if (logdet) logdet[c] = ld_sum;
           if (failed) atomicMin((unsigned long long*)bad, (unsigned long long)c);
         }
       }
