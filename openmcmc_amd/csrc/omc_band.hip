@@ -1045,7 +1045,8 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
                                      uint64_t draw_index, double* x, int64_t ld_x, double* mean, int64_t ld_mean,
                                      double* logdet) {
   if (!ctx || n < 1 || w < 0 || w > BAND_WMAX || !terms || terms->n_terms < 1 || terms->n_terms > OMC_MAX_TERMS || !x ||
-      ld_x < n || (rhs_chain && ld_rhs < n) || (z_inject && ld_z < n) || (mean && ld_mean < n))
+      ld_x < n || (rhs_chain && ld_rhs < n) || (z_inject && ld_z < n) || (mean && ld_mean < n) || x == mean ||
+      (z_inject && (z_inject == x || z_inject == mean)))
     return OMC_INVALID_ARG;
   BandTermsDev T;
   T.n_terms = terms->n_terms;

@@ -140,3 +140,58 @@ def test_per_chain_right_hand_side_on_the_lane_routes(n, C, order, algo):
     Q = lam_c[c] * P.toarray() + tau_c[c] * np.eye(n)
     mu = np.linalg.solve(Q, tau_c[c] * y + rc[c])
     assert np.abs(out[algo][1][c] - mu).max() < 1e-8 * max(1.0, np.abs(mu).max())
+
+
+def _engine_terms(n, C, order, lam=100.0, seed=0):
+    from openmcmc_amd.engine import Engine
+
+    rng = np.random.default_rng(seed)
+    eng = Engine(C, seed=4)
+    _, band = rw_band(n, order)
+    t = np.arange(n) * 60.0 / n
+    y = np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + rng.standard_normal(n)
+    terms = [{"band": eng.to_device(band), "scale": eng.to_device(lam * (0.5 + rng.random(C)))},
+             {"rhs": eng.to_device(y), "scale": eng.to_device(0.5 + rng.random(C))}]
+    return eng, eng.band_terms(terms, n), rng
+
+
+@pytest.mark.parametrize("n,C,order", [(5000, 70, 2), (3001, 129, 1)])
+def test_rows_with_a_stride_keep_their_padding(n, C, order):
+    """PHASE 2 writes the caller's rows itself (aligned tiles of 32 columns): rows longer than n, segment borders that cut
+    a tile, a last group of fewer than 64 chains -- same numbers as into contiguous rows, nothing outside [0, n) touched."""
+    eng, T, rng = _engine_terms(n, C, order)
+    z = eng.to_device(rng.standard_normal((C, n)))
+    x0, m0 = eng.empty(C, n), eng.empty(C, n)
+    eng.band_sample_canonical(n, T, x0, z=z, mean_out=m0)
+    pad = 37
+    X, M = eng.full((C, n + pad), -7.0), eng.full((C, n + pad), -9.0)
+    eng.band_sample_canonical(n, T, X[:, :n], z=z, mean_out=M[:, :n])
+    eng.check_status()
+    assert eng.counter("band_join_fallbacks") == 0
+    assert np.array_equal(X[:, :n].cpu().numpy(), x0.cpu().numpy())
+    assert np.array_equal(M[:, :n].cpu().numpy(), m0.cpu().numpy())
+    assert (X[:, n:] == -7.0).all().item() and (M[:, n:] == -9.0).all().item()
+    eng.close()
+
+
+def test_the_draws_may_not_be_the_output_array():
+    """(rows of x are written while other rows' draws are still being read: include/omcmc_hip.h)"""
+    eng, T, rng = _engine_terms(600, 8, 2)
+    x = eng.to_device(rng.standard_normal((8, 600)))
+    with pytest.raises(ValueError):
+        eng.band_sample_canonical(600, T, x, z=x)
+    with pytest.raises(ValueError):
+        eng.band_sample_canonical(600, T, x, mean_out=x)
+    eng.close()
+
+
+def test_full_size_draw_equals_the_one_piece_kernel():
+    """RW2 at the headline's size (n = 10 000, 1024 chains: sixteen groups, one wave per SIMD) against the one-lane-per-chain
+    kernel in one piece, generated draws."""
+    xs, ms, ls, fb, _ = draw(10000, 1024, 2, 100.0, 1.0, 0, inject=False)
+    x1, m1, l1, fb1, _ = draw(10000, 1024, 2, 100.0, 1.0, 1, inject=False)
+    assert fb == 0 and fb1 == 0
+    scale = np.abs(x1).max()
+    assert np.abs(xs - x1).max() < 1e-10 * scale
+    assert np.abs(ms - m1).max() < 1e-10 * scale
+    assert np.abs(ls - l1).max() < 1e-9 * np.abs(l1).max()
