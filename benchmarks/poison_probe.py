@@ -30,7 +30,8 @@ if "nanempty" in sys.argv:  # every uninitialised float64 allocation comes back 
     torch.empty, torch.empty_like = empty, empty_like
 if "bandtests" in sys.argv:
     import pytest
-    pytest.main(["-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_band_seg_gpu.py")])
+    pytest.main(["-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_band_seg_gpu.py"),
+                 os.path.join(root, "tests", "test_band_gpu.py"), os.path.join(root, "tests", "test_hier_gpu.py"), "-k", "not at_size"])
 for a in sys.argv[1:]:
     if a.startswith("band") and a[4:].isdigit():
         out = B.draw(10000, 1024, 2, 100.0, 1.0, int(a[4:]), inject=False)
@@ -39,12 +40,25 @@ rng = np.random.default_rng(1)
 G = T._synthetic(10000, rng, n_burn=20, n_iter=30)
 M, _ = T.build(G, "s_", 1024, seed=3)
 eng = M.engine
-for rep in range(4):
+for a in sys.argv[1:]:
+    if a.startswith("opt:"):
+        name, val = a[4:].split("=")
+        eng.set_option(name, int(val))
+        print("option", name, val)
+for rep in range(int(os.environ.get("RUNS", "4"))):
     try:
         M.run_mcmc()
         print("run", rep, "status ok", flush=True)
     except Exception as e:
         print("run", rep, "FAILED", type(e).__name__, e, flush=True)
+        for key in ("lambda", "tau"):
+            if key in M.state:
+                v = M.state[key]
+                v = v.data if hasattr(v, "data") and not isinstance(v, torch.Tensor) else v
+                if isinstance(v, torch.Tensor):
+                    w = v.reshape(-1).cpu().numpy()
+                    print("   state", key, "chain 773:", w[773] if w.size > 773 else None, "non-finite:", np.flatnonzero(~np.isfinite(w))[:8],
+                          "non-positive:", np.flatnonzero(w <= 0)[:8])
         break
 for name in ("tridiag_join_fallbacks", "run_handoff_timeouts", "band_join_fallbacks", "band_join_retries"):
     try:

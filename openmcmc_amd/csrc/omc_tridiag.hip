@@ -2067,8 +2067,12 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
     if (SMO && park_diag) {
       // the LDS-DMA has landed: vector-memory operations retire in order, so it is enough that no more than the prefetch
       // loads issued BEHIND it are still out (they are not needed before the quadratic forms)
+      // (SIG 3 without a shared centre issues NO prefetch loads -- issue_pfq sets the slice to zero --, and then "at most
+      // PFQ_LOADS still out" says nothing about the transfer: the diagonal was read before it had landed now and then, and
+      // the late transfer overwrote the x this wave had meanwhile put into the tile.  One chain in a few thousand sweeps of
+      // the hierarchical smoother at n = 10 000 x 1024 chains, found by benchmarks/determinism_hier.py.)
       if (!diag_staged) {
-        if (PFQ && pfq && !(EARLY && OMC_EARLY_PFQ_AHEAD)) __builtin_amdgcn_s_waitcnt(0x0F70 | PFQ_LOADS);
+        if (PFQ && pfq && (!SHIFT || vIc) && !(EARLY && OMC_EARLY_PFQ_AHEAD)) __builtin_amdgcn_s_waitcnt(0x0F70 | PFQ_LOADS);
         else __builtin_amdgcn_s_waitcnt(0x0F70);
       }
       wave_lds_fence();
