@@ -10,11 +10,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=10000); ap.add_argument("--chains", type=int, default=1024)
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--w", type=int, default=2)
 ap.add_argument("--overlap", type=int, default=0); ap.add_argument("--algo", type=int, default=0)
+ap.add_argument("--segments", type=int, default=0)
 a = ap.parse_args()
 from openmcmc_amd.engine import Engine
 n, C = a.n, a.chains
 eng = Engine(C, seed=2)
 eng.set_option("band_algo", a.algo)
+if a.segments:
+    eng.set_option("band_seg_count", a.segments)
 if a.overlap:
     eng.set_option("band_seg_overlap", a.overlap)
 rng = np.random.default_rng(0)
@@ -37,4 +40,4 @@ for i in range(a.steps):
     eng.band_sample_canonical(n, T, x, draw_index=3 + i)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
 print(json.dumps({"workload": f"band draw RW{a.w} n={n} chains={C}", "ms_per_draw": 1e3 * dt, "chain_updates_per_s": C / dt,
-                  "join_fallbacks": eng.counter("band_join_fallbacks"), "overlap": a.overlap or 192}))
+                  "join_fallbacks": eng.counter("band_join_fallbacks"), "overlap": a.overlap or 192, "segments": a.segments or "auto"}))

@@ -1084,6 +1084,7 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
       if (best < 0 || cost < best) { best = cost; nseg = cand; }
     }
   }
+  if (ctx->band_seg_count >= 2 && (int64_t)ctx->band_seg_count * 8 <= n) nseg = ctx->band_seg_count;
   const bool segmented = lane_fits && w <= 3 && nseg >= 2 && ctx->band_algo != 1;
   // factor, then per column the zero-state u and its w unit responses (segmented route) / u alone
   const size_t base_doubles = (size_t)Cn * n * (segmented ? 2 * (w + 1) : (w + 2));
