@@ -486,6 +486,8 @@ __global__ void __launch_bounds__(64) k_band_lane(int64_t C, int64_t chain_offse
 // acknowledgement per step.  Natural-order Cholesky throughout: the factor, u = L^-1 b and x = L^-T (u + z) are
 // k_band_lane's to rounding (the updates of a column are added in another order).
 #define BSEG_MAX 128
+#define BSEG_BS 8      // segments per block (two-level composition of the incoming states)
+#define BSEG_BROW 32   // scratch entries per block: forward map (W*W + W), backward map (W*W + 2 W)
 #define BSEG_RC 32  // columns per staged piece of a per-chain right-hand side
 template <int W, int PHASE>
 __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset, int64_t n, BandLaneArgs P, int nseg,
@@ -493,7 +495,7 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
                                                  omc_rng_key key, double* Lws, double* x_out, int64_t ld_x, double* mean_out,
                                                  int64_t ld_mean, double* scratch,
                                                  const int* gate, int* group_flag, double* logdet, long long* bad,
-                                                 unsigned long long* n_fallback) {
+                                                 unsigned long long* n_fallback, int* blk_count) {
   constexpr int W1 = W + 1;
   constexpr int NJ = W * (W + 1) / 2;  // window entries that carry eliminated columns' updates: A[b][d] with b + d < W
   constexpr int NF = W * W + W;        // forward map: G (W x W) and g (W)
@@ -503,6 +505,8 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
   constexpr int NS = 2 * NJ + NF + NB + 2 + W + 1;
   constexpr int O_JS = 0, O_JE = NJ, O_F = 2 * NJ, O_B = 2 * NJ + NF, O_LD = 2 * NJ + NF + NB, O_FAIL = O_LD + 1;
   constexpr int O_DIN = O_FAIL + 1, O_CF = O_DIN + W;
+  constexpr int O_BV = 2 * W * W + 3 * W;  // block rows: forward map, backward map, then joins ok / failed / log-det part
+  static_assert(O_BV + 3 <= BSEG_BROW, "block scratch row");
   static_assert(NS <= 48, "scratch rows are allocated 48 entries long");
   __shared__ double stage_all[2 * (W1 + OMC_MAX_TERMS) * 64];
   __shared__ double rc_tile[PHASE == 0 ? BSEG_RC : 1][64];  // per-chain right-hand side of the current BSEG_RC columns
@@ -517,7 +521,39 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
   const int64_t c = c0 + lane;
   const bool live = c < C;
   const int64_t cc = live ? c : C - 1;
-  double* sc = scratch + grp * (int64_t)nseg * NS * 64;  // [seg][entry][lane]
+  // Segments in blocks of BSEG_BS: the LAST wave of a block to finish a phase composes the block's map from its segments'
+  // maps (one batch of loads) and leaves it behind the segments' rows; a wave of the next phase then walks over whole
+  // blocks and over the segments of its own block only.  Every wave walking over every segment before (or behind) it read
+  // O(segments^2) rows of this scratch -- 100 MB per phase at 64 segments and 1024 chains, a quarter of the factor's own
+  // bytes, out of L2/MALL, and the longest walk set the phase's length.
+  const int nblk = (nseg + BSEG_BS - 1) / BSEG_BS;
+  double* sc = scratch + grp * ((int64_t)nseg * NS + (int64_t)nblk * BSEG_BROW) * 64;  // [seg][entry][lane], then [block][entry][lane]
+  double* bsc = sc + (int64_t)nseg * NS * 64;
+  auto bput = [&](int bk, int e, double v) { bsc[((int64_t)bk * BSEG_BROW + e) * 64 + lane] = v; };
+  auto bget = [&](int bk, int e) -> double { return bsc[((int64_t)bk * BSEG_BROW + e) * 64 + lane]; };
+  // The rows the last wave of a block reads from its fellows go out as agent-scope (write-through) stores and come in as
+  // agent-scope loads: a release FENCE at agent scope writes the whole L2 back -- the factor's half gigabyte sits there
+  // dirty -- and 1024 waves doing that at their ends cost 40-70 us per phase (measured, twice).
+  auto sput_ag = [&](int sg, int e, double v) {
+    __hip_atomic_store((unsigned long long*)&sc[((int64_t)sg * NS + e) * 64 + lane], (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto sget_ag = [&](int sg, int e) -> double {
+    return __longlong_as_double((long long)__hip_atomic_load((unsigned long long*)&sc[((int64_t)sg * NS + e) * 64 + lane],
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  };
+  // has every other wave of this wave's block finished the phase?  (counters zeroed per launch by the host)
+  auto last_of_block = [&](int bk) -> bool {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's write-through rows are at their destination
+    const int members = (bk + 1) * BSEG_BS <= nseg ? BSEG_BS : nseg - bk * BSEG_BS;
+    int last_one = 0;
+    if (lane == 0)
+      last_one = __hip_atomic_fetch_add(&blk_count[grp * nblk + bk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1;
+    if (!__builtin_amdgcn_readfirstlane(last_one)) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
+  };
   auto sput = [&](int sg, int e, double v) { sc[((int64_t)sg * NS + e) * 64 + lane] = v; };
   auto sget = [&](int sg, int e) -> double { return sc[((int64_t)sg * NS + e) * 64 + lane]; };
   const double sb = P.s_band ? P.s_band[cc] : 1.0;
@@ -636,7 +672,7 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
         for (int b = 0; b < W; ++b)
 #pragma unroll
           for (int d = 0; d < W; ++d)
-            if (b + d < W) sput(seg, O_JS + e++, A[b][d]);
+            if (b + d < W) sput_ag(seg, O_JS + e++, A[b][d]);
       }
       const double pivot = A[0][0];
       const bool ok = pivot > 0.0;
@@ -708,16 +744,87 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
     for (int b = 0; b < W; ++b)
 #pragma unroll
       for (int d = 0; d < W; ++d)
-        if (b + d < W) sput(seg, O_JE + e++, A[b][d]);
+        if (b + d < W) sput_ag(seg, O_JE + e++, A[b][d]);
     e = 0;
 #pragma unroll
     for (int k = 0; k < W; ++k)
 #pragma unroll
-      for (int b = 0; b < W; ++b) sput(seg, O_F + e++, E[k][b]);  // d(out state b) / d(in state k)
+      for (int b = 0; b < W; ++b) sput_ag(seg, O_F + e++, E[k][b]);  // d(out state b) / d(in state k)
 #pragma unroll
-    for (int b = 0; b < W; ++b) sput(seg, O_F + e++, Rc[b]);
-    sput(seg, O_LD, log(ld_mant) + (double)ld_exp * 0.69314718055994530942);
-    sput(seg, O_FAIL, fail ? 1.0 : 0.0);
+    for (int b = 0; b < W; ++b) sput_ag(seg, O_F + e++, Rc[b]);
+    sput_ag(seg, O_LD, log(ld_mant) + (double)ld_exp * 0.69314718055994530942);
+    sput_ag(seg, O_FAIL, fail ? 1.0 : 0.0);
+    {  // the block's forward map, by the last of its waves to get here: out[b] = g[b] + sum_k G[k][b] in[k]
+      const int bk = seg / BSEG_BS;
+      if (!last_of_block(bk)) return;
+      double mp[BSEG_BS][NF];
+#pragma unroll
+      for (int i = 0; i < BSEG_BS; ++i) {
+        const int sg = (bk * BSEG_BS + i < nseg) ? bk * BSEG_BS + i : nseg - 1;
+#pragma unroll
+        for (int e2 = 0; e2 < NF; ++e2) mp[i][e2] = sget_ag(sg, O_F + e2);
+      }
+      double G[W][W], g[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        g[k] = 0.0;
+#pragma unroll
+        for (int b = 0; b < W; ++b) G[k][b] = (k == b) ? 1.0 : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < BSEG_BS; ++i) {
+        if (bk * BSEG_BS + i < nseg) {
+          double nG[W][W], ng[W];
+#pragma unroll
+          for (int b = 0; b < W; ++b) {
+            double a = mp[i][W * W + b];
+#pragma unroll
+            for (int k = 0; k < W; ++k) a = fma(mp[i][k * W + b], g[k], a);
+            ng[b] = a;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              double t = 0.0;
+#pragma unroll
+              for (int k = 0; k < W; ++k) t = fma(mp[i][k * W + b], G[j][k], t);
+              nG[j][b] = t;
+            }
+          }
+#pragma unroll
+          for (int b = 0; b < W; ++b) {
+            g[b] = ng[b];
+#pragma unroll
+            for (int j = 0; j < W; ++j) G[j][b] = nG[j][b];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+#pragma unroll
+        for (int b = 0; b < W; ++b) bput(bk, j * W + b, G[j][b]);
+#pragma unroll
+      for (int b = 0; b < W; ++b) bput(bk, W * W + b, g[b]);
+      // ... and what the group's verdict needs from this block: the joins inside it, any failed pivot, its log-det part
+      bool okb = true, failb = false;
+      double ldb = 0.0;
+#pragma unroll
+      for (int i = 0; i < BSEG_BS; ++i) {
+        const int sg = bk * BSEG_BS + i;
+        if (sg < nseg) {
+          failb |= sget_ag(sg, O_FAIL) != 0.0;
+          ldb += sget_ag(sg, O_LD);
+          if (i + 1 < BSEG_BS && sg + 1 < nseg) {
+            const double scale = fabs(sget_ag(sg, O_JE));
+            bool good = true;
+#pragma unroll
+            for (int e2 = 0; e2 < NJ; ++e2) good &= fabs(sget_ag(sg + 1, O_JS + e2) - sget_ag(sg, O_JE + e2)) <= tol * scale;
+            okb &= good;
+          }
+        }
+      }
+      bput(bk, O_BV, okb ? 1.0 : 0.0);
+      bput(bk, O_BV + 1, failb ? 1.0 : 0.0);
+      bput(bk, O_BV + 2, ldb);
+    }
     return;
   } else {
     // ---- joins of the whole group: the first segment's wave of PHASE 1 looks at all of them and leaves the verdict (the
@@ -732,18 +839,23 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
     for (int b = 0; b < W; ++b) din[b] = 0.0;
     if (PHASE == 1) {
       if (seg == 0) {
+        // (the joins inside a block, its failures and its log-det part were looked at by the block's last wave of PHASE 0;
+        // left here: the joins between blocks)
         bool okj = true;
-        double ld_sum = 0.0;  // (summed in this loop: a loop of its own was 64 round trips to memory one after the other)
+        double ld_sum = 0.0;
 #pragma unroll 8
-        for (int sg = 0; sg < nseg; ++sg) {
-          failed |= sget(sg, O_FAIL) != 0.0;
-          ld_sum += sget(sg, O_LD);
-          const int nx = (sg + 1 < nseg) ? sg + 1 : sg;  // the last segment compares its own start with itself... skipped below
-          const double scale = fabs(sget(sg, O_JE));
-          bool good = true;
+        for (int bk = 0; bk < nblk; ++bk) {
+          okj &= bget(bk, O_BV) != 0.0;
+          failed |= bget(bk, O_BV + 1) != 0.0;
+          ld_sum += bget(bk, O_BV + 2);
+          const int sg = (bk + 1) * BSEG_BS - 1;  // the block's last segment against the next block's first
+          if (sg + 1 < nseg) {
+            const double scale = fabs(sget(sg, O_JE));
+            bool good = true;
 #pragma unroll
-          for (int e = 0; e < NJ; ++e) good &= fabs(sget(nx, O_JS + e) - sget(sg, O_JE + e)) <= tol * scale;
-          okj &= good | (sg + 1 >= nseg);
+            for (int e = 0; e < NJ; ++e) good &= fabs(sget(sg + 1, O_JS + e) - sget(sg, O_JE + e)) <= tol * scale;
+            okj &= good;
+          }
         }
         const bool chain_bad = live && !failed && !okj;  // (a chain that is not positive definite is reported, not retried)
         if (__builtin_amdgcn_readfirstlane((int)(__ballot(chain_bad) != 0ull))) {
@@ -760,9 +872,23 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
           if (failed) atomicMin((unsigned long long*)bad, (unsigned long long)c);
         }
       }
-      // ---- the segment's true incoming forward state (kept for PHASE 2)
+      // ---- the segment's true incoming forward state (kept for PHASE 2): whole blocks, then the segments of its own block
+      const int myblk = seg / BSEG_BS;
 #pragma unroll 8
-      for (int sg = 0; sg < seg; ++sg) {
+      for (int bk = 0; bk < myblk; ++bk) {
+        double nx[W];
+#pragma unroll
+        for (int b = 0; b < W; ++b) {
+          double a = bget(bk, W * W + b);
+#pragma unroll
+          for (int k = 0; k < W; ++k) a = fma(bget(bk, k * W + b), din[k], a);
+          nx[b] = a;
+        }
+#pragma unroll
+        for (int b = 0; b < W; ++b) din[b] = nx[b];
+      }
+#pragma unroll 8
+      for (int sg = myblk * BSEG_BS; sg < seg; ++sg) {
         double nx[W];
 #pragma unroll
         for (int b = 0; b < W; ++b) {
@@ -788,11 +914,32 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
 #pragma unroll
     for (int d = 0; d < W1; ++d) { xs[d] = 0.0; ms[d] = 0.0; }
     if (PHASE == 2 && !last) {
+      // from beyond the last segment (state 0) down: whole blocks above this one, then the segments of its own block
       double xin[W], min_[W];
 #pragma unroll
-      for (int b = 0; b < W; ++b) { xin[b] = sget(nseg - 1, O_B + W * W + b); min_[b] = sget(nseg - 1, O_B + W * W + W + b); }
+      for (int b = 0; b < W; ++b) { xin[b] = 0.0; min_[b] = 0.0; }
+      const int myblk = seg / BSEG_BS;
+      constexpr int O_BB = W * W + W;  // the block's backward map behind its forward map
+#pragma unroll 4
+      for (int bk = nblk - 1; bk > myblk; --bk) {
+        double nx[W], nm[W];
+#pragma unroll
+        for (int b = 0; b < W; ++b) {
+          double a = bget(bk, O_BB + W * W + b), am = bget(bk, O_BB + W * W + W + b);
+#pragma unroll
+          for (int k = 0; k < W; ++k) {
+            const double hkb = bget(bk, O_BB + k * W + b);
+            a = fma(hkb, xin[k], a);
+            am = fma(hkb, min_[k], am);
+          }
+          nx[b] = a; nm[b] = am;
+        }
+#pragma unroll
+        for (int b = 0; b < W; ++b) { xin[b] = nx[b]; min_[b] = nm[b]; }
+      }
+      const int top = ((myblk + 1) * BSEG_BS < nseg ? (myblk + 1) * BSEG_BS : nseg) - 1;  // last segment of this block
 #pragma unroll 8
-      for (int sg = nseg - 2; sg > seg; --sg) {
+      for (int sg = top; sg > seg; --sg) {
         double nx[W], nm[W];
 #pragma unroll
         for (int b = 0; b < W; ++b) {
@@ -963,11 +1110,66 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
 #pragma unroll
       for (int k = 0; k < W; ++k)
 #pragma unroll
-        for (int b = 0; b < W; ++b) sput(seg, O_B + e++, Xk[k][b + 1]);
+        for (int b = 0; b < W; ++b) sput_ag(seg, O_B + e++, Xk[k][b + 1]);
 #pragma unroll
-      for (int b = 0; b < W; ++b) sput(seg, O_B + e++, xs[b + 1]);
+      for (int b = 0; b < W; ++b) sput_ag(seg, O_B + e++, xs[b + 1]);
 #pragma unroll
-      for (int b = 0; b < W; ++b) sput(seg, O_B + e++, ms[b + 1]);
+      for (int b = 0; b < W; ++b) sput_ag(seg, O_B + e++, ms[b + 1]);
+      // the block's backward map (its segments from the top one down), by the last of its waves to get here:
+      // out[b] = h[b] + sum_k H[k][b] in[k], the same H for the draw's and the mean's states
+      const int bk = seg / BSEG_BS;
+      if (!last_of_block(bk)) return;
+      double mp[BSEG_BS][NB];
+      const int top = ((bk + 1) * BSEG_BS < nseg ? (bk + 1) * BSEG_BS : nseg) - 1;
+#pragma unroll
+      for (int i = 0; i < BSEG_BS; ++i) {
+        const int sg = (top - i >= bk * BSEG_BS) ? top - i : bk * BSEG_BS;
+#pragma unroll
+        for (int e2 = 0; e2 < NB; ++e2) mp[i][e2] = sget_ag(sg, O_B + e2);
+      }
+      double H[W][W], h[W], hm[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        h[k] = 0.0; hm[k] = 0.0;
+#pragma unroll
+        for (int b = 0; b < W; ++b) H[k][b] = (k == b) ? 1.0 : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < BSEG_BS; ++i) {
+        if (top - i >= bk * BSEG_BS) {
+          double nH[W][W], nh[W], nhm[W];
+#pragma unroll
+          for (int b = 0; b < W; ++b) {
+            double a = mp[i][W * W + b], am = mp[i][W * W + W + b];
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+              a = fma(mp[i][k * W + b], h[k], a);
+              am = fma(mp[i][k * W + b], hm[k], am);
+            }
+            nh[b] = a; nhm[b] = am;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              double t = 0.0;
+#pragma unroll
+              for (int k = 0; k < W; ++k) t = fma(mp[i][k * W + b], H[j][k], t);
+              nH[j][b] = t;
+            }
+          }
+#pragma unroll
+          for (int b = 0; b < W; ++b) {
+            h[b] = nh[b]; hm[b] = nhm[b];
+#pragma unroll
+            for (int j = 0; j < W; ++j) H[j][b] = nH[j][b];
+          }
+        }
+      }
+      constexpr int O_BB = W * W + W;
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+#pragma unroll
+        for (int b = 0; b < W; ++b) bput(bk, O_BB + j * W + b, H[j][b]);
+#pragma unroll
+      for (int b = 0; b < W; ++b) { bput(bk, O_BB + W * W + b, h[b]); bput(bk, O_BB + W * W + W + b, hm[b]); }
     }
   }
 }
@@ -1088,7 +1290,10 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
   const bool segmented = lane_fits && w <= 3 && nseg >= 2 && ctx->band_algo != 1;
   // factor, then per column the zero-state u and its w unit responses (segmented route) / u alone
   const size_t base_doubles = (size_t)Cn * n * (segmented ? 2 * (w + 1) : (w + 2));
-  const size_t seg_doubles = segmented ? (size_t)groups * nseg * 48 * 64 + 2 * (size_t)groups : 0;
+  const int nblk = (nseg + BSEG_BS - 1) / BSEG_BS;
+  const size_t scr_doubles = (size_t)groups * ((size_t)nseg * 48 + (size_t)nblk * BSEG_BROW) * 64;
+  // + flags (2 per group) and the block counters of the four launches that compose (ints)
+  const size_t seg_doubles = segmented ? scr_doubles + (size_t)groups + 2 * (size_t)groups * nblk + 2 : 0;
   const size_t rt_doubles = (lane_fits && rhs_chain) ? (size_t)n * groups * 64 : 0;  // the per-chain right-hand side, transposed
   omc_status st = omc_ensure_bytes(ctx, (void**)&ctx->workspace, &ctx->workspace_bytes,
                                    (base_doubles + seg_doubles + rt_doubles) * sizeof(double));
@@ -1106,7 +1311,10 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
     while ((int64_t)(nseg - 1) * mseg >= n) --nseg;  // no empty segment
     double* Lws = ctx->workspace;
     double* scratch = ctx->workspace + base_doubles;
-    int* flags = (int*)(scratch + (size_t)groups * nseg * 48 * 64);
+    int* flags = (int*)(scratch + scr_doubles);
+    int* counts = flags + 2 * groups;  // [launch 0..3][group][block], zero at the start of every call
+    const size_t cnt_n = (size_t)groups * nblk;
+    hipMemsetAsync(counts, 0, 4 * cnt_n * sizeof(int), ctx->stream);
     const omc_rng_key lane_key = omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL);
     const double tol = 1e-13;
     const dim3 sg((unsigned)nseg, (unsigned)groups);
@@ -1114,18 +1322,18 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
     int* flag1 = flags;
     int* flag2 = flags + groups;
     const int ov2 = 4 * ov;  // second attempt for the groups whose joins did not close (a long-memory prior): 4 x the warm-up
-#define OMC_BSEG(Wv, PH, OV, GATE, FLAG, CNT)                                                                                     \
+#define OMC_BSEG(Wv, PH, OV, GATE, FLAG, CNT, BCNT)                                                                               \
   hipLaunchKernelGGL((k_band_seg<Wv, PH>), sg, dim3(64), 0, ctx->stream, Cn, ctx->chain_offset, n, LP, nseg, mseg, OV, tol,       \
                      z_inject, ld_z, lane_key, Lws, x, ld_x, mean, ld_mean, scratch, (const int*)(GATE), FLAG, logdet,           \
-                     ctx->d_bad_chain, CNT)
+                     ctx->d_bad_chain, CNT, BCNT)
 #define OMC_BSEG_ALL(Wv)                                                                                                          \
   do {                                                                                                                            \
-    OMC_BSEG(Wv, 0, ov, nullptr, flag1, ctx->d_fallbacks + 3);                                                                    \
-    OMC_BSEG(Wv, 1, ov, nullptr, flag1, ctx->d_fallbacks + 3);                                                                    \
+    OMC_BSEG(Wv, 0, ov, nullptr, flag1, ctx->d_fallbacks + 3, counts);                                                            \
+    OMC_BSEG(Wv, 1, ov, nullptr, flag1, ctx->d_fallbacks + 3, counts + cnt_n);                                                    \
     hipMemcpyAsync(flag2, flag1, (size_t)groups * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);                             \
-    OMC_BSEG(Wv, 0, ov2, flag1, flag2, ctx->d_fallbacks + 2);                                                                     \
-    OMC_BSEG(Wv, 1, ov2, flag1, flag2, ctx->d_fallbacks + 2);                                                                     \
-    OMC_BSEG(Wv, 2, ov, nullptr, flag2, ctx->d_fallbacks + 2);                                                                    \
+    OMC_BSEG(Wv, 0, ov2, flag1, flag2, ctx->d_fallbacks + 2, counts + 2 * cnt_n);                                                 \
+    OMC_BSEG(Wv, 1, ov2, flag1, flag2, ctx->d_fallbacks + 2, counts + 3 * cnt_n);                                                 \
+    OMC_BSEG(Wv, 2, ov, nullptr, flag2, ctx->d_fallbacks + 2, nullptr);                                                           \
   } while (0)
     if (w == 1) OMC_BSEG_ALL(1); else if (w == 2) OMC_BSEG_ALL(2); else OMC_BSEG_ALL(3);
 #undef OMC_BSEG_ALL
