@@ -474,17 +474,22 @@ __global__ void __launch_bounds__(64) k_band_lane(int64_t C, int64_t chain_offse
 //     its successor started from to `tol` relative to the pivot; if any join of any of a group's 64 chains fails (a very
 //     weak likelihood: long memory) the group is redone in one piece by k_band_lane.  No silent loss of accuracy.
 //   * forward and backward substitution (linear): exact.  A segment is run from a zero incoming state together with W
-//     unit incoming states (its affine map: W x W matrix + W vector); the maps of the segments are composed in order
-//     (at most 64 small products, redone by every wave that needs them) and the segment's true solution follows from its
-//     true incoming state.
-// Three launches, the launch boundaries being the only synchronisation:
-//   PHASE 0  factor + forward map:  L, the zero-state u and its W unit responses, join windows, log-det parts
-//   PHASE 1  joins checked, incoming forward state composed, backward map of the segment (draws made, nothing stored)
-//   PHASE 2  incoming backward state composed, the segment's x (draws made again) and mean stored as [column][chain]
-// then a transpose into the caller's chain-major arrays.  No loop both loads and stores what it waits for: on this
-// hardware a load returns behind every older store (one in-order counter), which made a combined loop pay a store
-// acknowledgement per step.  Natural-order Cholesky throughout: the factor, u = L^-1 b and x = L^-T (u + z) are
-// k_band_lane's to rounding (the updates of a column are added in another order).
+//     unit incoming states (its affine map: W x W matrix + W vector); the maps are composed in order -- in two levels,
+//     blocks of BSEG_BS segments whose map the last wave of the block to finish a phase leaves behind -- and the
+//     segment's true solution follows from its true incoming state.
+// Three launches, the launch boundaries being the only synchronisation between phases (inside a phase: one counter per
+// block, never waited for):
+//   PHASE 0  factor + forward map:  L, the zero-state u and its W unit responses, join windows, log-det parts; per
+//            block: forward map, joins inside the block, log-det part
+//   PHASE 1  (first segment's wave: joins between blocks, the group's verdict, log det;) incoming forward state, backward
+//            map of the segment (draws made, nothing stored); per block: backward map
+//   PHASE 2  incoming backward state, the segment's x (draws made again) and mean, written to the caller's chain-major
+//            rows through an LDS tile
+// No loop both loads and stores what it waits for: on this hardware a load returns behind every older store (one
+// in-order counter), which made a combined loop pay a store acknowledgement per step.  Natural-order Cholesky
+// throughout: the factor, u = L^-1 b and x = L^-T (u + z) are k_band_lane's to rounding (the updates of a column are
+// added in another order, the incoming states through block maps).  The number of segments: see
+// omc_band_sample_canonical (chosen for the SIMDs).
 #define BSEG_MAX 128
 #define BSEG_BS 8      // segments per block (two-level composition of the incoming states)
 #define BSEG_BROW 32   // scratch entries per block: forward map (W*W + W), backward map (W*W + 2 W)
