@@ -2518,18 +2518,48 @@ __global__ void __launch_bounds__(256) k_tridiag_quadform(TermsDev T, CentreChai
 // log det of one shared tridiagonal matrix of any length: D_i = a_i - b_{i-1}^2 / D_{i-1}, sum log D_i (gmrf.py:489-520)
 __global__ void __launch_bounds__(64) k_tridiag_logdet_serial(int64_t n, const double* diag, const double* off, double* logdet,
                                                               long long* bad) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double D = diag ? diag[0] : 1.0, acc = 0.0;
-  bool neg = !(D > 0.0);
-  acc = log(D);
-  for (int64_t i = 1; i < n; ++i) {
-    const double b = off ? off[i - 1] : 0.0;
-    D = fma(-b * omc_rcp_nr(D), b, diag ? diag[i] : 1.0);
-    neg |= !(D > 0.0);
-    acc += log(D);
+  if (blockIdx.x != 0) return;
+  // One dependent chain -- but the chain is the recurrence alone.  The wave fetches 64 columns at a time (one coalesced
+  // load per vector, the next 64 while the current ones are consumed), every lane runs the same recurrence on values
+  // handed round by v_readlane (no branch, no load inside the chain), and the logarithm is taken of a running product of
+  // mantissas, once per 64 columns.  (One lane with its loads inside the chain: a trip to memory per column, 7.6 ms at
+  // n = 20 000 and 22 ms at n = 50 000 -- more than ten sweeps of the model this is the set-up of.)
+  const int lane = threadIdx.x;
+  auto fetch = [&](int64_t i0, double& a, double& b) {  // padding: a = 1, b = 0 (pivot 1, log 0)
+    const int64_t i = i0 + lane;
+    a = (diag && i < n) ? diag[i] : 1.0;
+    b = (off && i >= 1 && i < n) ? off[i - 1] : 0.0;
+  };
+  auto bcast = [&](double v, int t) -> double {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), t), __builtin_amdgcn_readlane(__double2loint(v), t));
+  };
+  double D = 1.0, mant = 1.0;
+  long long ex = 0;
+  bool neg = false;
+  double a_cur, b_cur, a_nxt, b_nxt;
+  fetch(0, a_cur, b_cur);
+  for (int64_t i0 = 0; i0 < n; i0 += 64) {
+    fetch(i0 + 64, a_nxt, b_nxt);
+#pragma unroll
+    for (int t = 0; t < 64; ++t) {
+      const double a = bcast(a_cur, t), b = bcast(b_cur, t);
+      D = fma(-b * omc_rcp_nr(D), b, a);  // (the first column: b = 0)
+      const bool ok = D > 0.0;
+      neg |= !ok;
+      const double Dp = ok ? D : 1.0;
+      mant *= __builtin_amdgcn_frexp_mant(Dp);
+      ex += __builtin_amdgcn_frexp_exp(Dp);
+      if ((t & 15) == 15) {
+        ex += __builtin_amdgcn_frexp_exp(mant);
+        mant = __builtin_amdgcn_frexp_mant(mant);
+      }
+    }
+    a_cur = a_nxt; b_cur = b_nxt;
   }
-  logdet[0] = acc;
-  if (neg) atomicMin((unsigned long long*)bad, 0ull);
+  if (lane == 0) {
+    logdet[0] = neg ? NAN : log(mant) + (double)ex * 0.69314718055994530942;
+    if (neg) atomicMin((unsigned long long*)bad, 0ull);
+  }
 }
 
 // ------------------------------------------------------------------------------------------

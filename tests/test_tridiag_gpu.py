@@ -629,3 +629,31 @@ def test_per_chain_centres_are_refused_where_no_kernel_takes_them(torch):
     with pytest.raises(NotImplementedError):
         eng.tridiag_sample_canonical(n, terms, eng.empty(3, n), z=eng.zeros(3, n))
     eng.close()
+
+
+@pytest.mark.parametrize("n", [16385, 20001, 50000])
+def test_logdet_of_a_chain_longer_than_one_workgroup(n):
+    """omc_tridiag_logdet beyond the segmented kernel's reach (one lane, entries fetched ahead of the recurrence, the
+    logarithm taken of a running product of mantissas): against the recurrence in extended precision (gmrf.py:489-520)."""
+    from openmcmc_amd.engine import Engine
+
+    rng = np.random.default_rng(n)
+    off = -(0.5 + rng.random(n - 1))
+    diag = 1e-3 + 0.3 * rng.random(n)
+    diag[:-1] -= off
+    diag[1:] -= off
+    eng = Engine(1)
+    got = eng.tridiag_logdet(n, eng.to_device(diag), eng.to_device(off)).cpu().numpy()[0]
+    eng.check_status()
+    D = np.longdouble(diag[0])
+    want = np.log(D)
+    for i in range(1, n):
+        D = np.longdouble(diag[i]) - np.longdouble(off[i - 1]) ** 2 / D
+        want += np.log(D)
+    assert abs(got - float(want)) < 1e-11 * abs(float(want))
+    # a matrix that is not positive definite is reported
+    diag[n // 2] = -1.0
+    eng.tridiag_logdet(n, eng.to_device(diag), eng.to_device(off))
+    with pytest.raises(np.linalg.LinAlgError):
+        eng.check_status()
+    eng.close()
