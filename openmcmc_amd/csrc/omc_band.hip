@@ -1295,6 +1295,8 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
   const bool segmented = lane_fits && w <= 3 && nseg >= 2 && ctx->band_algo != 1;
   // factor, then per column the zero-state u and its w unit responses (segmented route) / u alone
   const size_t base_doubles = (size_t)Cn * n * (segmented ? 2 * (w + 1) : (w + 2));
+  const int64_t mseg = segmented ? (n + nseg - 1) / nseg : 0;
+  while (segmented && (int64_t)(nseg - 1) * mseg >= n) --nseg;  // no empty segment
   const int nblk = (nseg + BSEG_BS - 1) / BSEG_BS;
   const size_t scr_doubles = (size_t)groups * ((size_t)nseg * 48 + (size_t)nblk * BSEG_BROW) * 64;
   // + flags (2 per group) and the block counters of the four launches that compose (ints)
@@ -1312,8 +1314,6 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
     LP.ld_t = groups * 64;
   }
   if (segmented) {
-    const int64_t mseg = (n + nseg - 1) / nseg;
-    while ((int64_t)(nseg - 1) * mseg >= n) --nseg;  // no empty segment
     double* Lws = ctx->workspace;
     double* scratch = ctx->workspace + base_doubles;
     int* flags = (int*)(scratch + scr_doubles);
