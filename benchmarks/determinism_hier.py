@@ -32,8 +32,7 @@ for r in range(int(os.environ.get("RUNS", "2"))):
     runs.append({k: v.clone() for k, v in M.store.items() if isinstance(v, torch.Tensor)})
     lam = runs[-1]["lambda"].reshape(runs[-1]["lambda"].shape[0], -1)
     tau = runs[-1]["tau"].reshape(lam.shape[0], -1)
-    print("   lambda range", float(lam.min()), float(lam.max()), " tau range", float(tau.min()), float(tau.max()),
-          " chains 770-805 lambda", float(lam[:, 770:806].min()), float(lam[:, 770:806].max()))
+    print("   lambda range", float(lam.min()), float(lam.max()), " tau range", float(tau.min()), float(tau.max()))
     M.engine.close()
     del M
 a = runs[0]
