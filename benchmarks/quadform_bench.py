@@ -1,6 +1,6 @@
 """Bandwidth of the standalone quadratic form omc_tridiag_quadform (long-chain route, non-fused paths): one workgroup per
-chain streams the chain's row.  1.9 TB/s on the row with one term, 1.4 with two (n = 10 000-20 000 x 1024 chains; 1.2-1.4
-and 0.9-1.0 before the loop lost its null tests); requesting four strides ahead by hand made it slower: still well below
+chain streams the chain's row.  2.3-2.5 TB/s on the row with one term, 1.6 with two (n = 10 000-20 000 x 1024 chains; 1.2-1.4
+and 0.9-1.0 before the loop lost its null tests and its 64-bit address arithmetic; more threads per chain: +5 %); requesting four strides ahead by hand made it slower: still well below
 the fused kernels, open.  python benchmarks/quadform_bench.py"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())

@@ -2495,7 +2495,7 @@ __global__ void __launch_bounds__(256) k_chain_lincomb(int64_t n, double a, cons
 // before the loop: absent vectors are read from the chain's own row (a valid address) and replaced by a select, so the
 // loop carries no branch but the row's end -- with a null test in front of every load it issued ~100 instructions per
 // node and ran at 1.2 TB/s.  Every term's sum is accumulated in the order it always was.
-template <int NT>
+template <int NT, bool CCV>
 __device__ __forceinline__ void quadform_row(const TermsDev& T, const CentreChain& CC, int64_t n, const double* xc, const double* ccv,
                                              double (&acc)[OMC_MAX_TERMS]) {
   const double* pd[NT]; const double* po[NT]; const double* pc[NT];
@@ -2503,15 +2503,18 @@ __device__ __forceinline__ void quadform_row(const TermsDev& T, const CentreChai
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     hd[k] = T.diag[k] != nullptr; ho[k] = T.off[k] != nullptr && n > 1; hc[k] = T.center[k] != nullptr;
-    hcc[k] = ccv && CC.k == k;
+    hcc[k] = CCV && CC.k == k;
     pd[k] = hd[k] ? T.diag[k] : xc; po[k] = ho[k] ? T.off[k] : xc; pc[k] = hc[k] ? T.center[k] : xc;
   }
-  const double* pcc = ccv ? ccv : xc;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const bool has_next = i < n - 1;
-    const int64_t in = has_next ? i + 1 : i, io = has_next ? i : (i > 0 ? i - 1 : 0);  // (the off-diagonal has n - 1 entries)
+  // (32-bit element indices on uniform base pointers: the loads take the scalar-base form, no 64-bit address arithmetic
+  // per load; n < 2^31 is checked by the entry point)
+  const unsigned nn = (unsigned)n, step = blockDim.x;
+  for (unsigned i = threadIdx.x; i < nn; i += step) {
+    const bool has_next = i + 1 < nn;
+    const unsigned in = has_next ? i + 1 : i, io = has_next ? i : (i > 0 ? i - 1 : 0);  // (the off-diagonal has n - 1 entries)
     const double xi = xc[i], xn = xc[in];
-    const double ci = pcc[i], cn = pcc[in];
+    double ci = 0.0, cn = 0.0;
+    if constexpr (CCV) { ci = ccv[i]; cn = ccv[in]; }
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
       const double dg = pd[k][i], of = po[k][io], c0 = pc[k][i], c1 = pc[k][in];
@@ -2533,11 +2536,20 @@ __global__ void __launch_bounds__(256) k_tridiag_quadform(TermsDev T, CentreChai
   double acc[OMC_MAX_TERMS];
 #pragma unroll
   for (int k = 0; k < OMC_MAX_TERMS; ++k) acc[k] = 0.0;
-  switch (T.n_terms) {
-    case 1: quadform_row<1>(T, CC, n, xc, ccv, acc); break;
-    case 2: quadform_row<2>(T, CC, n, xc, ccv, acc); break;
-    case 3: quadform_row<3>(T, CC, n, xc, ccv, acc); break;
-    default: quadform_row<4>(T, CC, n, xc, ccv, acc); break;
+  if (ccv) {
+    switch (T.n_terms) {
+      case 1: quadform_row<1, true>(T, CC, n, xc, ccv, acc); break;
+      case 2: quadform_row<2, true>(T, CC, n, xc, ccv, acc); break;
+      case 3: quadform_row<3, true>(T, CC, n, xc, ccv, acc); break;
+      default: quadform_row<4, true>(T, CC, n, xc, ccv, acc); break;
+    }
+  } else {
+    switch (T.n_terms) {
+      case 1: quadform_row<1, false>(T, CC, n, xc, ccv, acc); break;
+      case 2: quadform_row<2, false>(T, CC, n, xc, ccv, acc); break;
+      case 3: quadform_row<3, false>(T, CC, n, xc, ccv, acc); break;
+      default: quadform_row<4, false>(T, CC, n, xc, ccv, acc); break;
+    }
   }
 #pragma unroll
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
@@ -3126,6 +3138,7 @@ int32_t omc_tridiag_takes_center_chain(omc_ctx* ctx, int64_t n) { return (ctx &&
 omc_status omc_tridiag_quadform(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms, const double* x,
                                 int64_t ld_x, double* quad_out) {
   if (!ctx || n < 1 || !x || ld_x < n || !quad_out) return OMC_INVALID_ARG;
+  if (n >= (int64_t)1 << 31) return OMC_UNSUPPORTED;  // (32-bit element indices in the kernel)
   TermsDev T;
   CentreChain CC;
   if (!terms_to_dev(terms, &T, &CC)) return OMC_INVALID_ARG;
