@@ -2491,38 +2491,39 @@ __global__ void __launch_bounds__(256) k_chain_lincomb(int64_t n, double a, cons
 }
 
 // one workgroup per chain: quad[k][c] = (x-m_k)' M_k (x-m_k)
-// One pass over the chain's row for all NT terms.  What a term has (diagonal, off-diagonal, shared centre) is decided
-// before the loop: absent vectors are read from the chain's own row (a valid address) and replaced by a select, so the
-// loop carries no branch but the row's end -- with a null test in front of every load it issued ~100 instructions per
-// node and ran at 1.2 TB/s.  Every term's sum is accumulated in the order it always was.
+// One pass over the chain's row for all NT terms: the row (the only per-chain operand) is read once, a vector a term does
+// not have is not read at all (uniform branches on flags set before the loop: an identity term around a shared centre
+// runs at the row's bandwidth), and the element indices are 32-bit on uniform base pointers (scalar-base loads, no
+// 64-bit address arithmetic per load).  Every term's sum is accumulated in the order it always was.
 template <int NT, bool CCV>
 __device__ __forceinline__ void quadform_row(const TermsDev& T, const CentreChain& CC, int64_t n, const double* xc, const double* ccv,
                                              double (&acc)[OMC_MAX_TERMS]) {
-  const double* pd[NT]; const double* po[NT]; const double* pc[NT];
-  bool hd[NT], ho[NT], hc[NT], hcc[NT];
+  bool hd[NT], ho[NT], hc[NT], hcc[NT], any_off = false;
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     hd[k] = T.diag[k] != nullptr; ho[k] = T.off[k] != nullptr && n > 1; hc[k] = T.center[k] != nullptr;
     hcc[k] = CCV && CC.k == k;
-    pd[k] = hd[k] ? T.diag[k] : xc; po[k] = ho[k] ? T.off[k] : xc; pc[k] = hc[k] ? T.center[k] : xc;
+    any_off |= ho[k];
   }
-  // (32-bit element indices on uniform base pointers: the loads take the scalar-base form, no 64-bit address arithmetic
-  // per load; n < 2^31 is checked by the entry point)
-  const unsigned nn = (unsigned)n, step = blockDim.x;
+  const unsigned nn = (unsigned)n, step = blockDim.x;  // (n < 2^31: checked by the entry point)
   for (unsigned i = threadIdx.x; i < nn; i += step) {
     const bool has_next = i + 1 < nn;
-    const unsigned in = has_next ? i + 1 : i, io = has_next ? i : (i > 0 ? i - 1 : 0);  // (the off-diagonal has n - 1 entries)
-    const double xi = xc[i], xn = xc[in];
-    double ci = 0.0, cn = 0.0;
-    if constexpr (CCV) { ci = ccv[i]; cn = ccv[in]; }
+    const unsigned in = has_next ? i + 1 : i;
+    const double xi = xc[i];
+    double xn = 0.0, ci = 0.0, cn = 0.0;
+    if (any_off) xn = xc[in];
+    if constexpr (CCV) {
+      ci = ccv[i];
+      if (any_off) cn = ccv[in];
+    }
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-      const double dg = pd[k][i], of = po[k][io], c0 = pc[k][i], c1 = pc[k][in];
-      const double r = xi - (hc[k] ? c0 : 0.0) - (hcc[k] ? ci : 0.0);
-      double a = fma((hd[k] ? dg : 1.0) * r, r, acc[k]);
-      const double rn = xn - (hc[k] ? c1 : 0.0) - (hcc[k] ? cn : 0.0);
-      const double a2 = fma(2.0 * of * r, rn, a);
-      acc[k] = (ho[k] && has_next) ? a2 : a;
+      const double r = xi - (hc[k] ? T.center[k][i] : 0.0) - (hcc[k] ? ci : 0.0);
+      acc[k] = fma((hd[k] ? T.diag[k][i] : 1.0) * r, r, acc[k]);
+      if (ho[k] && has_next) {
+        const double rn = xn - (hc[k] ? T.center[k][in] : 0.0) - (hcc[k] ? cn : 0.0);
+        acc[k] = fma(2.0 * T.off[k][i] * r, rn, acc[k]);
+      }
     }
   }
 }
