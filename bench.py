@@ -590,19 +590,46 @@ def main():
             spl = 1 if (args.python_loop or args.unfused) else min(spl, args.steps)
             alg_sweep = ALG_BYTES_PER_CHAIN_UPDATE * (n / N_NODES) * C
             achieved = alg_sweep / (kern_ms * 1e-3) / 1e9
-            traffic = None
+            traffic, rec = None, {}
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 rec = json.load(open(tpath))
                 if rec.get("nodes") == n and rec.get("chains") == C:
                     traffic = rec.get("hbm_bytes_per_sweep") * spl
+                else:
+                    rec = {}
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "kernel": "k_tridiag_seg", "kernel_ms": kern_ms,
                                "sweeps_per_launch": spl, "launch_ms": kern_ms * spl,
                                "alg_bytes_per_launch": alg_sweep * spl,
-                               "note": "achieved = alg_bytes_per_launch / launch_ms; traffic = PMC HBM bytes per launch "
-                                       "(profiles/traffic.json, per sweep x sweeps_per_launch)"}
+                               "note": "achieved = alg_bytes_per_launch / launch_ms (SURVEY 8d's 40 n B per chain-update, the contract's "
+                                       "figure); traffic = PMC HBM bytes per launch (profiles/traffic.json, per sweep x "
+                                       "sweeps_per_launch).  The chain stays on chip: the bytes that really cross the HBM pins are in "
+                                       "hbm_measured, and what limits the kernel is in roofline_valu_issue"}
+            if traffic:
+                # the rate at the HBM pins: counter bytes / this run's launch time (north_star's 'rocprof HBM GB/s')
+                gbs = traffic / (kern_ms * spl * 1e-3) / 1e9
+                out["roofline"]["hbm_measured"] = {"GBps": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS,
+                                                   "bytes_per_launch": traffic, "source": rec.get("source")}
+            if rec.get("valu_instructions_per_wave_and_sweep"):
+                # The bound the counters point at: vector-ALU issue.  One workgroup (16 waves, 4 per SIMD) owns a CU for a
+                # chain's sweep; the C chains take ceil(C / CUs) rounds.  issue cycles of a workgroup-sweep on one SIMD =
+                # instructions per wave x waves per SIMD x measured cycles per instruction (benchmarks/micro/valu_rates.hip);
+                # available = the sweep's share of the launch in core cycles.
+                cus, ghz = 256, float(rec.get("core_clock_ghz", 2.4))
+                rounds = -(-C // cus)
+                cyc_avail = kern_ms * 1e-3 * ghz * 1e9 / rounds
+                ipw, cpi = float(rec["valu_instructions_per_wave_and_sweep"]), float(rec.get("cycles_per_valu_instruction", 5.1))
+                issue = ipw * 4 * cpi
+                out["roofline_valu_issue"] = {
+                    "bound": "valu_issue", "achieved": issue, "peak": cyc_avail, "unit": "SIMD cycles per workgroup-sweep",
+                    "frac": issue / cyc_avail, "valu_instructions_per_wave_and_sweep": ipw, "waves_per_simd": 4,
+                    "cycles_per_instruction": cpi, "core_clock_ghz": ghz, "rounds_of_workgroups": rounds,
+                    "source": rec.get("source"),
+                    "note": "share of a workgroup-sweep's time its SIMDs spend issuing vector instructions (counter instruction "
+                            "count x cycles per fp64/int instruction measured at 4 waves per SIMD); the rest is latency at the "
+                            "phase barriers of a one-workgroup-per-CU design"}
         return out
 
     m = measure(args.scaling, diagnostics=True)
@@ -622,7 +649,10 @@ def main():
             if rank == 0 and fallback_line:
                 fallback_line["config"]["store_gather"] = {"error": f"not finished after {args.collective_timeout:.0f} s: gave up (watchdog)"}
                 print(json.dumps(fallback_line), flush=True)
-            os._exit(0)
+            # a collective that hangs is a defect: the measured line is out, but the job must not read as a success
+            print(f"rank {rank}: collective part not finished after {args.collective_timeout:.0f} s (watchdog), exiting 3",
+                  file=sys.stderr, flush=True)
+            os._exit(3)
 
         watchdog = threading.Timer(args.collective_timeout, give_up)
         watchdog.daemon = True

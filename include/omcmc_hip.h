@@ -150,7 +150,11 @@ int32_t omc_abi_version(void);
  *   x_out      [C][ld_x]   the draw
  *   mean_out   [C][ld_mean] optional mu = Q^{-1} b (NULL = skip)
  *   quad_out   [n_terms][C] optional quadratic forms around center[k] (NULL = skip)
- *   logdet_out [C]         optional log det Q_c = 2 sum log L_ii (NULL = skip)               */
+ *   logdet_out [C]         optional log det Q_c = 2 sum log L_ii (NULL = skip)
+ * Chains longer than one workgroup takes (n > 16 384) go through the segmented band kernels (omc_band_sample_canonical,
+ * w = 1), and that route is stricter in two ways: z_inject must not alias x_out or mean_out (OMC_INVALID_ARG; the
+ * workgroup-per-chain kernels accept z_inject == x_out), and the option "tridiag_quad_skip" is ignored -- every requested
+ * quad_out row is computed (by omc_tridiag_quadform behind the draw).                                  */
 omc_status omc_tridiag_sample_canonical(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
                                         const double* rhs_chain, int64_t ld_rhs,
                                         const double* z_inject, int64_t ld_z, uint64_t draw_index,

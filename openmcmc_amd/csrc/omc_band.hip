@@ -548,6 +548,15 @@ __global__ void __launch_bounds__(64) k_band_seg(int64_t C, int64_t chain_offset
                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   };
   // has every other wave of this wave's block finished the phase?  (counters zeroed per launch by the host)
+  // Memory-model note: the rows travel as RELAXED agent-scope stores, ordered in front of the RELAXED counter increment by
+  // `s_waitcnt vmcnt(0)` (a write-through store has reached the L2 -- the agent's point of coherence -- when vmcnt counts it
+  // down), and the reader's agent-scope loads bypass its own L1.  That is a property of gfx942/gfx950's memory pipeline, not a
+  // happens-before edge of the HIP/LLVM memory model; the formal route (release fence / acquire at AGENT scope) costs a
+  // write-back of the whole dirty L2 per wave (see above).  Hence the architecture check below, and
+  // benchmarks/determinism_all.py band as the gating run after any toolchain bump.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_band_seg's block hand-over relies on gfx950's write-through stores + in-order vmcnt; use agent-scope release/acquire on the counter elsewhere"
+#endif
   auto last_of_block = [&](int bk) -> bool {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's write-through rows are at their destination
@@ -1255,7 +1264,7 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
       ld_x < n || (rhs_chain && ld_rhs < n) || (z_inject && ld_z < n) || (mean && ld_mean < n) || x == mean ||
       (z_inject && (z_inject == x || z_inject == mean)))
     return OMC_INVALID_ARG;
-  BandTermsDev T;
+  BandTermsDev T{};
   T.n_terms = terms->n_terms;
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
     const bool on = k < terms->n_terms;
@@ -1268,7 +1277,7 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   const int64_t Cn = ctx->n_chains;
   const int64_t groups = (Cn + 63) / 64;
-  BandLaneArgs LP;
+  BandLaneArgs LP{};
   const bool lane_fits = w >= 1 && w <= 8 && ctx->band_algo != 2 && band_lane_args(T, &LP);
   // Segmented route: segments of at least 96 columns and at least half the warm-up, their number chosen for the SIMDs.
   // The factor phase is bound by instruction issue, not by latency (measured: 0.5 us a column for a wave alone on its

@@ -306,9 +306,11 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   }
   if (!strcmp(name, "sweep_times_cap")) {
     if (value != 0 && value < OMC_SWEEP_RING_MIN) return OMC_INVALID_ARG;
+    // a ring set earlier was sized for the OLD capacity: the clock stays off until a pointer is given for the new one
+    // (a larger capacity on the old pointer would have omc_gmrf_run write records past the ring's end)
+    if (value != ctx->sweep_times_cap) ctx->sweep_times = nullptr;
     ctx->sweep_times_cap = value;
     ctx->sweep_times_pos = 0;
-    if (value == 0) ctx->sweep_times = nullptr;
     return OMC_OK;
   }
   if (!strcmp(name, "stamps_ptr")) {  // diagnostic: device buffer [n_chains][16][16] of uint64, 0 = off

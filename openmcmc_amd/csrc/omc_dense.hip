@@ -518,7 +518,7 @@ omc_status omc_dense_sample_canonical(omc_ctx* ctx, int64_t p, const omc_dense_t
   if (st != OMC_OK) return st;
   st = omc_ensure_bytes(ctx, (void**)&ctx->dense_info, &ctx->dense_info_bytes, (size_t)C * sizeof(int));
   if (st != OMC_OK) return st;
-  DenseTermsDev T;
+  DenseTermsDev T{};
   T.n_terms = terms->n_terms;
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
     const bool on = k < terms->n_terms;
@@ -602,7 +602,7 @@ omc_status omc_dense_spectral_sample(omc_ctx* ctx, int64_t p, const omc_dense_te
   if (st != OMC_OK) return st;
   double* W = ctx->dense_factor;       // [C][p]: V' rhs, then y
   double* Mw = W + C * p;              // [C][p]: m in the eigenbasis
-  DenseTermsDev T;
+  DenseTermsDev T{};
   T.n_terms = terms->n_terms;
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
     const bool on = k < terms->n_terms;

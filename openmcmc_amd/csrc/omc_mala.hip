@@ -272,7 +272,7 @@ omc_status omc_mala_step(omc_ctx* ctx, int64_t d, const double* Q, const double*
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   omc_status st = omc_ensure_blas(ctx);
   if (st != OMC_OK) return st;
-  MhWork w;
+  MhWork w{};
   st = mh_workspace(ctx, d, &w);
   if (st != OMC_OK) return st;
   st = mala_prepare(ctx, d, Q, L, step);
@@ -450,7 +450,7 @@ omc_status omc_mala_step_white(omc_ctx* ctx, int64_t d, const double* mu, const 
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   omc_status st = omc_ensure_blas(ctx);
   if (st != OMC_OK) return st;
-  MhWork w;
+  MhWork w{};
   st = mh_workspace(ctx, d, &w);
   if (st != OMC_OK) return st;
   st = white_prepare(ctx, d, L, mu);
@@ -487,7 +487,7 @@ omc_status omc_rw_step(omc_ctx* ctx, int64_t d, const double* mu, const double* 
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   omc_status st = omc_ensure_blas(ctx);
   if (st != OMC_OK) return st;
-  MhWork w;
+  MhWork w{};
   st = mh_workspace(ctx, d, &w);
   if (st != OMC_OK) return st;
   rocblas_handle h = (rocblas_handle)ctx->blas;
@@ -589,7 +589,7 @@ omc_status omc_rw_step_white(omc_ctx* ctx, int64_t d, const double* mu, const do
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   omc_status st = omc_ensure_blas(ctx);
   if (st != OMC_OK) return st;
-  MhWork w;
+  MhWork w{};
   st = mh_workspace(ctx, d, &w);
   if (st != OMC_OK) return st;
   hipStream_t s = ctx->stream;

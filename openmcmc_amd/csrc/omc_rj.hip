@@ -780,7 +780,7 @@ omc_status omc_chain_select(omc_ctx* ctx, const int32_t* accept, int64_t width, 
 omc_status omc_chain_select_multi(omc_ctx* ctx, const int32_t* accept, int32_t n_items, const int64_t* widths,
                                   const double* const* srcs, double* const* dsts) {
   if (!ctx || !accept || n_items < 1 || n_items > OMC_SELECT_MAX || !widths || !srcs || !dsts) return OMC_INVALID_ARG;
-  SelectItems it;
+  SelectItems it{};
   it.n = n_items;
   int64_t wmax = 1;
   for (int e = 0; e < OMC_SELECT_MAX; ++e) {

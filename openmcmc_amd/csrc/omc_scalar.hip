@@ -216,7 +216,7 @@ omc_status omc_scaled_gauss_logpdf(omc_ctx* ctx, int64_t n, const double* scale,
 
 omc_status omc_log_post_sum(omc_ctx* ctx, int32_t n_pieces, const omc_logp_piece* pieces, double host_const, double* out) {
   if (!ctx || n_pieces < 1 || n_pieces > OMC_LOGP_MAX || !pieces || !out) return OMC_INVALID_ARG;
-  LogpArgs P;
+  LogpArgs P{};
   P.n = n_pieces;
   for (int i = 0; i < n_pieces; ++i) {
     const omc_logp_piece& q = pieces[i];

@@ -2883,7 +2883,7 @@ omc_status omc_tridiag_sample_canonical(omc_ctx* ctx, int64_t n, const omc_tridi
                                         double* mean_out, int64_t ld_mean, double* quad_out, double* logdet_out) {
   if (!ctx || n < 1 || !x_out || ld_x < n) return OMC_INVALID_ARG;
   if ((rhs_chain && ld_rhs < n) || (z_inject && ld_z < n) || (mean_out && ld_mean < n)) return OMC_INVALID_ARG;
-  TriArgs A;
+  TriArgs A{};
   args_defaults(ctx, &A, n);
   if (!terms_to_dev(terms, &A.T, &A.cc)) return OMC_INVALID_ARG;
   if (has_center_chain(A.cc) && (A.cc.k < 0 || !takes_wg_per_chain(ctx, n) || A.cc.ld < n)) return OMC_UNSUPPORTED;
@@ -2913,7 +2913,7 @@ omc_status omc_gmrf_sweep(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* term
                           uint64_t draw_index, double* x_out, int64_t ld_x, double* log_post_out) {
   if (!ctx || n < 1 || !x_out || ld_x < n || !blocks) return OMC_INVALID_ARG;
   if ((rhs_chain && ld_rhs < n) || (z_inject && ld_z < n)) return OMC_INVALID_ARG;
-  TriArgs A;
+  TriArgs A{};
   args_defaults(ctx, &A, n);
   if (!terms_to_dev(terms, &A.T, &A.cc)) return OMC_INVALID_ARG;
   if (has_center_chain(A.cc) && (A.cc.k < 0 || !takes_wg_per_chain(ctx, n) || A.cc.ld < n)) return OMC_UNSUPPORTED;
@@ -3000,7 +3000,7 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
     // dispatched in index order, so a producer is always on the chip before its consumer; the consumer's wait is
     // bounded anyway and a hand-over that never came is reported by omc_ctx_status.  What this buys: the ramp, tail
     // and boundary of a launch (7.4 us against 21 us per round of workgroups) are paid once per OMC_RUN_MAX sweeps.
-    TriArgs A;
+    TriArgs A{};
     args_defaults(ctx, &A, n);
     if (!terms_to_dev(terms, &A.T, &A.cc)) return OMC_INVALID_ARG;
   if (has_center_chain(A.cc) && (A.cc.k < 0 || !takes_wg_per_chain(ctx, n) || A.cc.ld < n)) return OMC_UNSUPPORTED;
@@ -3140,8 +3140,8 @@ omc_status omc_tridiag_quadform(omc_ctx* ctx, int64_t n, const omc_tridiag_terms
                                 int64_t ld_x, double* quad_out) {
   if (!ctx || n < 1 || !x || ld_x < n || !quad_out) return OMC_INVALID_ARG;
   if (n >= (int64_t)1 << 31) return OMC_UNSUPPORTED;  // (32-bit element indices in the kernel)
-  TermsDev T;
-  CentreChain CC;
+  TermsDev T{};
+  CentreChain CC{};
   if (!terms_to_dev(terms, &T, &CC)) return OMC_INVALID_ARG;
   if (has_center_chain(CC) && CC.k < 0) return OMC_UNSUPPORTED;
   if (has_center_chain(CC) && CC.ld < n) return OMC_INVALID_ARG;
@@ -3195,7 +3195,7 @@ omc_status omc_tridiag_logdet(omc_ctx* ctx, int64_t n, const double* diag, const
     OMC_HIP_CHECK(hipGetLastError());
     return OMC_OK;
   }
-  TriArgs A;
+  TriArgs A{};
   args_defaults(ctx, &A, n);
   A.T.n_terms = 1;  // (args_defaults has cleared every pointer of the terms)
   A.T.diag[0] = diag;

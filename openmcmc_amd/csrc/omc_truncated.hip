@@ -343,7 +343,7 @@ omc_status omc_tridiag_gibbs_truncated(omc_ctx* ctx, int64_t n, const omc_tridia
   for (int k = 0; k < terms->n_terms; ++k)
     if (terms->center_chain[k]) return OMC_UNSUPPORTED;  // (per-chain centres: the exact draw only)
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  TruncTerms T;
+  TruncTerms T{};
   T.n_terms = terms->n_terms;
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
     const bool on = k < terms->n_terms;
@@ -383,7 +383,7 @@ omc_status omc_band_gibbs_truncated(omc_ctx* ctx, int64_t n, int64_t w, const om
       (rhs_chain && ld_rhs < n) || (u_inject && ld_u < n))
     return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  TruncBand T;
+  TruncBand T{};
   T.n_terms = terms->n_terms;
   for (int k = 0; k < OMC_MAX_TERMS; ++k) {
     const bool on = k < terms->n_terms;

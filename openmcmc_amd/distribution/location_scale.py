@@ -482,7 +482,10 @@ class Normal(Distribution):
         x = engine.empty(engine.n_chains, d)
         bad = torch.ones(engine.n_chains, dtype=torch.bool, device=x.device)
         pen = engine.empty(engine.n_chains)
-        attempts = 100000 if tape is None else tape.shape[0]
+        # attempt a draws from stream draw_index + (a << 24): 16 bits of attempts below bit 40, where MCMC's prior-draw field
+        # starts ((1 << 40) + position; the sub-stream field of _column_draw sits at bit 44) -- one more bit and a late
+        # attempt of one draw would replay another draw's early attempts
+        attempts = 65536 if tape is None else tape.shape[0]
         for a in range(attempts):
             cand = draw(a, None if tape is None else tape[a].contiguous()).contiguous()
             pen.zero_()

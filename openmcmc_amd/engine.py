@@ -1076,7 +1076,9 @@ class Engine:
 
 # Engine methods that write into tensors the caller hands in (parameter names): the calls are recorded (Engine.note_write) so that
 # a cache derived from a state tensor can tell whether the library has touched that tensor since.  (Methods that return fresh
-# tensors need no entry; the whitened Metropolis-Hastings steps are the cache's owners and record nothing.)
+# tensors need no entry.  The whitened Metropolis-Hastings steps write x in place behind torch's version counter like the others
+# and are recorded like them: a quadratic form cached for a Normal-Gamma block further down the sweep must not survive them; the
+# samplers take `_white_serial` AFTER the call, so their own whitened image stays valid.)
 _WRITES = {
     "tridiag_sample_canonical": ("x_out", "mean_out"), "gmrf_sweep": ("x_out",), "dense_sample_canonical": ("x_out", "mean_out"),
     "dense_spectral_sample": ("x_out", "mean_out"), "band_sample_canonical": ("x_out", "mean_out"),
@@ -1084,6 +1086,7 @@ _WRITES = {
     "chain_lincomb": ("out",), "chain_copy": ("dst",), "chain_select": ("dst",), "mala_step": ("x",), "rw_step": ("x",),
     "tridiag_matvec_chain": ("out",), "band_matvec_chain": ("out",), "design_predict": ("fitted",),
     "design_predict_batched": ("out",), "knot_loop": ("B", "beta", "theta"), "gaussian_basis": ("out",), "mala_diag": ("x",),
+    "mala_step_white": ("x",), "rw_step_white": ("x",),
 }
 
 

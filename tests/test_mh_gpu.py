@@ -481,3 +481,32 @@ def test_cached_whitened_state_notices_library_writes(cls_name):
         eng.close()
     assert np.array_equal(outs[0][1], outs[1][1])
     assert relerr(outs[1][0], outs[0][0]) < 1e-10
+
+
+@pytest.mark.parametrize("kind", ["mala", "rw"])
+def test_whitened_steps_are_in_the_write_log(kind):
+    """omc_mala_step_white / omc_rw_step_white write x in place where torch's version counter does not see it: a quadratic form
+    cached from x (Engine.quad_cache_*, what a Normal-Gamma block further down the sweep would read) must not survive them."""
+    d, C = 12, 5
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((d, 2 * d))
+    Qh = np.linalg.inv(A @ A.T / (2 * d))
+    Qh = (Qh + Qh.T) / 2
+    eng = make_engine(C, seed=4)
+    x = eng.to_device(rng.standard_normal((C, d)))
+    scale = 4.0 if kind == "mala" else 1.0
+    L, sl = eng.dense_cholesky(eng.to_device(Qh), scale)
+    holder = object()
+    eng.quad_cache_put(holder, eng.empty(1, C), [x])
+    assert eng.quad_cache_get(holder, [x]) is not None
+    serial = eng._write_serial
+    version = x._version
+    if kind == "mala":
+        eng.mala_step_white(None, L, sl, 0.5, x, draw_index=1)
+    else:
+        eng.rw_step_white(None, L, sl, 0.1, x, draw_index=1)
+    eng.check_status()
+    assert x._version == version  # torch saw nothing ...
+    assert eng.written_since(x, serial)  # ... the library's own log did
+    assert eng.quad_cache_get(holder, [x]) is None
+    eng.close()
