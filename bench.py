@@ -191,8 +191,17 @@ def cpu_baseline(n, seconds_budget=12.0):
         blas = [{"api": i.get("internal_api"), "threads": i.get("num_threads")} for i in threadpool_info()]
     except Exception:
         pass
+    ratio = None
+    try:  # measured in the build container, reference and oracle on the same cores (tests/golden/make_golden.py)
+        ratio = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_timing.json"))).get("oracle_over_reference_speed")
+    except (OSError, ValueError):
+        pass
     return {
         "value": k / dt, "unit": "chain-updates/s", "cores": 1, "kind": "port",
+        "oracle_over_reference_speed": ratio,
+        "reference_equivalent": (k / dt / ratio) if ratio else None,
+        "reference_equivalent_note": "value / (oracle speed over the imported reference's on one host, "
+                                     "tests/golden/reference_timing.json): what openMCMC itself would do on these cores",
         "cpu_model": cpu_model, "os_cpu_count": os.cpu_count(), "blas_threadpools": blas,
         "threads_note": "the sparse route (SuperLU factor + solves) and the C Thomas sweep are single-threaded; BLAS pools are idle here",
         "parallel_projection": k / dt * (os.cpu_count() or 1),

@@ -400,22 +400,56 @@ def gen_precision_builders():
 
 # ----------------------------------------------------------------------------- timings
 def gen_reference_timing():
-    """Single-chain reference rate on cfg3 (sparse route), this container's cores; BASELINE.md section 3."""
+    """Single-chain rates on cfg3 (sparse route) of the REFERENCE and of the oracle's restatement, same process, same cores,
+    interleaved (the ratio that carries the GPU box's oracle timing over to the reference)."""
     import json
     import time
 
-    n = 10000
+    from scipy import sparse
+
+    sys.path.insert(0, os.path.abspath(os.path.join(OUT, "..", "..")))
+    from oracle import sweep_ref
+
+    n, k = 10000, 30
     y = gmrf_data(n, seed=0)
     mdl = gmrf_model(True)
-    samplers = [NormalNormal("b", mdl), NormalGamma("lambda", mdl), NormalGamma("tau", mdl)]
-    M = MCMC(gmrf_state(n, y, True), samplers, model=mdl, n_burn=0, n_iter=30)
-    t0 = time.perf_counter()
-    M.run_mcmc()
-    dt = time.perf_counter() - t0
+
+    def run_reference():
+        samplers = [NormalNormal("b", mdl), NormalGamma("lambda", mdl), NormalGamma("tau", mdl)]
+        M = MCMC(gmrf_state(n, y, True), samplers, model=mdl, n_burn=0, n_iter=k)
+        t0 = time.perf_counter()
+        M.run_mcmc()
+        return time.perf_counter() - t0
+
+    d = np.full(n, 2.0)
+    d[0] = d[-1] = 1.0
+    d[0] += 1e-3
+    off = -np.ones(n - 1)
+    P = sparse.diags((off, d, off), offsets=[-1, 0, 1], format="csc")
+    rng = np.random.default_rng(1)
+    z, g = rng.standard_normal((k, n)), rng.standard_gamma(5000.0, size=(k, 2))
+
+    def run_oracle():
+        t0 = time.perf_counter()
+        sweep_ref.gmrf_smoother_chain(y.ravel(), P, 0, k, z, g)
+        return time.perf_counter() - t0
+
+    run_reference(), run_oracle()  # warm both (imports, first-touch)
+    ref, orc = [], []
+    for _ in range(3):
+        ref.append(run_reference())
+        orc.append(run_oracle())
+    t_ref, t_orc = min(ref), min(orc)
     rec = {
-        "config": "cfg3 sparse route, n=10000, 1 chain, 30 sweeps incl. store+log_post",
-        "ms_per_chain_update": 1e3 * dt / 30,
-        "chain_updates_per_s": 30 / dt,
+        "config": f"cfg3 sparse route, n={n}, 1 chain, {k} sweeps incl. store+log_post; best of 3 interleaved runs each",
+        "ms_per_chain_update": 1e3 * t_ref / k,
+        "chain_updates_per_s": k / t_ref,
+        "oracle_ms_per_chain_update": 1e3 * t_orc / k,
+        "oracle_chain_updates_per_s": k / t_orc,
+        "oracle_over_reference_speed": t_ref / t_orc,
+        "note": "oracle = oracle/sweep_ref.gmrf_smoother_chain (bench.py's cpu_baseline leg); reference = openmcmc MCMC.run_mcmc; "
+                "reference rate on another host ~ that host's oracle rate / oracle_over_reference_speed",
+        "all_runs_s": {"reference": ref, "oracle": orc},
         "cpu_count": os.cpu_count(),
         "numpy": np.__version__,
     }
