@@ -692,6 +692,22 @@ omc_status omc_mixture_gather2(omc_ctx* ctx, int64_t kmax, int64_t m, const doub
  * Saves gathering the whole store (82 MB per iteration at cfg3) when only summaries are wanted.   */
 omc_status omc_store_moments(omc_ctx* ctx, int64_t n_iter, int64_t size, const double* store,
                              int32_t pooled, double* mean_out, double* var_out);
+/* Quantiles of the same store, np.quantile's default ("linear") method, what a user of the reference computes on
+ * MCMC.store[param] (host arrays there: mcmc.py:105-111, sampler/sampler.py:89-118):
+ *   q        [n_q]  (HOST) levels in [0, 1]
+ *   pooled == 0: out [n_q][C][size]: per chain over its n_iter stored iterations (np.quantile(store_c, q, axis=-1));
+ *   pooled != 0: out [n_q][size]:    over all chains and iterations.
+ *   omit_nan != 0: NaN entries (the padding of variable-size parameters beyond the live length, sampler.py:81-87; iterations
+ *   not yet written) are left out per element like np.nanquantile, an element with no valid value gives NaN;
+ *   omit_nan == 0: an element with any NaN gives NaN (np.quantile).
+ * Exact order statistics by radix refinement on the device (eight passes over the store per group of four levels; no sort,
+ * no copy of the store), then numpy's interpolation operation by operation: results are bit-equal to np.quantile's.      */
+omc_status omc_store_quantiles(omc_ctx* ctx, int64_t n_iter, int64_t size, const double* store, int32_t pooled, int32_t n_q,
+                               const double* q, int32_t omit_nan, double* out);
+/* Thinned copy of the store for a thinned gather: out[j] = store[first + j * every] (slabs of C * size doubles),
+ * j = 0 .. ceil((n_iter - first) / every) - 1 (that count is left in *n_out when n_out is not NULL, host).           */
+omc_status omc_store_thin(omc_ctx* ctx, int64_t n_iter, int64_t size, const double* store, int64_t first, int64_t every,
+                          double* out, int64_t* n_out);
 
 /* ---- the one collective of the path: gather of the per-rank stores on a root (RCCL over xGMI) ----
  * Nothing in the reference to replace (it has one chain and no collective; SURVEY section 2.2 COLL row, section 8b

@@ -147,6 +147,8 @@ SIGNATURES = {
                                     c_dp]),
     "omc_store_ragged": (i32, [C.c_void_p, i64, c_dp, i64, c_dp, c_dp, i64]),
     "omc_store_moments": (i32, [C.c_void_p, i64, i64, c_dp, i32, c_dp, c_dp]),
+    "omc_store_quantiles": (i32, [C.c_void_p, i64, i64, c_dp, i32, i32, C.POINTER(C.c_double), i32, c_dp]),
+    "omc_store_thin": (i32, [C.c_void_p, i64, i64, c_dp, i64, i64, c_dp, C.POINTER(i64)]),
     "omc_band_sample_canonical": (
         i32, [C.c_void_p, i64, i64, C.POINTER(BandTerms), c_dp, i64, c_dp, i64, u64, c_dp, i64, c_dp, i64, c_dp]),
     "omc_band_quadform": (i32, [C.c_void_p, i64, i64, c_dp, c_dp, c_dp, i64, c_dp]),

@@ -29,6 +29,7 @@ struct omc_ctx {
   double* long_quad; size_t long_quad_bytes;  // ... and the sweep's quadratic forms [term][chain]
   double* workspace;       // scratch for the serial kernel (l vectors), grown on demand
   size_t workspace_bytes;
+  void* store_ws; size_t store_ws_bytes;  // omc_store.hip: histograms / partial moments of the store summaries
   // dense path (omc_dense.hip): rocBLAS handle and workspaces, created on first use
   void* blas;
   // blocked dense factorisation: second half of the chains on a side stream (forked from / joined into `stream` by events),
@@ -84,6 +85,7 @@ omc_status omc_dgemm_small(omc_ctx* ctx, int M, int N, const double* A0, int64_t
                            const double* A1, int64_t lda1, const double* B1, int64_t ldb1, int K1, int tri, const double* addv,
                            double* Cout, int64_t ldc, const int* colmask = nullptr);
 omc_status omc_ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need);  // grow-on-demand workspace (omc_dense.hip)
+omc_status omc_col_moments(omc_ctx* ctx, const double* data, int64_t R, int64_t K, double* mean_out, double* var_out);  // omc_store.hip
 extern "C" omc_status omc_gram_mfma_launch(omc_ctx* ctx, int64_t n, int64_t p, const double* X, const double* w, double* G_out);  // omc_gram.hip  // destroys the rocBLAS handle if one was created
 
 #define OMC_HIP_CHECK(expr)                  \

@@ -37,6 +37,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->long_band = nullptr; c->long_band_bytes = 0; c->long_quad = nullptr; c->long_quad_bytes = 0;
   c->workspace_bytes = 0;
   c->blas = nullptr;
+  c->store_ws = nullptr; c->store_ws_bytes = 0;
   c->dense_factor = nullptr; c->dense_factor_bytes = 0;
   c->dense_info = nullptr; c->dense_info_bytes = 0;
   c->slice_buf = nullptr; c->slice_buf_bytes = 0;
@@ -91,6 +92,7 @@ omc_status omc_ctx_destroy(omc_ctx* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (ctx->workspace) hipFree(ctx->workspace);
+  if (ctx->store_ws) hipFree(ctx->store_ws);
   if (ctx->long_band) hipFree(ctx->long_band);
   if (ctx->long_quad) hipFree(ctx->long_quad);
   if (ctx->d_gamma_tab) hipFree(ctx->d_gamma_tab);

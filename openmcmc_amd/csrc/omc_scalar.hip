@@ -169,25 +169,6 @@ __global__ void k_rj_move(int64_t C, int64_t chain_offset, long long n_max, doub
 
 // mean / variance over stored iterations (and chains when pooled): one lane per output element,
 // coalesced across the element index, Welford accumulation
-__global__ void k_store_moments(int64_t n_iter, int64_t C, int64_t size, const double* store, int pooled,
-                                double* mean_out, double* var_out) {
-  const int64_t n_out = pooled ? size : C * size;
-  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += (int64_t)gridDim.x * blockDim.x) {
-    double mean = 0.0, m2 = 0.0, cnt = 0.0;
-    const int64_t c0 = pooled ? 0 : o / size, c1 = pooled ? C : c0 + 1, i = pooled ? o : o % size;
-    for (int64_t it = 0; it < n_iter; ++it)
-      for (int64_t c = c0; c < c1; ++c) {
-        const double v = store[(it * C + c) * size + i];
-        cnt += 1.0;
-        const double dlt = v - mean;
-        mean += dlt / cnt;
-        m2 = fma(dlt, v - mean, m2);
-      }
-    if (mean_out) mean_out[o] = mean;
-    if (var_out) var_out[o] = cnt > 1.0 ? m2 / (cnt - 1.0) : 0.0;
-  }
-}
-
 static inline unsigned grid1(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
 extern "C" {
@@ -304,13 +285,9 @@ omc_status omc_store_moments(omc_ctx* ctx, int64_t n_iter, int64_t size, const d
                              double* mean_out, double* var_out) {
   if (!ctx || n_iter < 1 || size < 1 || !store || (!mean_out && !var_out)) return OMC_INVALID_ARG;
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
-  const int64_t n_out = pooled ? size : ctx->n_chains * size;
-  unsigned g = grid1(n_out, 256);
-  if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(k_store_moments, dim3(g), dim3(256), 0, ctx->stream, n_iter, ctx->n_chains, size, store, (int)pooled,
-                     mean_out, var_out);
-  OMC_HIP_CHECK(hipGetLastError());
-  return OMC_OK;
+  // both summaries are column moments of one row-major matrix (omc_store.hip): pooled [n_iter C][size], per chain [n_iter][C size]
+  const int64_t C = ctx->n_chains;
+  return omc_col_moments(ctx, store, pooled ? n_iter * C : n_iter, pooled ? size : C * size, mean_out, var_out);
 }
 
 omc_status omc_fill_normal(omc_ctx* ctx, int64_t n, uint64_t draw_index, double* out, int64_t ld) {

@@ -1055,6 +1055,36 @@ class Engine:
         check(lib.omc_store_moments(self._ctx, n_iter, size, self._p(store), int(pooled), self._p(mean), self._p(var)))
         return mean, var
 
+    def store_quantiles(self, store, q, pooled=False, omit_nan=True):
+        """np.quantile (omit_nan=False) / np.nanquantile (True) of a device store (n_iter, C, size) along the iterations,
+        default "linear" method: (len(q), C, size) per chain or (len(q), size) pooled over chains; computed on the device."""
+        if store.dim() != 3 or store.shape[1] != self.n_chains or not store.is_contiguous():
+            raise ValueError("store must be a contiguous (n_iter, C, size) tensor")
+        qs = np.ascontiguousarray(np.atleast_1d(np.asarray(q, dtype=np.float64)))
+        if qs.ndim != 1 or qs.size < 1:
+            raise ValueError("q must be a scalar or a one-dimensional sequence")
+        if not np.all((qs >= 0) & (qs <= 1)):
+            raise ValueError("Quantiles must be in the range [0, 1]")  # np.quantile's own message
+        n_iter, _, size = store.shape
+        out = self.empty(*((qs.size, size) if pooled else (qs.size, self.n_chains, size)))
+        check(lib.omc_store_quantiles(self._ctx, n_iter, size, self._p(store), int(pooled), qs.size,
+                                      qs.ctypes.data_as(C.POINTER(C.c_double)), int(bool(omit_nan)), self._p(out)))
+        return out
+
+    def store_thin(self, store, every, first=0):
+        """store[first::every] of a device store (n_iter, C, ...) as a packed device tensor (one launch)."""
+        if store.dim() < 2 or store.shape[1] != self.n_chains or not store.is_contiguous():
+            raise ValueError("store must be a contiguous (n_iter, C, ...) tensor")
+        n_iter = store.shape[0]
+        every, first = int(every), int(first)
+        if every < 1 or not 0 <= first < n_iter:
+            raise ValueError("every must be >= 1 and first inside the store")
+        n_out = (n_iter - first + every - 1) // every
+        size = int(np.prod(store.shape[2:])) if store.dim() > 2 else 1
+        out = self.empty(*((n_out,) + tuple(store.shape[1:])))
+        check(lib.omc_store_thin(self._ctx, n_iter, size, self._p(store), first, every, self._p(out), None))
+        return out
+
     # ------------------------------------------------------------------ the gather of the stores (RCCL)
     def communicator(self, world, rank, unique_id):
         """RCCL communicator of this rank (omc_comm_create); collective over all ranks.  `unique_id` is the bytes

@@ -40,7 +40,7 @@ def make_communicator(engine, group=None):
     return engine.communicator(world, rank, box[0])
 
 
-def gather_chains(t, chain_dim, dst=0, group=None, comm=None):
+def gather_chains(t, chain_dim, dst=0, group=None, comm=None, counts=None):
     """Gather a per-rank tensor whose dimension `chain_dim` indexes this rank's chains: on `dst` the tensor with the
     chains of all ranks concatenated in rank order (= global chain order), None elsewhere.  Ranks may hold
     different chain counts.  With `comm` (an engine.Communicator) the transfer is the library's omc_gather_samples
@@ -52,8 +52,9 @@ def gather_chains(t, chain_dim, dst=0, group=None, comm=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return t
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    counts = [None] * world
-    dist.all_gather_object(counts, int(t.shape[chain_dim]), group=group)
+    if counts is None:  # (a caller that gathers many blocks of the same sharding passes the counts it already has)
+        counts = [None] * world
+        dist.all_gather_object(counts, int(t.shape[chain_dim]), group=group)
     if comm is not None:
         # (outer..., C, inner...) -> (n_outer, C, row): the dimensions in front of the chains are the outer index
         lead = t.shape[:chain_dim]
@@ -99,3 +100,71 @@ def gather_store(store, dst=0, group=None, comm=None):
         if rank == dst:
             result[key] = store_to_reference_layout(key, full.cpu().numpy())
     return result
+
+
+class GatherSink:
+    """Streaming form of the run's one collective, for MCMC(store_ring=R, sink=GatherSink(...)): every half of the ring the
+    drain stream empties goes straight to rank `dst` (chains of all ranks in global chain order) while the chains keep
+    sampling, so no rank ever holds more than R iteration slabs on its GPU and the root never receives the whole store in
+    one burst at the end.  `result()` (after run_mcmc) -> the dict of MCMC.gather() on dst, None elsewhere.
+
+    comm="library": the transfers are omc_gather_samples on a second context bound to the drain stream (RCCL, every peer
+    point to point into the root); None: torch.distributed's gather on the group's backend (gloo ranks stage through the host).
+    every=k keeps iterations 0, k, 2k, ... only (a thinned streaming gather)."""
+
+    def __init__(self, dst=0, group=None, comm=None, every=1):
+        self.dst, self.group, self.comm_kind, self.every = int(dst), group, comm, max(1, int(every))
+        self.comm, self.host, self.counts, self._eng2, self.n_iter = None, {}, None, None, None
+
+    def bind(self, mcmc, stream):
+        """called once by the ring's drain (under the drain stream) before the first chunk"""
+        import torch
+        import torch.distributed as dist
+
+        self.n_iter = mcmc.n_iter
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        self.rank = dist.get_rank(self.group) if self.active else 0
+        self.cpu_staged = self.active and dist.get_backend(self.group) != "nccl"
+        if self.active:
+            counts = [None] * dist.get_world_size(self.group)
+            dist.all_gather_object(counts, int(mcmc.n_chains), group=self.group)
+            self.counts = counts
+            if self.comm_kind == "library" and not self.cpu_staged:
+                from openmcmc_amd.engine import Engine
+
+                with torch.cuda.stream(stream):  # a context of its own on the drain stream: its collective must not queue behind the sweeps
+                    self._eng2 = Engine(mcmc.n_chains, seed=mcmc.seed, device=mcmc.engine.device_index, chain_id_offset=mcmc.chain_id_offset)
+                    self.comm = make_communicator(self._eng2, self.group)
+
+    def __call__(self, key, it0, it1, block):
+        import torch
+
+        first = (-it0) % self.every  # first iteration of the chunk that is a multiple of `every`
+        if first >= it1 - it0:
+            return
+        part = block[first:: self.every]
+        j0 = (it0 + first) // self.every
+        if self.cpu_staged:
+            part = part.cpu()
+        full = gather_chains(part, 1, dst=self.dst, group=self.group, comm=self.comm, counts=self.counts) if self.active else part
+        if self.rank != self.dst:
+            return
+        if key not in self.host:
+            kept = (self.n_iter + self.every - 1) // self.every
+            self.host[key] = torch.empty((kept,) + tuple(full.shape[1:]), dtype=full.dtype, pin_memory=torch.cuda.is_available())
+        self.host[key][j0: j0 + full.shape[0]].copy_(full, non_blocking=True)
+
+    def result(self):
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+        if self._eng2 is not None:
+            self._eng2.close()
+            self._eng2 = None
+        if self.rank != self.dst:
+            return None
+        return {key: store_to_reference_layout(key, t.numpy()) for key, t in self.host.items()}

@@ -15,7 +15,7 @@ def relerr(a, b):
     return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
 
 
-def build(G, k, sparse_route, n_chains, fuse, n_burn=None, n_iter=None, seed=0):
+def build(G, k, sparse_route, n_chains, fuse, n_burn=None, n_iter=None, seed=0, **mcmc_kw):
     from openmcmc_amd.distribution.distribution import Gamma
     from openmcmc_amd.distribution.location_scale import Normal
     from openmcmc_amd.mcmc import MCMC
@@ -40,7 +40,7 @@ def build(G, k, sparse_route, n_chains, fuse, n_burn=None, n_iter=None, seed=0):
         state["A"] = sparse.identity(n, format="csc")
     samplers = [NormalNormal("b", mdl), NormalGamma("lambda", mdl), NormalGamma("tau", mdl)]
     M = MCMC(state, samplers, model=mdl, n_burn=int(G[k + "n_burn"]) if n_burn is None else n_burn,
-             n_iter=int(G[k + "n_iter"]) if n_iter is None else n_iter, n_chains=n_chains, fuse=fuse, seed=seed)
+             n_iter=int(G[k + "n_iter"]) if n_iter is None else n_iter, n_chains=n_chains, fuse=fuse, seed=seed, **mcmc_kw)
     return M, samplers
 
 

@@ -17,17 +17,17 @@ def _nan0(a, fill=0.5):
     return np.where(np.isnan(a), fill, a)
 
 
-def run_with_tape(G, chains, n_iter, trace_sweeps=()):
+def run_with_tape(G, chains, n_iter, trace_sweeps=(), **mcmc_kw):
     n_max = int(G["n_max"])
     P = np.diag(G["P_diag"]) + np.diag(G["P_off"], 1) + np.diag(G["P_off"], -1)
     k0 = G["init_k"][chains]
     init_theta = [G["init_theta"][c][: int(k)] for c, k in zip(chains, k0)]
     init_beta = [G["init_beta"][c][: int(k)] for c, k in zip(chains, k0)]
     tape = {k[5:]: G[k][chains] for k in G.files if k.startswith("tape_")}
-    return mcmc_with_tape(G["y"], G["X"], P, n_max, init_theta, init_beta, k0, tape, n_iter)
+    return mcmc_with_tape(G["y"], G["X"], P, n_max, init_theta, init_beta, k0, tape, n_iter, **mcmc_kw)
 
 
-def mcmc_with_tape(y, X, P, n_max, init_theta, init_beta, k0, tape, n_iter):
+def mcmc_with_tape(y, X, P, n_max, init_theta, init_beta, k0, tape, n_iter, **mcmc_kw):
     """MCMC over len(k0) chains with every draw injected from `tape` (arrays with a leading chain axis)."""
     import torch
 
@@ -55,7 +55,7 @@ def mcmc_with_tape(y, X, P, n_max, init_theta, init_beta, k0, tape, n_iter):
     s_rj.inject_associated = lambda s, it: {"theta": t(_nan0(tape["rj_theta_u"][:, it]).reshape(C, 1))}
     s_rj.inject_match = lambda s, it: t(_nan0(tape["rj_beta_u"][:, it]))
     s_rj.inject_uniform = lambda s, it: t(_nan0(tape["rj_acc_u"][:, it]))
-    M = MCMC(state, samplers, model=mdl, n_burn=0, n_iter=n_iter, n_chains=C, engine=eng)
+    M = MCMC(state, samplers, model=mdl, n_burn=0, n_iter=n_iter, n_chains=C, engine=eng, **mcmc_kw)
     return M, samplers, tape
 
 
