@@ -34,6 +34,49 @@ __device__ __forceinline__ double q_val(uint64_t k) {
   return __longlong_as_double((long long)b);
 }
 
+// np.quantile, method "linear": virtual index (n - 1) q, its floor and the next index (lib/_function_base_impl.py:
+// _get_indexes / _get_gamma) for a column with nv valid values -> the two ranks and the interpolation weight
+__device__ __forceinline__ void q_ranks(int64_t nv, double q, int64_t& lo, int64_t& hi, double& frac) {
+  const double h = (double)(nv - 1) * q;
+  lo = (int64_t)floor(h);
+  if (lo < 0) lo = 0;
+  if (lo > nv - 1) lo = nv - 1;
+  hi = lo + 1 < nv ? lo + 1 : nv - 1;
+  if (h >= (double)(nv - 1)) lo = hi = nv - 1;
+  if (nv <= 0) lo = hi = 0;
+  frac = (nv > 0 && h < (double)(nv - 1)) ? h - (double)lo : 0.0;
+}
+
+// one wave on one row of 256 counts: the bin the rank falls into and the count in front of it.  (No lane claims the rank
+// only when the column has no valid value at all -- the result is NaN then anyway.)
+__device__ __forceinline__ void q_pick(const uint32_t* hrow, int lane, int64_t rk, int& dg_out, int64_t& before_out) {
+  const uint4 c = *reinterpret_cast<const uint4*>(hrow + 4 * lane);
+  const int64_t mine = (int64_t)c.x + c.y + c.z + c.w;
+  int64_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int64_t o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  const int64_t excl = incl - mine;
+  const unsigned long long m = __ballot(rk >= excl && rk < incl);
+  const int src = m ? __ffsll((long long)m) - 1 : 63;
+  int dg = 4 * lane;
+  int64_t before = excl;
+  if (rk >= before + c.x) { before += c.x; ++dg; if (rk >= before + c.y) { before += c.y; ++dg; if (rk >= before + c.z) { before += c.z; ++dg; } } }
+  dg_out = __shfl(dg, src, 64);
+  before_out = __shfl(before, src, 64);
+}
+
+// numpy's _lerp (lib/_function_base_impl.py), operation by operation: a + (b - a) t, and b - (b - a)(1 - t) where t >= 0.5.
+// (HIP's __dmul_rn / __dadd_rn are plain operators the compiler may still fuse into an fma: contraction is switched off here)
+__device__ __noinline__ double q_lerp(double a, double b, double t) {
+#pragma clang fp contract(off)
+  const double diff = b - a;
+  const double up = a + diff * t, down = b - diff * (1.0 - t);
+  return t >= 0.5 ? down : up;
+}
+
 // hist [T][Kc][256], prefix [T][Kc]; pass 0 fills target 0's histogram only (no prefix yet: the same for every target)
 __global__ void __launch_bounds__(256) k_q_hist(const double* __restrict__ data, int64_t R, int64_t K, int64_t k0, int64_t Kc, int pass, int T,
                                                 const uint64_t* __restrict__ prefix, uint32_t* __restrict__ hist,
@@ -112,46 +155,24 @@ __global__ void __launch_bounds__(256) k_q_scan(int pass, int T, int64_t Kc, int
   const int64_t kc = w % Kc;
   int64_t rk;
   if (pass == 0) {
-    // np.quantile, method "linear": virtual index (n - 1) q, its floor and the next one (lib/_function_base_impl.py)
-    const int64_t nv = R - (int64_t)nan_count[kc];
-    const double h = (double)(nv - 1) * q[t >> 1];
-    int64_t lo = (int64_t)floor(h);
-    if (lo < 0) lo = 0;
-    if (lo > nv - 1) lo = nv - 1;
-    int64_t hi = lo + 1 < nv ? lo + 1 : nv - 1;
-    if (h >= (double)(nv - 1)) lo = hi = nv - 1;
-    if (nv <= 0) lo = hi = 0;
+    int64_t lo, hi;
+    double fr;
+    q_ranks(R - (int64_t)nan_count[kc], q[t >> 1], lo, hi, fr);
     rk = (t & 1) ? hi : lo;
-    if (!(t & 1) && lane == 0) frac[(int64_t)(t >> 1) * Kc + kc] = (nv > 0 && h < (double)(nv - 1)) ? h - (double)lo : 0.0;
+    if (!(t & 1) && lane == 0) frac[(int64_t)(t >> 1) * Kc + kc] = fr;
   } else {
     rk = rank[(int64_t)t * Kc + kc];
   }
-  uint32_t* hrow = hist + ((int64_t)(pass == 0 ? 0 : t) * Kc + kc) * 256;
-  const uint4 c = *reinterpret_cast<const uint4*>(hrow + 4 * lane);
-  const int64_t mine = (int64_t)c.x + c.y + c.z + c.w;
-  int64_t incl = mine;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int64_t o = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += o;
-  }
-  const int64_t excl = incl - mine;
-  const bool here = rk >= excl && rk < incl;
-  const unsigned long long m = __ballot(here);
-  // (no lane claims the rank only when the column has no valid value: nv = 0, every count is a NaN's -- the result is NaN anyway)
-  const int src = m ? __ffsll((long long)m) - 1 : 63;
-  int dg = 4 * lane;
-  int64_t before = excl;
-  if (rk >= before + c.x) { before += c.x; ++dg; if (rk >= before + c.y) { before += c.y; ++dg; if (rk >= before + c.z) { before += c.z; ++dg; } } }
-  dg = __shfl(dg, src, 64);
-  before = __shfl(before, src, 64);
+  uint32_t* hrow = hist + ((int64_t)(pass == 0 ? 0 : t) * Kc + kc) * 256;  // (pass 0: one histogram serves every target)
+  int dg;
+  int64_t before;
+  q_pick(hrow, lane, rk, dg, before);
   if (lane == 0) {
     const uint64_t old = pass == 0 ? 0 : prefix[(int64_t)t * Kc + kc];
     prefix[(int64_t)t * Kc + kc] = (old << 8) | (uint64_t)dg;
     rank[(int64_t)t * Kc + kc] = rk - before;
   }
-  // pass 0 reads target 0's row on behalf of every target: it is cleared by the launch's LAST wave on that row -- simpler:
-  // a separate clear after pass 0 (host); later passes clear their own row
+  // (pass 0's shared row is cleared by the host behind this launch; later passes clear their own)
   if (pass > 0) *reinterpret_cast<uint4*>(hrow + 4 * lane) = make_uint4(0, 0, 0, 0);
 }
 
@@ -168,11 +189,99 @@ __global__ void k_q_finish(int nq, int64_t Kc, int64_t k0, int64_t K, int64_t R,
   } else {
     const double a = q_val(prefix[(int64_t)(2 * j) * Kc + kc]), b = q_val(prefix[(int64_t)(2 * j + 1) * Kc + kc]);
     const double t = frac[(int64_t)j * Kc + kc];
-    // numpy's _lerp, operation by operation (no contraction): a + (b - a) t, and b - (b - a)(1 - t) where t >= 0.5
-    const double diff = __dsub_rn(b, a);
-    r = t >= 0.5 ? __dsub_rn(b, __dmul_rn(diff, __dsub_rn(1.0, t))) : __dadd_rn(a, __dmul_rn(diff, t));
+    r = q_lerp(a, b, t);
   }
   out[(int64_t)j * K + k0 + kc] = r;
+}
+
+// Many columns (the per-chain summaries: C x size of them): a workgroup OWNS OC adjacent columns -- all their rows -- and runs the
+// eight passes in one launch; histograms, prefixes and ranks never leave LDS, and the re-reads of the workgroup's column
+// strip come out of L2 / MALL for short stores.  (The row-sliced route above needs 8 KB of global histogram per column
+// and two launches per pass: at 10 M columns that is hundreds of chunks.)
+constexpr int OC = 8;            // columns per workgroup: 64-byte row pieces, 64 KB of histograms -> two workgroups per CU
+constexpr int OROW = 256 / OC;   // rows per step
+
+__global__ void __launch_bounds__(256) k_q_owned(const double* __restrict__ data, int64_t R, int64_t K, int T, int nq,
+                                                 const double* __restrict__ q, int omit_nan, double* __restrict__ out) {
+  extern __shared__ uint32_t lh[];  // [T][OC][256]
+  __shared__ uint64_t s_prefix[Q_TARGETS][OC];
+  __shared__ int64_t s_rank[Q_TARGETS][OC];
+  __shared__ double s_frac[Q_TARGETS / 2][OC];
+  __shared__ uint32_t s_nan[OC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = tid & (OC - 1);
+  const int64_t k = (int64_t)blockIdx.x * OC + col;
+  const bool live = k < K;
+  const double* p = data + (live ? k : 0);
+  if (tid < OC) s_nan[tid] = 0;
+  for (int pass = 0; pass < 8; ++pass) {
+    const int Tl = pass == 0 ? 1 : T;
+    for (int i = tid; i < Tl * OC * 256; i += 256) lh[i] = 0;
+    uint64_t pf[Q_TARGETS];
+#pragma unroll
+    for (int t = 0; t < Q_TARGETS; ++t) pf[t] = (pass > 0 && t < T) ? s_prefix[t][col] : 0;
+    __syncthreads();
+    const int shift = 56 - 8 * pass;
+    if (live) {
+      uint32_t nans = 0;
+      auto take = [&](double v) {
+        const uint64_t key = q_key(v);
+        if (pass == 0) {
+          nans += key == ~0ull;
+          atomicAdd(&lh[col * 256 + (int)(key >> 56)], 1u);
+        } else {
+          const uint64_t hi = key >> (shift + 8);
+          const int dg = (int)(key >> shift) & 255;
+#pragma unroll
+          for (int t = 0; t < Q_TARGETS; ++t)
+            if (t < T && hi == pf[t]) atomicAdd(&lh[(t * OC + col) * 256 + dg], 1u);
+        }
+      };
+      int64_t r = tid / OC;
+      for (; r + 3 * OROW < R; r += 4 * OROW) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = p[(r + u * OROW) * K];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) take(v[u]);
+      }
+      for (; r < R; r += OROW) take(p[r * K]);
+      if (pass == 0 && nans) atomicAdd(&s_nan[col], nans);
+    }
+    __syncthreads();
+    for (int pr = wave; pr < T * OC; pr += 4) {  // (target, column) pairs, one wave each
+      const int t = pr / OC, c = pr % OC;
+      int64_t rk;
+      if (pass == 0) {
+        int64_t lo, hi;
+        double fr;
+        q_ranks(R - (int64_t)s_nan[c], q[t >> 1], lo, hi, fr);
+        rk = (t & 1) ? hi : lo;
+        if (!(t & 1) && lane == 0) s_frac[t >> 1][c] = fr;
+      } else {
+        rk = s_rank[t][c];
+      }
+      int dg;
+      int64_t before;
+      q_pick(&lh[((pass == 0 ? 0 : t) * OC + c) * 256], lane, rk, dg, before);
+      if (lane == 0) {
+        s_prefix[t][c] = ((pass == 0 ? 0 : s_prefix[t][c]) << 8) | (uint64_t)dg;
+        s_rank[t][c] = rk - before;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < nq * OC) {
+    const int j = tid / OC, c = tid % OC;
+    const int64_t kk = (int64_t)blockIdx.x * OC + c;
+    if (kk < K) {
+      const uint32_t nn = s_nan[c];
+      double r;
+      if ((int64_t)nn >= R || (nn && !omit_nan)) r = __longlong_as_double(0x7ff8000000000000LL);
+      else r = q_lerp(q_val(s_prefix[2 * j][c]), q_val(s_prefix[2 * j + 1][c]), s_frac[j][c]);
+      out[(int64_t)j * K + kk] = r;
+    }
+  }
 }
 
 // mean and unbiased variance of every column of [R][K]: row slices combined by Chan's pairwise update through a small
@@ -260,14 +369,24 @@ omc_status omc_store_quantiles(omc_ctx* ctx, int64_t n_iter, int64_t size, const
   double* dq = (double*)ws;                                         ws += (Q_TARGETS / 2) * 8;
   uint32_t* nanc = (uint32_t*)ws;
   hipStream_t s = ctx->stream;
+  // enough columns to fill the chip with column-owning workgroups (and rows few enough for one workgroup to walk): one launch
+  const bool owned = K >= 8192 && R <= ((int64_t)1 << 22) && (K + OC - 1) / OC <= 0x7fffffffLL;
   for (int j0 = 0; j0 < n_q; j0 += Q_TARGETS / 2) {
     const int nq = (n_q - j0 < Q_TARGETS / 2) ? n_q - j0 : Q_TARGETS / 2;
     const int T = 2 * nq;
     // (the quantile levels of this group; pageable host memory: the copy has left the host buffer when the call returns)
     OMC_HIP_CHECK(hipMemcpyAsync(dq, q + j0, nq * sizeof(double), hipMemcpyHostToDevice, s));
+    if (owned) {
+      hipLaunchKernelGGL(k_q_owned, dim3((unsigned)((K + OC - 1) / OC)), dim3(256), (size_t)T * OC * 256 * 4, s, store, R, K, T, nq, dq,
+                         (int)omit_nan, out + (int64_t)j0 * K);
+      OMC_HIP_CHECK(hipGetLastError());
+      continue;
+    }
     for (int64_t k0 = 0; k0 < K; k0 += Kc) {
       const int64_t kc = (K - k0 < Kc) ? K - k0 : Kc;
-      OMC_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)kc * 256 * 4, s));  // target 0's rows (pass 0); later passes clear their own
+      // every target's rows start at zero (a fresh workspace holds anything, and an earlier call laid its rows out for another
+      // column count); from then on a pass leaves its rows cleared for the next one
+      OMC_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)T * kc * 256 * 4, s));
       OMC_HIP_CHECK(hipMemsetAsync(nanc, 0, (size_t)kc * 4, s));
       const unsigned tiles = (unsigned)((kc + Q_COLS - 1) / Q_COLS);
       // row slices: enough workgroups to fill the chip (256 CUs x a few), no slice shorter than 64 rows

@@ -25,18 +25,30 @@ def make_engine(C, seed=0):
     return Engine(C, seed=seed)
 
 
+def same(got, want):
+    """bit-for-bit up to the sign of zero and the payload of NaN; says where it is not"""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    bad = ~((got == want) | (np.isnan(got) & np.isnan(want)))
+    if bad.any():
+        idx = np.argwhere(bad)[:6]
+        raise AssertionError("differs at " + "; ".join(f"{tuple(i)}: {got[tuple(i)]!r} vs {want[tuple(i)]!r}" for i in idx))
+    return True
+
+
 def awkward_store(rng, n_iter, C, size):
     """ties, both zeros, infinities, a constant column, values of both signs over many binades"""
     a = rng.standard_normal((n_iter, C, size)) * np.exp(rng.uniform(-30, 30, size=(1, 1, size)))
     a[:, :, 0] = 1.5                                   # a constant element
     a[:, :, 1] = rng.integers(-2, 3, size=(n_iter, C))  # heavy ties, incl. +0.0
     a[::3, :, 1] *= -1.0                                # ... and -0.0
-    a[0, 0, 2], a[1, 0, 2] = np.inf, -np.inf
+    a[0, 0, 2], a[-1, -1, 2] = np.inf, -np.inf
     a[:, :, 3] = np.abs(a[:, :, 3])                    # one sign only
     return a
 
 
 @pytest.mark.parametrize("shape", [(1, 3, 5), (2, 1, 1), (37, 5, 23), (300, 64, 1000)])
+@pytest.mark.filterwarnings("ignore:invalid value")
 def test_store_quantiles_are_numpys(shape):
     n_iter, C, size = shape
     rng = np.random.default_rng(sum(shape))
@@ -45,11 +57,12 @@ def test_store_quantiles_are_numpys(shape):
     t = eng.to_device(a)
     got = eng.store_quantiles(t, QS, pooled=False, omit_nan=False).cpu().numpy()
     want = np.quantile(a, QS, axis=0)               # (nq, C, size): per chain over its iterations
-    assert got.shape == want.shape and np.array_equal(got, want)
+    # (inf - inf inside numpy's interpolation is NaN there and here: equal_nan)
+    assert same(got, want)
     got = eng.store_quantiles(t, QS, pooled=True, omit_nan=False).cpu().numpy()
     want = np.quantile(a.reshape(n_iter * C, size), QS, axis=0)
-    assert np.array_equal(got, want)
-    assert np.array_equal(eng.store_quantiles(t, 0.5, pooled=True).cpu().numpy()[0], np.median(a.reshape(-1, size), axis=0))
+    assert same(got, want)
+    assert same(eng.store_quantiles(t, 0.5, pooled=True).cpu().numpy()[0], np.quantile(a.reshape(-1, size), 0.5, axis=0))  # a scalar level
     eng.check_status()
     eng.close()
 
@@ -73,10 +86,10 @@ def test_store_quantiles_with_the_nan_padding_of_variable_size_entries():
             want_p = np.nanquantile(a.reshape(-1, size), QS, axis=0)
             prop_c = np.quantile(a, QS, axis=0)
     got = eng.store_quantiles(t, QS, pooled=False, omit_nan=True).cpu().numpy()
-    assert np.array_equal(got, want_c, equal_nan=True)
+    assert same(got, want_c)
     assert np.all(np.isnan(got[:, 2, size - 1])) and np.all(np.isnan(got[:, :, size - 2]))
-    assert np.array_equal(eng.store_quantiles(t, QS, pooled=True, omit_nan=True).cpu().numpy(), want_p, equal_nan=True)
-    assert np.array_equal(eng.store_quantiles(t, QS, pooled=False, omit_nan=False).cpu().numpy(), prop_c, equal_nan=True)
+    assert same(eng.store_quantiles(t, QS, pooled=True, omit_nan=True).cpu().numpy(), want_p)
+    assert same(eng.store_quantiles(t, QS, pooled=False, omit_nan=False).cpu().numpy(), prop_c)
     with pytest.raises(ValueError):
         eng.store_quantiles(t, [0.5, 1.5])
     eng.close()
