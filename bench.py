@@ -228,7 +228,7 @@ def secondary_lines(args):
     plan = {"cfg2": (0.25, 5), "cfg4": (0.03, 20), "cfg5": (1.0, 3)}
     for name, (ms_guess, warm) in plan.items():
         steps = int(max(20, min(20000, args.secondary_ms / ms_guess)))
-        a = types.SimpleNamespace(steps=steps, warmup=warm, chains=None, no_cpu=args.no_cpu, mala_products=False, config=name,
+        a = types.SimpleNamespace(steps=steps, warmup=warm, chains=None, no_cpu=args.no_cpu, mala_products=False, mala_single=False, config=name,
                                   condition_ms=min(200.0, args.secondary_ms / 4))
         t0 = time.perf_counter()
         try:
@@ -284,6 +284,7 @@ def main():
     ap.add_argument("--seg", type=int, default=0, help="nodes per lane of the segmented kernel (0 = auto)")
     ap.add_argument("--mala-products", action="store_true",
                     help="cfg4: the step as dense products (omc_mala_step) instead of the whitened step")
+    ap.add_argument("--mala-single", action="store_true", help="cfg4: one launch pair per step (omc_mala_step_white) instead of blocks of steps")
     ap.add_argument("--reenter", type=int, default=None, choices=[0, 1, 2],
                     help="omc_gmrf_run: 1 = workgroups restart themselves for the next sweep of a launch (default: the library's)")
     ap.add_argument("--sweeps-per-launch", type=int, default=0, help="omc_gmrf_run: sweeps per launch (0 = library default, 32)")

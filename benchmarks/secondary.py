@@ -155,17 +155,52 @@ def cfg4(args, torch):
     prop = torch.zeros(C, dtype=torch.int64, device="cuda")
 
     products = bool(getattr(args, "mala_products", False))
+    single = bool(getattr(args, "mala_single", False))
     seen = []
 
     def one(it):
         if products:   # the step as 3 full + 1 triangular product (omc_mala_step)
             eng.mala_step(Q, None, L, sl, step, x, draw_index=it, accept_count=acc, proposal_count=prop)
-        else:          # the step in whitened coordinates (omc_mala_step_white): what ManifoldMALA.sample issues
+        else:          # the step in whitened coordinates (omc_mala_step_white): one launch pair per step
             eng.mala_step_white(None, L, sl, step, x, state_is_current=bool(seen), draw_index=it, accept_count=acc,
                                 proposal_count=prop)
             seen.append(1)
 
-    dt = _timed(torch, one, args.steps, args.warmup, condition_ms=getattr(args, "condition_ms", 200.0))
+    burn_dt = None
+    if products or single:
+        dt = _timed(torch, one, args.steps, args.warmup, condition_ms=getattr(args, "condition_ms", 200.0))
+    else:
+        # What ManifoldMALA issues under MCMC.run_mcmc (omc_mala_run_white): blocks of 32 steps per launch, the state of EVERY
+        # step and its log density stored (sampler.store + log_post of every iteration, mcmc.py:105-108): one step here is one
+        # chain-update of every chain plus that bookkeeping.
+        B = 64
+        xs, lps = eng.empty(B, C, d), eng.empty(B, C)
+        calls = max(1, (args.steps + B - 1) // B)
+        it = [0]
+
+        def block(store=True):
+            eng.mala_run_white(None, L, sl, step, x, B, state_is_current=it[0] > 0, draw_index0=it[0], draw_stride=1,
+                               x_store=xs if store else None, logp_store=lps if store else None, accept_count=acc, proposal_count=prop)
+            it[0] += B
+
+        t_c = time.perf_counter()
+        while time.perf_counter() - t_c < getattr(args, "condition_ms", 200.0) * 1e-3:
+            block()
+            torch.cuda.synchronize()
+        for _ in range(max(1, args.warmup // B)):
+            block()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            block()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / (calls * B)
+        args.steps = calls * B
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            block(store=False)  # burn-in: nothing stored, no product until the last step
+        torch.cuda.synchronize()
+        burn_dt = (time.perf_counter() - t0) / (calls * B)
     eng.check_status()
     ref_flop = 14.0 * d * d                              # the reference's algorithm per chain-update
     flop = 9.0 * d * d if products else 2.0 * d * d      # what this route puts on the matrix cores (triangular counted dense)
@@ -180,7 +215,12 @@ def cfg4(args, torch):
                                 "whitened step: ONE triangular d x d product per chain (counted dense, 2 d^2) + an element-wise "
                                 "kernel; two launches of ~8 us each -- bound by launch and load latency at this size, not by "
                                 "the matrix cores; the reference's algorithm would need 14 d^2")}
-    out["config"]["route"] = "omc_mala_step (products)" if products else "omc_mala_step_white"
+    out["config"]["route"] = "omc_mala_step (products)" if products else ("omc_mala_step_white" if single else "omc_mala_run_white")
+    if burn_dt is not None:
+        out["config"]["burn_in_ms_per_step"] = 1e3 * burn_dt
+        out["roofline"]["note"] = ("blocks of 32 whitened steps per launch + ONE triangular d x d by d x (32 C) product per block into the "
+                                   "store (counted dense, 2 d^2 per chain-update); every step's state and log density stored; "
+                                   "burn_in_ms_per_step: the same steps with nothing stored")
     if not args.no_cpu:
         rg = np.random.default_rng(1)
         xc = np.asarray(np.linalg.solve(np.linalg.cholesky(Qh).T, rg.standard_normal((d, 1))))

@@ -348,6 +348,19 @@ omc_status omc_mala_step(omc_ctx* ctx, int64_t d, const double* Q, const double*
 omc_status omc_mala_step_white(omc_ctx* ctx, int64_t d, const double* mu, const double* L, const double* sumlogL, double step,
                                const double* z_inject, int64_t ld_z, const double* u_inject, uint64_t draw_index, double* x,
                                int64_t ld_x, int32_t state_is_current, int64_t* accept_count, int64_t* proposal_count, double* log_p_out);
+/* n_steps of omc_mala_step_white in a row -- the loop of MCMC.run_mcmc over a one-sampler model (mcmc.py:97-111) -- issued
+ * as ONE launch per block of 32 steps: a chain's whitened state stays in registers for the block, and one triangular
+ * product per block maps the block's states back into the store.  Step t draws from stream draw_index0 + t * draw_stride
+ * (what the loop would pass as draw_index); results are bit-identical to n_steps single calls (state, counters, log_p).
+ *   z_inject [n_steps][C][ld_z], u_inject [n_steps][C]: injected draws (NULL = generate);
+ *   x_store    [n_steps][C][d] or NULL: the state after every step (sampler.store of every iteration, sampler.py:89-118);
+ *   logp_store [n_steps][C]    or NULL: the target's log density at those states (mcmc.py:108);
+ *   x: the current state on entry (see state_is_current), the state after the last step on return; log_p_out [C] or NULL.
+ * d <= 2048 (OMC_UNSUPPORTED beyond: use the single step).                                                            */
+omc_status omc_mala_run_white(omc_ctx* ctx, int64_t d, const double* mu, const double* L, const double* sumlogL, double step,
+                              const double* z_inject, int64_t ld_z, const double* u_inject, uint64_t draw_index0,
+                              uint64_t draw_stride, int64_t n_steps, double* x, int64_t ld_x, int32_t state_is_current,
+                              double* x_store, double* logp_store, int64_t* accept_count, int64_t* proposal_count, double* log_p_out);
 omc_status omc_rw_step(omc_ctx* ctx, int64_t d, const double* mu, const double* LQ, const double* sumlogLQ,
                        double step, const double* z_inject, int64_t ld_z, const double* u_inject,
                        uint64_t draw_index, double* x, int64_t ld_x, int64_t* accept_count,

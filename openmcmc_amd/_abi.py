@@ -121,6 +121,10 @@ SIGNATURES = {
         i32,
         [C.c_void_p, i64, c_dp, c_dp, c_dp, C.c_double, c_dp, i64, c_dp, u64, c_dp, i64, i32, c_dp, c_dp, c_dp],
     ),
+    "omc_mala_run_white": (
+        i32,
+        [C.c_void_p, i64, c_dp, c_dp, c_dp, C.c_double, c_dp, i64, c_dp, u64, u64, i64, c_dp, i64, i32, c_dp, c_dp, c_dp, c_dp, c_dp],
+    ),
     "omc_mala_step": (
         i32,
         [C.c_void_p, i64, c_dp, c_dp, c_dp, c_dp, C.c_double, c_dp, i64, c_dp, u64, c_dp, i64, c_dp, c_dp],

@@ -49,6 +49,8 @@ struct omc_ctx {
   const double* mala_Q; const double* mala_L; double mala_step; int64_t mala_d;
   double* white_prep; size_t white_prep_bytes; const double* white_L; const double* white_mu; int64_t white_d;  // omc_mala_step_white
   double* white_a; size_t white_a_bytes; const double* white_x; int64_t white_ld;  // a = L'(x - mu) of the state at white_x
+  double* white_traj; size_t white_traj_bytes;  // omc_mala_run_white: the whitened states of two blocks of steps [2][32][C][d]
+  hipEvent_t white_ev[4];  // ... trajectory of block b written (0, 1) / mapped back by the product on the side stream (2, 3)
   double* rww_a; size_t rww_a_bytes; const double* rww_x; int64_t rww_ld; const double* rww_mu; double* rww_mu_neg; size_t rww_mu_bytes;  // omc_rw_step_white
   double* rw_prep; size_t rw_prep_bytes; const double* rw_LQ; int64_t rw_d;  // omc_rw_step: LQ with a zero upper triangle
   int tridiag_algo;  // 0 auto, 1 serial, 2 segmented
@@ -83,8 +85,12 @@ int omc_reentry_probe_result(omc_ctx* ctx);  // omc_tridiag.hip: 1 if the loaded
 // omc_gemm.hip: small-state fp64 MFMA GEMM, C = A0 B0 (+ A1 B1) (+ addv per column), column-major
 omc_status omc_dgemm_small(omc_ctx* ctx, int M, int N, const double* A0, int64_t lda0, const double* B0, int64_t ldb0, int K0,
                            const double* A1, int64_t lda1, const double* B1, int64_t ldb1, int K1, int tri, const double* addv,
-                           double* Cout, int64_t ldc, const int* colmask = nullptr);
+                           double* Cout, int64_t ldc, const int* colmask = nullptr, int ksplit = 0);
 omc_status omc_ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need);  // grow-on-demand workspace (omc_dense.hip)
+// omc_gemm.hip: C = A B (+ addv per column) for thousands of columns (64 x 64 tiles, one operand pair)
+omc_status omc_dgemm_wide(omc_ctx* ctx, int M, int N, const double* A, int64_t lda, const double* B, int64_t ldb, int K, int tri,
+                          const double* addv, double* Cout, int64_t ldc);
+omc_status omc_ensure_aux(omc_ctx* ctx);  // side stream + its events and BLAS handle, made on first use (omc_dense.hip)
 omc_status omc_col_moments(omc_ctx* ctx, const double* data, int64_t R, int64_t K, double* mean_out, double* var_out);  // omc_store.hip
 extern "C" omc_status omc_gram_mfma_launch(omc_ctx* ctx, int64_t n, int64_t p, const double* X, const double* w, double* G_out);  // omc_gram.hip  // destroys the rocBLAS handle if one was created
 

@@ -46,6 +46,8 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->mh_work = nullptr; c->mh_work_bytes = 0;
   c->white_prep = nullptr; c->white_prep_bytes = 0; c->white_L = nullptr; c->white_mu = nullptr; c->white_d = 0;
   c->white_a = nullptr; c->white_a_bytes = 0; c->white_x = nullptr; c->white_ld = 0;
+  c->white_traj = nullptr; c->white_traj_bytes = 0;
+  for (int i = 0; i < 4; ++i) c->white_ev[i] = nullptr;
   c->rww_a = nullptr; c->rww_a_bytes = 0; c->rww_x = nullptr; c->rww_ld = 0; c->rww_mu = nullptr; c->rww_mu_neg = nullptr; c->rww_mu_bytes = 0;
   c->rw_prep = nullptr; c->rw_prep_bytes = 0; c->rw_LQ = nullptr; c->rw_d = 0;
   c->mala_prep = nullptr; c->mala_prep_bytes = 0; c->mala_Q = nullptr; c->mala_L = nullptr; c->mala_step = 0.0; c->mala_d = 0;
@@ -106,6 +108,7 @@ omc_status omc_ctx_destroy(omc_ctx* ctx) {
   if (ctx->mala_prep) hipFree(ctx->mala_prep);
   if (ctx->white_prep) hipFree(ctx->white_prep);
   if (ctx->white_a) hipFree(ctx->white_a);
+  if (ctx->white_traj) hipFree(ctx->white_traj);
   if (ctx->rww_a) hipFree(ctx->rww_a);
   if (ctx->rww_mu_neg) hipFree(ctx->rww_mu_neg);
   if (ctx->rw_prep) hipFree(ctx->rw_prep);

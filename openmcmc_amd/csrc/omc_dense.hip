@@ -36,7 +36,7 @@ omc_status omc_ensure_blas(omc_ctx* ctx) {
 }
 
 // side stream, its BLAS handle and the fork / join events of the blocked factorisation (made on first use)
-static omc_status ensure_aux(omc_ctx* ctx) {
+omc_status omc_ensure_aux(omc_ctx* ctx) {
   if (ctx->blas_aux) return OMC_OK;
   OMC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
   OMC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -451,7 +451,7 @@ static omc_status potrf_blocked(omc_ctx* ctx, rocblas_handle h, int64_t p, doubl
   // two alternate and each leaves most of the chip idle in turn.  Two halves of the chains on two streams (fork and join by
   // events: the caller still sees one stream) let one half's panels run under the other half's GEMMs.
   if (!ctx->dense_overlap || C < 64) return potrf_blocked_part(ctx, h, ctx->stream, p, Q, 0, C);
-  omc_status st = ensure_aux(ctx);
+  omc_status st = omc_ensure_aux(ctx);
   if (st != OMC_OK) return st;
   const int64_t C0 = C / 2;
   OMC_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -496,6 +496,8 @@ void omc_dense_release(omc_ctx* ctx) {
     hipEventDestroy(ctx->ev_fork);
     hipEventDestroy(ctx->ev_join);
     hipStreamDestroy(ctx->aux_stream);
+    for (int i = 0; i < 4; ++i)
+      if (ctx->white_ev[i]) { hipEventDestroy(ctx->white_ev[i]); ctx->white_ev[i] = nullptr; }
     ctx->blas_aux = nullptr;
   }
 }

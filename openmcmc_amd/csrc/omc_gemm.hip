@@ -144,16 +144,121 @@ __global__ void __launch_bounds__(256 * KS) k_dgemm_64x16(int M, int N, GemmPair
   }
 }
 
+// ---- the same product for MANY columns (the states of a block of steps: N = 32 C, omc_mala_run_white) ---------------------
+// With thousands of columns the chip is full without small tiles, and the 64 x 16 tile's cost shows: every 16 columns re-read
+// their 64 x K strip of A from L2 into LDS.  Here a workgroup makes a 64 x 64 tile -- each of its four waves 16 rows x 64
+// columns = four accumulators fed by ONE A fragment per contraction step -- so A crosses L2 -> LDS a quarter as often and a wave
+// issues four independent MFMAs per LDS round.  Upper-triangular A: the slabs in front of the tile's first row are skipped.
+#define GW_TN 64
+template <bool VEC>
+__global__ void __launch_bounds__(256) k_dgemm_64x64(int M, int N, GemmPair P, int tri, const double* __restrict__ addv,
+                                                     double* __restrict__ Cout, int64_t ldc) {
+  __shared__ double As[2][GM_BK][GM_LDA];
+  __shared__ double Bs[2][GW_TN][GM_LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.x * GM_TM, j0 = blockIdx.y * GW_TN;
+  double4_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int kbeg = tri ? (i0 / GM_BK) * GM_BK : 0;
+  const int nslab = (P.K - kbeg + GM_BK - 1) / GM_BK;
+  double ra[GM_BK / 4], rb[GM_BK / 4];
+  auto fetch = [&](int k0) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int q = 0; q < GM_BK / 8; ++q) {  // A slab as pairs: pair e = q*256 + tid: k = e / 32, i = 2 (e % 32)
+        const int e = q * 256 + tid, k = k0 + (e >> 5), i = i0 + 2 * (e & 31);
+        double2_t v = {0.0, 0.0};
+        if (k < P.K && i < M) v = *reinterpret_cast<const double2_t*>(P.A + (int64_t)k * P.lda + i);
+        ra[2 * q] = v.x; ra[2 * q + 1] = v.y;
+      }
+#pragma unroll
+      for (int q = 0; q < GM_BK / 8; ++q) {  // B slab as pairs: pair e: j = e / 16, k = 2 (e % 16)
+        const int e = q * 256 + tid, j = j0 + (e >> 4), k = k0 + 2 * (e & 15);
+        double2_t v = {0.0, 0.0};
+        if (k < P.K && j < N) v = *reinterpret_cast<const double2_t*>(P.B + (int64_t)j * P.ldb + k);
+        rb[2 * q] = v.x; rb[2 * q + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < GM_BK / 4; ++q) {
+        const int e = q * 256 + tid, k = k0 + (e >> 6), i = i0 + (e & 63);
+        ra[q] = (k < P.K && i < M) ? P.A[(int64_t)k * P.lda + i] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < GM_BK / 4; ++q) {
+        const int e = q * 256 + tid, j = j0 + e / GM_BK, k = k0 + e % GM_BK;
+        rb[q] = (k < P.K && j < N) ? P.B[(int64_t)j * P.ldb + k] : 0.0;
+      }
+    }
+  };
+  auto park = [&](int b) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int q = 0; q < GM_BK / 8; ++q) {
+        const int e = q * 256 + tid;
+        *reinterpret_cast<double2_t*>(&As[b][e >> 5][2 * (e & 31)]) = double2_t{ra[2 * q], ra[2 * q + 1]};
+        *reinterpret_cast<double2_t*>(&Bs[b][e >> 4][2 * (e & 15)]) = double2_t{rb[2 * q], rb[2 * q + 1]};
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < GM_BK / 4; ++q) {
+        const int e = q * 256 + tid;
+        As[b][e >> 6][e & 63] = ra[q];
+        Bs[b][e / GM_BK][e % GM_BK] = rb[q];
+      }
+    }
+  };
+  if (nslab > 0) {
+    fetch(kbeg);
+    park(0);
+  }
+  for (int sl = 0; sl < nslab; ++sl) {
+    const int b = sl & 1;
+    __syncthreads();                                             // slab sl is in As/Bs[b]; everyone is done with buffer b ^ 1
+    if (sl + 1 < nslab) fetch(kbeg + (sl + 1) * GM_BK);          // in flight under the multiplications
+#pragma unroll
+    for (int kk = 0; kk < GM_BK; kk += 4) {
+      const int kr = kk + (lane >> 4), cl = lane & 15;
+      const double af = As[b][kr][wave * 16 + cl];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, Bs[b][16 * t + cl][kr], acc[t], 0, 0, 0);
+    }
+    if (sl + 1 < nslab) park(b ^ 1);
+  }
+  // C/D of the f64 form: column = lane & 15, row = (lane >> 4) + 4 * register
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int j = j0 + 16 * t + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + wave * 16 + (lane >> 4) + 4 * r;
+      if (i < M && j < N) Cout[(int64_t)j * ldc + i] = acc[t][r] + (addv ? addv[i] : 0.0);
+    }
+  }
+}
+
+omc_status omc_dgemm_wide(omc_ctx* ctx, int M, int N, const double* A, int64_t lda, const double* B, int64_t ldb, int K, int tri,
+                          const double* addv, double* Cout, int64_t ldc) {
+  GemmPair p{A, lda, B, ldb, K};
+  const dim3 grid((unsigned)((M + GM_TM - 1) / GM_TM), (unsigned)((N + GW_TN - 1) / GW_TN));
+  const bool vec = (M & 1) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15u) == 0 && (lda & 1) == 0 && (ldb & 1) == 0 && (K & 1) == 0;
+  if (vec) hipLaunchKernelGGL((k_dgemm_64x64<true>), grid, dim3(256), 0, ctx->stream, M, N, p, tri, addv, Cout, ldc);
+  else hipLaunchKernelGGL((k_dgemm_64x64<false>), grid, dim3(256), 0, ctx->stream, M, N, p, tri, addv, Cout, ldc);
+  OMC_HIP_CHECK(hipGetLastError());
+  return OMC_OK;
+}
+
 // C[M x N] = A0[M x K0] B0[K0 x N] (+ A1 B1) (+ addv per column); everything column-major, device pointers;
 // colmask (N ints or NULL): only the columns with a non-zero entry are written
 omc_status omc_dgemm_small(omc_ctx* ctx, int M, int N, const double* A0, int64_t lda0, const double* B0, int64_t ldb0, int K0,
                            const double* A1, int64_t lda1, const double* B1, int64_t ldb1, int K1, int tri, const double* addv,
-                           double* Cout, int64_t ldc, const int* colmask) {
+                           double* Cout, int64_t ldc, const int* colmask, int ksplit) {
   GemmPair p0{A0, lda0, B0, ldb0, K0}, p1{A1, lda1, B1, ldb1, A1 ? K1 : 0};
   const dim3 grid((unsigned)((M + GM_TM - 1) / GM_TM), (unsigned)((N + GM_TN - 1) / GM_TN));
   auto even16 = [](const double* p, int64_t ld, int K) { return !p || (((uintptr_t)p & 15u) == 0 && (ld & 1) == 0 && (K & 1) == 0); };
   const bool vec = (M & 1) == 0 && even16(A0, lda0, K0) && even16(B0, ldb0, K0) && even16(A1, lda1, K1) && even16(B1, ldb1, K1);
-  const int ks = ctx->mh_gemm_ksplit;
+  const int ks = ksplit > 0 ? ksplit : ctx->mh_gemm_ksplit;  // (a product with thousands of columns fills the chip without the in-workgroup split)
 #define OMC_GEMM_LAUNCH(V, K) hipLaunchKernelGGL((k_dgemm_64x16<V, K>), grid, dim3(256 * K), 0, ctx->stream, M, N, p0, p1, tri, addv, Cout, ldc, colmask)
   if (vec) {
     if (ks >= 4) OMC_GEMM_LAUNCH(true, 4); else if (ks == 2) OMC_GEMM_LAUNCH(true, 2); else OMC_GEMM_LAUNCH(true, 1);

@@ -214,19 +214,21 @@ __global__ void __launch_bounds__(256) k_mh_finish(int64_t d, int64_t chain_offs
 
 // lower triangle of a column-major d x d matrix, zeros above the diagonal: the triangular products below run as
 // plain GEMMs on this image (rocBLAS's out-of-place TRMM reached 5.6 TFLOP/s at d = 500, its DGEMM 37)
+// (grid-stride like every kernel launched with gx(), which caps the grid at 4096 blocks: as plain one-element-per-thread
+//  kernels these two left everything beyond 2^20 elements -- d > 1024 -- unwritten)
 __global__ void k_lower_copy(int64_t d, const double* L, double* out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d * d) return;
-  const int64_t col = i / d, row = i - col * d;
-  out[i] = row >= col ? L[i] : 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d * d; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t col = i / d, row = i - col * d;
+    out[i] = row >= col ? L[i] : 0.0;
+  }
 }
 
 // U = L' as a dense upper-triangular column-major matrix (zeros below the diagonal): the own GEMM takes A as it stands
 __global__ void k_lower_transpose(int64_t d, const double* L, double* out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= d * d) return;
-  const int64_t k = e / d, i = e - k * d;  // out(i, k) = L(k, i) for k >= i
-  out[e] = k >= i ? L[i * d + k] : 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < d * d; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = e / d, i = e - k * d;  // out(i, k) = L(k, i) for k >= i
+    out[e] = k >= i ? L[i * d + k] : 0.0;
+  }
 }
 
 static omc_status mala_prepare(omc_ctx* ctx, int64_t d, const double* Q, const double* L, double step) {
@@ -473,6 +475,214 @@ omc_status omc_mala_step_white(omc_ctx* ctx, int64_t d, const double* mu, const 
   // x = mu + L^{-T} a on the chains that accepted (the others keep their x bit for bit)
   st = omc_dgemm_small(ctx, (int)d, (int)C, LinvT, d, a, d, (int)d, nullptr, 0, nullptr, 0, 0, 1, mu, x, ld_x, w.flag);
   if (st != OMC_OK) return st;
+  ctx->white_x = x; ctx->white_ld = ld_x;
+  return OMC_OK;
+}
+
+// ---- several whitened steps per launch ----------------------------------------------------------------------------------
+// The whitened step is element-wise in a = L'(x - mu) plus four sums and one decision per chain: nothing in it needs x.  K steps
+// are therefore ONE launch that keeps a chain's a in registers (a workgroup per chain, a pair of elements per thread), leaves
+// the whitened trajectory a_t behind, and ONE triangular product afterwards maps all K x C states back, x_t = mu + L^-T a_t,
+// straight into the store slabs (mcmc.py:105-106 stores the state of every iteration) -- a d x d by d x (K C) product that
+// fills the chip, where a product per step (d x C) occupies a quarter of it for 12 us.  Same draws (stream draw_index0 +
+// t draw_stride for step t), same sums in the same order, same decision as K calls of omc_mala_step_white: bit-identical a
+// and counters, and x of every stored step equal to what the single steps leave (same product, column by column).
+}  // extern "C"  (a template)
+template <int NP>
+__global__ void __launch_bounds__(256) k_mala_white_run(int64_t d, int64_t C, int64_t chain_offset, uint64_t seed, uint64_t draw_index0,
+                                                        uint64_t draw_stride, int n_steps, const double* __restrict__ zin, int64_t ld_z,
+                                                        const double* __restrict__ u_in, const double* __restrict__ sumlogL,
+                                                        double log_step_term, double lp_scale, double kappa, double* __restrict__ a,
+                                                        double* __restrict__ a_traj, long long* __restrict__ acc_cnt,
+                                                        long long* __restrict__ prop_cnt, double* __restrict__ logp_traj,
+                                                        double* __restrict__ logp_last) {
+  __shared__ double red[2][4][4];
+  const int64_t c = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int64_t npairs = (d + 1) / 2;
+  double av[NP][2];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int64_t i = 2 * ((int64_t)tid + 256 * p) + e;
+      av[p][e] = i < d ? a[c * d + i] : 0.0;
+    }
+  const double sl = sumlogL[0];
+  const double logdetQ = 2.0 * (sl + log_step_term);
+  const double dnum = (double)d;
+  long long n_acc = 0;
+  double lp_state = 0.0;
+  for (int t = 0; t < n_steps; ++t) {
+    const omc_rng_key nkey = omc_make_key(seed, draw_index0 + (uint64_t)t * draw_stride, OMC_RNG_NORMAL);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double ap[NP][2];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int64_t q = (int64_t)tid + 256 * p;
+      ap[p][0] = ap[p][1] = 0.0;
+      if (q < npairs) {
+        double z[2];
+        if (zin) {
+          const double* zr = zin + ((int64_t)t * C + c) * ld_z;
+          z[0] = zr[2 * q];
+          z[1] = (2 * q + 1 < d) ? zr[2 * q + 1] : 0.0;
+        } else {
+          omc_normal_pair(omc_rng_block(nkey, chain_offset + c, (uint32_t)q), z[0], z[1]);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          if (2 * q + e >= d) break;
+          const double v = av[p][e];
+          const double pv = fma(kappa, v, z[e]);
+          const double rv = fma(-kappa, pv, v);
+          ap[p][e] = pv;
+          s0 = fma(v, v, s0);
+          s1 = fma(pv, pv, s1);
+          s2 = fma(rv, rv, s2);
+          s3 = fma(z[e], z[e], s3);
+        }
+      }
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+      s0 += __shfl_xor(s0, s, 64); s1 += __shfl_xor(s1, s, 64);
+      s2 += __shfl_xor(s2, s, 64); s3 += __shfl_xor(s3, s, 64);
+    }
+    double(*rd)[4] = red[t & 1];  // two buffers: a wave that is a step ahead never writes what a slower one still reads
+    if ((tid & 63) == 0) {
+      const int w = tid >> 6;
+      rd[0][w] = s0; rd[1][w] = s1; rd[2][w] = s2; rd[3][w] = s3;
+    }
+    __syncthreads();
+    // every thread forms the decision (k_mala_white's, term for term): no second barrier, no broadcast
+    const double ss_cur = (rd[0][0] + rd[0][1]) + (rd[0][2] + rd[0][3]);
+    const double ss_prop = (rd[1][0] + rd[1][1]) + (rd[1][2] + rd[1][3]);
+    const double ss_rev = (rd[2][0] + rd[2][1]) + (rd[2][2] + rd[2][3]);
+    const double ss_fwd = (rd[3][0] + rd[3][1]) + (rd[3][2] + rd[3][3]);
+    const double lp_cur = 0.5 * (logdetQ - dnum * 1.8378770664093453 - lp_scale * ss_cur);
+    const double lp_prop = 0.5 * (logdetQ - dnum * 1.8378770664093453 - lp_scale * ss_prop);
+    const double lq_fwd = sl - 0.5 * ss_fwd, lq_rev = sl - 0.5 * ss_rev;
+    const double log_alpha = lp_prop + lq_rev - (lp_cur + lq_fwd);
+    double u;
+    if (u_in) {
+      u = u_in[(int64_t)t * C + c];
+    } else {
+      const uint4 w = omc_rng_block(omc_make_key(seed, draw_index0 + (uint64_t)t * draw_stride, OMC_RNG_UNIFORM), chain_offset + c, 0u);
+      u = omc_u53(w.x, w.y);
+    }
+    const bool ok = log(u) < log_alpha;
+    lp_state = ok ? lp_prop : lp_cur;
+    n_acc += ok;
+    if (ok) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) { av[p][0] = ap[p][0]; av[p][1] = ap[p][1]; }
+    }
+    if (a_traj) {
+      double* row = a_traj + ((int64_t)t * C + c) * d;
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int64_t i = 2 * ((int64_t)tid + 256 * p) + e;
+          if (i < d) row[i] = av[p][e];
+        }
+    }
+    if (tid == 0 && logp_traj) logp_traj[(int64_t)t * C + c] = lp_state;
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int64_t i = 2 * ((int64_t)tid + 256 * p) + e;
+      if (i < d) a[c * d + i] = av[p][e];
+    }
+  if (tid == 0) {
+    if (prop_cnt) prop_cnt[c] += n_steps;
+    if (acc_cnt) acc_cnt[c] += n_acc;
+    if (logp_last && n_steps > 0) logp_last[c] = lp_state;
+  }
+}
+
+extern "C" {
+
+#define OMC_WHITE_RUN_BLOCK 32  // steps per launch (the whitened trajectory of a block: 32 x C x d doubles of workspace)
+
+omc_status omc_mala_run_white(omc_ctx* ctx, int64_t d, const double* mu, const double* L, const double* sumlogL, double step,
+                              const double* z_inject, int64_t ld_z, const double* u_inject, uint64_t draw_index0, uint64_t draw_stride,
+                              int64_t n_steps, double* x, int64_t ld_x, int32_t state_is_current, double* x_store, double* logp_store,
+                              int64_t* accept_count, int64_t* proposal_count, double* log_p_out) {
+  if (!ctx || d < 1 || d > 2048 || !L || !sumlogL || !x || ld_x < d || (z_inject && ld_z < d) || !(step > 0.0) || n_steps < 0)
+    return d > 2048 ? OMC_UNSUPPORTED : OMC_INVALID_ARG;
+  const int64_t C = ctx->n_chains;
+  if (C > 65535) return OMC_UNSUPPORTED;
+  OMC_HIP_CHECK(hipSetDevice(ctx->device));
+  omc_status st = omc_ensure_blas(ctx);
+  if (st != OMC_OK) return st;
+  st = white_prepare(ctx, d, L, mu);
+  if (st != OMC_OK) return st;
+  st = omc_ensure_bytes(ctx, (void**)&ctx->white_a, &ctx->white_a_bytes, (size_t)C * d * sizeof(double));
+  if (st != OMC_OK) return st;
+  const int64_t KB = OMC_WHITE_RUN_BLOCK;
+  if (x_store) {
+    // two trajectory buffers: the product of block b runs on the side stream while the steps of block b + 1 run here
+    st = omc_ensure_bytes(ctx, (void**)&ctx->white_traj, &ctx->white_traj_bytes, (size_t)2 * KB * C * d * sizeof(double));
+    if (st != OMC_OK) return st;
+    st = omc_ensure_aux(ctx);
+    if (st != OMC_OK) return st;
+    for (int i = 0; i < 4; ++i)
+      if (!ctx->white_ev[i]) OMC_HIP_CHECK(hipEventCreateWithFlags(&ctx->white_ev[i], hipEventDisableTiming));
+  }
+  const double* LinvT = ctx->white_prep;
+  const double* Lt = ctx->white_prep + d * d;
+  const double* negLtmu = mu ? ctx->white_prep + 2 * d * d : nullptr;
+  double* a = ctx->white_a;
+  if (!(state_is_current && ctx->white_x == x && ctx->white_ld == ld_x)) {  // a = L'(x - mu) = L'x - L'mu
+    st = omc_dgemm_small(ctx, (int)d, (int)C, Lt, d, x, ld_x, (int)d, nullptr, 0, nullptr, 0, 0, 1, negLtmu, a, d);
+    if (st != OMC_OK) return st;
+  }
+  const int np = (int)(((d + 1) / 2 + 255) / 256);
+  int64_t blk = 0;
+  for (int64_t t0 = 0; t0 < n_steps; t0 += KB, ++blk) {
+    const int nb = (int)((n_steps - t0 < KB) ? n_steps - t0 : KB);
+    const int buf = (int)(blk & 1);
+    double* traj = x_store ? ctx->white_traj + (size_t)buf * KB * C * d : nullptr;
+    if (x_store && blk >= 2) OMC_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->white_ev[2 + buf], 0));  // block b - 2's product has read this buffer
+#define OMC_WRUN(NP)                                                                                                                   \
+  hipLaunchKernelGGL((k_mala_white_run<NP>), dim3((unsigned)C), dim3(256), 0, ctx->stream, d, C, ctx->chain_offset, ctx->seed,         \
+                     draw_index0 + (uint64_t)t0 * draw_stride, draw_stride, nb, z_inject ? z_inject + t0 * C * ld_z : nullptr, ld_z,   \
+                     u_inject ? u_inject + t0 * C : nullptr, sumlogL, (double)d * log(step), step * step, 1.0 - 0.5 * step * step, a,    \
+                     traj, (long long*)accept_count, (long long*)proposal_count, logp_store ? logp_store + t0 * C : nullptr, log_p_out)
+    if (np <= 1) OMC_WRUN(1); else if (np == 2) OMC_WRUN(2); else OMC_WRUN(4);
+#undef OMC_WRUN
+    OMC_HIP_CHECK(hipGetLastError());
+    if (x_store) {  // x_t = mu + L^-T a_t for the whole block, into the store slabs [t][c][:] -- on the side stream
+      OMC_HIP_CHECK(hipEventRecord(ctx->white_ev[buf], ctx->stream));
+      OMC_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->white_ev[buf], 0));
+      hipStream_t mine = ctx->stream;
+      ctx->stream = ctx->aux_stream;  // (omc_dgemm_small launches on the context's stream)
+      // (a few thousand columns and more: 64 x 64 tiles; below that the step's own small-tile kernel, bit for bit what the
+      //  single steps compute)
+      if (nb * C >= 4096 && !ctx->mh_use_rocblas)
+        st = omc_dgemm_wide(ctx, (int)d, (int)(nb * C), LinvT, d, traj, d, (int)d, 1, mu, x_store + t0 * C * d, d);
+      else
+        st = omc_dgemm_small(ctx, (int)d, (int)(nb * C), LinvT, d, traj, d, (int)d, nullptr, 0, nullptr, 0, 0, 1, mu, x_store + t0 * C * d, d);
+      ctx->stream = mine;
+      if (st != OMC_OK) return st;
+      OMC_HIP_CHECK(hipEventRecord(ctx->white_ev[2 + buf], ctx->aux_stream));
+    }
+  }
+  if (x_store) {  // join: everything behind this call on the context's stream sees the whole store
+    for (int i = 0; i < 2 && i < blk; ++i) OMC_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->white_ev[2 + ((blk - 1 - i) & 1)], 0));
+  }
+  if (n_steps > 0) {
+    if (x_store) {  // the state the run leaves is its last stored one
+      OMC_HIP_CHECK(hipMemcpy2DAsync(x, (size_t)ld_x * sizeof(double), x_store + (n_steps - 1) * C * d, (size_t)d * sizeof(double),
+                                     (size_t)d * sizeof(double), (size_t)C, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+      st = omc_dgemm_small(ctx, (int)d, (int)C, LinvT, d, a, d, (int)d, nullptr, 0, nullptr, 0, 0, 1, mu, x, ld_x);
+      if (st != OMC_OK) return st;
+    }
+  }
   ctx->white_x = x; ctx->white_ld = ld_x;
   return OMC_OK;
 }

@@ -465,6 +465,26 @@ class Engine:
                                       int(draw_index), self._p(x, self.n_chains, d), x.stride(0), int(bool(state_is_current)),
                                       self._ip(accept_count), self._ip(proposal_count), self._chain_scalar(log_p_out)))
 
+    def mala_run_white(self, mu, L, sumlogL, step, x, n_steps, state_is_current=False, z=None, u=None, draw_index0=0, draw_stride=1,
+                       x_store=None, logp_store=None, accept_count=None, proposal_count=None, log_p_out=None):
+        """omc_mala_run_white: n_steps whitened ManifoldMALA steps, one launch per block of 32 steps and one product per block
+        into x_store (n_steps, C, d) / logp_store (n_steps, C); z (n_steps, C, d) and u (n_steps, C) inject the draws."""
+        d = L.shape[0]
+        n_steps = int(n_steps)
+        if z is not None and (z.dim() != 3 or z.shape[0] < n_steps or z.shape[1] != self.n_chains or not z.is_contiguous()):
+            raise ValueError("z must be a contiguous (n_steps, C, d) tensor")
+        if u is not None and (u.dim() != 2 or u.shape[0] < n_steps or u.shape[1] != self.n_chains or not u.is_contiguous()):
+            raise ValueError("u must be a contiguous (n_steps, C) tensor")
+        if x_store is not None and (tuple(x_store.shape) != (n_steps, self.n_chains, d) or not x_store.is_contiguous()):
+            raise ValueError("x_store must be a contiguous (n_steps, C, d) tensor")
+        if logp_store is not None and (tuple(logp_store.shape) != (n_steps, self.n_chains) or not logp_store.is_contiguous()):
+            raise ValueError("logp_store must be a contiguous (n_steps, C) tensor")
+        check(lib.omc_mala_run_white(self._ctx, d, self._vec(mu, d), self._p(L), self._p(sumlogL), float(step), self._p(z),
+                                     0 if z is None else z.stride(1), self._p(u), int(draw_index0), int(draw_stride), n_steps,
+                                     self._p(x, self.n_chains, d), x.stride(0), int(bool(state_is_current)), self._p(x_store),
+                                     self._p(logp_store), self._ip(accept_count), self._ip(proposal_count),
+                                     self._chain_scalar(log_p_out)))
+
     def rw_step(self, mu, LQ, sumlogLQ, step, x, z=None, u=None, draw_index=0, accept_count=None,
                 proposal_count=None):
         d = LQ.shape[0]
@@ -1116,7 +1136,7 @@ _WRITES = {
     "chain_lincomb": ("out",), "chain_copy": ("dst",), "chain_select": ("dst",), "mala_step": ("x",), "rw_step": ("x",),
     "tridiag_matvec_chain": ("out",), "band_matvec_chain": ("out",), "design_predict": ("fitted",),
     "design_predict_batched": ("out",), "knot_loop": ("B", "beta", "theta"), "gaussian_basis": ("out",), "mala_diag": ("x",),
-    "mala_step_white": ("x",), "rw_step_white": ("x",),
+    "mala_step_white": ("x",), "rw_step_white": ("x",), "mala_run_white": ("x", "x_store"),
 }
 
 

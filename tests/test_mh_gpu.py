@@ -510,3 +510,65 @@ def test_whitened_steps_are_in_the_write_log(kind):
     assert eng.written_since(x, serial)  # ... the library's own log did
     assert eng.quad_cache_get(holder, [x]) is None
     eng.close()
+
+
+@pytest.mark.parametrize("d,C,steps,inject", [(5, 3, 7, True), (500, 33, 70, False), (137, 70, 40, True), (1100, 5, 9, False),
+                                              (500, 140, 37, False), (137, 131, 33, False)])
+def test_whitened_mala_run_is_the_single_steps_in_a_row(d, C, steps, inject):
+    """omc_mala_run_white (a block of steps per launch, one product per block into the store) against `steps` calls of
+    omc_mala_step_white on the same draws or streams: stored states, state left behind, counters and log densities bit for bit."""
+    import torch
+
+    rng = np.random.default_rng(d + steps)
+    A = rng.standard_normal((d, 2 * d))
+    Qh = np.linalg.inv(A @ A.T / (2 * d))
+    Qh = (Qh + Qh.T) / 2
+    mu = rng.standard_normal(d)
+    step = 0.5 if d <= 500 else 0.3
+    x0 = mu + np.linalg.solve(np.linalg.cholesky(Qh).T, rng.standard_normal((d, C))).T  # a draw from the target
+    zs = rng.standard_normal((steps, C, d)) if inject else None
+    us = rng.random((steps, C)) if inject else None
+    eng = make_engine(C, seed=21)
+    L, sl = eng.dense_cholesky(eng.to_device(Qh), 1.0 / step**2)
+    dmu = eng.to_device(mu)
+    # the single steps
+    x = eng.to_device(x0)
+    acc, prop = (torch.zeros(C, dtype=torch.int64, device="cuda") for _ in range(2))
+    lp = eng.empty(C)
+    want_x, want_lp, flags = [], [], []
+    for i in range(steps):
+        before = acc.clone()
+        eng.mala_step_white(dmu, L, sl, step, x, state_is_current=i > 0, z=None if zs is None else eng.to_device(zs[i]),
+                            u=None if us is None else eng.to_device(us[i]), draw_index=100 + 3 * i, accept_count=acc,
+                            proposal_count=prop, log_p_out=lp)
+        want_x.append(x.cpu().numpy().copy())
+        want_lp.append(lp.cpu().numpy().copy())
+        flags.append((acc - before).cpu().numpy())
+    # the run
+    x2 = eng.to_device(x0)
+    acc2, prop2 = (torch.zeros(C, dtype=torch.int64, device="cuda") for _ in range(2))
+    xs, lps, lp2 = eng.empty(steps, C, d), eng.empty(steps, C), eng.empty(C)
+    eng.mala_run_white(dmu, L, sl, step, x2, steps, z=None if zs is None else eng.to_device(zs), u=None if us is None else eng.to_device(us),
+                       draw_index0=100, draw_stride=3, x_store=xs, logp_store=lps, accept_count=acc2, proposal_count=prop2, log_p_out=lp2)
+    eng.check_status()
+    assert np.array_equal(acc2.cpu().numpy(), acc.cpu().numpy()) and np.array_equal(prop2.cpu().numpy(), prop.cpu().numpy())
+    assert 0 < acc.sum().item() < steps * C  # both outcomes occur
+    assert np.array_equal(lps.cpu().numpy(), np.array(want_lp))
+    assert np.array_equal(lp2.cpu().numpy(), want_lp[-1])
+    got, want = xs.cpu().numpy(), np.array(want_x)
+    # From a chain's first accepted proposal on, both routes hold x = mu + L^-T a of the same a through the same product, column
+    # by column: bit-equal.  Before it the single steps still hold the caller's x0 untouched, the run holds mu + L^-T L'(x0 - mu):
+    # equal to rounding.
+    moved = np.cumsum(np.array(flags), axis=0) > 0  # (steps, C)
+    assert moved.any()
+    assert d < 100 or not moved.all()
+    if 32 * C < 4096:  # (blocks of 4096 columns and more go through the 64 x 64-tile product: another summation order)
+        assert np.array_equal(got[moved], want[moved])
+    assert relerr(got, want) < 1e-12
+    assert relerr(x2.cpu().numpy(), want_x[-1]) < 1e-12
+    # without a store: only the last state comes back, and it is the same one
+    x3 = eng.to_device(x0)
+    eng.mala_run_white(dmu, L, sl, step, x3, steps, z=None if zs is None else eng.to_device(zs), u=None if us is None else eng.to_device(us),
+                       draw_index0=100, draw_stride=3)
+    assert relerr(x3.cpu().numpy(), want_x[-1]) < 1e-12
+    eng.close()
