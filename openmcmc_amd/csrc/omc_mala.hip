@@ -548,6 +548,16 @@ __global__ void __launch_bounds__(256) k_mala_white_run(int64_t d, int64_t C, in
       s0 += __shfl_xor(s0, s, 64); s1 += __shfl_xor(s1, s, 64);
       s2 += __shfl_xor(s2, s, 64); s3 += __shfl_xor(s3, s, 64);
     }
+    // the step's uniform and its logarithm depend on nothing of the step: formed in front of the barrier, in the shadow of the
+    // slowest wave's sums
+    double u;
+    if (u_in) {
+      u = u_in[(int64_t)t * C + c];
+    } else {
+      const uint4 w = omc_rng_block(omc_make_key(seed, draw_index0 + (uint64_t)t * draw_stride, OMC_RNG_UNIFORM), chain_offset + c, 0u);
+      u = omc_u53(w.x, w.y);
+    }
+    const double log_u = log(u);
     double(*rd)[4] = red[t & 1];  // two buffers: a wave that is a step ahead never writes what a slower one still reads
     if ((tid & 63) == 0) {
       const int w = tid >> 6;
@@ -563,14 +573,7 @@ __global__ void __launch_bounds__(256) k_mala_white_run(int64_t d, int64_t C, in
     const double lp_prop = 0.5 * (logdetQ - dnum * 1.8378770664093453 - lp_scale * ss_prop);
     const double lq_fwd = sl - 0.5 * ss_fwd, lq_rev = sl - 0.5 * ss_rev;
     const double log_alpha = lp_prop + lq_rev - (lp_cur + lq_fwd);
-    double u;
-    if (u_in) {
-      u = u_in[(int64_t)t * C + c];
-    } else {
-      const uint4 w = omc_rng_block(omc_make_key(seed, draw_index0 + (uint64_t)t * draw_stride, OMC_RNG_UNIFORM), chain_offset + c, 0u);
-      u = omc_u53(w.x, w.y);
-    }
-    const bool ok = log(u) < log_alpha;
+    const bool ok = log_u < log_alpha;
     lp_state = ok ? lp_prop : lp_cur;
     n_acc += ok;
     if (ok) {

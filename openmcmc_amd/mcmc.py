@@ -248,6 +248,13 @@ class MCMC:
             if self._drain is not None:
                 self._drain.wait()  # like the reference, run_mcmc returns with the whole store where the user reads it
             return
+        if self._mala_block_route():
+            self._run_mala_blocks()
+            eng.check_status()
+            if self._drain is not None:
+                self._drain.wait()
+            self._print_acceptance()
+            return
         early = self._early_freeze_plan()
         for i_it in range(-self.n_burn, self.n_iter):
             storing = i_it >= 0
@@ -310,11 +317,45 @@ class MCMC:
         eng.check_status()  # raises numpy.linalg.LinAlgError like gmrf.py:518 if a factorisation failed
         if self._drain is not None:
             self._drain.wait()
+        self._print_acceptance()
+
+    def _print_acceptance(self):
         from openmcmc_amd.sampler.metropolis_hastings import MetropolisHastings
 
         for sampler in self.samplers:  # mcmc.py:113-115
             if isinstance(sampler, MetropolisHastings):
                 print(f"{sampler.param}: {sampler.accept_rate.get_acceptance_rate()}")
+
+    # ------------------------------------------------------------------ one ManifoldMALA sampler on a Gaussian target (cfg4)
+    def _mala_block_route(self):
+        """[ManifoldMALA(x)] alone on the one-Normal model of the fused whitened step, every iteration stored: the loop is then
+        blocks of steps issued by the library (omc_mala_run_white), the store slabs written by one product per block."""
+        from openmcmc_amd.sampler.metropolis_hastings import ManifoldMALA
+
+        if len(self.samplers) != 1 or self.n_thin != 1 or self.model.response is not None or len(self.model) != 1:
+            return False
+        smp = self.samplers[0]
+        if type(smp) is not ManifoldMALA or smp.max_variable_size is not None or not smp.can_run_block(self.state):
+            return False
+        cur, st = self.state.get(smp.param), self.store.get(smp.param)
+        return (is_chain(cur) and cur.ragged is None and cur.shape[1] == 1 and st is not None and st.dim() == 3
+                and st.shape[2] == cur.shape[0] and st.is_contiguous())
+
+    def _run_mala_blocks(self):
+        smp = self.samplers[0]
+        if self.n_burn > 0:
+            self.state = smp.run_block(self.state, self.n_burn)  # nothing stored: no product until the last step
+        it = 0
+        while it < self.n_iter:
+            k = min(self._half, self.n_iter - it)
+            if self._drain is not None:
+                self._drain.acquire(it)
+            lo = it % self._n_dev
+            self.state = smp.run_block(self.state, k, x_store=self.store[smp.param][lo: lo + k],
+                                       logp_store=self.store["log_post"][lo: lo + k])
+            if self._drain is not None:
+                self._drain.release(it, it + k)
+            it += k
 
     # ------------------------------------------------------------------ results
     def _whole_store_on_device(self, what):

@@ -560,6 +560,31 @@ class ManifoldMALA(MetropolisHastings):
         u = self.inject_uniform(self, self._sweep) if self.inject_uniform is not None else None
         return self._accept_reject_proposal(current_state, prop_state, lq_f, lq_r, u=u, sub=(d + 1) // 2 + 1)
 
+    def can_run_block(self, state) -> bool:
+        """May MCMC.run_mcmc hand this sampler whole blocks of iterations (omc_mala_run_white)?  The fused whitened route, no
+        injected draws, no trace, and `sample` not replaced by the caller."""
+        return (self.whitened and self.inject is None and self.inject_uniform is None and self.trace is None
+                and getattr(self.sample, "__func__", None) is ManifoldMALA.sample and self._gaussian_target(state))
+
+    def run_block(self, current_state: dict, n_steps: int, x_store=None, logp_store=None) -> dict:
+        """n_steps calls of `sample` as one library call: blocks of 32 steps per launch, the state of every step into
+        x_store (n_steps, C, d) and the target's log density there into logp_store (n_steps, C) when given (what
+        sampler.store and mcmc.py:108 keep per iteration).  Same streams, same decisions, same states as the single steps."""
+        eng = self._need_engine()
+        Q, mu, d = self._target(current_state)
+        step = float(self.step.item())
+        L, sl = self._factor_plan(eng, current_state, Q, 1.0 / step**2)
+        x = self._x(current_state)
+        tag = self._white_state_tag(current_state, x, L, mu)
+        eng.mala_run_white(mu, L, sl, step, x, int(n_steps), state_is_current=self._white_state_is_current(eng, x, tag),
+                           draw_index0=self._draw_index(), draw_stride=self._n_samplers, x_store=x_store, logp_store=logp_store,
+                           accept_count=self.accept_rate.accept, proposal_count=self.accept_rate.proposal,
+                           log_p_out=self._log_p_buffer(eng))
+        self._white_tag, self._white_serial = tag, eng._write_serial
+        self.last_log_p = (self._log_p_buf, x)
+        self._sweep += int(n_steps)
+        return current_state
+
     def sample(self, current_state: dict) -> dict:
         self.last_log_p = None  # set again by the fused whitened steps only
         eng = self._need_engine()

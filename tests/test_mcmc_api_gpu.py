@@ -537,3 +537,43 @@ def test_log_post_of_the_fused_mh_steps_is_the_models_log_p(kind):
         assert np.max(np.abs(lp[c].ravel() - ref)) < 1e-9 * max(1.0, np.abs(ref).max())
     assert np.array_equal(out[True]["x"], out[False]["x"])
     assert np.max(np.abs(out[True]["log_post"] - out[False]["log_post"])) < 1e-9 * np.abs(out[False]["log_post"]).max()
+
+
+@pytest.mark.parametrize("ring", [0, 10])
+def test_run_mcmc_hands_manifold_mala_whole_blocks(ring):
+    """MCMC.run_mcmc on the cfg4 model with ManifoldMALA alone: the loop goes to the library in blocks (omc_mala_run_white);
+    store, log_post, counters and final state are those of the loop that calls sample() once per iteration -- also with a
+    ring store drained while it runs."""
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.sampler.metropolis_hastings import ManifoldMALA
+
+    d, C, n_burn, n_iter = 40, 6, 37, 45
+    rng = np.random.default_rng(8)
+    A = rng.standard_normal((d, 2 * d))
+    Qh = np.linalg.inv(A @ A.T / (2 * d))
+    Qh = (Qh + Qh.T) / 2
+    mu = rng.standard_normal((d, 1))
+    x0 = mu.T + np.linalg.solve(np.linalg.cholesky(Qh).T, rng.standard_normal((d, C))).T
+    outs = []
+    for blocks in (False, True):
+        mdl = Model([Normal("x", mean="mu", precision="Q")])
+        smp = ManifoldMALA("x", mdl, step=np.array([[0.6]]))
+        from openmcmc_amd.chains import ChainArray
+        from openmcmc_amd.engine import Engine
+
+        eng = Engine(C, seed=12)
+        state = {"x": ChainArray(eng.to_device(x0[:, :, None])), "mu": mu, "Q": Qh}
+        M = MCMC(state, [smp], model=mdl, n_burn=n_burn, n_iter=n_iter, n_chains=C, engine=eng, store_ring=ring if blocks else 0)
+        if not blocks:
+            smp.can_run_block = lambda st: False  # the loop of single steps
+        assert M._mala_block_route() == blocks
+        M.run_mcmc()
+        outs.append((M.collect(), smp.accept_rate.accept.cpu().numpy().copy(), smp.accept_rate.proposal.cpu().numpy().copy(),
+                     M.state["x"].data.cpu().numpy().copy()))
+        eng.close()
+    (s0, a0, p0, x_0), (s1, a1, p1, x_1) = outs
+    assert np.array_equal(a0, a1) and np.array_equal(p0, p1) and p0[0] == n_burn + n_iter and 0 < a0.sum() < p0.sum()
+    assert np.array_equal(s0["log_post"], s1["log_post"])
+    assert relerr(s1["x"], s0["x"]) < 1e-12 and relerr(x_1, x_0) < 1e-12
