@@ -443,12 +443,10 @@ def main():
         counter_names = ["tridiag_join_fallbacks", "run_handoff_timeouts"]
 
         def run_k(events):
-            if c_loop:  # one library call issues all K launches; the events bracket them on the launch stream
-                if events:
-                    events[0][0].record()
+            if c_loop:  # one library call issues all K launches; the events bracket them on the launch stream -- recorded by
+                #         the library itself around its launches (options run_event_begin / run_event_end, set below): two
+                #         interpreter-level event calls cost more than the launch and are no part of a step
                 sweep.run_fused(args.steps)
-                if events:
-                    events[0][1].record()
             else:
                 for i in range(args.steps):
                     sweep.step(events[i] if events else None)
@@ -462,8 +460,12 @@ def main():
                 a.record()
                 b.record()
             torch.cuda.synchronize()
+            if c_loop:  # the raw handles exist now; omc_gmrf_run records them on its stream from here on
+                sweep.eng.set_option("run_event_begin", events[0][0].cuda_event)
+                sweep.eng.set_option("run_event_end", events[0][1].cuda_event)
 
         ring_idx = None
+        stream_now = torch.cuda.current_stream()  # (the launch stream: fixed for the process, looked up once)
 
         def timed():
             """-> (seconds, MAX over ranks; kernel ms per sweep from the events; raw material of the run's diagnostics)"""
@@ -476,7 +478,6 @@ def main():
             run_k(events)
             # (a blocking synchronize sleeps and is woken some 20 us after the last kernel has retired -- 1.3 % of a 20-sweep
             # run; the stream is polled first, the synchronize of the contract then returns at once)
-            stream_now = torch.cuda.current_stream()
             while not stream_now.query():
                 pass
             torch.cuda.synchronize()

@@ -111,6 +111,8 @@ omc_status omc_ctx_synchronize(omc_ctx* ctx);
  * constant-rate counter (s_memrealtime; rate: counter "wall_clock_khz") at its entry and at its exit in record
  * (position + sweep) mod cap; the position restarts at 0 when either option is set and advances by the sweeps of every
  * launch (counter "sweep_times_pos"); 0 = off (the default).  One 16-byte store per workgroup and sweep.
+ * "run_event_begin" / "run_event_end" = a caller-owned hipEvent_t (as an integer; 0 = none, the default): omc_gmrf_run records
+ * it on the context's stream in front of its first / behind its last launch (several-sweeps-per-launch route).
  * Unknown name -> OMC_INVALID_ARG.                                                            */
 omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value);
 /* Diagnostic counters, by name (synchronises): "tridiag_join_fallbacks" = chain-updates of the segmented

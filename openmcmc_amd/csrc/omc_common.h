@@ -25,6 +25,7 @@ struct omc_ctx {
   int run_reenter;                  // omc_gmrf_run: 1, 2 = a chain's workgroup restarts itself for the next sweep of the launch
   int run_block_sweeps;             // omc_gmrf_run: sweeps a self-restarting workgroup walks before a fresh one takes over (0: the whole launch)
   int run_reenter_force;            // 1: take that form whatever the chain count (tests); 0: only when the chains fill the CUs in whole rounds
+  hipEvent_t run_ev_begin, run_ev_end;  // options "run_event_begin" / "run_event_end": caller-owned events omc_gmrf_run records around its launches
   double* long_band; size_t long_band_bytes;  // chains beyond one workgroup: the terms in band storage (omc_tridiag.hip, long_chain_draw)
   double* long_quad; size_t long_quad_bytes;  // ... and the sweep's quadratic forms [term][chain]
   double* workspace;       // scratch for the serial kernel (l vectors), grown on demand

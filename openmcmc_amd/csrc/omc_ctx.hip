@@ -78,6 +78,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
     c->stream = (hipStream_t)stream;
   }
   c->d_gamma_tab = nullptr;
+  c->run_ev_begin = c->run_ev_end = nullptr;
   c->d_handoff = nullptr; c->run_epoch = 1; c->run_sweeps_per_launch = 32; c->run_reenter = 2; c->run_reenter_force = 0; c->run_block_sweeps = 0;
   hipError_t e = hipMalloc(&c->d_bad_chain, 8 * sizeof(long long));
   if (e != hipSuccess) { omc_set_error("hipMalloc", e); delete c; return OMC_HIP_ERROR; }
@@ -316,6 +317,12 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
     if (value != ctx->sweep_times_cap) ctx->sweep_times = nullptr;
     ctx->sweep_times_cap = value;
     ctx->sweep_times_pos = 0;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "run_event_begin") || !strcmp(name, "run_event_end")) {
+    // a caller-owned hipEvent_t (0 = none): omc_gmrf_run records it on the context's stream in front of its first / behind its
+    // last launch -- the timing events of a caller whose own event calls cost more than the launch (an interpreter)
+    (name[10] == 'b' ? ctx->run_ev_begin : ctx->run_ev_end) = (hipEvent_t)(uintptr_t)value;
     return OMC_OK;
   }
   if (!strcmp(name, "stamps_ptr")) {  // diagnostic: device buffer [n_chains][16][16] of uint64, 0 = off

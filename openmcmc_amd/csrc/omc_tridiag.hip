@@ -3058,6 +3058,7 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
     const int64_t stored_per_launch_max = (A.reenter == 0 && n_slots < per) ? n_slots : per;
     ctx->launch_log_n = 0; ctx->launch_log_total = 0;
     const bool clock_on = ctx->sweep_times && ctx->sweep_times_cap >= OMC_SWEEP_RING_MIN;
+    if (ctx->run_ev_begin) OMC_HIP_CHECK(hipEventRecord(ctx->run_ev_begin, ctx->stream));
     for (int64_t t0 = 0; t0 < total;) {
       int k_sw = (int)(total - t0 < per ? total - t0 : per);
       if (stored_per_launch_max < per) {  // end the launch before a store slot would repeat inside it
@@ -3107,6 +3108,7 @@ omc_status omc_gmrf_run(omc_ctx* ctx, int64_t n, const omc_tridiag_terms* terms,
       if (clock_on) ctx->sweep_times_pos = (ctx->sweep_times_pos + k_sw) % ctx->sweep_times_cap;
       t0 += k_sw;
     }
+    if (ctx->run_ev_end) OMC_HIP_CHECK(hipEventRecord(ctx->run_ev_end, ctx->stream));
     return OMC_OK;
   }
   ctx->launch_log_n = 0; ctx->launch_log_total = 0;
