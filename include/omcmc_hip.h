@@ -105,7 +105,9 @@ omc_status omc_ctx_synchronize(omc_ctx* ctx);
  * "dense_overlap" (0/1, default 1: the blocked dense factorisation runs the two halves of the chains on two streams,
  * forked from and joined into the context's stream by events; bit-identical results), "dense_use_rocsolver" (1: rocSOLVER's
  * potrf instead of the blocked route; cross-checks), "dense_blocked_min" (default 144: smallest order that takes the blocked
- * factorisation; rocSOLVER's small kernels below).
+ * factorisation; rocSOLVER's small kernels below), "dense_panel_old" (1: the blocked factorisation's panel as ONE kernel per
+ * block column, as in rounds 1-3, instead of the register-resident diagonal factor + matrix-core row update; same factor bit for
+ * bit, cross-checks and A/B timing).
  * Diagnostics of omc_gmrf_run: "sweep_times_cap" then "sweep_times_ptr" = capacity (in sweeps, >= 64) and device address
  * of a caller-owned ring [cap][C][2] of uint64: wave 0 of the workgroup of every (sweep, chain) leaves the device's
  * constant-rate counter (s_memrealtime; rate: counter "wall_clock_khz") at its entry and at its exit in record

@@ -41,6 +41,8 @@ struct omc_ctx {
   int dense_blocked_min;  // option "dense_blocked_min": smallest order that takes the blocked factorisation (rocSOLVER below)
   int dense_overlap;  // option "dense_overlap": 1 (default) = split the chains in two halves when there are >= 64; 0 = one batch
   double* dense_factor; size_t dense_factor_bytes;
+  double* dense_winv; size_t dense_winv_bytes;  // blocked factorisation: inverses of the current diagonal blocks [C][64][64]
+  int dense_panel_old;  // option "dense_panel_old": 1 = the one-kernel panel of rounds 1-3 (cross-checks)
   int* dense_info; size_t dense_info_bytes;
   double* slice_buf; size_t slice_buf_bytes;  // partial products of a sliced contraction (omc_design_predict) [S][C][n]
   double* dense_tmp; size_t dense_tmp_bytes;

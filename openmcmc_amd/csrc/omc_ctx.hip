@@ -39,6 +39,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->blas = nullptr;
   c->store_ws = nullptr; c->store_ws_bytes = 0;
   c->dense_factor = nullptr; c->dense_factor_bytes = 0;
+  c->dense_winv = nullptr; c->dense_winv_bytes = 0; c->dense_panel_old = 0;
   c->dense_info = nullptr; c->dense_info_bytes = 0;
   c->slice_buf = nullptr; c->slice_buf_bytes = 0;
   c->dense_tmp = nullptr; c->dense_tmp_bytes = 0;
@@ -101,6 +102,7 @@ omc_status omc_ctx_destroy(omc_ctx* ctx) {
   if (ctx->d_gamma_tab) hipFree(ctx->d_gamma_tab);
   if (ctx->d_handoff) hipFree(ctx->d_handoff);
   if (ctx->dense_factor) hipFree(ctx->dense_factor);
+  if (ctx->dense_winv) hipFree(ctx->dense_winv);
   if (ctx->dense_info) hipFree(ctx->dense_info);
   if (ctx->slice_buf) hipFree(ctx->slice_buf);
   if (ctx->dense_tmp) hipFree(ctx->dense_tmp);
@@ -297,6 +299,11 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "dense_blocked_min")) {
     if (value < 1 || value > 32768) return OMC_INVALID_ARG;
     ctx->dense_blocked_min = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "dense_panel_old")) {
+    if (value != 0 && value != 1) return OMC_INVALID_ARG;
+    ctx->dense_panel_old = (int)value;
     return OMC_OK;
   }
   if (!strcmp(name, "dense_overlap")) {

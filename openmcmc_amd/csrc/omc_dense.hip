@@ -324,7 +324,9 @@ __device__ __forceinline__ void lds_barrier() {  // workgroup barrier that waits
 }
 
 __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int nb, double* Qall, int* info,
-                                                    long long* bad, int64_t chain0) {
+                                                    long long* bad, int64_t chain0, unsigned long long* dbg) {
+#define PANEL_STAMP(i) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[(j0 / CH_NB) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+  PANEL_STAMP(0);
   __shared__ double D[CH_NB][CH_NB + 1];  // diagonal block, then its Cholesky factor (zero outside the live nb x nb)
   __shared__ double LiT[CH_NB][CH_NB];    // transposed inverse of the factor (row t: column t of L_JJ^-1)
   __shared__ double dinv[CH_NB], dsq[CH_NB];
@@ -340,6 +342,7 @@ __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int n
   if (tid < CH_NB) dinv[tid] = 0.0;
   if (tid == 0) failed = 0;
   __syncthreads();
+  PANEL_STAMP(1);
   // unblocked right-looking Cholesky of the block: all 256 threads tile the (r, cc) update square 16 x 16, two
   // LDS-only barriers per column (lds_barrier: no wait on vector memory)
   {
@@ -363,6 +366,7 @@ __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int n
       lds_barrier();
     }
   }
+  PANEL_STAMP(2);
   // inverse of the diagonal factor, one column per group of four adjacent lanes (forward substitution on e_j, the
   // inner sum split four ways and combined with two shuffles), stored transposed:
   // LiT[t][cc] = (L_JJ^-1)[cc][t], so that the row update below reads 64 consecutive doubles per t
@@ -386,10 +390,12 @@ __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int n
     }
   }
   __syncthreads();
+  PANEL_STAMP(3);
   for (int t = tid; t < nb * nb; t += 256) {
     const int r = t % nb, cc = t / nb;
     if (cc <= r) A[r + (int64_t)cc * p] = (cc == r) ? dsq[r] : D[r][cc];
   }
+  PANEL_STAMP(4);
   if (tid == 0 && failed) {
     info[c] = (int)j0 + 1;
     atomicMin((unsigned long long*)bad, (unsigned long long)(chain0 + c));
@@ -424,6 +430,87 @@ __global__ void __launch_bounds__(256) k_chol_panel(int64_t p, int64_t j0, int n
     for (int cc = 0; cc < CH_NB; ++cc)
       if (cc < nb) A[r + (int64_t)cc * p] = acc[cc];
   }
+  PANEL_STAMP(5);
+#undef PANEL_STAMP
+}
+
+// ---- the panel in two kernels (round 4) ---------------------------------------------------------------------------------------
+// Stamps of k_chol_panel at p = 1000 (benchmarks/micro/panel_stamps.py): 44-80 us in the 64 x 64 diagonal factor (two workgroup
+// barriers per column), 31 us in its inverse, 20-90 us in the rows below (one thread per row, 64 accumulators, an LDS broadcast
+// per multiply-add) -- 168 us per panel, sixteen panels in a row per draw, and the update GEMMs wait for every one of them.
+//   k_chol_diag   one WAVE per chain: lane r keeps row r of the block in registers; column k is scaled and the trailing
+//                 columns updated with the pivot column's entries broadcast by v_readlane -- no LDS, no barrier on the
+//                 column-to-column path; then L^-1 by forward substitution (lane c: column c), L read as LDS broadcasts.
+//                 Same operations in the same order per entry as the old factor: bit-identical L.
+//   k_panel_rows  X = A_panel L^-T on the matrix cores, in place: a workgroup takes 64 rows x 64 columns, reads its tile of A
+//                 whole (two contraction slabs) before it writes; batched over the chains in the grid's z.
+typedef double chol_d4 __attribute__((ext_vector_type(4)));
+// (omc_choldiag.hip: a translation unit of its own -- 64 fully unrolled column steps take minutes to compile and depend on no
+//  header of the library)
+void omc_launch_chol_diag(hipStream_t stream, int64_t Cn, int64_t p, int64_t j0, int nb, double* Qall, double* Winv_all, int* info,
+                          long long* bad, int64_t chain0);
+
+// rows j0 + nb .. p - 1 of the block column: X[r][cc] = sum_t A[r][t] W[cc][t], in place.  grid (groups of PR_RT row tiles, 1, chains).
+// A workgroup walks PR_RT tiles of 64 rows with W staged once; the next tile's 64 x 64 entries of A are in flight (registers) while
+// the current one is multiplied, and a tile is written only after every thread has read it: in place is safe (other workgroups
+// own other rows).  Traffic-bound by design: 2 x 32 KB per 0.5 Mflop tile.
+#define PR_RT 4
+__global__ void __launch_bounds__(256) k_panel_rows(int64_t p, int64_t j0, int nb, double* Qall, const double* __restrict__ Winv_all) {
+  __shared__ double As[CH_NB][CH_NB + 16];  // As[k][i]: row stride 80: the two rows of a half-wave in different bank halves
+  __shared__ double Bs[CH_NB][CH_NB + 2];   // Bs[j][k] = W[j][k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t c = blockIdx.z;
+  const int64_t m = p - j0 - nb;            // rows below the diagonal block
+  double* A = Qall + c * p * p + (j0 + nb) + j0 * p;  // element (r, t) at A[r + t * p]
+  const double* W = Winv_all + c * (int64_t)(CH_NB * CH_NB);
+  const int64_t tile0 = (int64_t)blockIdx.x * PR_RT;
+  const int64_t ntile = (m + 63) / 64;
+  double ra[16];
+  auto fetch = [&](int64_t tile) {
+    const int64_t i0 = tile * 64;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = q * 256 + tid, k = e >> 6, i = e & 63;   // contiguous in i
+      ra[q] = (tile < ntile && k < nb && i0 + i < m) ? A[(i0 + i) + (int64_t)k * p] : 0.0;
+    }
+  };
+  fetch(tile0);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int e = q * 256 + tid;
+    Bs[e >> 6][e & 63] = W[e];                               // W stored [j][k] with k contiguous
+  }
+  for (int t = 0; t < PR_RT && tile0 + t < ntile; ++t) {
+    const int64_t i0 = (tile0 + t) * 64;
+    __syncthreads();                                          // the previous tile's reads of As are done
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = q * 256 + tid;
+      As[e >> 6][e & 63] = ra[q];
+    }
+    __syncthreads();
+    if (t + 1 < PR_RT) fetch(tile0 + t + 1);                  // in flight under the multiplications
+    chol_d4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = chol_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < CH_NB; kk += 4) {
+      const int kr = kk + (lane >> 4), cl = lane & 15;
+      const double af = As[kr][wave * 16 + cl];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, Bs[16 * u + cl][kr], acc[u], 0, 0, 0);
+    }
+    // C/D of the f64 form: column = lane & 15, row = (lane >> 4) + 4 * register
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = 16 * u + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t i = i0 + wave * 16 + (lane >> 4) + 4 * r;
+        if (i < m && j < nb) A[i + (int64_t)j * p] = acc[u][r];
+      }
+    }
+  }
 }
 
 // block columns of the chains [c0, c0 + Cn) on one stream
@@ -438,8 +525,16 @@ static omc_status potrf_blocked_part(omc_ctx* ctx, rocblas_handle h, hipStream_t
                                                    Qp + j0, (rocblas_int)p, (rocblas_stride)(p * p), Qp + j0, (rocblas_int)p,
                                                    (rocblas_stride)(p * p), &one, Qp + j0 + j0 * p, (rocblas_int)p,
                                                    (rocblas_stride)(p * p), (rocblas_int)Cn));
-    hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)Cn), dim3(256), 0, stream, p, j0, nb, Qp, ctx->dense_info + c0,
-                       ctx->d_bad_chain, c0);
+    if (ctx->dense_panel_old) {
+      hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)Cn), dim3(256), 0, stream, p, j0, nb, Qp, ctx->dense_info + c0,
+                         ctx->d_bad_chain, c0, c0 == 0 ? ctx->stamps : nullptr);
+    } else {
+      double* Winv = ctx->dense_winv + c0 * (int64_t)(CH_NB * CH_NB);
+      omc_launch_chol_diag(stream, Cn, p, j0, nb, Qp, Winv, ctx->dense_info + c0, ctx->d_bad_chain, c0);
+      const int64_t m = p - j0 - nb;
+      if (m > 0)
+        hipLaunchKernelGGL(k_panel_rows, dim3((unsigned)((m + 64 * PR_RT - 1) / (64 * PR_RT)), 1, (unsigned)Cn), dim3(256), 0, stream, p, j0, nb, Qp, Winv);
+    }
     OMC_HIP_CHECK(hipGetLastError());
   }
   return OMC_OK;
@@ -447,6 +542,10 @@ static omc_status potrf_blocked_part(omc_ctx* ctx, rocblas_handle h, hipStream_t
 
 static omc_status potrf_blocked(omc_ctx* ctx, rocblas_handle h, int64_t p, double* Q, int64_t C) {
   OMC_HIP_CHECK(hipMemsetAsync(ctx->dense_info, 0, (size_t)C * sizeof(int), ctx->stream));
+  {
+    const omc_status st0 = omc_ensure_bytes(ctx, (void**)&ctx->dense_winv, &ctx->dense_winv_bytes, (size_t)C * CH_NB * CH_NB * sizeof(double));
+    if (st0 != OMC_OK) return st0;
+  }
   // The panel kernel is one latency-bound workgroup per chain and the update GEMM cannot start before it: in one batch the
   // two alternate and each leaves most of the chip idle in turn.  Two halves of the chains on two streams (fork and join by
   // events: the caller still sees one stream) let one half's panels run under the other half's GEMMs.
