@@ -8,6 +8,7 @@ from dataclasses import dataclass
 from typing import Union
 
 import numpy as np
+from math import lgamma as _lgamma
 
 from openmcmc_amd.chains import ChainArray, is_chain
 from openmcmc_amd.parameter import Identity, LinearCombination, MixtureParameterVector
@@ -144,7 +145,19 @@ class Gamma(Distribution):
 
             return float(np.sum(stats.gamma.logpdf(np.asarray(x, dtype=np.float64), a, scale=1.0 / b)))
         if by_observation:
-            raise NotImplementedError("by_observation on a per-chain response (use log_p_last)")
+            # distribution.py:255-259: the sum over the p rows stays, the replicate columns are kept: (C, n_rep); NaN padding of
+            # a ragged response stays out of the sum and reads 0 beyond the live length
+            import torch
+
+            v = x.data  # (C, p, n_rep)
+            lp = (a * float(np.log(b)) - float(_lgamma(a))) + (a - 1.0) * torch.log(v) - b * v
+            lp = torch.where(v > 0, lp, torch.full_like(lp, float("-inf")))
+            if x.ragged is not None:
+                axis = x.ragged[1]
+                live = torch.arange(v.shape[1 + axis], device=v.device).reshape((1, -1, 1) if axis == 0 else (1, 1, -1)) \
+                    < x.count(state).reshape(-1, 1, 1)
+                lp = torch.where(live, lp, torch.zeros_like(lp))
+            return lp.sum(dim=1)
         if engine is None:
             raise RuntimeError("Gamma.log_p on a per-chain response needs the engine (use Model.log_p)")
         out = engine.empty(engine.n_chains) if out is None else out
@@ -223,8 +236,15 @@ class Uniform(Distribution):
         x = state[self.response]
         per = self.log_p_per_replicate(state)
         if by_observation:
-            if is_chain(x):
-                raise NotImplementedError("by_observation on a per-chain response (use log_p_per_replicate)")
+            if is_chain(x):  # distribution.py:436-440: the same constant for every replicate, 0 beyond a ragged response's live length
+                import torch
+
+                k = x.data.shape[2]
+                out_ = torch.full((x.n_chains, k), float(per), dtype=torch.float64, device=x.data.device)
+                if x.ragged is not None and x.ragged[1] == 1:
+                    live = torch.arange(k, device=x.data.device).reshape(1, -1) < x.count(state).reshape(-1, 1)
+                    out_ = torch.where(live, out_, torch.zeros_like(out_))
+                return out_
             return np.ones(x.shape[1]) * per
         if not is_chain(x):
             return x.shape[1] * per

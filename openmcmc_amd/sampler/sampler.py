@@ -363,9 +363,18 @@ class NormalNormal(MCMCSampler):
                 mat = None if (st.diag is None and st.off is None) else eng.shared(st.matrix)
                 rhs = center if mat is None else eng.design_rhs(mat, center)  # M' m = M m, once per model
                 op = mat
+            elif st.diag is False or st.off is not None:
+                # a correlated response (tridiagonal, banded or dense W, any symmetric matrix the reference accepts:
+                # sampler.py:185-192 forms A'QA and A'Q(y - d) with whatever Q is): W A once per model on the host (a band or
+                # sparse product), then the same contraction as the diagonal case, A'(W A), on the device
+                Ad = A.toarray() if hasattr(A, "toarray") else np.asarray(A, dtype=np.float64)
+                WA = eng.to_device(np.ascontiguousarray(np.asarray(st.matrix @ Ad, dtype=np.float64)))  # (n_obs, p)
+                dA = eng.shared(A)
+                mat = dA.t().contiguous() @ WA
+                mat = (0.5 * (mat + mat.t())).contiguous()
+                rhs = (WA.t().contiguous() @ center.reshape(-1, 1)).reshape(-1).contiguous()
+                op = WA.t().contiguous() if per_chain else None  # A' W as a (p, n_obs) operator on per-chain vectors
             else:
-                if st.diag is False or st.off is not None:
-                    raise NotImplementedError("regression likelihood needs a diagonal response precision")
                 dA = eng.shared(A)
                 w = None if st.diag is None else eng.to_device(st.diag)
                 mat, rhs = eng.gram(dA, w), eng.design_rhs(dA, center, w)

@@ -572,3 +572,43 @@ def test_whitened_mala_run_is_the_single_steps_in_a_row(d, C, steps, inject):
                        draw_index0=100, draw_stride=3)
     assert relerr(x3.cpu().numpy(), want_x[-1]) < 1e-12
     eng.close()
+
+
+def test_manifold_mala_on_eighty_regression_coefficients(golden):
+    """The same structure as test_manifold_mala_on_regression_coefficients beyond one wave's worth of coefficients (p = 80 > 64: the
+    per-chain Hessian combination goes through the dense route): 25 steps of the reference (tests/golden/mala_wide.npz, made by
+    tests/golden/make_golden_r4.py), same accept decisions, states to 1e-9."""
+    import torch
+    from scipy import sparse
+
+    from openmcmc_amd.chains import ChainArray
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import LinearCombination, ScaledMatrix
+    from openmcmc_amd.sampler.metropolis_hastings import ManifoldMALA
+
+    G = golden("mala_wide")
+    X, w, y = G["X"], G["w"], G["y"]
+    n, p = X.shape
+    C = 3
+    eng = make_engine(C)
+    mdl = Model([Normal("y", mean=LinearCombination({"beta": "X"}), precision=ScaledMatrix("P_tau", "tau")),
+                 Normal("beta", mean="mu", precision=ScaledMatrix("P_lam", "lam"))])
+    dev = eng.device
+    full = lambda v: ChainArray(eng.full((C, 1, 1), float(v)))  # noqa: E731
+    state = {"y": y.reshape(n, 1), "X": X, "beta": ChainArray(eng.to_device(np.tile(G["beta0"], (C, 1)))),
+             "P_tau": sparse.diags(w, format="csc"), "tau": full(G["tau"]), "P_lam": G["P"], "lam": full(G["lam"]),
+             "mu": np.full((p, 1), float(G["mu"]))}
+    smp = ManifoldMALA("beta", mdl, step=np.array(float(G["step"]))).bind(eng)
+    smp.inject = lambda s, it: torch.as_tensor(np.tile(G["z"][it], (C, 1)), device=dev)
+    smp.inject_uniform = lambda s, it: torch.full((C,), float(G["u"][it]), dtype=torch.float64, device=dev)
+    for it in range(int(G["n_steps"])):
+        before = smp.accept_rate.accept.clone()
+        state = smp.sample(state)
+        eng.check_status()
+        got = state["beta"].numpy()[:, :, 0]
+        ref = G["x"][it]
+        assert np.max(np.abs(got - ref[None, :])) < 1e-9 * max(1.0, np.abs(ref).max()), it
+        assert (smp.accept_rate.accept - before).cpu().numpy().tolist() == [int(G["accept"][it])] * C, it
+    assert 0 < G["accept"].sum() < G["n_steps"]
+    eng.close()

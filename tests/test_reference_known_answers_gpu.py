@@ -14,6 +14,12 @@ def relerr(a, b):
     return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
 
 
+def make_engine(C, seed=0):
+    from openmcmc_amd.engine import Engine
+
+    return Engine(C, seed=seed)
+
+
 def regression_setup(n_resp, n_par, C, seed=0):
     """The reference's shared test model, Normal-Normal part: response ~ N(X parameter, (tau P)^-1),
     parameter ~ N(prior_mean, (lambda I)^-1)."""
@@ -168,3 +174,96 @@ def test_run_mcmc_call_counts(golden):
     assert counts["store"] == 4 * len(samplers)
     assert counts["log_p"] == 4
     assert not np.isnan(M.collect()["b"]).any()
+
+
+@pytest.mark.parametrize("tag", ["tri", "band", "dense"])
+def test_regression_under_a_correlated_response_replays_reference(golden, tag):
+    """y ~ N(X beta, (tau W)^-1) with W tridiagonal, pentadiagonal or dense (sampler/sampler.py:179-192 and
+    location_scale.py:190-250 accept any Q): NormalNormal(beta) + NormalGamma(tau) + NormalGamma(lambda) through MCMC.run_mcmc
+    on the reference's recorded draws, its gradient / Hessian through the mean and its log density
+    (tests/golden/correlated_regression.npz, made by tests/golden/make_golden_r4.py running the reference)."""
+    from scipy import sparse
+
+    from openmcmc_amd.chains import ChainArray
+    from openmcmc_amd.distribution.distribution import Gamma
+    from openmcmc_amd.distribution.location_scale import Normal, ScaledHessian
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import LinearCombination, ScaledMatrix
+    from openmcmc_amd.sampler.sampler import NormalGamma, NormalNormal
+
+    G = golden("correlated_regression")
+    k = tag + "_"
+    N, p = int(G["N"]), int(G["p"])
+    W = G[k + "W"] if tag == "dense" else sparse.csc_matrix(G[k + "W"])
+    mdl = Model([Normal("y", mean=LinearCombination(form={"beta": "X"}), precision=ScaledMatrix(matrix="W", scalar="tau")),
+                 Normal("beta", mean="mu_b", precision=ScaledMatrix(matrix="P_lambda", scalar="lambda")),
+                 Gamma("tau", shape="a_tau", rate="b_tau"), Gamma("lambda", shape="a_lambda", rate="b_lambda")],
+                response={"y": "mean"})
+    state = {"y": G["y"], "X": G["X"], "beta": np.full(p, 0.1), "mu_b": np.full(p, 0.2), "W": W, "tau": 1.5,
+             "P_lambda": sparse.identity(p, format="csc"), "lambda": 0.3, "a_tau": 1e-2, "b_tau": 1e-2, "a_lambda": 1e-2, "b_lambda": 1e-2}
+    nn, g_tau, g_lam = NormalNormal("beta", mdl), NormalGamma("tau", mdl), NormalGamma("lambda", mdl)
+    C = 3
+    M = MCMC(state, [nn, g_tau, g_lam], model=mdl, n_burn=int(G["n_burn"]), n_iter=int(G["n_iter"]), n_chains=C)
+    eng = M.engine
+    # gradient through the mean and log density at the start state (before anything moves)
+    grad, H = mdl["y"].grad_log_p(M.state, "beta", engine=eng)
+    assert isinstance(H, ScaledHessian)
+    for c in range(C):
+        assert relerr(grad.data[c].cpu().numpy().ravel(), G[k + "grad"]) < 1e-11
+    assert relerr(1.5 * np.asarray(H.matrix), G[k + "hess"]) < 1e-12 and relerr(H.scale.cpu().numpy(), np.full(C, 1.5)) < 1e-15
+    assert relerr(mdl["y"].log_p(M.state, engine=eng).cpu().numpy(), np.full(C, G[k + "log_p"])) < 1e-11
+    nn.inject = lambda s_, t: eng.to_device(np.tile(G[k + "z"][t], (C, 1)))
+    g_tau.inject = lambda s_, t: eng.full((C,), G[k + "g"][t, 0])
+    g_lam.inject = lambda s_, t: eng.full((C,), G[k + "g"][t, 1])
+    M.run_mcmc()
+    out = M.collect()
+    for c in range(C):
+        for key in ("beta", "tau", "lambda", "log_post", "y"):
+            assert relerr(out[key][c], G[k + "store_" + key]) < 1e-9, (key, c)
+    eng.close()
+
+
+@pytest.mark.parametrize("tag", ["tri", "dense"])
+def test_by_observation_of_a_fixed_size_replicated_response(golden, tag):
+    """Normal.log_p(by_observation=True) (location_scale.py:145-167 -> gmrf.py:321-348): one log density per replicate column,
+    for shared data under a per-chain mean and scalar, and for a per-chain replicated response; Gamma and Uniform alike."""
+    from scipy import sparse, stats
+
+    from openmcmc_amd.chains import ChainArray
+    from openmcmc_amd.distribution.distribution import Gamma, Uniform
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.parameter import ScaledMatrix
+
+    G = golden("correlated_regression")
+    Y, mu, tau = G["byobs_Y"], G["byobs_mu"].reshape(-1, 1), float(G["byobs_tau"])
+    d, n_rep = Y.shape
+    W = G["byobs_" + tag + "_W"] if tag == "dense" else sparse.csc_matrix(G["byobs_" + tag + "_W"])
+    want = G["byobs_" + tag + "_logp"]
+    C = 4
+    eng = make_engine(C)
+    dist = Normal("Y", mean="mu", precision=ScaledMatrix(matrix="W", scalar="tau"))
+    # (i) shared data, per-chain scalar (all chains at the reference's value) and per-chain mean
+    st = {"Y": Y, "mu": ChainArray(eng.to_device(np.tile(mu.reshape(1, d, 1), (C, 1, 1)))), "W": W,
+          "tau": ChainArray(eng.full((C, 1, 1), tau))}
+    got = dist.log_p(st, by_observation=True, engine=eng).cpu().numpy()
+    assert got.shape == (C, n_rep) and relerr(got, np.tile(want, (C, 1))) < 1e-12
+    assert relerr(got.sum(axis=1), np.full(C, G["byobs_" + tag + "_total"])) < 1e-12
+    # (ii) the response per chain (every chain its own shift), shared mean
+    shift = np.arange(C, dtype=float).reshape(C, 1, 1) * 0.1
+    st2 = {"Y": ChainArray(eng.to_device(Y[None] + shift)), "mu": mu, "W": W, "tau": ChainArray(eng.full((C, 1, 1), tau))}
+    got2 = dist.log_p(st2, by_observation=True, engine=eng).cpu().numpy()
+    Wd = W.toarray() if sparse.issparse(W) else W
+    for c in range(C):
+        r = Y + shift[c] - mu
+        ref = 0.5 * (np.linalg.slogdet(tau * Wd)[1] - d * np.log(2 * np.pi) - np.sum(r * (tau * Wd @ r), axis=0))
+        assert relerr(got2[c], ref) < 1e-12
+    # Gamma / Uniform on a per-chain (p, n_rep) response (distribution.py:255-259, 436-440)
+    xg = np.abs(Y) + 0.1
+    gm = Gamma("g", shape="a", rate="b")
+    gl = gm.log_p({"g": ChainArray(eng.to_device(np.tile(xg[None], (C, 1, 1)))), "a": 2.5, "b": 1.7}, by_observation=True, engine=eng).cpu().numpy()
+    assert relerr(gl, np.tile(np.sum(stats.gamma.logpdf(xg, 2.5, scale=1 / 1.7), axis=0), (C, 1))) < 1e-12
+    un = Uniform("u", domain_response_lower=np.full((d, 1), -4.0), domain_response_upper=np.full((d, 1), 5.0))
+    ul = un.log_p({"u": ChainArray(eng.to_device(np.tile(Y[None], (C, 1, 1))))}, by_observation=True, engine=eng).cpu().numpy()
+    assert relerr(ul, np.full((C, n_rep), -d * np.log(9.0))) < 1e-14
+    eng.close()
