@@ -1905,6 +1905,10 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
   double qcp[PFQ ? M : 1], qop[PFQ ? M : 1];
   double qcc[SHIFT ? M : 1];  // SIG 3: the chain's centre slice in the coalesced mapping (quadratic form's centre, x = c + e)
   bool pfq = false;
+  // vector-memory loads issue_pfq has put on the wire, counted WHERE they are issued: the count-based wait in front of the parked
+  // diagonal (below) is taken only if this says that at least PFQ_LOADS loads went out behind the transfer -- the wait's safety
+  // follows from the counter, not from a remark about which paths issue loads (round 3's race was such a remark going stale)
+  int pfq_behind = 0;
   auto issue_pfq = [&]() {
     if constexpr (PFQ) {
       const bool wq = A.quad || A.fused;
@@ -1922,6 +1926,7 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         if (!SHIFT || vIc) {
 #pragma unroll
           for (int t = 0; t < M; ++t) qcp[t] = (vIc + wbase)[(unsigned)(lane + 64 * t)];
+          pfq_behind += M;
         } else {
 #pragma unroll
           for (int t = 0; t < M; ++t) qcp[t] = 0.0;
@@ -1929,10 +1934,12 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
         if constexpr (SHIFT && OMC_SHIFT_PREFETCH) {
 #pragma unroll
           for (int t = 0; t < M; ++t) qcc[t] = (vSh + wbase)[(unsigned)(lane + 64 * t)];
+          pfq_behind += M;
         }
         if (OMC_PREFETCH_QUAD > 1) {
 #pragma unroll
           for (int t = 2 * NZB; t < M; ++t) qop[t] = (vPark + wbase)[(unsigned)(lane + 64 * t)];
+          pfq_behind += M - 2 * NZB;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -2072,7 +2079,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
       // the late transfer overwrote the x this wave had meanwhile put into the tile.  One chain in a few thousand sweeps of
       // the hierarchical smoother at n = 10 000 x 1024 chains, found by benchmarks/determinism_hier.py.)
       if (!diag_staged) {
-        if (PFQ && pfq && (!SHIFT || vIc) && !(EARLY && OMC_EARLY_PFQ_AHEAD)) __builtin_amdgcn_s_waitcnt(0x0F70 | PFQ_LOADS);
+        // (issue_pfq ran behind the transfer -- not in the EARLY && OMC_EARLY_PFQ_AHEAD order -- and left at least PFQ_LOADS
+        //  loads behind it: then "at most PFQ_LOADS still out" means the transfer is not among them)
+        if (PFQ && !(EARLY && OMC_EARLY_PFQ_AHEAD) && pfq_behind >= PFQ_LOADS) __builtin_amdgcn_s_waitcnt(0x0F70 | PFQ_LOADS);
         else __builtin_amdgcn_s_waitcnt(0x0F70);
       }
       wave_lds_fence();
@@ -2135,7 +2144,9 @@ __global__ void __launch_bounds__(MAXT) k_tridiag_seg(TriArgs A, int G) {
           if (park_off && SHIFT && OMC_SHIFT_PARK_C) {  // the parked slice is the chain's centre; the off-diagonal comes from L2
             const double* zf = &lds_z[wave][0][0];
             coal_load<M>(qo, vPo + wbase, lane, nvo);
-            __builtin_amdgcn_s_waitcnt(0x0F70 | M);  // the transfers (older than these M loads) have landed
+            // the transfers (older than these M loads) have landed.  The M loads are M instructions issued right here on every
+            // path: park_off says the wave is full, so nvo >= 64 M - 1 and no load has all its lanes predicated off
+            __builtin_amdgcn_s_waitcnt(0x0F70 | M);
             wave_lds_fence();
 #pragma unroll
             for (int t = 0; t < M; ++t)

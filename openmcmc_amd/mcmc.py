@@ -241,6 +241,8 @@ class MCMC:
     def run_mcmc(self):
         eng = self.engine
         self._check_stream()
+        if not self.store_ring:  # (a caller may have re-sized n_iter and the store after construction)
+            self._n_dev = self._half = self.n_iter
         if (self._fused is not None and self._fused["log_post"] and self.n_iter > 0
                 and all(getattr(s, "inject", None) is None for s in self.samplers)):
             self._run_fused_in_c()
@@ -359,7 +361,7 @@ class MCMC:
 
     # ------------------------------------------------------------------ results
     def _whole_store_on_device(self, what):
-        if self._n_dev != self.n_iter:
+        if self.store_ring and self._n_dev != self.n_iter:
             raise ValueError(f"{what} reduces the device store, and with store_ring the device holds the last {self._n_dev} of "
                              f"{self.n_iter} iterations only: reduce the drained store (host_store) instead")
 
