@@ -1,4 +1,6 @@
-"""RW(w) band draws only (for rocprofv3): python benchmarks/band_profile.py [--n 10000 --chains 1024 --w 2 --steps 20]"""
+"""RW(w) band draws only (for rocprofv3): python benchmarks/band_profile.py [--n 10000 --chains 1024 --w 2 --steps 20]
+--lattice K: a K x K first-order lattice GMRF instead (4-neighbour Laplacian + ridge, row-major order: n = K^2, bandwidth K --
+SURVEY 8f rank 1's "2-D lattice GMRF with bandwidth sqrt(n)", gmrf.py:489-520 on a sparse precision of that shape)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import argparse, json, time
@@ -11,7 +13,10 @@ ap.add_argument("--n", type=int, default=10000); ap.add_argument("--chains", typ
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--w", type=int, default=2)
 ap.add_argument("--overlap", type=int, default=0); ap.add_argument("--algo", type=int, default=0)
 ap.add_argument("--segments", type=int, default=0)
+ap.add_argument("--lattice", type=int, default=0)
 a = ap.parse_args()
+if a.lattice:
+    a.n, a.w = a.lattice * a.lattice, a.lattice
 from openmcmc_amd.engine import Engine
 n, C = a.n, a.chains
 eng = Engine(C, seed=2)
@@ -23,10 +28,17 @@ if a.overlap:
 rng = np.random.default_rng(0)
 t = np.arange(n) * 60.0 / n
 y = np.sin(t / 20) + 2 * np.cos(t / 12) + 2 + rng.standard_normal(n)
-D = sparse.identity(n, format="csr")
-for _ in range(a.w):
-    D = D[1:] - D[:-1]
-P = (D.T @ D + 1e-3 * sparse.identity(n)).tocsc()
+if a.lattice:
+    K = a.lattice
+    D1 = sparse.identity(K, format="csr")
+    D1 = D1[1:] - D1[:-1]
+    L1 = (D1.T @ D1)
+    P = (sparse.kron(sparse.identity(K), L1) + sparse.kron(L1, sparse.identity(K)) + 1e-3 * sparse.identity(n)).tocsc()
+else:
+    D = sparse.identity(n, format="csr")
+    for _ in range(a.w):
+        D = D[1:] - D[:-1]
+    P = (D.T @ D + 1e-3 * sparse.identity(n)).tocsc()
 band = np.zeros((a.w + 1, n))
 for d in range(a.w + 1):
     band[d, : n - d] = P.diagonal(-d)
@@ -39,5 +51,7 @@ eng.check_status(); torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(a.steps):
     eng.band_sample_canonical(n, T, x, draw_index=3 + i)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
-print(json.dumps({"workload": f"band draw RW{a.w} n={n} chains={C}", "ms_per_draw": 1e3 * dt, "chain_updates_per_s": C / dt,
+flop = C * (n * a.w * a.w + 6.0 * n * a.w)  # band Cholesky n w^2 + three band solves 2 n w each
+print(json.dumps({"workload": (f"band draw {a.lattice} x {a.lattice} lattice (w = {a.w})" if a.lattice else f"band draw RW{a.w}") + f" n={n} chains={C}",
+                  "tflops_on_n_w2": flop / dt / 1e12, "factor_workspace_GB": C * n * (a.w + 1) * 8 / 1e9, "ms_per_draw": 1e3 * dt, "chain_updates_per_s": C / dt,
                   "join_fallbacks": eng.counter("band_join_fallbacks"), "overlap": a.overlap or 192, "segments": a.segments or "auto"}))
