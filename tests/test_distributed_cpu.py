@@ -66,3 +66,58 @@ def test_gather_uneven_shards():
     assert out["b"].shape == (5, 4, 3)
     for c in range(5):
         assert np.array_equal(out["b"][c, :, 0], 100 * c + np.arange(4.0))
+
+
+def _stream_worker(rank, world, port, total, every, q):
+    """The streaming form of the same collective: a ring store's halves go to the root one by one (parallel.GatherSink)."""
+    import types
+
+    from openmcmc_amd.parallel import GatherSink
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_local, offset = shard_chains(total, world, rank)
+    n_iter, size, half = 7, 4, 2
+    it = torch.arange(n_iter, dtype=torch.float64)[:, None, None]
+    ch = (offset + torch.arange(n_local, dtype=torch.float64))[None, :, None]
+    el = torch.arange(size, dtype=torch.float64)[None, None, :]
+    full = {"b": 10000 * it + 100 * ch + el, "log_post": ((10 * it + ch)[:, :, 0]).contiguous()}
+    sink = GatherSink(dst=0, every=every)
+    sink.bind(types.SimpleNamespace(n_iter=n_iter, n_chains=n_local, seed=0, chain_id_offset=offset, engine=None), None)
+    for it0 in range(0, n_iter, half):           # what the ring's drain hands over, chunk by chunk
+        it1 = min(n_iter, it0 + half)
+        for key, t in full.items():
+            sink(key, it0, it1, t[it0:it1])
+    out = sink.result()
+    if rank == 0:
+        q.put(out)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_stream(total, every):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, total, every, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return out
+
+
+def test_streaming_gather_places_every_chunk():
+    for every in (1, 3):
+        out = _run_stream(5, every)  # ranks hold 3 and 2 chains; 7 iterations in halves of 2
+        kept = list(range(0, 7, every))
+        assert out["b"].shape == (5, 4, len(kept)) and out["log_post"].shape == (5, len(kept), 1)
+        for c in range(5):
+            for j, i in enumerate(kept):
+                assert np.array_equal(out["b"][c, :, j], 10000 * i + 100 * c + np.arange(4.0))
+                assert out["log_post"][c, j, 0] == 10 * i + c
