@@ -928,6 +928,34 @@ class Engine:
                                     self._chain_scalar(logdet)))
         return Av, quad, logdet
 
+    # per-chain SPD matrices beyond one wave's 64 columns (the generic ManifoldMALA route with a parameter-dependent Hessian):
+    # batched dense factorisations as tensor expressions on the context's stream -- a rarely taken generic branch, natural-order
+    # Cholesky like everywhere else (the factor is unique: the same draw for the same z as the small-matrix kernels)
+    def chain_spd_ops(self, A, v=None, want_Av=False, want_quad=False, want_logdet=False):
+        torch = _torch()
+        Av = torch.bmm(A, v.unsqueeze(2)).squeeze(2) if (want_Av or want_quad) else None
+        quad = (v * Av).sum(dim=1) if want_quad else None
+        logdet = None
+        if want_logdet:
+            L, info = torch.linalg.cholesky_ex(A)
+            if bool((info != 0).any().item()):
+                raise np.linalg.LinAlgError(f"Matrix is not positive definite (chain {int(torch.nonzero(info)[0].item())})")
+            logdet = 2.0 * torch.log(torch.diagonal(L, dim1=1, dim2=2)).sum(dim=1)
+        return (Av if want_Av else None), quad, logdet
+
+    def chain_sample_canonical(self, A, b, z=None, draw_index=0, mean_out=None):
+        """x = A^-1 b + L^-T z per chain, L = chol(A) (gmrf.py:167-198 for a dense per-chain precision of any order)."""
+        torch = _torch()
+        Cn, k, _ = A.shape
+        L, info = torch.linalg.cholesky_ex(A)
+        if bool((info != 0).any().item()):
+            raise np.linalg.LinAlgError(f"Matrix is not positive definite (chain {int(torch.nonzero(info)[0].item())})")
+        w = torch.linalg.solve_triangular(L, b.unsqueeze(2), upper=False)
+        if mean_out is not None:
+            mean_out.copy_(torch.linalg.solve_triangular(L.transpose(1, 2), w, upper=True).squeeze(2))
+        zz = self.fill_normal(k, draw_index) if z is None else z
+        return torch.linalg.solve_triangular(L.transpose(1, 2), w + zz.unsqueeze(2), upper=True).squeeze(2).contiguous()
+
     def rj_matched_transition(self, gram_cur, gram_prop, count, birth, del_index, coef_cur, scale, limits, lq_fwd,
                               lq_rev, inject=None, draw_index=0, sub=0):
         """coef_prop (C, kmax); lq_fwd / lq_rev (C,) are added to in place."""

@@ -525,35 +525,48 @@ class ManifoldMALA(MetropolisHastings):
         return grad.contiguous(), H.contiguous()
 
     def _general_step(self, current_state: dict) -> dict:
-        """Any model whose device log_p exists, for a small fixed-size parameter (d <= 64): gradient and Hessian of every
+        """Any model whose device log_p exists, for a fixed-size parameter: gradient and Hessian of every
         member as the reference's generic path computes them (analytic where a distribution has one, central differences
         otherwise, distribution.py:90-198), a per-chain Lambda_c = H_c / step^2 factorised per chain in natural order
         (omc_small_sample_canonical: x' = m + L^-T z and m at once; again with z = 0 at the proposed state for the reverse
         mean), log q = (1/2) log det Lambda - (1/2)(. - m)' Lambda (. - m) (metropolis_hastings.py:301-373)."""
         eng = self.engine
         x = current_state[self.param]
-        if x.ragged is not None or x.shape[1] != 1 or x.size > 64:
-            raise NotImplementedError("generic ManifoldMALA route: fixed-size (d, 1) parameter with d <= 64")
+        if x.ragged is not None or x.shape[1] != 1:
+            raise NotImplementedError("generic ManifoldMALA route: fixed-size (d, 1) parameter")
         xv = x.vector().contiguous()
         Cn, d = xv.shape
         s2 = float(self.step.item()) ** 2
         zero = eng.zeros(Cn, d)
+        # up to one wave's 64 columns the library's small-matrix kernels (one wave per chain); beyond, the same operations as
+        # batched dense factorisations (Engine.chain_spd_ops / chain_sample_canonical): the reference has no size limit here
+        # (metropolis_hastings.py:325-348)
+        if d <= 64:
+            spd_ops = eng.small_spd_ops
+
+            def draw(Lam_, b_, z_, mean_out):
+                return eng.small_sample_canonical(Lam_, b_, zero, z=z_, draw_index=self._draw_index(), mean_out=mean_out)
+        else:
+            spd_ops = eng.chain_spd_ops
+
+            def draw(Lam_, b_, z_, mean_out):
+                return eng.chain_sample_canonical(Lam_, b_, z=z_, draw_index=self._draw_index(), mean_out=mean_out)
         grad, H = self._grad_hess_per_chain(current_state)
         Lam = H / s2
-        Lx, _, logdet_f = eng.small_spd_ops(Lam, xv, want_Av=True, want_logdet=True)
+        Lx, _, logdet_f = spd_ops(Lam, xv, want_Av=True, want_logdet=True)
         z = self.inject(self, self._sweep) if self.inject is not None else None
         mu_f = eng.empty(Cn, d)
-        xp = eng.small_sample_canonical(Lam, _lin(eng, 1.0, Lx, 0.5, grad), zero, z=z, draw_index=self._draw_index(), mean_out=mu_f)
-        _, quad_f, _ = eng.small_spd_ops(Lam, _lin(eng, 1.0, xp, -1.0, mu_f), want_quad=True)
+        xp = draw(Lam, _lin(eng, 1.0, Lx, 0.5, grad), z, mu_f)
+        _, quad_f, _ = spd_ops(Lam, _lin(eng, 1.0, xp, -1.0, mu_f), want_quad=True)
         lq_f = _lin(eng, 0.5, logdet_f, -0.5, quad_f)
         prop_state = dict(current_state)
         prop_state[self.param] = x.like(xp.unsqueeze(2))
         grad_p, H_p = self._grad_hess_per_chain(prop_state)
         Lam_p = H_p / s2
-        Lxp, _, logdet_r = eng.small_spd_ops(Lam_p, xp, want_Av=True, want_logdet=True)
+        Lxp, _, logdet_r = spd_ops(Lam_p, xp, want_Av=True, want_logdet=True)
         mu_r = eng.empty(Cn, d)
-        eng.small_sample_canonical(Lam_p, _lin(eng, 1.0, Lxp, 0.5, grad_p), zero, z=zero, mean_out=mu_r)
-        _, quad_r, _ = eng.small_spd_ops(Lam_p, _lin(eng, 1.0, xv, -1.0, mu_r), want_quad=True)
+        draw(Lam_p, _lin(eng, 1.0, Lxp, 0.5, grad_p), zero, mu_r)
+        _, quad_r, _ = spd_ops(Lam_p, _lin(eng, 1.0, xv, -1.0, mu_r), want_quad=True)
         lq_r = _lin(eng, 0.5, logdet_r, -0.5, quad_r)
         if self.trace is not None:
             self.trace.setdefault("steps", []).append({"prop": xp.clone(), "lq_fwd": lq_f.clone(), "lq_rev": lq_r.clone()})

@@ -84,3 +84,56 @@ def test_cfg5_full_size_runs_and_keeps_its_invariants():
     assert np.any(nb[:, -1] != k0)                                                           # some chain has jumped
     assert 0 < samplers[4].accept_rate.accept.sum().item() < samplers[4].accept_rate.proposal.sum().item()
     eng.close()
+
+
+def test_spectral_route_at_cfg2_size_has_the_factorisation_routes_conditional_law():
+    """cfg2's production route is the spectral draw, which is not the path-wise image of the reference's (gmrf.py:481,462,434).
+    At the config's full size (p = 1000, 256 chains with their own scales): (i) its mean and log det are the factorisation
+    route's; (ii) per chain, the residual whitened with a square root of Q_c the TEST computes (numpy eigh of the Gram matrix,
+    nothing of the route under test) is standard normal beyond its Mahalanobis mean: mean, variance, skewness, kurtosis, the
+    KS distance of all coordinates over repeated draws, and no correlation between consecutive draws or neighbouring chains."""
+    import torch
+    from scipy import stats
+
+    from openmcmc_amd.engine import Engine
+
+    p, C, n_obs, draws = 1000, 256, 4000, 12
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((n_obs, p))
+    y = X @ rng.standard_normal(p) + 0.5 * rng.standard_normal(n_obs)
+    eng = Engine(C, seed=5)
+    dX = eng.to_device(X)
+    G, Xty = eng.gram(dX), eng.design_rhs(dX, eng.to_device(y))
+    lam, tau = 0.05 + rng.random(C), 0.5 + 2 * rng.random(C)
+    terms = [{"mat": None, "scale": eng.to_device(lam)}, {"mat": G, "rhs": Xty, "scale": eng.to_device(tau)}]
+    V, ev = eng.dense_spectral_prepare(G)
+    xs, ms, ls = eng.empty(C, p), eng.empty(C, p), eng.empty(C)
+    xc, mc, lc = eng.empty(C, p), eng.empty(C, p), eng.empty(C)
+    eng.dense_sample_canonical(p, terms, xc, mean_out=mc, logdet_out=lc, draw_index=1)
+    eng.dense_spectral_sample(p, terms, 1, V, ev, xs, mean_out=ms, logdet_out=ls, draw_index=1)
+    eng.check_status()
+    assert (ms - mc).abs().max().item() < 1e-10 * mc.abs().max().item()
+    assert ((ls - lc).abs() / lc.abs()).max().item() < 1e-12
+    # the test's own square root: Q_c = U diag(lam_c + tau_c w) U'
+    w_h, U_h = np.linalg.eigh(G.cpu().numpy())
+    U = eng.to_device(U_h)
+    root = torch.sqrt(eng.to_device(lam).reshape(C, 1) + eng.to_device(tau).reshape(C, 1) * eng.to_device(w_h).reshape(1, p))  # (C, p)
+    W = []
+    for k in range(draws):
+        eng.dense_spectral_sample(p, terms, 1, V, ev, xs, mean_out=ms, draw_index=10 + k)
+        W.append(((xs - ms) @ U) * root)  # rows: diag(sqrt(.)) U'(x - mu)
+    eng.check_status()
+    W = torch.stack(W).cpu().numpy()  # (draws, C, p)
+    per_chain = W.transpose(1, 0, 2).reshape(C, draws * p)
+    n = draws * p
+    assert np.max(np.abs(per_chain.mean(axis=1))) < 5.0 / np.sqrt(n)
+    assert np.max(np.abs(per_chain.var(axis=1) - 1.0)) < 5.0 * np.sqrt(2.0 / n)
+    assert np.max(np.abs(stats.skew(per_chain, axis=1))) < 5.0 * np.sqrt(6.0 / n)
+    assert np.max(np.abs(stats.kurtosis(per_chain, axis=1))) < 5.0 * np.sqrt(24.0 / n)
+    assert stats.kstest(W[:, ::16].ravel(), "norm").pvalue > 1e-4
+    # independence: consecutive draws of a chain, neighbouring chains of a draw, neighbouring coordinates
+    m = W.size
+    assert abs(np.mean(W[1:] * W[:-1])) < 5.0 / np.sqrt(m)
+    assert abs(np.mean(W[:, 1:] * W[:, :-1])) < 5.0 / np.sqrt(m)
+    assert abs(np.mean(W[:, :, 1:] * W[:, :, :-1])) < 5.0 / np.sqrt(m)
+    eng.close()

@@ -612,3 +612,42 @@ def test_manifold_mala_on_eighty_regression_coefficients(golden):
         assert (smp.accept_rate.accept - before).cpu().numpy().tolist() == [int(G["accept"][it])] * C, it
     assert 0 < G["accept"].sum() < G["n_steps"]
     eng.close()
+
+
+def test_generic_manifold_mala_beyond_one_waves_columns(golden):
+    """The generic route (a Hessian that depends on the sampled vector: one Lambda_c = H_c / step^2 per chain and step) at d = 70,
+    beyond the small-matrix kernels' 64 columns: 15 steps of the reference on a LogNormal-prior vector under a regression
+    likelihood (tests/golden/mala_lognormal_wide.npz), decisions identical, states to 1e-8 (metropolis_hastings.py:325-348 has no
+    size limit)."""
+    from scipy import sparse
+
+    from openmcmc_amd.chains import ChainArray
+    from openmcmc_amd.distribution.location_scale import LogNormal, Normal
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import LinearCombination, ScaledMatrix
+    from openmcmc_amd.sampler.metropolis_hastings import ManifoldMALA
+
+    G = golden("mala_lognormal_wide")
+    C, n_obs = 3, G["A"].shape[0]
+    eng = make_engine(C, seed=1)
+    mdl = Model([Normal("y", mean=LinearCombination(form={"s": "A"}), precision=ScaledMatrix(matrix="P_y", scalar="tau")),
+                 LogNormal("s", mean="mu_s", precision="Q_s")])
+    state = {"y": G["y"].reshape(-1, 1), "A": G["A"], "s": ChainArray(eng.to_device(np.tile(G["s0"], (C, 1)))),
+             "tau": ChainArray(eng.full((C, 1, 1), float(G["tau"]))), "P_y": sparse.csc_matrix(np.eye(n_obs)),
+             "mu_s": G["mu_s"].reshape(-1, 1), "Q_s": G["Q_s"]}
+    smp = ManifoldMALA("s", mdl, step=np.array([float(G["step"])]))
+    smp.bind(eng, 0, 1)
+    smp.inject = lambda s_, t: eng.to_device(np.tile(G["z"][t], (C, 1)))
+    smp.inject_uniform = lambda s_, t: eng.full((C,), G["u"][t])
+    flags = []
+    for t in range(int(G["n_steps"])):
+        before = smp.accept_rate.accept.clone()
+        state = smp.sample(state)
+        flags.append((smp.accept_rate.accept - before).cpu().numpy())
+        assert relerr(state["s"].data[2, :, 0].cpu().numpy(), G["x"][t]) < 1e-8, t
+    eng.check_status()
+    flags = np.array(flags)
+    for c in range(C):
+        assert np.array_equal(flags[:, c], G["accept"])
+    assert 0 < G["accept"].sum() < G["n_steps"]
+    eng.close()
