@@ -14,9 +14,11 @@ ap.add_argument("--steps", type=int, default=20); ap.add_argument("--w", type=in
 ap.add_argument("--overlap", type=int, default=0); ap.add_argument("--algo", type=int, default=0)
 ap.add_argument("--segments", type=int, default=0)
 ap.add_argument("--lattice", type=int, default=0)
+ap.add_argument("--rows", type=int, default=0, help="--lattice K --rows R: an R x K lattice (n = R K, bandwidth K)")
 a = ap.parse_args()
 if a.lattice:
-    a.n, a.w = a.lattice * a.lattice, a.lattice
+    a.rows = a.rows or a.lattice
+    a.n, a.w = a.rows * a.lattice, a.lattice
 from openmcmc_amd.engine import Engine
 n, C = a.n, a.chains
 eng = Engine(C, seed=2)
@@ -33,7 +35,10 @@ if a.lattice:
     D1 = sparse.identity(K, format="csr")
     D1 = D1[1:] - D1[:-1]
     L1 = (D1.T @ D1)
-    P = (sparse.kron(sparse.identity(K), L1) + sparse.kron(L1, sparse.identity(K)) + 1e-3 * sparse.identity(n)).tocsc()
+    DR = sparse.identity(a.rows, format="csr")
+    DR = DR[1:] - DR[:-1]
+    LR = (DR.T @ DR)
+    P = (sparse.kron(sparse.identity(a.rows), L1) + sparse.kron(LR, sparse.identity(K)) + 1e-3 * sparse.identity(n)).tocsc()
 else:
     D = sparse.identity(n, format="csr")
     for _ in range(a.w):
@@ -52,6 +57,15 @@ for i in range(a.steps):
     eng.band_sample_canonical(n, T, x, draw_index=3 + i)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
 flop = C * (n * a.w * a.w + 6.0 * n * a.w)  # band Cholesky n w^2 + three band solves 2 n w each
-print(json.dumps({"workload": (f"band draw {a.lattice} x {a.lattice} lattice (w = {a.w})" if a.lattice else f"band draw RW{a.w}") + f" n={n} chains={C}",
+if os.environ.get("OMC_WIDE_STAMPS"):
+    st = torch.zeros(4096, dtype=torch.int64, device="cuda")
+    eng.set_option("stamps_ptr", st.data_ptr())
+    eng.band_sample_canonical(n, T, x, draw_index=99)
+    torch.cuda.synchronize()
+    v = st.cpu().numpy()[:8].astype(float)
+    names = ["prefetch", "S1 diag+panel", "S2 solve", "S3 store+mfma", "S4 refill", "u+z", "back S1", "back S2"]
+    print("stamps (cycles, chain 0):", {k: int(a) for k, a in zip(names, v)}, "total", int(v.sum()), file=sys.stderr)
+    eng.set_option("stamps_ptr", 0)
+print(json.dumps({"workload": (f"band draw {a.rows} x {a.lattice} lattice (w = {a.w})" if a.lattice else f"band draw RW{a.w}") + f" n={n} chains={C}",
                   "tflops_on_n_w2": flop / dt / 1e12, "factor_workspace_GB": C * n * (a.w + 1) * 8 / 1e9, "ms_per_draw": 1e3 * dt, "chain_updates_per_s": C / dt,
                   "join_fallbacks": eng.counter("band_join_fallbacks"), "overlap": a.overlap or 192, "segments": a.segments or "auto"}))

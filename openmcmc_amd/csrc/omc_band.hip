@@ -17,6 +17,9 @@
 #include "omc_common.h"
 
 omc_status omc_ensure_bytes(omc_ctx* ctx, void** buf, size_t* have, size_t need);  // omc_dense.hip
+bool omc_band_blocked_launch(omc_ctx* ctx, int64_t n, int w, const void* terms, const double* rhs_chain, int64_t ld_rhs,
+                             const double* z_inject, int64_t ld_z, omc_rng_key key, double* Lws, double* x, int64_t ld_x, double* mean,
+                             int64_t ld_mean, double* logdet);  // omc_bandwide.hip
 
 #define BAND_WMAX 128
 
@@ -1381,6 +1384,13 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
   const size_t lds_back = (size_t)(2 * W1 + 8) * sizeof(double);
   if (lds < lds_back) lds = lds_back;
   const omc_rng_key key = omc_make_key(ctx->seed, draw_index, OMC_RNG_NORMAL);
+  // wide bands (lattice GMRFs): NB columns per step, the window update on the matrix cores (omc_bandwide.hip); "band_algo" 3
+  // forces it for any bandwidth, 2 keeps the column-at-a-time kernel
+  if ((ctx->band_algo == 3 || (ctx->band_algo != 2 && w >= 9)) &&
+      omc_band_blocked_launch(ctx, n, (int)w, &T, rhs_chain, ld_rhs, z_inject, ld_z, key, ctx->workspace, x, ld_x, mean, ld_mean, logdet)) {
+    OMC_HIP_CHECK(hipGetLastError());
+    return OMC_OK;
+  }
   if (w <= 7) {
     // narrow band: one wave per chain -- the two barriers per column cost nothing inside a single wave, and the
     // 8 x 8 thread tile already covers the (w x w)/2 update

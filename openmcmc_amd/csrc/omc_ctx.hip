@@ -261,7 +261,7 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
     return OMC_OK;
   }
   if (!strcmp(name, "band_algo")) {
-    if (value < 0 || value > 2) return OMC_INVALID_ARG;
+    if (value < 0 || value > 3) return OMC_INVALID_ARG;
     ctx->band_algo = (int)value;
     return OMC_OK;
   }

@@ -337,3 +337,53 @@ def test_long_tridiagonal_chains_take_the_band_route():
     for key in ("b", "lambda", "tau", "log_post"):
         a, b = out["band"][key], out["tridiag"][key]
         assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-9, key
+
+
+@pytest.mark.parametrize("w,n", [(1, 9), (3, 50), (7, 130), (9, 10), (9, 200), (12, 333), (15, 16), (16, 17), (17, 100), (20, 21), (20, 400), (31, 95), (64, 200),
+                                  (100, 350), (112, 113), (120, 250), (124, 300), (128, 129), (128, 600)])
+def test_blocked_wide_band_kernel(w, n):
+    """The blocked workgroup-per-chain kernel (omc_bandwide.hip: 16 columns per step -- 8 where the window would not fit the LDS
+    --, diagonal block in registers, window update on the matrix cores), forced for every bandwidth: against the oracle like the
+    column-at-a-time kernel, on lengths that end inside a block, with and without a per-chain right-hand side, and against that
+    kernel itself."""
+    rng = np.random.default_rng(100 * w + n + 1)
+    C = 4
+    eng = make_engine(C)
+    eng.set_option("band_algo", 3)
+    for per_chain in (True, False):
+        worst = check_case(eng, random_band_spd(n, w, rng), w, rng, C, per_chain_rhs=per_chain)
+        assert worst < RTOL, (worst, per_chain)
+    M = random_band_spd(n, w, rng)
+    band = eng.to_device(band_of(M, w))
+    z = eng.to_device(rng.standard_normal((C, n)))
+    extra = eng.to_device(rng.standard_normal((C, n)))
+    a, b, ma, mb, la, lb = eng.empty(C, n), eng.empty(C, n), eng.empty(C, n), eng.empty(C, n), eng.empty(C), eng.empty(C)
+    eng.band_sample_canonical(n, [{"band": band}], a, z=z, rhs_chain=extra, mean_out=ma, logdet_out=la)
+    eng.set_option("band_algo", 2)
+    eng.band_sample_canonical(n, [{"band": band}], b, z=z, rhs_chain=extra, mean_out=mb, logdet_out=lb)
+    eng.check_status()
+    scale = max(1.0, np.abs(b.cpu().numpy()).max())
+    assert np.max(np.abs(a.cpu().numpy() - b.cpu().numpy())) < 1e-11 * scale
+    assert np.max(np.abs(ma.cpu().numpy() - mb.cpu().numpy())) < 1e-11 * scale
+    assert np.max(np.abs(la.cpu().numpy() - lb.cpu().numpy())) < 1e-12 * max(1.0, np.abs(lb.cpu().numpy()).max())
+    eng.close()
+
+
+def test_blocked_wide_band_kernel_latches_a_failed_chain_and_draws_in_kernel():
+    n, w, C = 300, 40, 3
+    rng = np.random.default_rng(5)
+    M = random_band_spd(n, w, rng)
+    eng = make_engine(C, seed=9)
+    band = eng.to_device(band_of(M, w))
+    x, y = eng.empty(C, n), eng.empty(C, n)
+    eng.band_sample_canonical(n, [{"band": band}], x, draw_index=4)      # auto: the blocked kernel from w = 9
+    eng.set_option("band_algo", 2)
+    eng.band_sample_canonical(n, [{"band": band}], y, draw_index=4)      # same streams through the column-at-a-time kernel
+    eng.check_status()
+    assert np.max(np.abs(x.cpu().numpy() - y.cpu().numpy())) < 1e-11 * max(1.0, np.abs(y.cpu().numpy()).max())
+    eng.set_option("band_algo", 0)
+    scale = eng.to_device(np.array([1.0, -1.0, 2.0]))  # chain 1: negative definite
+    eng.band_sample_canonical(n, [{"band": band, "scale": scale}], x)
+    with pytest.raises(np.linalg.LinAlgError, match="chain 1"):
+        eng.check_status()
+    eng.close()
