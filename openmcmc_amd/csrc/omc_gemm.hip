@@ -153,8 +153,8 @@ __global__ void __launch_bounds__(256 * KS) k_dgemm_64x16(int M, int N, GemmPair
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_dgemm_64x64(int M, int N, GemmPair P, int tri, const double* __restrict__ addv,
                                                      double* __restrict__ Cout, int64_t ldc) {
-  __shared__ double As[2][GM_BK][GM_LDA];
-  __shared__ double Bs[2][GW_TN][GM_LDB];
+  __shared__ double As[1][GM_BK][GM_LDA];
+  __shared__ double Bs[1][GW_TN][GM_LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i0 = blockIdx.x * GM_TM, j0 = blockIdx.y * GW_TN;
   double4_t acc[4];
@@ -209,22 +209,22 @@ __global__ void __launch_bounds__(256) k_dgemm_64x64(int M, int N, GemmPair P, i
       }
     }
   };
-  if (nslab > 0) {
-    fetch(kbeg);
-    park(0);
-  }
+  // One LDS buffer per operand (the next slab waits in registers): 37 KB per workgroup, so FOUR workgroups share a CU and their
+  // loads, barriers and matrix-core phases interleave -- with two buffers (75 KB, two workgroups per CU) the counters showed the
+  // waves waiting half their cycles on memory and barriers with the matrix cores 31 % busy.
+  if (nslab > 0) fetch(kbeg);
   for (int sl = 0; sl < nslab; ++sl) {
-    const int b = sl & 1;
-    __syncthreads();                                             // slab sl is in As/Bs[b]; everyone is done with buffer b ^ 1
+    __syncthreads();                                             // everyone is done reading the previous slab
+    park(0);
+    __syncthreads();
     if (sl + 1 < nslab) fetch(kbeg + (sl + 1) * GM_BK);          // in flight under the multiplications
 #pragma unroll
     for (int kk = 0; kk < GM_BK; kk += 4) {
       const int kr = kk + (lane >> 4), cl = lane & 15;
-      const double af = As[b][kr][wave * 16 + cl];
+      const double af = As[0][kr][wave * 16 + cl];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, Bs[b][16 * t + cl][kr], acc[t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, Bs[0][16 * t + cl][kr], acc[t], 0, 0, 0);
     }
-    if (sl + 1 < nslab) park(b ^ 1);
   }
   // C/D of the f64 form: column = lane & 15, row = (lane >> 4) + 4 * register
 #pragma unroll
