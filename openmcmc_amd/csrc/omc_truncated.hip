@@ -38,9 +38,16 @@ __device__ __forceinline__ double trunc_uniform(const double* u_in, int64_t ld, 
 //     (the usual case) t = Phi^-1(u) does not depend on the mean, i.e. not on the neighbours: it is evaluated ahead of
 //     the one dependent chain of the scan (mean_i needs x_{i-1}) instead of inside it; a site near a limit takes the full
 //     log-space route as before.
+// Round 4: FOUR waves per 64 chains.  A wave alone on its SIMD issues one instruction per ~8.5 cycles whatever their
+// dependences, and 250 of a site's ~290 instructions (Philox rounds, the far-limits quantile, 1/Q_ii and its square root) do not
+// depend on the state: the sites of a 32-site block are split over the four waves (eight each: the same statement-by-statement
+// vector code as before) and left in LDS; then wave 0 alone walks the block's one dependent chain (mean_i needs x_{i-1}) --
+// ~30 instructions a site.  Same formulas on the same values in the same order: results are bit-identical to the one-wave form.
 #define TG_LD 65
+#define TG_BLK 32   // sites per production / scan round (8 per wave)
+#define TG_NF 5     // fields kept per site and chain: zf, uu, v, sd, b
 template <bool INJ, int NT>
-__global__ void __launch_bounds__(64) k_tridiag_gibbs_truncated(int64_t C, int64_t chain_offset, int64_t n, TruncTerms T,
+__global__ void __launch_bounds__(256) k_tridiag_gibbs_truncated(int64_t C, int64_t chain_offset, int64_t n, TruncTerms T,
                                                                 const double* rhs_chain, int64_t ld_rhs, const double* lower,
                                                                 const double* upper, const double* u_in, int64_t ld_u,
                                                                 omc_rng_key key, double* x, int64_t ld_x, long long* bad) {
@@ -48,7 +55,8 @@ __global__ void __launch_bounds__(64) k_tridiag_gibbs_truncated(int64_t C, int64
   double* xt = sm;                                   // [64 chains][65]: x of the block's 64 sites + the first of the next
   double* rt = sm + 64 * TG_LD;                      // [64][65] per-chain right-hand side (only if rhs_chain)
   double* stage = rt + (rhs_chain ? 64 * TG_LD : 0); // [3 n_terms + 2][64]: diag / off / rhs of every term, lower, upper
-  const int lane = threadIdx.x;
+  double* fld = stage + (3 * NT + 2) * 64;           // [TG_BLK][TG_NF][64]: what the production leaves for the scan
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t c0 = (int64_t)blockIdx.x * 64;
   const int64_t c = c0 + lane;
   const bool live = c < C;
@@ -72,13 +80,13 @@ __global__ void __launch_bounds__(64) k_tridiag_gibbs_truncated(int64_t C, int64
   for (int64_t i0 = 0; i0 < n; i0 += 64) {
     const int len = (int)((n - i0 < 64) ? n - i0 : 64);
     // ---- block in: rows of 64 sites (coalesced), one more column for the last site's right neighbour
-    for (int r = 0; r < 64; ++r) {
+    for (int r = wave; r < 64; r += 4) {
       const bool okr = c0 + r < C && lane < len;
       xt[r * TG_LD + lane] = okr ? x[(c0 + r) * ld_x + i0 + lane] : 0.0;
       if (rhs_chain) rt[r * TG_LD + lane] = okr ? rhs_chain[(c0 + r) * ld_rhs + i0 + lane] : 0.0;
     }
-    xt[lane * TG_LD + 64] = (live && i0 + 64 < n) ? x[c * ld_x + i0 + 64] : 0.0;
-    {
+    if (wave == 1) xt[lane * TG_LD + 64] = (live && i0 + 64 < n) ? x[c * ld_x + i0 + 64] : 0.0;
+    if (wave == 0) {
       const int64_t i = i0 + lane;
       const bool oki = lane < len;
       for (int k = 0; k < NT; ++k) {
@@ -89,12 +97,11 @@ __global__ void __launch_bounds__(64) k_tridiag_gibbs_truncated(int64_t C, int64
       st_lo[lane] = (oki && lower) ? lower[i] : -INFINITY;
       st_hi[lane] = (oki && upper) ? upper[i] : INFINITY;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();
     double* xrow = xt + lane * TG_LD;
     const double* rrow = rt + lane * TG_LD;
-    for (int t0 = 0; t0 < len; t0 += TG_U) {
+    for (int tb = 0; tb < len; tb += TG_BLK) {
+      const int t0 = tb + TG_U * wave;  // this wave's eight sites of the round
       Site S[TG_U];
       // uniforms: sites 2m and 2m+1 share a Philox block (t0 and i0 are multiples of TG_U): TG_U / 2 blocks, their rounds interleaved
       typedef omc_dv<TG_U> dvu;
@@ -160,38 +167,51 @@ __global__ void __launch_bounds__(64) k_tridiag_gibbs_truncated(int64_t C, int64
         S[q].v = (a4[q] > 0.0) ? v4[q] : 1.0;
         S[q].sd = sd4[q];
       }
-      // ---- the scan proper: one dependent chain
+      // what the scan needs of them goes to LDS (a, o and the limits it takes from the staged vectors itself)
 #pragma unroll
       for (int q = 0; q < TG_U; ++q) {
-        const int t = t0 + q;
-        if (t < len) {
-          const double a = S[q].a, o = S[q].o, sd = S[q].sd;
-          const double x_cur = xrow[t], x_next = xrow[t + 1];
-          if (!(a > 0.0)) fail = true;
-          const double inv_sd = a * sd;  // sqrt(a)
-          // gmrf.py:255-262: v_i * (b_i - Q[i,:] @ x + Q_ii x_i), row product in column order; n = 1: b v (gmrf.py:244-247)
-          const double row = fma(o, x_next, fma(a, x_cur, off_prev * x_prev));
-          const double mean = single ? S[q].b * S[q].v : S[q].v * ((S[q].b - row) + a * x_cur);
-          const double as = (S[q].lo - mean) * inv_sd, bs = (S[q].hi - mean) * inv_sd;
-          double xi = fma(S[q].zf, sd, mean);  // omc_truncnorm_ppf's far-limits branch: t = Phi^-1(u), x = t * sd + mean
-          if (!(as < -13.0 && bs > 13.0 && S[q].zok)) xi = omc_truncnorm_ppf(S[q].uu, as, bs) * sd + mean;
-          xrow[t] = xi;
-          x_prev = xi;
-          off_prev = o;
+        double* f = fld + (int64_t)((TG_U * wave + q) * TG_NF) * 64 + lane;
+        f[0 * 64] = S[q].zf; f[1 * 64] = S[q].uu; f[2 * 64] = S[q].v; f[3 * 64] = S[q].sd; f[4 * 64] = S[q].b;
+      }
+      __syncthreads();
+      // ---- the scan proper: one dependent chain, wave 0
+      if (wave == 0) {
+#pragma unroll 4
+        for (int qq = 0; qq < TG_BLK; ++qq) {
+          const int t = tb + qq;
+          if (t < len) {
+            const double* f = fld + (int64_t)(qq * TG_NF) * 64 + lane;
+            const double zf = f[0 * 64], uu = f[1 * 64], v = f[2 * 64], sd = f[3 * 64], bb = f[4 * 64];
+            const bool zok = uu > 1e-15 && uu < 1.0 - 1e-15;
+            double a = 0.0, o = 0.0;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+              a = fma(s[k], stage[(3 * k + 0) * 64 + t], a);
+              o = fma(s[k], stage[(3 * k + 1) * 64 + t], o);
+            }
+            const double x_cur = xrow[t], x_next = xrow[t + 1];
+            if (!(a > 0.0)) fail = true;
+            const double inv_sd = a * sd;  // sqrt(a)
+            // gmrf.py:255-262: v_i * (b_i - Q[i,:] @ x + Q_ii x_i), row product in column order; n = 1: b v (gmrf.py:244-247)
+            const double row = fma(o, x_next, fma(a, x_cur, off_prev * x_prev));
+            const double mean = single ? bb * v : v * ((bb - row) + a * x_cur);
+            const double as = (st_lo[t] - mean) * inv_sd, bs = (st_hi[t] - mean) * inv_sd;
+            double xi = fma(zf, sd, mean);  // omc_truncnorm_ppf's far-limits branch: t = Phi^-1(u), x = t * sd + mean
+            if (!(as < -13.0 && bs > 13.0 && zok)) xi = omc_truncnorm_ppf(uu, as, bs) * sd + mean;
+            xrow[t] = xi;
+            x_prev = xi;
+            off_prev = o;
+          }
         }
       }
+      __syncthreads();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- block out
-    for (int r = 0; r < 64; ++r)
+    for (int r = wave; r < 64; r += 4)
       if (c0 + r < C && lane < len) x[(c0 + r) * ld_x + i0 + lane] = xt[r * TG_LD + lane];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();
   }
-  if (fail && live) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+  if (wave == 0 && fail && live) atomicMin((unsigned long long*)bad, (unsigned long long)c);
 }
 
 // banded precision of bandwidth w (Q_c = sum_k s_k[c] M_k, M_k in the band storage of omc_band_terms: band[d*n + i] =
@@ -352,13 +372,13 @@ omc_status omc_tridiag_gibbs_truncated(omc_ctx* ctx, int64_t n, const omc_tridia
     T.rhs[k] = on ? terms->rhs[k] : nullptr;
     T.scale[k] = on ? terms->scale[k] : nullptr;
   }
-  const size_t lds = (size_t)((rhs_chain ? 2 : 1) * 64 * TG_LD + (3 * T.n_terms + 2) * 64) * sizeof(double);
+  const size_t lds = (size_t)((rhs_chain ? 2 : 1) * 64 * TG_LD + (3 * T.n_terms + 2) * 64 + TG_BLK * TG_NF * 64) * sizeof(double);
 #define OMC_TG_LAUNCH(INJv, NTv)                                                                                               \
   do {                                                                                                                          \
     if (lds > 48 * 1024)                                                                                                        \
       OMC_HIP_CHECK(hipFuncSetAttribute((const void*)(k_tridiag_gibbs_truncated<INJv, NTv>),                                    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
-    hipLaunchKernelGGL((k_tridiag_gibbs_truncated<INJv, NTv>), dim3(grid1(ctx->n_chains, 64)), dim3(64), lds, ctx->stream,      \
+    hipLaunchKernelGGL((k_tridiag_gibbs_truncated<INJv, NTv>), dim3(grid1(ctx->n_chains, 64)), dim3(256), lds, ctx->stream,      \
                        ctx->n_chains, ctx->chain_offset, n, T, rhs_chain, ld_rhs, lower, upper, u_inject, ld_u,                 \
                        omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), x, ld_x, ctx->d_bad_chain);                        \
   } while (0)
