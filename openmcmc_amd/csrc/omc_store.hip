@@ -284,6 +284,97 @@ __global__ void __launch_bounds__(256) k_q_owned(const double* __restrict__ data
   }
 }
 
+// Short columns (a chain's few hundred stored iterations): with 8-bit digits a pass zeroes and scans 64 KB of histograms to place
+// a handful of values (139 ms for 10 M columns of 128).  Here the digits are 4 bits wide: sixteen passes, 16-bin histograms
+// (T x 16 columns x 16 bins = 8 KB), a (target, column) pair picked by sixteen lanes -- four pairs per wave at once.
+constexpr int SC = 16;            // columns per workgroup: 128-byte row pieces
+constexpr int SROW = 256 / SC;
+
+__global__ void __launch_bounds__(256) k_q_owned4(const double* __restrict__ data, int64_t R, int64_t K, int T, int nq,
+                                                  const double* __restrict__ q, int omit_nan, double* __restrict__ out) {
+  __shared__ uint32_t lh[Q_TARGETS][SC][16];
+  __shared__ uint64_t s_prefix[Q_TARGETS][SC];
+  __shared__ int64_t s_rank[Q_TARGETS][SC];
+  __shared__ double s_frac[Q_TARGETS / 2][SC];
+  __shared__ uint32_t s_nan[SC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = tid & (SC - 1);
+  const int64_t k = (int64_t)blockIdx.x * SC + col;
+  const bool live = k < K;
+  const double* p = data + (live ? k : 0);
+  if (tid < SC) s_nan[tid] = 0;
+  for (int pass = 0; pass < 16; ++pass) {
+    for (int i = tid; i < Q_TARGETS * SC * 16; i += 256) (&lh[0][0][0])[i] = 0;
+    uint64_t pf[Q_TARGETS];
+#pragma unroll
+    for (int t = 0; t < Q_TARGETS; ++t) pf[t] = (pass > 0 && t < T) ? s_prefix[t][col] : 0;
+    __syncthreads();
+    const int shift = 60 - 4 * pass;
+    if (live) {
+      uint32_t nans = 0;
+      for (int64_t r = tid / SC; r < R; r += SROW) {
+        const uint64_t key = q_key(p[r * K]);
+        if (pass == 0) {
+          nans += key == ~0ull;
+          atomicAdd(&lh[0][col][(int)(key >> 60)], 1u);
+        } else {
+          const uint64_t hi = key >> (shift + 4);
+          const int dg = (int)(key >> shift) & 15;
+#pragma unroll
+          for (int t = 0; t < Q_TARGETS; ++t)
+            if (t < T && hi == pf[t]) atomicAdd(&lh[t][col][dg], 1u);
+        }
+      }
+      if (pass == 0 && nans) atomicAdd(&s_nan[col], nans);
+    }
+    __syncthreads();
+    // (target, column) pairs: sixteen lanes each, four pairs per wave and step
+    const int sub = lane & 15, grp = lane >> 4;
+    for (int base = 0; base < T * SC; base += 16) {   // sixteen pairs per step of the workgroup: four per wave
+      const int pidx = base + 4 * wave + grp;
+      const bool on = pidx < T * SC;
+      const int t = on ? pidx / SC : 0, c = on ? pidx % SC : 0;
+      int64_t rk = 0;
+      if (pass == 0) {
+        int64_t lo, hi;
+        double fr;
+        q_ranks(R - (int64_t)s_nan[c], q[t >> 1], lo, hi, fr);
+        rk = (t & 1) ? hi : lo;
+        if (on && !(t & 1) && sub == 0) s_frac[t >> 1][c] = fr;
+      } else {
+        rk = s_rank[t][c];
+      }
+      const int64_t mine = (int64_t)lh[pass == 0 ? 0 : t][c][sub];
+      int64_t incl = mine;
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const int64_t o = __shfl_up(incl, d, 16);
+        if (sub >= d) incl += o;
+      }
+      const int64_t excl = incl - mine;
+      const unsigned long long m = (__ballot(rk >= excl && rk < incl) >> (16 * grp)) & 0xffffull;
+      const int dg = m ? __ffsll((long long)m) - 1 : 15;  // (no bin claims the rank only when the column has no valid value: NaN anyway)
+      const int64_t before = __shfl(excl, 16 * grp + dg, 64);
+      if (on && sub == 0) {
+        s_prefix[t][c] = ((pass == 0 ? 0 : s_prefix[t][c]) << 4) | (uint64_t)dg;
+        s_rank[t][c] = rk - before;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < nq * SC) {
+    const int j = tid / SC, c = tid % SC;
+    const int64_t kk = (int64_t)blockIdx.x * SC + c;
+    if (kk < K) {
+      const uint32_t nn = s_nan[c];
+      double r;
+      if ((int64_t)nn >= R || (nn && !omit_nan)) r = __longlong_as_double(0x7ff8000000000000LL);
+      else r = q_lerp(q_val(s_prefix[2 * j][c]), q_val(s_prefix[2 * j + 1][c]), s_frac[j][c]);
+      out[(int64_t)j * K + kk] = r;
+    }
+  }
+}
+
 // mean and unbiased variance of every column of [R][K]: row slices combined by Chan's pairwise update through a small
 // [slices][2][K] scratch (deterministic: fixed slice boundaries, fixed combination order)
 __global__ void __launch_bounds__(256) k_col_moments_part(const double* __restrict__ data, int64_t R, int64_t K, int64_t rows_per_block,
@@ -376,6 +467,12 @@ omc_status omc_store_quantiles(omc_ctx* ctx, int64_t n_iter, int64_t size, const
     const int T = 2 * nq;
     // (the quantile levels of this group; pageable host memory: the copy has left the host buffer when the call returns)
     OMC_HIP_CHECK(hipMemcpyAsync(dq, q + j0, nq * sizeof(double), hipMemcpyHostToDevice, s));
+    if (owned && R <= 2048) {  // short columns: 4-bit digits (see k_q_owned4)
+      hipLaunchKernelGGL(k_q_owned4, dim3((unsigned)((K + SC - 1) / SC)), dim3(256), 0, s, store, R, K, T, nq, dq, (int)omit_nan,
+                         out + (int64_t)j0 * K);
+      OMC_HIP_CHECK(hipGetLastError());
+      continue;
+    }
     if (owned) {
       hipLaunchKernelGGL(k_q_owned, dim3((unsigned)((K + OC - 1) / OC)), dim3(256), (size_t)T * OC * 256 * 4, s, store, R, K, T, nq, dq,
                          (int)omit_nan, out + (int64_t)j0 * K);

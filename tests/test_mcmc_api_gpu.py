@@ -152,6 +152,28 @@ def test_dense_prior_and_unsupported_structures():
     eng.close()
 
 
+def build_linreg(G, k, C, **mcmc_kw):
+    """examples/3_linear_regression.ipynb's model and sampler list on C chains (in-kernel draws unless the caller injects)."""
+    from openmcmc_amd.distribution.distribution import Gamma
+    from openmcmc_amd.distribution.location_scale import Normal
+    from openmcmc_amd.mcmc import MCMC
+    from openmcmc_amd.model import Model
+    from openmcmc_amd.parameter import LinearCombination, ScaledMatrix
+    from openmcmc_amd.sampler.sampler import NormalGamma, NormalNormal
+
+    X, y = G[k + "X"], G[k + "y"]
+    N, p = X.shape
+    mdl = Model([Normal("y", mean=LinearCombination(form={"beta": "X"}), precision=ScaledMatrix(matrix="P_tau", scalar="tau")),
+                 Normal("beta", mean="mu", precision=ScaledMatrix(matrix="P_lambda", scalar="lambda")),
+                 Gamma("tau", shape="a_tau", rate="b_tau"),
+                 Gamma("lambda", shape="a_lambda", rate="b_lambda")], response={"y": "mean"})
+    samplers = [NormalNormal("beta", mdl), NormalGamma("tau", mdl), NormalGamma("lambda", mdl)]
+    state = {"y": y, "X": X, "beta": [0.0] * p, "P_tau": sparse.csc_matrix(np.eye(N)), "tau": 1,
+             "P_lambda": sparse.csc_matrix(np.eye(p)), "mu": [0.0] * p, "lambda": 0.01,
+             "a_tau": 1e-3, "b_tau": 1e-3, "a_lambda": 1e-3, "b_lambda": 1e-3}
+    return MCMC(state, samplers, model=mdl, n_burn=int(G[k + "n_burn"]), n_iter=int(G[k + "n_iter"]), n_chains=C, seed=13, **mcmc_kw)
+
+
 @pytest.mark.parametrize("tag", ["ex3", "p7"])
 def test_linear_regression_example_replays_reference(golden, tag):
     """BASELINE configs[0]: examples/3_linear_regression.ipynb verbatim (model, samplers, state,

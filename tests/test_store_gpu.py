@@ -47,9 +47,11 @@ def awkward_store(rng, n_iter, C, size):
     return a
 
 
-@pytest.mark.parametrize("shape", [(1, 3, 5), (2, 1, 1), (37, 5, 23), (300, 64, 1000)])
+@pytest.mark.parametrize("shape", [(1, 3, 5), (2, 1, 1), (37, 5, 23), (300, 64, 1000), (2100, 2, 5000), (3, 2, 9000)])
 @pytest.mark.filterwarnings("ignore:invalid value")
 def test_store_quantiles_are_numpys(shape):
+    """(shapes chosen to reach all three kernels: row-sliced global histograms for few columns; a workgroup per 8 columns with 8-bit
+    digits for many long columns (2100 iterations x 10 000 columns per chain); per 16 columns with 4-bit digits for many short ones)"""
     n_iter, C, size = shape
     rng = np.random.default_rng(sum(shape))
     a = awkward_store(rng, n_iter, C, size) if size >= 5 else rng.standard_normal(shape)
@@ -211,3 +213,58 @@ def test_streaming_gather_two_ranks_share_the_gpu(golden, tmp_path):
     for key in want:
         assert np.array_equal(got[key], want[key]), key
     assert np.array_equal(got["thin_b"], want["b"][..., ::3])
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_ring_store_with_thinning(golden, fuse):
+    """n_thin = 3: only every third sweep is stored (mcmc.py:97-106); the ring holds stored iterations, not sweeps."""
+    G = golden("gmrf_chain")
+    outs = []
+    for ring in (0, 4):
+        M, _ = build(G, "sparse_", True, 4, fuse=fuse, n_burn=2, n_iter=9, seed=6, store_ring=ring)
+        M.n_thin = 3
+        M.run_mcmc()
+        outs.append(M.collect())
+        M.engine.close()
+    for key in outs[0]:
+        assert np.array_equal(outs[0][key], outs[1][key]), key
+
+
+def test_ring_store_keeps_the_fitted_values_of_a_regression(golden):
+    """Example 3 (linear regression) stores the response's fitted values next to the parameters (mcmc.py:109-111): they ride the ring
+    like every other entry."""
+    from test_mcmc_api_gpu import build_linreg
+
+    G = golden("linreg_chain")
+    outs = []
+    for ring in (0, 6):
+        M = build_linreg(G, "ex3_", 3, store_ring=ring)
+        M.run_mcmc()
+        outs.append(M.collect())
+        M.engine.close()
+    assert "y" in outs[0]
+    for key in outs[0]:
+        assert np.array_equal(outs[0][key], outs[1][key], equal_nan=True), key
+
+
+def test_quantiles_of_a_ragged_store_ignore_the_padding(golden):
+    """The reversible-jump model's theta / beta stores are NaN beyond the live length: MCMC.quantiles leaves the padding out per
+    element like np.nanquantile on the collected store (an element that no iteration of a chain ever had reads NaN)."""
+    import warnings
+
+    from test_rj_chain_gpu import run_with_tape
+
+    G = golden("rj_gmrf_chain")
+    chains = np.arange(G["init_k"].shape[0])
+    M, _, _ = run_with_tape(G, chains, 60)
+    M.run_mcmc()
+    out = M.collect()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for key in ("theta", "beta", "n_basis", "lambda"):
+            arr = out[key].reshape(out[key].shape[0], -1, out[key].shape[-1])          # (C, size, n_iter)
+            got = M.quantiles(key, [0.1, 0.5, 0.9], pooled=False)
+            assert same(got, np.nanquantile(arr, [0.1, 0.5, 0.9], axis=2)), key
+            flat = np.transpose(arr, (1, 0, 2)).reshape(arr.shape[1], -1)
+            assert same(M.quantiles(key, [0.1, 0.5, 0.9], pooled=True), np.nanquantile(flat, [0.1, 0.5, 0.9], axis=1)), key
+    M.engine.close()
