@@ -38,16 +38,17 @@ __device__ __forceinline__ double trunc_uniform(const double* u_in, int64_t ld, 
 //     (the usual case) t = Phi^-1(u) does not depend on the mean, i.e. not on the neighbours: it is evaluated ahead of
 //     the one dependent chain of the scan (mean_i needs x_{i-1}) instead of inside it; a site near a limit takes the full
 //     log-space route as before.
-// Round 4: FOUR waves per 64 chains.  A wave alone on its SIMD issues one instruction per ~8.5 cycles whatever their
+// Round 4: NINE waves per 64 chains.  A wave alone on its SIMD issues one instruction per ~8.5 cycles whatever their
 // dependences, and 250 of a site's ~290 instructions (Philox rounds, the far-limits quantile, 1/Q_ii and its square root) do not
-// depend on the state: the sites of a 32-site block are split over the four waves (eight each: the same statement-by-statement
-// vector code as before) and left in LDS; then wave 0 alone walks the block's one dependent chain (mean_i needs x_{i-1}) --
-// ~30 instructions a site.  Same formulas on the same values in the same order: results are bit-identical to the one-wave form.
+// depend on the state: the sites of a 16-site round are split over eight producing waves (two each: the same statement-by-statement
+// vector code as before) and left in LDS, while wave 0 walks the dependent chain (mean_i needs x_{i-1}: ~30 instructions a
+// site) of the round made in the step before -- a two-stage pipeline with a barrier per step.  Same formulas on the same values in the same order: results are bit-identical to the one-wave form.
 #define TG_LD 65
-#define TG_BLK 32   // sites per production / scan round (8 per wave)
+#define TG_BLK 16   // sites per production / scan round (2 per producing wave)
+#define TG_NW 9     // waves: wave 0 walks the dependent chain, waves 1 .. 8 produce
 #define TG_NF 5     // fields kept per site and chain: zf, uu, v, sd, b
 template <bool INJ, int NT>
-__global__ void __launch_bounds__(256) k_tridiag_gibbs_truncated(int64_t C, int64_t chain_offset, int64_t n, TruncTerms T,
+__global__ void __launch_bounds__(64 * TG_NW) k_tridiag_gibbs_truncated(int64_t C, int64_t chain_offset, int64_t n, TruncTerms T,
                                                                 const double* rhs_chain, int64_t ld_rhs, const double* lower,
                                                                 const double* upper, const double* u_in, int64_t ld_u,
                                                                 omc_rng_key key, double* x, int64_t ld_x, long long* bad) {
@@ -55,7 +56,7 @@ __global__ void __launch_bounds__(256) k_tridiag_gibbs_truncated(int64_t C, int6
   double* xt = sm;                                   // [64 chains][65]: x of the block's 64 sites + the first of the next
   double* rt = sm + 64 * TG_LD;                      // [64][65] per-chain right-hand side (only if rhs_chain)
   double* stage = rt + (rhs_chain ? 64 * TG_LD : 0); // [3 n_terms + 2][64]: diag / off / rhs of every term, lower, upper
-  double* fld = stage + (3 * NT + 2) * 64;           // [TG_BLK][TG_NF][64]: what the production leaves for the scan
+  double* fld = stage + (3 * NT + 2) * 64;           // [2][TG_BLK][TG_NF][64]: what the production leaves for the scan, two rounds
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t c0 = (int64_t)blockIdx.x * 64;
   const int64_t c = c0 + lane;
@@ -74,13 +75,13 @@ __global__ void __launch_bounds__(256) k_tridiag_gibbs_truncated(int64_t C, int6
   // 1/sqrt(Q_ii) -- for TG_U sites at a time in one straight piece of code (vectors of TG_U: statement by statement): the wave is alone on its SIMD, so the only
   // thing that can fill the latency of one site's long dependent chains (Philox rounds, two Horner chains, log, sqrt) is
   // the same work of its neighbours
-  constexpr int TG_U = 8;
+  constexpr int TG_U = 2;  // sites per producing wave and round: eight waves x 2 = TG_BLK
   const bool single = n == 1;
   struct Site { double uu, zf, a, o, b, lo, hi, v, sd; bool zok; };
   for (int64_t i0 = 0; i0 < n; i0 += 64) {
     const int len = (int)((n - i0 < 64) ? n - i0 : 64);
     // ---- block in: rows of 64 sites (coalesced), one more column for the last site's right neighbour
-    for (int r = wave; r < 64; r += 4) {
+    for (int r = wave; r < 64; r += TG_NW) {
       const bool okr = c0 + r < C && lane < len;
       xt[r * TG_LD + lane] = okr ? x[(c0 + r) * ld_x + i0 + lane] : 0.0;
       if (rhs_chain) rt[r * TG_LD + lane] = okr ? rhs_chain[(c0 + r) * ld_rhs + i0 + lane] : 0.0;
@@ -100,8 +101,15 @@ __global__ void __launch_bounds__(256) k_tridiag_gibbs_truncated(int64_t C, int6
     __syncthreads();
     double* xrow = xt + lane * TG_LD;
     const double* rrow = rt + lane * TG_LD;
-    for (int tb = 0; tb < len; tb += TG_BLK) {
-      const int t0 = tb + TG_U * wave;  // this wave's eight sites of the round
+    // The block's rounds as a two-stage pipeline: in step k the eight producing waves make round k while wave 0 walks round
+    // k - 1 (made in the step before, in the other buffer); a barrier between steps.  The pipeline drains at the block's end:
+    // the next block's staged vectors replace this one's.
+    const int n_rounds = (len + TG_BLK - 1) / TG_BLK;
+    for (int step = 0; step <= n_rounds; ++step) {
+      if (wave > 0 && step < n_rounds) {
+      const int tb = step * TG_BLK;
+      double* const fbuf = fld + (int64_t)(step & 1) * TG_BLK * TG_NF * 64;
+      const int t0 = tb + TG_U * (wave - 1);  // this wave's sites of the round
       Site S[TG_U];
       // uniforms: sites 2m and 2m+1 share a Philox block (t0 and i0 are multiples of TG_U): TG_U / 2 blocks, their rounds interleaved
       typedef omc_dv<TG_U> dvu;
@@ -170,17 +178,19 @@ __global__ void __launch_bounds__(256) k_tridiag_gibbs_truncated(int64_t C, int6
       // what the scan needs of them goes to LDS (a, o and the limits it takes from the staged vectors itself)
 #pragma unroll
       for (int q = 0; q < TG_U; ++q) {
-        double* f = fld + (int64_t)((TG_U * wave + q) * TG_NF) * 64 + lane;
+        double* f = fbuf + (int64_t)((TG_U * (wave - 1) + q) * TG_NF) * 64 + lane;
         f[0 * 64] = S[q].zf; f[1 * 64] = S[q].uu; f[2 * 64] = S[q].v; f[3 * 64] = S[q].sd; f[4 * 64] = S[q].b;
       }
-      __syncthreads();
-      // ---- the scan proper: one dependent chain, wave 0
-      if (wave == 0) {
+      }  // producers
+      // ---- the scan proper: one dependent chain, wave 0, one round behind
+      if (wave == 0 && step > 0) {
+        const int tb = (step - 1) * TG_BLK;
+        const double* const fbuf = fld + (int64_t)((step - 1) & 1) * TG_BLK * TG_NF * 64;
 #pragma unroll 4
         for (int qq = 0; qq < TG_BLK; ++qq) {
           const int t = tb + qq;
           if (t < len) {
-            const double* f = fld + (int64_t)(qq * TG_NF) * 64 + lane;
+            const double* f = fbuf + (int64_t)(qq * TG_NF) * 64 + lane;
             const double zf = f[0 * 64], uu = f[1 * 64], v = f[2 * 64], sd = f[3 * 64], bb = f[4 * 64];
             const bool zok = uu > 1e-15 && uu < 1.0 - 1e-15;
             double a = 0.0, o = 0.0;
@@ -207,7 +217,7 @@ __global__ void __launch_bounds__(256) k_tridiag_gibbs_truncated(int64_t C, int6
       __syncthreads();
     }
     // ---- block out
-    for (int r = wave; r < 64; r += 4)
+    for (int r = wave; r < 64; r += TG_NW)
       if (c0 + r < C && lane < len) x[(c0 + r) * ld_x + i0 + lane] = xt[r * TG_LD + lane];
     __syncthreads();
   }
@@ -372,13 +382,13 @@ omc_status omc_tridiag_gibbs_truncated(omc_ctx* ctx, int64_t n, const omc_tridia
     T.rhs[k] = on ? terms->rhs[k] : nullptr;
     T.scale[k] = on ? terms->scale[k] : nullptr;
   }
-  const size_t lds = (size_t)((rhs_chain ? 2 : 1) * 64 * TG_LD + (3 * T.n_terms + 2) * 64 + TG_BLK * TG_NF * 64) * sizeof(double);
+  const size_t lds = (size_t)((rhs_chain ? 2 : 1) * 64 * TG_LD + (3 * T.n_terms + 2) * 64 + 2 * TG_BLK * TG_NF * 64) * sizeof(double);
 #define OMC_TG_LAUNCH(INJv, NTv)                                                                                               \
   do {                                                                                                                          \
     if (lds > 48 * 1024)                                                                                                        \
       OMC_HIP_CHECK(hipFuncSetAttribute((const void*)(k_tridiag_gibbs_truncated<INJv, NTv>),                                    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
-    hipLaunchKernelGGL((k_tridiag_gibbs_truncated<INJv, NTv>), dim3(grid1(ctx->n_chains, 64)), dim3(256), lds, ctx->stream,      \
+    hipLaunchKernelGGL((k_tridiag_gibbs_truncated<INJv, NTv>), dim3(grid1(ctx->n_chains, 64)), dim3(64 * TG_NW), lds, ctx->stream,      \
                        ctx->n_chains, ctx->chain_offset, n, T, rhs_chain, ld_rhs, lower, upper, u_inject, ld_u,                 \
                        omc_make_key(ctx->seed, draw_index, OMC_RNG_UNIFORM), x, ld_x, ctx->d_bad_chain);                        \
   } while (0)
