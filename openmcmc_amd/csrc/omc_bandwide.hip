@@ -83,7 +83,7 @@ struct DiagStep {
     }
     dinv[K] = rinv;
     const double lk = D[K] * rinv;
-    D[K] = ((int)threadIdx.x == K) ? sq : lk;
+    D[K] = ((int)(threadIdx.x & 63) == K) ? sq : lk;
 #pragma unroll
     for (int cc = K + 1; cc < NB; ++cc) D[cc] = fma(-lk, readlane_d(lk, cc), D[cc]);
     DiagStep<K + 1, NB>::run(D, dinv, failed, ld_mant, ld_exp, live);
@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   }
   for (int t = tid; t < WS; t += NT) rring[t] = rhs_w(T, s, n, t, rc);
   if (tid == 0) misc[0] = 0.0;
+  for (int t = tid; t < WP * PS; t += NT) P[t] = 0.0;  // (rows w .. WP - 1 pad the last tile: never written again)
   __syncthreads();
 
   double ld_mant = 1.0;
@@ -166,69 +167,60 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
       }
     }
     WSTAMP(0);
-    // ---- S1: wave 0 factorises the diagonal block in registers; the other waves lay the panel out densely
-    if (wave == 0) {
-      double D[NB], dinv[NB];
+    // ---- S1 (+ S2): the block column as ONE tall right-looking factorisation in registers.  Lanes 0 .. NB-1 of every taking-part
+    // wave hold the diagonal block's rows (the same in each of these waves: the pivot column's entries reach the other lanes by
+    // v_readlane), the lanes behind them 64 - NB rows of the panel below -- and one of them the right-hand side, which is one more
+    // row of the matrix being factorised.  Scaling column K and updating the columns behind it is then the SAME instruction for
+    // block, panel and right-hand side: the panel's triangular solve (5.4 k cycles and a barrier as a phase of its own) costs
+    // nothing beyond the diagonal block's factorisation.
+    {
+      constexpr int RPW = 64 - NB;                       // panel rows per wave
+      const int npw = (w + 1 + RPW - 1) / RPW;           // waves that take part: w panel rows + the right-hand side
+      if (wave < npw) {
+        double D[NB], dinv[NB];
+        const int i = RPW * wave + (lane - NB);          // panel row of this lane (lane >= NB); i == w: the right-hand side
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        int sl = slot0 + b;
-        if (sl >= WS) sl -= WS;
-        const bool in = lane < nb && b < nb && b <= lane && lane - b <= w;  // (a band narrower than the block: zeros beyond it)
-        D[b] = in ? ring[sl * W1 + (lane - b)] : ((lane < NB && b == lane && lane >= nb) ? 1.0 : 0.0);
-      }
-      bool failed = false;
-      DiagStep<0, NB>::run(D, dinv, failed, ld_mant, ld_exp, nb);
-      if (lane < NB) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b) Ld[lane * PS + b] = (b <= lane) ? D[b] : 0.0;
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b) dv[b] = dinv[b];
-        if (failed) misc[0] = 1.0;
-      }
-    } else {
-      for (int e = tid - 64; e < WP * NB; e += NT - 64) {
-        const int i = e / NB, b = e % NB;
-        const int d = NB + i - b;              // row j + NB + i against column j + b
-        double v = 0.0;
-        if (i < w && b < nb && d <= w && j + NB + i < n) {
+        for (int b = 0; b < NB; ++b) {
           int sl = slot0 + b;
           if (sl >= WS) sl -= WS;
-          v = ring[sl * W1 + d];
+          double v;
+          if (lane < NB) {
+            const bool in = lane < nb && b < nb && b <= lane && lane - b <= w;  // (a band narrower than the block: zeros beyond it)
+            v = in ? ring[sl * W1 + (lane - b)] : ((b == lane && lane >= nb) ? 1.0 : 0.0);
+          } else if (i < w) {
+            const int d = NB + i - b;                    // row j + NB + i against column j + b
+            v = (b < nb && d <= w && j + NB + i < n) ? ring[sl * W1 + d] : 0.0;
+          } else {
+            v = (i == w && b < nb) ? rring[sl] : 0.0;
+          }
+          D[b] = v;
         }
-        P[i * PS + b] = v;
+        bool failed = false;
+        DiagStep<0, NB>::run(D, dinv, failed, ld_mant, ld_exp, nb);
+        if (lane < NB) {
+          if (wave == 0) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) Ld[lane * PS + b] = (b <= lane) ? D[b] : 0.0;
+          }
+        } else if (i < w) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) P[i * PS + b] = D[b];
+        } else if (i == w) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            Us[b] = D[b];
+            if (b < nb) xc[j + b] = D[b];  // forward-substituted right-hand side, overwritten by the draw in the backward pass
+          }
+        }
+        if (wave == 0 && lane == 0) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) dv[b] = dinv[b];
+          if (failed) misc[0] = 1.0;
+        }
       }
     }
     lds_barrier_w();
     WSTAMP(1);
-    // ---- S2: panel rows against the block (x L11' = p, forward in b), one thread per row; the right-hand side likewise
-    if (tid < w) {
-      double xr[NB];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        double acc = P[tid * PS + b];
-#pragma unroll
-        for (int t = 0; t < b; ++t) acc = fma(-xr[t], Ld[b * PS + t], acc);
-        xr[b] = acc * dv[b];
-      }
-#pragma unroll
-      for (int b = 0; b < NB; ++b) P[tid * PS + b] = xr[b];
-    } else if (tid == NT - 1) {
-      double u[NB];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        int sl = slot0 + b;
-        if (sl >= WS) sl -= WS;
-        double acc = (b < nb) ? rring[sl] : 0.0;
-#pragma unroll
-        for (int t = 0; t < b; ++t) acc = fma(-u[t], Ld[b * PS + t], acc);
-        u[b] = acc * dv[b];
-        Us[b] = u[b];
-        if (b < nb) xc[j + b] = u[b];  // forward-substituted right-hand side, overwritten by the draw in the backward pass
-      }
-    }
-    lds_barrier_w();
     WSTAMP(2);
     // ---- S3: the block's columns of the factor go to the workspace; the trailing window takes P P' on the matrix cores
     if (pcol < nb) {
