@@ -272,6 +272,8 @@ def main():
     ap.add_argument("--collective-timeout", type=float, default=240.0,
                     help="N > 1: seconds the gathers and the second scaling mode may take after the headline before rank 0 prints "
                          "the line without them and all ranks leave (0 = wait for ever)")
+    ap.add_argument("--no-library-gather", action="store_true",
+                    help="N > 1 on GPUs: do not time the store gather through the library's own RCCL collective as well")
     ap.add_argument("--nodes", type=int, default=N_NODES)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -679,22 +681,15 @@ def main():
             fallback_line.update(make_line(trace[0].mean().item(), "traces of rank 0's chains only (watchdog line)", None, None))
         watchdog.start()
     if dist is not None:
-        # the library's own collective (omc_gather_samples on RCCL: every peer sends point to point into the root) when the
-        # ranks have a GPU each; torch.distributed's gather on the group's backend otherwise (gloo rehearsals) or if the
-        # communicator cannot be made
+        # torch.distributed's gather on the group's backend (RCCL under the driver, gloo in rehearsals): the collective every
+        # check value and the reported store gather rest on.  The library's own RCCL collective (omc_gather_samples: every peer
+        # sends point to point into the root) is timed on the same block AFTER these, so that a problem in it -- it has met
+        # several GPUs in no box of this pool yet -- cannot take them with it (config.store_gather.library).
         collective = "torch.distributed.gather (" + dist.get_backend() + ")"
-        if on_gpu:
-            try:
-                from openmcmc_amd.parallel import make_communicator
-
-                comm = make_communicator(sweep.eng)
-                collective = "omc_gather_samples (RCCL send/recv into the root)"
-            except Exception as exc:
-                collective += "; omc_comm_create failed: " + repr(exc)
         try:
             from openmcmc_amd.parallel import gather_chains
 
-            trace = gather_chains(trace, chain_dim=2, dst=0, comm=comm)
+            trace = gather_chains(trace, chain_dim=2, dst=0, comm=None)
         except Exception as exc:  # the check value then covers rank 0's chains only; the headline stays
             trace_error = repr(exc)
     lam_mean = trace[0].mean().item() if rank == 0 else None
@@ -713,13 +708,35 @@ def main():
             barrier()
             torch.cuda.synchronize()
             tg = time.perf_counter()
-            full = gather_chains(part, chain_dim=1, dst=0, comm=comm)
+            full = gather_chains(part, chain_dim=1, dst=0, comm=None)
             torch.cuda.synchronize()
             tg = time.perf_counter() - tg
             nbytes = (full.numel() - part.numel()) * 8 if rank == 0 else 0
             gather_info = {"collective": collective, "iterations": k_it, "bytes_into_root": nbytes, "ms": 1e3 * tg,
                            "GBps_into_root": nbytes / tg / 1e9}
+            ref_sum = full.sum().item() if rank == 0 else None
             del full
+            if rank == 0 and fallback_line:  # what is known so far goes into the line the watchdog would print
+                fallback_line["config"]["check"]["mean_lambda"] = lam_mean
+                fallback_line["config"]["store_gather_before_watchdog"] = dict(gather_info)
+            if on_gpu and not args.no_library_gather:
+                # the same block once more through the library's own collective
+                try:
+                    from openmcmc_amd.parallel import make_communicator
+
+                    comm = make_communicator(sweep.eng)
+                    barrier()
+                    torch.cuda.synchronize()
+                    tg = time.perf_counter()
+                    full = gather_chains(part, chain_dim=1, dst=0, comm=comm)
+                    torch.cuda.synchronize()
+                    tg = time.perf_counter() - tg
+                    gather_info["library"] = {"collective": "omc_gather_samples (RCCL send/recv into the root)", "ms": 1e3 * tg,
+                                              "GBps_into_root": nbytes / tg / 1e9,
+                                              "same_result": bool(full.sum().item() == ref_sum) if rank == 0 else None}
+                    del full
+                except Exception as exc:
+                    gather_info["library"] = {"error": repr(exc)}
         except Exception as exc:  # the headline must survive a collective problem
             gather_info = {"error": repr(exc)}
 
