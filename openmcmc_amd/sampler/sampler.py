@@ -345,8 +345,16 @@ class NormalNormal(MCMCSampler):
                 chain_terms.append((("offset", pc["dist"]), st.scale_key, op))
             if pc.get("chain_vec") is not None:
                 chain_terms.append((pc["chain_vec"], st.scale_key, op))
-        return {"kind": "band", "n": n, "terms_list": terms, "terms": eng.band_terms(terms, n), "keys": keys,
+        plan = {"kind": "band", "n": n, "terms_list": terms, "terms": eng.band_terms(terms, n), "keys": keys,
                 "chain_terms": chain_terms}
+        # Long tridiagonal chains arrive here too (beyond one workgroup per chain the band route's segmented kernels, w = 1).  Their
+        # quadratic forms (x - m_k)' M_k (x - m_k) are the residual statistics NormalGamma and log_p ask for right after the
+        # draw: ONE launch over x for all terms (omc_tridiag_quadform) behind the draw, cached like the fused forms of the
+        # workgroup-per-chain kernel -- instead of one pass per distribution and caller (3.3 per sweep at n = 20 000).
+        if all(pc["st"].diag is not False and not pc["offset"] and pc.get("chain_vec") is None and not pc.get("replicated") for pc in pieces):
+            caches = [eng.model_cache(pc["dist"], state, pc["st"], pc["center"]) for pc in pieces]
+            plan["quad_terms"] = eng.tridiag_terms([{"diag": c["diag"], "off": c["off"], "center": c["center"]} for c in caches], n)
+        return plan
 
     def _dense_plan(self, state, n, pieces):
         """Q_c = sum_k s_k[c] M_k with dense M_k: prior precision as is, a regression likelihood as the
@@ -493,6 +501,13 @@ class NormalNormal(MCMCSampler):
                         eng.quad_cache_put(self.model[key], quad[k] if f == 1.0 else quad[k] * f, self.model[key].residual_inputs(new_state))
         elif p["kind"] == "band":
             eng.band_sample_canonical(n, p["terms"], x, z=z, rhs_chain=rhs_chain, draw_index=self._draw_index())
+            if p.get("quad_terms") is not None:
+                quad = eng.empty(len(p["keys"]), eng.n_chains)
+                eng.tridiag_quadform(n, p["quad_terms"], x, quad)
+                new_state = dict(current_state)
+                new_state[self.param] = ChainArray(x)
+                for k, key in enumerate(p["keys"]):
+                    eng.quad_cache_put(self.model[key], quad[k], self.model[key].residual_inputs(new_state))
         elif p.get("mixture_prior") is not None:
             # prior N(mean[alloc], diag(prec[alloc])^-1) (parameter.py:447,501): a per-chain diagonal on Q and
             # prec * mean on b (sampler.py:181-183), next to the shared likelihood terms
