@@ -63,7 +63,8 @@ if os.environ.get("OMC_WIDE_STAMPS"):
     eng.band_sample_canonical(n, T, x, draw_index=99)
     torch.cuda.synchronize()
     v = st.cpu().numpy()[:8].astype(float)
-    names = ["prefetch", "S1 diag+panel", "S2 solve", "S3 store+mfma", "S4 refill", "u+z", "back S1", "back S2"]
+    print("own work per wave in the look-ahead phase (cycles):", st.cpu().numpy()[8:16].tolist(), file=sys.stderr)
+    names = ["prefetch", "factor (first block; late ones of narrow bands)", "first tile column + rhs", "factor ahead | store + tiles", "S4 refill", "u+z", "back S1", "back S2"]
     print("stamps (cycles, chain 0):", {k: int(a) for k, a in zip(names, v)}, "total", int(v.sum()), file=sys.stderr)
     eng.set_option("stamps_ptr", 0)
 print(json.dumps({"workload": (f"band draw {a.rows} x {a.lattice} lattice (w = {a.w})" if a.lattice else f"band draw RW{a.w}") + f" n={n} chains={C}",

@@ -18,6 +18,7 @@
 #include "omc_common.h"
 
 #define BAND_WMAX_W 128
+#define BAND_W16_MAX 115  // 16 columns per step up to here (LDS: blocked_lds(116, 16) > 160 KB), 8 beyond
 
 namespace {
 
@@ -59,39 +60,41 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
-// column K of the NB x NB diagonal block (rows in lanes 0 .. NB-1, row r's entries D[0 .. r] in registers)
+// column K of the NB x NB diagonal block (rows in lanes 0 .. NB-1, row r's entries D[0 .. r] in registers; the lanes behind them
+// hold rows of the panel and the right-hand side, which take the same steps).  No branch on the pivot: a pivot that is not
+// positive is COUNTED (the chain's results are replaced by NaN at the end) and the arithmetic goes on with whatever it gives.
+// dkeep: lane K keeps 1 / L_KK.
 template <int K, int NB>
 struct DiagStep {
-  static __device__ __forceinline__ void run(double (&D)[NB], double (&dinv)[NB], bool& failed, double& ld_mant, long long& ld_exp, int live) {
+  static __device__ __forceinline__ void run(double (&D)[NB], double& dkeep, int& nfail, double& ld_mant, long long& ld_exp, bool keep_ld) {
     const double piv = readlane_d(D[K], K);
-    const bool ok = piv > 0.0 || K >= live;   // (columns beyond the chain's end are identity padding)
-    failed |= !ok;
-    double rinv = 1.0, sq = 1.0;
-    if (ok && K < live) {  // 1/sqrt(pivot) by rsq + two Newton steps, as k_band_sample does it
-      const double g = __builtin_amdgcn_rsq(piv);
-      const double h = 0.5 * g;
-      sq = piv * g;
-      double e = fma(-sq, sq, piv);
-      sq = fma(e, h, sq);
-      e = fma(-sq, sq, piv);
-      sq = fma(e, h, sq);
-      rinv = omc_rcp_nr(sq);
+    nfail += (piv > 0.0) ? 0 : 1;
+    // 1/sqrt(pivot) by rsq + two Newton steps, as k_band_sample does it
+    const double g = __builtin_amdgcn_rsq(piv);
+    const double h = 0.5 * g;
+    double sq = piv * g;
+    double e = fma(-sq, sq, piv);
+    sq = fma(e, h, sq);
+    e = fma(-sq, sq, piv);
+    sq = fma(e, h, sq);
+    const double rinv = omc_rcp_nr(sq);
+    if (keep_ld) {  // (uniform: one wave keeps the log determinant; identity padding beyond the chain's end adds log 1)
       ld_mant *= __builtin_amdgcn_frexp_mant(piv);
       ld_exp += __builtin_amdgcn_frexp_exp(piv);
       ld_exp += __builtin_amdgcn_frexp_exp(ld_mant);
       ld_mant = __builtin_amdgcn_frexp_mant(ld_mant);
     }
-    dinv[K] = rinv;
+    if ((int)(threadIdx.x & 63) == K) dkeep = rinv;
     const double lk = D[K] * rinv;
-    D[K] = ((int)(threadIdx.x & 63) == K) ? sq : lk;
+    D[K] = lk;  // (lane K: L_KK to rounding; the diagonal is never read from here, 1 / L_KK is)
 #pragma unroll
     for (int cc = K + 1; cc < NB; ++cc) D[cc] = fma(-lk, readlane_d(lk, cc), D[cc]);
-    DiagStep<K + 1, NB>::run(D, dinv, failed, ld_mant, ld_exp, live);
+    DiagStep<K + 1, NB>::run(D, dkeep, nfail, ld_mant, ld_exp, keep_ld);
   }
 };
 template <int NB>
 struct DiagStep<NB, NB> {
-  static __device__ __forceinline__ void run(double (&)[NB], double (&)[NB], bool&, double&, long long&, int) {}
+  static __device__ __forceinline__ void run(double (&)[NB], double&, int&, double&, long long&, bool) {}
 };
 
 typedef double wide_d4 __attribute__((ext_vector_type(4)));
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
                                                       int64_t ld_rhs, const double* z_in, int64_t ld_z, omc_rng_key key, double* Lws, double* x,
                                                       int64_t ld_x, double* mean, int64_t ld_mean, double* logdet, long long* bad, unsigned long long* dbg) {
   extern __shared__ double sm[];
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter(), twork = 0;
 #define WSTAMP(i) do { if (dbg) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; } } while (0)
   const int W1 = w + 1;
   const int WS = w + NB;                 // columns of the window (ring slots)
@@ -109,11 +112,13 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   constexpr int PS = NB + 1;             // panel row stride
   double* ring = sm;                               // WS x W1: ring[slot(col) * W1 + d] = open entry Q[col + d, col]
   double* rring = ring + (int64_t)WS * W1;         // WS: open right-hand side
+  // a factorised block column, TWO copies (the block being applied and the one factorised ahead of it), FBS doubles apart:
   double* P = rring + WS;                          // WP x PS: the panel below the diagonal block (zero outside the band)
   double* Ld = P + (int64_t)WP * PS;               // NB x PS: the diagonal block's factor
   double* dv = Ld + NB * PS;                       // NB: 1 / L_jj of the block
   double* Us = dv + NB;                            // NB: forward-substituted right-hand side of the block
-  double* misc = Us + NB;                          // [0] fail flag
+  const int FBS = WP * PS + NB * PS + 2 * NB;
+  double* misc = P + 2 * FBS;                      // [0] fail flag
   const int64_t c = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double s[OMC_MAX_TERMS];
@@ -129,170 +134,229 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
     ring[col * W1 + d] = entry_w(T, s, n, col, d);
   }
   for (int t = tid; t < WS; t += NT) rring[t] = rhs_w(T, s, n, t, rc);
-  if (tid == 0) misc[0] = 0.0;
-  for (int t = tid; t < WP * PS; t += NT) P[t] = 0.0;  // (rows w .. WP - 1 pad the last tile: never written again)
+  if (tid == 0) misc[0] = misc[1] = 0.0;  // [0] a pivot was not positive, [1] a zero to read
+  for (int t = tid; t < WP * PS; t += NT) P[t] = P[FBS + t] = 0.0;  // (rows w .. WP - 1 pad the last tile: never written again)
   __syncthreads();
 
   double ld_mant = 1.0;
   long long ld_exp = 0;
-  // the NB entering columns (their W1 band entries and their right-hand side, entry W1): 256 / NB threads per column, no division
+  // the NB entering columns (their W1 band entries and their right-hand side, entry W1): NT / NB threads per column, no division.
+  // What does not change from block to block -- which term has an entry at this thread's distance from the diagonal, and where
+  // its row of the band storage starts -- is worked out once: a block then asks for its entries with a compare and a load each.
   constexpr int TPC = NT / NB;                                   // threads per column
-  constexpr int NPRE = (BAND_WMAX_W + 2 + TPC - 1) / TPC;         // entries per thread
+  constexpr int WMAX_NB = (NB == 16) ? BAND_W16_MAX : BAND_WMAX_W;  // widest band this block size is launched for
+  constexpr int NPRE = (WMAX_NB + 2 + TPC - 1) / TPC;             // entries per thread
   const int pcol = tid / TPC, pq = tid % TPC;                    // (NB is a power of two: shifts)
-  int slot0 = 0;  // slot of column j
-  for (int64_t j = 0; j < n; j += NB) {
+  const double* pbase[NPRE][OMC_MAX_TERMS];                      // term k's row d of the band (or its right-hand side), NULL: no entry
+  const double* pchain[NPRE];                                    // the chain's own right-hand side (entry W1 only)
+  int plim[NPRE];                                                // the entry exists for columns < plim
+#pragma unroll
+  for (int q = 0; q < NPRE; ++q) {
+    const int d = pq + q * TPC;
+    plim[q] = (d < W1) ? (int)n - d : (d == W1 ? (int)n : 0);
+    pchain[q] = (d == W1) ? rc : nullptr;
+#pragma unroll
+    for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+      const double* p = nullptr;
+      if (k < T.n_terms) {
+        if (d < W1) { if (T.band[k] && d <= T.bw[k]) p = T.band[k] + (int64_t)d * n; }
+        else if (d == W1) p = T.rhs[k];
+      }
+      pbase[q][k] = p;
+    }
+  }
+  // look-ahead: block j + NB's columns are complete once the FIRST tile column of block j's window update is in, so its
+  // factorisation (one to three waves, the serial part: 14 k of the 30 k cycles of a block) runs beside the rest of that update
+  // on the other waves, into the second copy of P / Ld / dv / Us.  Bands narrower than a block (w < NB: the columns entering
+  // at the end of block j are already part of block j + NB) keep the plain order.
+  const bool ahead = w >= NB;
+  constexpr int RPW = 64 - NB;                       // panel rows per wave in the block factorisation
+  const int npw = (w + 1 + RPW - 1) / RPW;           // waves that take part in it: w panel rows + the right-hand side
+  // ---- the block column as ONE tall right-looking factorisation in registers.  Lanes 0 .. NB-1 of every taking-part wave hold
+  // the diagonal block's rows (the same in each of these waves: the pivot column's entries reach the other lanes by v_readlane),
+  // the lanes behind them 64 - NB rows of the panel below -- and one of them the right-hand side, which is one more row of the
+  // matrix being factorised.  Scaling column K and updating the columns behind it is then the SAME instruction for block, panel
+  // and right-hand side: the panel's triangular solve costs nothing beyond the diagonal block's factorisation.
+  // (the waves that factorise run at raised priority: they share their SIMDs with waves of the window update, and every issue slot
+  // lost to those is on the critical path)
+  const int frow_i = RPW * wave + (lane - NB);                    // panel row of this lane (lane >= NB); == w: the right-hand side
+  const bool f_rhs = lane >= NB && frow_i == w;
+  const int f_rowoff = lane < NB ? lane : NB + frow_i;            // row jj + f_rowoff of the matrix (the rhs lane: any value >= NB)
+  const bool f_row = lane < NB || frow_i < w;
+  // where the lane's entry against column jj + b sits: ring[slot * W1 + f_rowoff - b], the right-hand side rring[slot] (= ring[WS W1 + slot])
+  const int f_mul = f_rhs ? 1 : W1, f_base = f_rhs ? WS * W1 : f_rowoff, f_dec = f_rhs ? 0 : 1;
+  const int zero_at = (int)(misc + 1 - ring);                     // misc[1] == 0.0
+  auto factor_block = [&](const int64_t jj, const int slot, double* Pn, double* Ldn, double* dvn, double* Usn) {
+    __builtin_amdgcn_s_setprio(3);
+    const int nbj = (int)((n - jj < NB) ? n - jj : NB);
+    double D[NB];
+    // the columns b of the block this lane holds an entry against: b_lo .. b_hi (empty for a row beyond the chain's end and for an
+    // idle lane; a band narrower than the block leaves zeros beyond it)
+    const int offmax = (f_row && jj + f_rowoff < n) ? w : -1;
+    int b_lo = f_rhs ? 0 : ((f_rowoff - offmax > 0) ? f_rowoff - offmax : 0);
+    const int b_hi = (f_rowoff < nbj - 1) ? f_rowoff : nbj - 1;
+    if (b_hi < b_lo) b_lo = 0x10000;                       // (empty: no b passes the test below)
+    const unsigned span = (unsigned)(b_hi < b_lo ? 0 : b_hi - b_lo);
+    // the entry's place in the ring: slot (block-uniform, wraps) * f_mul + f_base - b * f_dec; lanes without an entry read a zero
+    // kept in LDS for them, so that the sixteen reads are issued back to back with nothing between a read and its use
+    int sl = slot, rest = f_base;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const bool in = (unsigned)(b - b_lo) <= span;
+      D[b] = ring[in ? sl * f_mul + rest : zero_at];
+      rest -= f_dec;
+      if (++sl == WS) sl = 0;
+    }
+    if (nbj < NB) {  // the last block of a chain whose length is no multiple of NB: identity padding
+      asm volatile("" ::: "memory");  // (a real branch: taken once per chain at most)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (lane == b && b >= nbj) D[b] = 1.0;
+    }
+    int nfail = 0;
+    double dkeep = 0.0;
+    DiagStep<0, NB>::run(D, dkeep, nfail, ld_mant, ld_exp, wave == 0);
+    // rows of the block (first wave only; entries on and above the diagonal are never read), rows of the panel, the right-hand side
+    double* dst = lane < NB ? (wave == 0 ? Ldn + lane * PS : nullptr) : (frow_i < w ? Pn + frow_i * PS : (f_rhs ? Usn : nullptr));
+    if (dst) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) dst[b] = D[b];
+    }
+    if (tid < NB) dvn[tid] = dkeep;
+    if (tid == 0 && nfail) misc[0] = 1.0;
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // one 16 x 16 tile of P P' off the window (rows 16 ti .., columns 16 tj .. behind the block)
+  const int cl = lane & 15, kr = lane >> 4;
+  auto window_tile = [&](const int64_t j, const int slot0, const double* Pc, const int ti, const int tj) {
+    wide_d4 acc = wide_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < NB / 4; ++ks)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pc[(16 * ti + cl) * PS + 4 * ks + kr], Pc[(16 * tj + cl) * PS + 4 * ks + kr], acc, 0, 0, 0);
+    // C/D of the f64 form: column = lane & 15, row = (lane >> 4) + 4 * register
+    const int ci = 16 * tj + cl;
+    int sl = slot0 + NB + ci;
+    if (sl >= WS) sl -= WS;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ri = 16 * ti + kr + 4 * r;
+      if (ri >= ci && ri < w && j + NB + ri < n) ring[sl * W1 + (ri - ci)] -= acc[r];
+    }
+  };
+  const int nt = WP / 16;  // tiles per side of the window (<= 8)
+  // block j's columns of the factor to the workspace (lanes along a column's entries) and the tiles (ti >= tj >= 1) of its window
+  // update, by the waves w0 .. NT / 64 - 1
+  auto store_and_tiles = [&](const int64_t j, const int nb, const int slot0, const double* Pc, const double* Ldc, const double* dvc,
+                             const int w0) {
+    const int nwk = NT / 64 - w0, wk = wave - w0;
+    for (int b = wk; b < nb; b += nwk) {
+      double* col = Lc + (j + b) * W1;
+      for (int d = lane; d < W1; d += 64) {
+        double v;
+        if (d == 0) v = dvc[b];                                     // the diagonal slot holds 1 / L_jj
+        else if (b + d < NB) v = (b + d < nb) ? Ldc[(b + d) * PS + b] : 0.0;
+        else v = (b + d - NB < w) ? Pc[(b + d - NB) * PS + b] : 0.0;
+        col[d] = v;
+      }
+    }
+    const int ntiles = nt * (nt - 1) / 2;
+    for (int tile = wk; tile < ntiles; tile += nwk) {
+      int ti = 0, rem = tile;
+      while (rem > ti) { rem -= ti + 1; ++ti; }
+      window_tile(j, slot0, Pc, ti + 1, rem + 1);
+    }
+  };
+  // S4: block j's slots take the columns j + WS .. j + WS + NB - 1 (requested at the top of the block)
+  // (macro: the raw entries live in registers of the enclosing scope)
+#define BAND_REFILL()                                                                      \
+  do {                                                                                     \
+    int sl_ = slot0 + pcol;                                                                \
+    if (sl_ >= WS) sl_ -= WS;                                                              \
+    const int64_t col_ = j + WS + pcol;                                                    \
+    _Pragma("unroll") for (int q = 0; q < NPRE; ++q) {                                     \
+      const int d = pq + q * TPC;                                                          \
+      double v = rawc[q];                                                                  \
+      _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) {                          \
+        if (k < T.n_terms) {                                                               \
+          if (d < W1 && !T.band[k]) { if (d == 0 && col_ < n) v += s[k]; } /* identity */  \
+          else v = fma(s[k], raw[q][k], v);                                                \
+        }                                                                                  \
+      }                                                                                    \
+      if (d < W1) ring[sl_ * W1 + d] = v;                                                  \
+      else if (d == W1) rring[sl_] = v;                                                    \
+    }                                                                                      \
+  } while (0)
+  // The loop starts one block early (j = -NB: nothing to apply, block 0 to factorise), so that the factorisation is written once.
+  int slot0 = WS - NB;     // slot of column j
+  int cur = 1;             // which copy of P / Ld / dv / Us holds block j
+  for (int64_t j = -NB; j < n; j += NB) {
+    const bool apply = j >= 0;
     const int nb = (int)((n - j < NB) ? n - j : NB);
+    const double* Pc = P + cur * FBS, * Ldc = Ld + cur * FBS, * dvc = dv + cur * FBS, * Usc = Us + cur * FBS;
+    const int nxt = cur ^ 1;
+    int slot1 = slot0 + NB;
+    if (slot1 >= WS) slot1 -= WS;
     // the NB columns that enter the window at the end of this block: their raw entries are REQUESTED now, all of them before any
     // is used (a load consumed inside a divergent branch is waited for on the spot: seven round trips in a row), combined and
     // stored in S4
     double raw[NPRE][OMC_MAX_TERMS], rawc[NPRE];
-    {
-      const int64_t col = j + WS + pcol;
+    if (apply) {
+      const int col = (int)j + WS + pcol;
 #pragma unroll
       for (int q = 0; q < NPRE; ++q) {
-        const int d = pq + q * TPC;
+        const bool in = col < plim[q];
+        rawc[q] = (in && pchain[q]) ? pchain[q][col] : 0.0;
+#pragma unroll
+        for (int k = 0; k < OMC_MAX_TERMS; ++k) raw[q][k] = (in && pbase[q][k]) ? pbase[q][k][col] : 0.0;
+      }
+      WSTAMP(0);
+      // ---- S2: what block j + NB waits for: the first tile column of the window update and the right-hand side
+      for (int ti = wave; ti < nt; ti += NT / 64) window_tile(j, slot0, Pc, ti, 0);
+      if (tid < w && j + NB + tid < n) {
+        double acc = 0.0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc = fma(Pc[tid * PS + b], Usc[b], acc);
+        int sl = slot1 + tid;
+        if (sl >= WS) sl -= WS;
+        rring[sl] -= acc;
+      }
+      // (the block's forward-substituted right-hand side: overwritten by the draw in the backward pass)
+      if (tid >= NT - 64 && lane < nb) xc[j + lane] = Usc[lane];
+      if (!ahead) store_and_tiles(j, nb, slot0, Pc, Ldc, dvc, 0);
+      lds_barrier_w();
+      WSTAMP(2);
+      if (!ahead) {
+        BAND_REFILL();
+        lds_barrier_w();
+        WSTAMP(4);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NPRE; ++q) {
         rawc[q] = 0.0;
 #pragma unroll
-        for (int k = 0; k < OMC_MAX_TERMS; ++k) {
-          raw[q][k] = 0.0;
-          if (k < T.n_terms && col < n) {
-            if (d < W1) {
-              if (T.band[k] && d <= T.bw[k] && col + d < n) raw[q][k] = T.band[k][(int64_t)d * n + col];
-            } else if (d == W1 && T.rhs[k]) {
-              raw[q][k] = T.rhs[k][col];
-            }
-          }
-        }
-        if (d == W1 && rc && col < n) rawc[q] = rc[col];
+        for (int k = 0; k < OMC_MAX_TERMS; ++k) raw[q][k] = 0.0;
       }
     }
-    WSTAMP(0);
-    // ---- S1 (+ S2): the block column as ONE tall right-looking factorisation in registers.  Lanes 0 .. NB-1 of every taking-part
-    // wave hold the diagonal block's rows (the same in each of these waves: the pivot column's entries reach the other lanes by
-    // v_readlane), the lanes behind them 64 - NB rows of the panel below -- and one of them the right-hand side, which is one more
-    // row of the matrix being factorised.  Scaling column K and updating the columns behind it is then the SAME instruction for
-    // block, panel and right-hand side: the panel's triangular solve (5.4 k cycles and a barrier as a phase of its own) costs
-    // nothing beyond the diagonal block's factorisation.
-    {
-      constexpr int RPW = 64 - NB;                       // panel rows per wave
-      const int npw = (w + 1 + RPW - 1) / RPW;           // waves that take part: w panel rows + the right-hand side
-      if (wave < npw) {
-        double D[NB], dinv[NB];
-        const int i = RPW * wave + (lane - NB);          // panel row of this lane (lane >= NB); i == w: the right-hand side
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          int sl = slot0 + b;
-          if (sl >= WS) sl -= WS;
-          double v;
-          if (lane < NB) {
-            const bool in = lane < nb && b < nb && b <= lane && lane - b <= w;  // (a band narrower than the block: zeros beyond it)
-            v = in ? ring[sl * W1 + (lane - b)] : ((b == lane && lane >= nb) ? 1.0 : 0.0);
-          } else if (i < w) {
-            const int d = NB + i - b;                    // row j + NB + i against column j + b
-            v = (b < nb && d <= w && j + NB + i < n) ? ring[sl * W1 + d] : 0.0;
-          } else {
-            v = (i == w && b < nb) ? rring[sl] : 0.0;
-          }
-          D[b] = v;
-        }
-        bool failed = false;
-        DiagStep<0, NB>::run(D, dinv, failed, ld_mant, ld_exp, nb);
-        if (lane < NB) {
-          if (wave == 0) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) Ld[lane * PS + b] = (b <= lane) ? D[b] : 0.0;
-          }
-        } else if (i < w) {
-#pragma unroll
-          for (int b = 0; b < NB; ++b) P[i * PS + b] = D[b];
-        } else if (i == w) {
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            Us[b] = D[b];
-            if (b < nb) xc[j + b] = D[b];  // forward-substituted right-hand side, overwritten by the draw in the backward pass
-          }
-        }
-        if (wave == 0 && lane == 0) {
-#pragma unroll
-          for (int b = 0; b < NB; ++b) dv[b] = dinv[b];
-          if (failed) misc[0] = 1.0;
-        }
-      }
+    // ---- S3: block j + NB factorised by the first waves, beside the rest of block j's work on the others
+    const unsigned long long tw0 = dbg ? __builtin_readcyclecounter() : 0;
+    if (wave < npw) {
+      if (j + NB < n) factor_block(j + NB, slot1, P + nxt * FBS, Ld + nxt * FBS, dv + nxt * FBS, Us + nxt * FBS);
+    } else if (ahead && apply) {
+      store_and_tiles(j, nb, slot0, Pc, Ldc, dvc, npw);
     }
-    lds_barrier_w();
-    WSTAMP(1);
-    WSTAMP(2);
-    // ---- S3: the block's columns of the factor go to the workspace; the trailing window takes P P' on the matrix cores
-    if (pcol < nb) {
-      double* col = Lc + (j + pcol) * W1;
-      for (int d = pq; d < W1; d += TPC) {
-        double v;
-        if (d == 0) v = dv[pcol];                                   // the diagonal slot holds 1 / L_jj
-        else if (pcol + d < NB) v = (pcol + d < nb) ? Ld[(pcol + d) * PS + pcol] : 0.0;
-        else v = (pcol + d - NB < w) ? P[(pcol + d - NB) * PS + pcol] : 0.0;
-        col[d] = v;
-      }
-    }
-    {
-      const int nt = WP / 16;
-      const int ntiles = nt * (nt + 1) / 2;
-      const int cl = lane & 15, kr = lane >> 4;
-      for (int tile = wave; tile < ntiles; tile += NT / 64) {
-        // tile -> (ti >= tj), rows 16 ti .., columns 16 tj ..
-        int ti = 0, rem = tile;
-        while (rem > ti) { rem -= ti + 1; ++ti; }
-        const int tj = rem;
-        wide_d4 acc = wide_d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(P[(16 * ti + cl) * PS + 4 * ks + kr], P[(16 * tj + cl) * PS + 4 * ks + kr], acc, 0, 0, 0);
-        // C/D of the f64 form: column = lane & 15, row = (lane >> 4) + 4 * register
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ri = 16 * ti + kr + 4 * r, ci = 16 * tj + cl;
-          if (ri >= ci && ri < w && j + NB + ri < n) {
-            int sl = slot0 + NB + ci;
-            if (sl >= WS) sl -= WS;
-            ring[sl * W1 + (ri - ci)] -= acc[r];
-          }
-        }
-      }
-    }
-    if (tid < w && j + NB + tid < n) {
-      double acc = 0.0;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) acc = fma(P[tid * PS + b], Us[b], acc);
-      int sl = slot0 + NB + tid;
-      if (sl >= WS) sl -= WS;
-      rring[sl] -= acc;
-    }
+    if (dbg) twork += __builtin_readcyclecounter() - tw0;   // (this wave's own work in S3, without the wait at the barrier)
     lds_barrier_w();
     WSTAMP(3);
-    // ---- S4: the block's slots take the columns j + WS .. j + WS + NB - 1
-    {
-      int sl = slot0 + pcol;
-      if (sl >= WS) sl -= WS;
-      const int64_t col = j + WS + pcol;
-#pragma unroll
-      for (int q = 0; q < NPRE; ++q) {
-        const int d = pq + q * TPC;
-        double v = rawc[q];
-#pragma unroll
-        for (int k = 0; k < OMC_MAX_TERMS; ++k) {
-          if (k < T.n_terms) {
-            if (d < W1 && !T.band[k]) { if (d == 0 && col < n) v += s[k]; }   // an identity term
-            else v = fma(s[k], raw[q][k], v);
-          }
-        }
-        if (d < W1) ring[sl * W1 + d] = v;
-        else if (d == W1) rring[sl] = v;
-      }
+    if (ahead && apply) {
+      BAND_REFILL();
+      lds_barrier_w();
+      WSTAMP(4);
     }
-    slot0 += NB;
-    if (slot0 >= WS) slot0 -= WS;
-    lds_barrier_w();
-    WSTAMP(4);
+    slot0 = slot1;
+    cur = nxt;
   }
+#undef BAND_REFILL
   const bool failed = misc[0] != 0.0;
   if (tid == 0) {
     if (logdet) logdet[c] = log(ld_mant) + (double)ld_exp * 0.69314718055994530942;
@@ -411,6 +475,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   }
   if (dbg && blockIdx.x == 0 && tid == 0)
     for (int i = 0; i < 8; ++i) dbg[i] = tacc[i];
+  if (dbg && blockIdx.x == 0 && lane == 0) dbg[8 + wave] = twork;   // S3 per wave
 #undef WSTAMP
 }
 
@@ -419,7 +484,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
 // LDS bytes of a block size NB at bandwidth w (the factor phase is the larger one)
 static size_t blocked_lds(int w, int NB) {
   const size_t W1 = (size_t)w + 1, WS = (size_t)w + NB, WP = ((size_t)w + 15) & ~(size_t)15, PS = (size_t)NB + 1;
-  return (WS * W1 + WS + WP * PS + (size_t)NB * PS + 2 * (size_t)NB + 2) * sizeof(double);
+  return (WS * W1 + WS + 2 * (WP * PS + (size_t)NB * PS + 2 * (size_t)NB) + 2) * sizeof(double);
 }
 
 // terms: omc_band.hip's BandTermsDev (the same layout as BandTermsW above); Lws: [C][n][w + 1] doubles.  Returns false if no block
@@ -431,7 +496,7 @@ bool omc_band_blocked_launch(omc_ctx* ctx, int64_t n, int w, const void* terms, 
   BandTermsW T;
   memcpy(&T, terms, sizeof(T));
   const size_t limit = 160 * 1024;
-  if (blocked_lds(w, 16) <= limit) {
+  if (w <= BAND_W16_MAX && blocked_lds(w, 16) <= limit) {
     hipLaunchKernelGGL((k_band_blocked<16, 512>), dim3((unsigned)ctx->n_chains), dim3(512), blocked_lds(w, 16), ctx->stream, ctx->n_chains,
                        ctx->chain_offset, n, w, T, rhs_chain, ld_rhs, z_inject, ld_z, key, Lws, x, ld_x, mean, ld_mean, logdet,
                        ctx->d_bad_chain, ctx->stamps);
