@@ -15,6 +15,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "omc_common.h"
 
 #define BAND_WMAX_W 128
@@ -99,10 +101,12 @@ struct DiagStep<NB, NB> {
 
 typedef double wide_d4 __attribute__((ext_vector_type(4)));
 
-template <int NB, int NT>
+// MT: the number of terms the kernel is compiled for (2 covers most models: their entries a block ahead are half the registers)
+template <int NB, int NT, int MT>
 __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_offset, int64_t n, int w, BandTermsW T, const double* rhs_chain,
                                                       int64_t ld_rhs, const double* z_in, int64_t ld_z, omc_rng_key key, double* Lws, double* x,
                                                       int64_t ld_x, double* mean, int64_t ld_mean, double* logdet, long long* bad, unsigned long long* dbg) {
+  static_assert(NT == 512, "eight waves: one per tile of the window's first tile column");
   extern __shared__ double sm[];
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter(), twork = 0;
 #define WSTAMP(i) do { if (dbg) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; } } while (0)
@@ -113,17 +117,17 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   double* ring = sm;                               // WS x W1: ring[slot(col) * W1 + d] = open entry Q[col + d, col]
   double* rring = ring + (int64_t)WS * W1;         // WS: open right-hand side
   // a factorised block column, TWO copies (the block being applied and the one factorised ahead of it), FBS doubles apart:
-  double* P = rring + WS;                          // WP x PS: the panel below the diagonal block (zero outside the band)
-  double* Ld = P + (int64_t)WP * PS;               // NB x PS: the diagonal block's factor
-  double* dv = Ld + NB * PS;                       // NB: 1 / L_jj of the block
+  double* Ld = rring + WS;                         // NB x PS: the diagonal block's factor (its strict lower triangle is what is read)
+  double* P = Ld + NB * PS;                        // WP x PS: the panel below it, right behind: row r of the block column = Ld[r * PS ..]
+  double* dv = P + (int64_t)WP * PS;               // NB: 1 / L_jj of the block
   double* Us = dv + NB;                            // NB: forward-substituted right-hand side of the block
   const int FBS = WP * PS + NB * PS + 2 * NB;
-  double* misc = P + 2 * FBS;                      // [0] fail flag
+  double* misc = Ld + 2 * FBS;                     // [0] fail flag, [1] a zero to read, [2 .. 65] a slot per lane to write to in vain
   const int64_t c = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double s[OMC_MAX_TERMS];
+  double s[MT];
 #pragma unroll
-  for (int k = 0; k < OMC_MAX_TERMS; ++k) s[k] = (k < T.n_terms && T.scale[k]) ? T.scale[k][c] : 1.0;
+  for (int k = 0; k < MT; ++k) s[k] = (k < T.n_terms && T.scale[k]) ? T.scale[k][c] : 1.0;
   double* Lc = Lws + c * n * W1;
   double* xc = x + c * ld_x;
   const double* rc = rhs_chain ? rhs_chain + c * ld_rhs : nullptr;
@@ -147,7 +151,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   constexpr int WMAX_NB = (NB == 16) ? BAND_W16_MAX : BAND_WMAX_W;  // widest band this block size is launched for
   constexpr int NPRE = (WMAX_NB + 2 + TPC - 1) / TPC;             // entries per thread
   const int pcol = tid / TPC, pq = tid % TPC;                    // (NB is a power of two: shifts)
-  const double* pbase[NPRE][OMC_MAX_TERMS];                      // term k's row d of the band (or its right-hand side), NULL: no entry
+  const double* pbase[NPRE][MT];                      // term k's row d of the band (or its right-hand side), NULL: no entry
   const double* pchain[NPRE];                                    // the chain's own right-hand side (entry W1 only)
   int plim[NPRE];                                                // the entry exists for columns < plim
 #pragma unroll
@@ -156,7 +160,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
     plim[q] = (d < W1) ? (int)n - d : (d == W1 ? (int)n : 0);
     pchain[q] = (d == W1) ? rc : nullptr;
 #pragma unroll
-    for (int k = 0; k < OMC_MAX_TERMS; ++k) {
+    for (int k = 0; k < MT; ++k) {
       const double* p = nullptr;
       if (k < T.n_terms) {
         if (d < W1) { if (T.band[k] && d <= T.bw[k]) p = T.band[k] + (int64_t)d * n; }
@@ -186,6 +190,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   // where the lane's entry against column jj + b sits: ring[slot * W1 + f_rowoff - b], the right-hand side rring[slot] (= ring[WS W1 + slot])
   const int f_mul = f_rhs ? 1 : W1, f_base = f_rhs ? WS * W1 : f_rowoff, f_dec = f_rhs ? 0 : 1;
   const int zero_at = (int)(misc + 1 - ring);                     // misc[1] == 0.0
+  const int dump_at = zero_at + 1 + lane;
   auto factor_block = [&](const int64_t jj, const int slot, double* Pn, double* Ldn, double* dvn, double* Usn) {
     __builtin_amdgcn_s_setprio(3);
     const int nbj = (int)((n - jj < NB) ? n - jj : NB);
@@ -200,10 +205,11 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
     // the entry's place in the ring: slot (block-uniform, wraps) * f_mul + f_base - b * f_dec; lanes without an entry read a zero
     // kept in LDS for them, so that the sixteen reads are issued back to back with nothing between a read and its use
     int sl = slot, rest = f_base;
+    asm volatile("" : "+v"(rest));  // (not worth sixteen registers held through the whole kernel to save a subtraction each)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const bool in = (unsigned)(b - b_lo) <= span;
-      D[b] = ring[in ? sl * f_mul + rest : zero_at];
+      D[b] = ring[in ? __mul24(sl, f_mul) + rest : zero_at];
       rest -= f_dec;
       if (++sl == WS) sl = 0;
     }
@@ -228,42 +234,96 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   };
   // one 16 x 16 tile of P P' off the window (rows 16 ti .., columns 16 tj .. behind the block)
   const int cl = lane & 15, kr = lane >> 4;
-  auto window_tile = [&](const int64_t j, const int slot0, const double* Pc, const int ti, const int tj) {
-    wide_d4 acc = wide_d4{0.0, 0.0, 0.0, 0.0};
+  // (two tiles at a time where there are two: the operand reads, the chained matrix-core steps and the read-modify-write of
+  // the ring are each a latency a lone tile waits out)
+  auto window_tiles = [&](auto two_c, const int64_t j, const int slot0, const double* Pc, const int ti0, const int tj0, const int ti1,
+                          const int tj1) {
+    constexpr bool two = decltype(two_c)::value;
+    double a0[NB / 4], b0[NB / 4], a1[NB / 4], b1[NB / 4];
 #pragma unroll
-    for (int ks = 0; ks < NB / 4; ++ks)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pc[(16 * ti + cl) * PS + 4 * ks + kr], Pc[(16 * tj + cl) * PS + 4 * ks + kr], acc, 0, 0, 0);
+    for (int ks = 0; ks < NB / 4; ++ks) {
+      a0[ks] = Pc[(16 * ti0 + cl) * PS + 4 * ks + kr];
+      b0[ks] = Pc[(16 * tj0 + cl) * PS + 4 * ks + kr];
+      a1[ks] = two ? Pc[(16 * ti1 + cl) * PS + 4 * ks + kr] : 0.0;
+      b1[ks] = two ? Pc[(16 * tj1 + cl) * PS + 4 * ks + kr] : 0.0;
+    }
+    wide_d4 acc0 = wide_d4{0.0, 0.0, 0.0, 0.0}, acc1 = wide_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < NB / 4; ++ks) {
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], b0[ks], acc0, 0, 0, 0);
+      if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], b1[ks], acc1, 0, 0, 0);
+    }
     // C/D of the f64 form: column = lane & 15, row = (lane >> 4) + 4 * register
-    const int ci = 16 * tj + cl;
-    int sl = slot0 + NB + ci;
-    if (sl >= WS) sl -= WS;
+    const int ci0 = 16 * tj0 + cl, ci1 = 16 * tj1 + cl;
+    int sl0 = slot0 + NB + ci0, sl1 = slot0 + NB + ci1;
+    if (sl0 >= WS) sl0 -= WS;
+    if (sl1 >= WS) sl1 -= WS;
+    const int rows_left = (n - j - NB < (int64_t)w) ? (int)(n - j - NB) : w;   // rows behind the block that exist
+    // (lanes outside the band or beyond the chain's end take the same steps on a slot of their own that nobody reads)
+    int at0[4], at1[4];
+    double c0[4], c1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int ri = 16 * ti + kr + 4 * r;
-      if (ri >= ci && ri < w && j + NB + ri < n) ring[sl * W1 + (ri - ci)] -= acc[r];
+      const int ri0 = 16 * ti0 + kr + 4 * r, ri1 = 16 * ti1 + kr + 4 * r;
+      at0[r] = (ri0 >= ci0 && ri0 < rows_left) ? sl0 * W1 + (ri0 - ci0) : dump_at;
+      c0[r] = ring[at0[r]];
+      if (two) {
+        at1[r] = (ri1 >= ci1 && ri1 < rows_left) ? sl1 * W1 + (ri1 - ci1) : dump_at;
+        c1[r] = ring[at1[r]];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ring[at0[r]] = c0[r] - acc0[r];
+      if (two) ring[at1[r]] = c1[r] - acc1[r];
     }
   };
   const int nt = WP / 16;  // tiles per side of the window (<= 8)
   // block j's columns of the factor to the workspace (lanes along a column's entries) and the tiles (ti >= tj >= 1) of its window
   // update, by the waves w0 .. NT / 64 - 1
-  auto store_and_tiles = [&](const int64_t j, const int nb, const int slot0, const double* Pc, const double* Ldc, const double* dvc,
-                             const int w0) {
-    const int nwk = NT / 64 - w0, wk = wave - w0;
+  // The tiles a wave takes do not change from block to block: up to three pairs, worked out once (wave-uniform, kept in scalar
+  // registers): ti0 | tj0 << 4 | ti1 << 8 | tj1 << 12 | two << 16 | any << 17, rows and columns counted from tile 1
+  const int w0_tiles = ahead ? npw : 0;  // first of the waves that apply block j beside the factorisation of block j + NB
+  int tile_tab[3];
+  {
+    const int nwk = NT / 64 - w0_tiles, wk = wave - w0_tiles, ntiles = nt * (nt - 1) / 2;
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr) {
+      const int tile = wk + 2 * pr * nwk;
+      int e = 0;
+      if (wk >= 0 && tile < ntiles) {
+        int ti0 = 0, tj0 = tile;
+        while (tj0 > ti0) { tj0 -= ti0 + 1; ++ti0; }
+        const bool two = tile + nwk < ntiles;
+        int ti1 = 0, tj1 = two ? tile + nwk : tile;
+        while (tj1 > ti1) { tj1 -= ti1 + 1; ++ti1; }
+        e = (ti0 + 1) | (tj0 + 1) << 4 | (ti1 + 1) << 8 | (tj1 + 1) << 12 | (two ? 1 << 16 : 0) | 1 << 17;
+      }
+      tile_tab[pr] = __builtin_amdgcn_readfirstlane(e);
+    }
+  }
+  // block j's columns of the factor to the workspace (lanes along a column's entries: 1 / L_jj in the diagonal slot, then the rows
+  // of the block column, which lie one behind the other in LDS) and the tiles (ti >= tj >= 1) of its window update, by the waves
+  // w0_tiles .. NT / 64 - 1
+  auto store_and_tiles = [&](const int64_t j, const int nb, const int slot0, const int cur) {
+    const int nwk = NT / 64 - w0_tiles, wk = wave - w0_tiles;
+    const int ld_at = (int)(Ld - ring) + cur * FBS, dv_at = (int)(dv - ring) + cur * FBS;
     for (int b = wk; b < nb; b += nwk) {
       double* col = Lc + (j + b) * W1;
       for (int d = lane; d < W1; d += 64) {
-        double v;
-        if (d == 0) v = dvc[b];                                     // the diagonal slot holds 1 / L_jj
-        else if (b + d < NB) v = (b + d < nb) ? Ldc[(b + d) * PS + b] : 0.0;
-        else v = (b + d - NB < w) ? Pc[(b + d - NB) * PS + b] : 0.0;
-        col[d] = v;
+        const int row = b + d;
+        const bool ok = row < nb || (row >= NB && row - NB < w);
+        col[d] = ring[d == 0 ? dv_at + b : (ok ? ld_at + row * PS + b : zero_at)];
       }
     }
-    const int ntiles = nt * (nt - 1) / 2;
-    for (int tile = wk; tile < ntiles; tile += nwk) {
-      int ti = 0, rem = tile;
-      while (rem > ti) { rem -= ti + 1; ++ti; }
-      window_tile(j, slot0, Pc, ti + 1, rem + 1);
+    const double* Pc = P + cur * FBS;
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr) {
+      const int e = tile_tab[pr];
+      if (e >> 17) {
+        if ((e >> 16) & 1) window_tiles(std::true_type{}, j, slot0, Pc, e & 15, (e >> 4) & 15, (e >> 8) & 15, (e >> 12) & 15);
+        else window_tiles(std::false_type{}, j, slot0, Pc, e & 15, (e >> 4) & 15, (e >> 8) & 15, (e >> 12) & 15);
+      }
     }
   };
   // S4: block j's slots take the columns j + WS .. j + WS + NB - 1 (requested at the top of the block)
@@ -276,7 +336,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
     _Pragma("unroll") for (int q = 0; q < NPRE; ++q) {                                     \
       const int d = pq + q * TPC;                                                          \
       double v = rawc[q];                                                                  \
-      _Pragma("unroll") for (int k = 0; k < OMC_MAX_TERMS; ++k) {                          \
+      _Pragma("unroll") for (int k = 0; k < MT; ++k) {                          \
         if (k < T.n_terms) {                                                               \
           if (d < W1 && !T.band[k]) { if (d == 0 && col_ < n) v += s[k]; } /* identity */  \
           else v = fma(s[k], raw[q][k], v);                                                \
@@ -292,14 +352,14 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   for (int64_t j = -NB; j < n; j += NB) {
     const bool apply = j >= 0;
     const int nb = (int)((n - j < NB) ? n - j : NB);
-    const double* Pc = P + cur * FBS, * Ldc = Ld + cur * FBS, * dvc = dv + cur * FBS, * Usc = Us + cur * FBS;
+    const double* Pc = P + cur * FBS, * Usc = Us + cur * FBS;
     const int nxt = cur ^ 1;
     int slot1 = slot0 + NB;
     if (slot1 >= WS) slot1 -= WS;
     // the NB columns that enter the window at the end of this block: their raw entries are REQUESTED now, all of them before any
     // is used (a load consumed inside a divergent branch is waited for on the spot: seven round trips in a row), combined and
     // stored in S4
-    double raw[NPRE][OMC_MAX_TERMS], rawc[NPRE];
+    double raw[NPRE][MT], rawc[NPRE];
     if (apply) {
       const int col = (int)j + WS + pcol;
 #pragma unroll
@@ -307,11 +367,11 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
         const bool in = col < plim[q];
         rawc[q] = (in && pchain[q]) ? pchain[q][col] : 0.0;
 #pragma unroll
-        for (int k = 0; k < OMC_MAX_TERMS; ++k) raw[q][k] = (in && pbase[q][k]) ? pbase[q][k][col] : 0.0;
+        for (int k = 0; k < MT; ++k) raw[q][k] = (in && pbase[q][k]) ? pbase[q][k][col] : 0.0;
       }
       WSTAMP(0);
       // ---- S2: what block j + NB waits for: the first tile column of the window update and the right-hand side
-      for (int ti = wave; ti < nt; ti += NT / 64) window_tile(j, slot0, Pc, ti, 0);
+      if (wave < nt) window_tiles(std::false_type{}, j, slot0, Pc, wave, 0, wave, 0);   // (nt <= 8 = NT / 64)
       if (tid < w && j + NB + tid < n) {
         double acc = 0.0;
 #pragma unroll
@@ -322,7 +382,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
       }
       // (the block's forward-substituted right-hand side: overwritten by the draw in the backward pass)
       if (tid >= NT - 64 && lane < nb) xc[j + lane] = Usc[lane];
-      if (!ahead) store_and_tiles(j, nb, slot0, Pc, Ldc, dvc, 0);
+      if (!ahead) store_and_tiles(j, nb, slot0, cur);
       lds_barrier_w();
       WSTAMP(2);
       if (!ahead) {
@@ -335,7 +395,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
       for (int q = 0; q < NPRE; ++q) {
         rawc[q] = 0.0;
 #pragma unroll
-        for (int k = 0; k < OMC_MAX_TERMS; ++k) raw[q][k] = 0.0;
+        for (int k = 0; k < MT; ++k) raw[q][k] = 0.0;
       }
     }
     // ---- S3: block j + NB factorised by the first waves, beside the rest of block j's work on the others
@@ -343,7 +403,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
     if (wave < npw) {
       if (j + NB < n) factor_block(j + NB, slot1, P + nxt * FBS, Ld + nxt * FBS, dv + nxt * FBS, Us + nxt * FBS);
     } else if (ahead && apply) {
-      store_and_tiles(j, nb, slot0, Pc, Ldc, dvc, npw);
+      store_and_tiles(j, nb, slot0, cur);
     }
     if (dbg) twork += __builtin_readcyclecounter() - tw0;   // (this wave's own work in S3, without the wait at the barrier)
     lds_barrier_w();
@@ -396,6 +456,16 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   __syncthreads();
   const int64_t nblk = (n + NB - 1) / NB;
   int slotJ = (int)(((nblk - 1) * NB) % WS);  // slot of the block's first column, kept incrementally
+  double lnext[NPRE];  // this thread's entries of the factor for the coming block
+  {
+    const int64_t j = (nblk - 1) * NB;
+    const int nb = (int)(n - j);
+#pragma unroll
+    for (int t = 0; t < NPRE; ++t) {
+      const int d = pq + t * TPC;
+      lnext[t] = (pcol < nb && d <= w) ? Lc[(j + pcol) * W1 + d] : 0.0;
+    }
+  }
   for (int64_t J = nblk - 1; J >= 0; --J) {
     const int64_t j = J * NB;
     const int nb = (int)((n - j < NB) ? n - j : NB);
@@ -407,12 +477,13 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
     {
       const int b = pcol, q = pq;
       double px = 0.0, pm = 0.0;
-      // the column's entries: all requested before the first is used
+      // the column's entries were requested a block ago; the next block's (a whole one: only the last is short) are requested now
       double lv[NPRE];
 #pragma unroll
       for (int t = 0; t < NPRE; ++t) {
+        lv[t] = lnext[t];
         const int d = q + t * TPC;
-        lv[t] = (b < nb && d <= w) ? Lc[(j + b) * W1 + d] : 0.0;
+        lnext[t] = (J > 0 && d <= w) ? Lc[(j - NB + b) * W1 + d] : 0.0;
       }
       if (b < nb) {
         int sl = slotJ + b + q;
@@ -484,7 +555,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
 // LDS bytes of a block size NB at bandwidth w (the factor phase is the larger one)
 static size_t blocked_lds(int w, int NB) {
   const size_t W1 = (size_t)w + 1, WS = (size_t)w + NB, WP = ((size_t)w + 15) & ~(size_t)15, PS = (size_t)NB + 1;
-  return (WS * W1 + WS + 2 * (WP * PS + (size_t)NB * PS + 2 * (size_t)NB) + 2) * sizeof(double);
+  return (WS * W1 + WS + 2 * (WP * PS + (size_t)NB * PS + 2 * (size_t)NB) + 2 + 64) * sizeof(double);
 }
 
 // terms: omc_band.hip's BandTermsDev (the same layout as BandTermsW above); Lws: [C][n][w + 1] doubles.  Returns false if no block
@@ -496,17 +567,21 @@ bool omc_band_blocked_launch(omc_ctx* ctx, int64_t n, int w, const void* terms, 
   BandTermsW T;
   memcpy(&T, terms, sizeof(T));
   const size_t limit = 160 * 1024;
+  const bool few = T.n_terms <= 2;
+#define OMC_BLOCKED_LAUNCH(NB_, MT_)                                                                                                  \
+  hipLaunchKernelGGL((k_band_blocked<NB_, 512, MT_>), dim3((unsigned)ctx->n_chains), dim3(512), blocked_lds(w, NB_), ctx->stream,      \
+                     ctx->n_chains, ctx->chain_offset, n, w, T, rhs_chain, ld_rhs, z_inject, ld_z, key, Lws, x, ld_x, mean, ld_mean,  \
+                     logdet, ctx->d_bad_chain, ctx->stamps)
   if (w <= BAND_W16_MAX && blocked_lds(w, 16) <= limit) {
-    hipLaunchKernelGGL((k_band_blocked<16, 512>), dim3((unsigned)ctx->n_chains), dim3(512), blocked_lds(w, 16), ctx->stream, ctx->n_chains,
-                       ctx->chain_offset, n, w, T, rhs_chain, ld_rhs, z_inject, ld_z, key, Lws, x, ld_x, mean, ld_mean, logdet,
-                       ctx->d_bad_chain, ctx->stamps);
+    if (few) OMC_BLOCKED_LAUNCH(16, 2);
+    else OMC_BLOCKED_LAUNCH(16, OMC_MAX_TERMS);
     return true;
   }
   if (blocked_lds(w, 8) <= limit) {
-    hipLaunchKernelGGL((k_band_blocked<8, 512>), dim3((unsigned)ctx->n_chains), dim3(512), blocked_lds(w, 8), ctx->stream, ctx->n_chains,
-                       ctx->chain_offset, n, w, T, rhs_chain, ld_rhs, z_inject, ld_z, key, Lws, x, ld_x, mean, ld_mean, logdet,
-                       ctx->d_bad_chain, ctx->stamps);
+    if (few) OMC_BLOCKED_LAUNCH(8, 2);
+    else OMC_BLOCKED_LAUNCH(8, OMC_MAX_TERMS);
     return true;
   }
+#undef OMC_BLOCKED_LAUNCH
   return false;
 }

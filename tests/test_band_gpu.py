@@ -369,6 +369,44 @@ def test_blocked_wide_band_kernel(w, n):
     eng.close()
 
 
+@pytest.mark.parametrize("w,n,algo", [(20, 157, 3), (100, 260, 0), (124, 300, 0), (5, 90, 3)])
+def test_blocked_wide_band_kernel_four_terms(w, n, algo):
+    """Three and four terms (the kernel is compiled once for up to two terms and once for OMC_MAX_TERMS): two band matrices of
+    different bandwidths and two identity terms with right-hand sides of their own, per-chain scales on all of them."""
+    from oracle import gmrf_ref
+
+    rng = np.random.default_rng(w * 1000 + n)
+    C = 3
+    eng = make_engine(C)
+    eng.set_option("band_algo", algo)
+    w2 = max(1, w // 3)
+    M1, M2 = random_band_spd(n, w, rng), random_band_spd(n, w2, rng)
+    m1, y3, y4 = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+    for n_terms in (3, 4):
+        sc = rng.random((4, C)) * 2 + 0.3
+        terms = [{"band": eng.to_device(band_of(M1, w)), "rhs": eng.to_device(M1 @ m1), "scale": eng.to_device(sc[0])},
+                 {"band": eng.to_device(band_of(M2, w2)), "scale": eng.to_device(sc[1])},
+                 {"rhs": eng.to_device(y3), "scale": eng.to_device(sc[2])},
+                 {"rhs": eng.to_device(y4), "scale": eng.to_device(sc[3])}][:n_terms]
+        z, extra = rng.standard_normal((C, n)), rng.standard_normal((C, n))
+        x, mu, ld = eng.empty(C, n), eng.empty(C, n), eng.empty(C)
+        eng.band_sample_canonical(n, terms, x, z=eng.to_device(z), rhs_chain=eng.to_device(extra), mean_out=mu, logdet_out=ld)
+        eng.check_status()
+        for c in range(C):
+            Q = sc[0, c] * M1 + sc[1, c] * M2 + sc[2, c] * sparse.identity(n)
+            b = sc[0, c] * (M1 @ m1) + sc[2, c] * y3 + extra[c]
+            if n_terms == 4:
+                Q = Q + sc[3, c] * sparse.identity(n)
+                b = b + sc[3, c] * y4
+            xo, mo, L = gmrf_ref.draw_canonical(b.reshape(n, 1), sparse.csc_matrix(Q), z[c].reshape(n, 1))
+            scale = max(1.0, np.max(np.abs(xo)))
+            assert np.max(np.abs(x[c].cpu().numpy() - xo.ravel())) < RTOL * scale
+            assert np.max(np.abs(mu[c].cpu().numpy() - mo.ravel())) < RTOL * scale
+            logdet = 2 * np.sum(np.log(L.diagonal()))
+            assert abs(float(ld[c]) - logdet) < RTOL * max(1.0, abs(logdet))
+    eng.close()
+
+
 def test_blocked_wide_band_kernel_latches_a_failed_chain_and_draws_in_kernel():
     n, w, C = 300, 40, 3
     rng = np.random.default_rng(5)
