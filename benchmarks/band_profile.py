@@ -64,7 +64,8 @@ if os.environ.get("OMC_WIDE_STAMPS"):
     torch.cuda.synchronize()
     v = st.cpu().numpy()[:8].astype(float)
     print("own work per wave in the look-ahead phase (cycles):", st.cpu().numpy()[8:16].tolist(), file=sys.stderr)
-    names = ["prefetch", "factor (first block; late ones of narrow bands)", "first tile column + rhs", "factor ahead | store + tiles", "S4 refill", "u+z", "back S1", "back S2"]
+    print("own work per wave in the backward pass (cycles):", st.cpu().numpy()[16:24].tolist(), file=sys.stderr)
+    names = ["prefetch", "factor (first block; late ones of narrow bands)", "first tile column + rhs", "factor ahead | store + tiles", "S4 refill", "u+z", "back: first far sums", "back: a block per barrier"]
     print("stamps (cycles, chain 0):", {k: int(a) for k, a in zip(names, v)}, "total", int(v.sum()), file=sys.stderr)
     eng.set_option("stamps_ptr", 0)
 print(json.dumps({"workload": (f"band draw {a.rows} x {a.lattice} lattice (w = {a.w})" if a.lattice else f"band draw RW{a.w}") + f" n={n} chains={C}",

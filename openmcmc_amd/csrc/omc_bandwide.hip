@@ -62,6 +62,13 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
+// v of the lane a DPP control word names (quad permutations, row mirrors), both halves of the double
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true));
+}
+
 // column K of the NB x NB diagonal block (rows in lanes 0 .. NB-1, row r's entries D[0 .. r] in registers; the lanes behind them
 // hold rows of the panel and the right-hand side, which take the same steps).  No branch on the pivot: a pivot that is not
 // positive is COUNTED (the chain's results are replaced by NaN at the end) and the arithmetic goes on with whatever it gives.
@@ -108,7 +115,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
                                                       int64_t ld_x, double* mean, int64_t ld_mean, double* logdet, long long* bad, unsigned long long* dbg) {
   static_assert(NT == 512, "eight waves: one per tile of the window's first tile column");
   extern __shared__ double sm[];
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter(), twork = 0;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter(), twork = 0, tback = 0;
 #define WSTAMP(i) do { if (dbg) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; } } while (0)
   const int W1 = w + 1;
   const int WS = w + NB;                 // columns of the window (ring slots)
@@ -446,107 +453,229 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   __syncthreads();
 
   WSTAMP(5);
-  // ---- backward pass L' x = t, NB columns per step.  xs / ms: the last WS solutions, slot = column % WS
+  // ---- backward pass L' x = t, NB columns per step, ONE barrier per step.  xs / ms: the last WS solutions, slot = column % WS.
+  // Column b of block J needs sum_d L[j+b+d][j+b] x[j+b+d] over the rows behind it.  The rows from block J + 2 on ("far":
+  // d >= 2 NB - b) are known a whole step before block J is solved: waves 1 .. 7 add them up for block J - 1 WHILE wave 0 solves
+  // block J -- the rows of block J + 1 ("near"), the far sums handed over through LDS, and the block's own triangle across its
+  // lanes.  Every sum is taken in a fixed order (partial sums per quad of threads, then in quad order): results do not depend on
+  // timing.
   double* xs = sm;
   double* ms = xs + WS;
   double* Sx = ms + WS;        // NB: sum over the rows behind the block, per column
   double* Sm = Sx + NB;
   double* Lb = Sm + NB;        // NB x PS: the block's own triangle of the factor, Lb[a][b] = L[j+a][j+b], a > b; dinv on the diagonal
+  constexpr int TPF = (NT - 64) / NB;   // threads per column for the far rows
+  constexpr int QPC = TPF / 4;          // their quads per column
+  constexpr int NPF = (WMAX_NB - NB + TPF - 1) / TPF;  // far entries per thread (d = 2 NB - b .. w: at most w - NB of them, b = NB - 1)
+  constexpr int LPC = 64 / NB;          // lanes of wave 0 per column for the block's own and the near rows
+  constexpr int KN = 2 * NB / LPC;      // entries per lane there (d = 0 .. 2 NB - 1 - b)
+  static_assert(TPF % 4 == 0 && TPF * NB == NT - 64, "quads of far threads do not straddle columns");
+  const int dump_b = NB * PS + 4 * NB * QPC + lane;  // (behind Part: a slot per lane to write to in vain)
+  const int diag_b = NB * PS + 4 * NB * QPC + 64;    // (and the block's 1 / L_jj: NB of them)
+  double* Part = Lb + NB * PS;  // [2][2][NB][QPC]: the far sums of the quads, for blocks of even and odd number, draw and mean
   for (int t = tid; t < 2 * WS; t += NT) sm[t] = 0.0;
+  for (int t = tid; t < NB * PS; t += NT) Lb[t] = 0.0;
+  if (tid < NB) Lb[diag_b + tid] = 0.0;
   __syncthreads();
   const int64_t nblk = (n + NB - 1) / NB;
-  int slotJ = (int)(((nblk - 1) * NB) % WS);  // slot of the block's first column, kept incrementally
-  double lnext[NPRE];  // this thread's entries of the factor for the coming block
-  {
-    const int64_t j = (nblk - 1) * NB;
-    const int nb = (int)(n - j);
+  const int ft = tid - 64, fb = ft >= 0 ? ft / TPF : 0, fq = ft >= 0 ? ft % TPF : 0;   // far threads: column, place in the column
+  const int gb = lane / LPC, gg = lane % LPC;                                         // wave 0: column, place in the column
+  const bool t_lane = wave == 0 && lane < 2 * NB && (lane < NB || mc);
+  // entries of the factor and of the right-hand side, asked for a step before they are used
+  // (every request is an UNCONDITIONAL load -- entries that do not exist are asked for at the chain's first factor entry and
+  // masked when they are used: a load under a condition becomes a branch with a wait for the data behind it, one round trip to
+  // memory after the other)
+  double fnext[NPF], nnext[KN], tnext = 0.0;
+  unsigned fmask_next = 0, nmask_next = 0;   // bit k: entry k exists; bit 31: the right-hand side entry does
+  const int ni = (int)n;
+  // what does not change from block to block: which of this thread's entries lie inside the band (bit k), and the rows they meet
+  // counted from the block's first column (far rows: 2 NB + fq + TPF k, the same for every column of the block)
+  unsigned fband = 0, nband = 0;
 #pragma unroll
-    for (int t = 0; t < NPRE; ++t) {
-      const int d = pq + t * TPC;
-      lnext[t] = (pcol < nb && d <= w) ? Lc[(j + pcol) * W1 + d] : 0.0;
+  for (int k = 0; k < NPF; ++k) fband |= (2 * NB - fb + fq + TPF * k <= w) ? 1u << k : 0u;
+#pragma unroll
+  for (int k = 0; k < KN; ++k) nband |= (gg + LPC * k <= w && gb + gg + LPC * k < 2 * NB) ? 1u << k : 0u;
+  const double* const tsrc = (lane < NB || !mc) ? xc : mc;
+  auto request = [&](const int Jt) {  // block Jt's entries for this thread's role (Jt == -1: none)
+    const int j0 = Jt * NB;
+    if (wave == 0) {
+      const double* col = Lc + (int64_t)(j0 + gb) * W1;
+      nmask_next = 0;
+#pragma unroll
+      for (int k = 0; k < KN; ++k) {
+        const int d = gg + LPC * k;
+        const bool ok = ((nband >> k) & 1) && Jt >= 0 && j0 + gb + d < ni;
+        nmask_next |= ok ? 1u << k : 0u;
+        const double* at = ok ? col + d : Lc;
+        nnext[k] = *at;
+      }
+      const int tb = lane & (NB - 1);
+      const bool ok = Jt >= 0 && t_lane && j0 + tb < ni;
+      nmask_next |= ok ? 1u << 31 : 0u;
+      tnext = tsrc[ok ? j0 + tb : 0];
+    } else {
+      const double* col = Lc + (int64_t)(j0 + fb) * W1 + (2 * NB - fb + fq);
+      fmask_next = 0;
+#pragma unroll
+      for (int k = 0; k < NPF; ++k) {
+        const bool ok = ((fband >> k) & 1) && Jt >= 0 && j0 + 2 * NB + fq + TPF * k < ni;
+        fmask_next |= ok ? 1u << k : 0u;
+        const double* at = ok ? col + TPF * k : Lc;
+        fnext[k] = *at;
+      }
     }
-  }
+  };
+  // far sums of block Jt (waves 1 .. 7; slotT: slot of its first column)
+  auto far_part = [&](const int Jt, const int slotT) {
+    double fl[NPF];
+    const unsigned fm = fmask_next;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (written out: see the note at the forward pass' entering columns)
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      fl[k] = fnext[k];
+      asm volatile("" : "+v"(fl[k]));
+    }
+    request(Jt - 1);
+    double px = 0.0, pm = 0.0;
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      // an entry that exists meets a row no further than w + NB - 1 = WS - 1 from the block's first column: one wrap at most
+      int sl = slotT + 2 * NB + fq + TPF * k;
+      if (sl >= WS) sl -= WS;
+      const bool ok = (fm >> k) & 1;
+      sl = ok ? sl : 0;
+      const double l = ok ? fl[k] : 0.0;
+      px = fma(l, xs[sl], px);
+      if (mc) pm = fma(l, ms[sl], pm);
+    }
+    px += dpp_d<0xB1>(px);  // quad: xor 1
+    px += dpp_d<0x4E>(px);  //       xor 2
+    if (mc) {
+      pm += dpp_d<0xB1>(pm);
+      pm += dpp_d<0x4E>(pm);
+    }
+    if ((fq & 3) == 0) {
+      double* dst = Part + (Jt & 1) * 2 * NB * QPC + fb * QPC + (fq >> 2);
+      dst[0] = px;
+      if (mc) dst[NB * QPC] = pm;
+    }
+  };
+  // a solved block goes to global memory a step later, from the ring, by wave 1: a store is not acknowledged for a microsecond,
+  // and the wave that solves waits for "all its memory operations" at the top of every step (its requests of a step ago)
+  auto store_block = [&](const int64_t Jb, const int slotB) {
+    const int b = lane & (NB - 1);
+    const int64_t i = Jb * NB + b;
+    if (lane < 2 * NB && i < n && (lane < NB || mc)) {
+      int sl = slotB + b;
+      if (sl >= WS) sl -= WS;
+      (lane < NB ? xc : mc)[i] = (lane < NB ? xs : ms)[sl];
+    }
+  };
+  int slotJ = (int)(((nblk - 1) * NB) % WS);  // slot of the block's first column, kept incrementally
+  request((int)nblk - 1);
+  if (wave > 0) far_part((int)nblk - 1, slotJ);    // (nothing behind the last block but zeros: its sums are written all the same)
+  lds_barrier_w();
+  WSTAMP(6);
   for (int64_t J = nblk - 1; J >= 0; --J) {
     const int64_t j = J * NB;
     const int nb = (int)((n - j < NB) ? n - j : NB);
-    // S1: 256 / NB lanes per column: s_b = sum over the rows behind the block of L[j+b+d][j+b] x[j+b+d]; the block's own triangle goes
-    // to LDS on the way
-    // (wave 0's first 2 NB lanes ask for their right-hand side entries now: used in S2)
-    double tval = 0.0;
-    if (wave == 0 && lane < 2 * NB && (lane & (NB - 1)) < nb && (lane < NB || mc)) tval = (lane < NB ? xc : mc)[j + (lane & (NB - 1))];
-    {
-      const int b = pcol, q = pq;
+    int slotP = slotJ - NB;                   // slot of block J - 1's first column
+    if (slotP < 0) slotP += WS;
+    const unsigned long long tb0 = dbg ? __builtin_readcyclecounter() : 0;
+    if (wave > 0) {
+      if (J > 0) far_part((int)J - 1, slotP);
+      if (wave == 1 && J + 1 < nblk) store_block(J + 1, slotJ + NB >= WS ? slotJ + NB - WS : slotJ + NB);
+    } else {
+      double nl[KN];
+      const unsigned nm = nmask_next;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < KN; ++k) {
+        nl[k] = nnext[k];
+        asm volatile("" : "+v"(nl[k]));
+      }
+      double tval = tnext;
+      asm volatile("" : "+v"(tval));
+      if (!(nm >> 31)) tval = 0.0;
+      request((int)J - 1);
+      // the block's own triangle to LDS, the near rows (block J + 1) against the solutions, LPC lanes per column
       double px = 0.0, pm = 0.0;
-      // the column's entries were requested a block ago; the next block's (a whole one: only the last is short) are requested now
-      double lv[NPRE];
 #pragma unroll
-      for (int t = 0; t < NPRE; ++t) {
-        lv[t] = lnext[t];
-        const int d = q + t * TPC;
-        lnext[t] = (J > 0 && d <= w) ? Lc[(j - NB + b) * W1 + d] : 0.0;
+      for (int k = 0; k < KN; ++k) {
+        const int d = gg + LPC * k, r = gb + d;
+        const bool ok = (nm >> k) & 1;
+        const bool mine = r < NB;                              // inside the block
+        // (rows of entries that exist lie no further than WS - 1 from the block's first column)
+        int sl = slotJ + r;
+        if (sl >= WS) sl -= WS;
+        sl = (ok && !mine) ? sl : 0;
+        const double l = (ok && !mine) ? nl[k] : 0.0;
+        px = fma(l, xs[sl], px);
+        if (mc) pm = fma(l, ms[sl], pm);
+        Lb[(ok && mine) ? (d == 0 ? diag_b + gb : r * PS + gb) : dump_b] = nl[k];   // (d == 0: 1 / L_jj, kept apart)
       }
-      if (b < nb) {
-        int sl = slotJ + b + q;
-        while (sl >= WS) sl -= WS;
+      // + the far sums of this lane's share of the quads
+      const double* part = Part + (int)(J & 1) * 2 * NB * QPC + gb * QPC;
 #pragma unroll
-        for (int t = 0; t < NPRE; ++t) {
-          const int d = q + t * TPC;
-          if (d <= w) {
-            const double l = lv[t];
-            if (d == 0) Lb[b * PS + b] = l;                               // 1 / L_jj
-            else if (b + d < nb) Lb[(b + d) * PS + b] = l;                // inside the block
-            else if (j + b + d < n) {
-              px = fma(l, xs[sl], px);
-              if (mc) pm = fma(l, ms[sl], pm);
-            }
-          }
-          sl += TPC;
-          while (sl >= WS) sl -= WS;
-        }
+      for (int k = gg; k < QPC; k += LPC) {
+        px += part[k];
+        if (mc) pm += part[NB * QPC + k];
       }
-#pragma unroll
-      for (int sh = TPC / 2; sh > 0; sh >>= 1) {
-        px += __shfl_xor(px, sh, 64);
-        pm += __shfl_xor(pm, sh, 64);
+      px += dpp_d<0xB1>(px);
+      px += dpp_d<0x4E>(px);
+      if (LPC == 8) px += dpp_d<0x141>(px);  // (quads agree by now: mirroring a half row swaps them)
+      if (mc) {
+        pm += dpp_d<0xB1>(pm);
+        pm += dpp_d<0x4E>(pm);
+        if (LPC == 8) pm += dpp_d<0x141>(pm);
       }
-      if (q == 0) { Sx[b] = px; Sm[b] = pm; }
-    }
-    lds_barrier_w();
-    WSTAMP(6);
-    // S2: the NB x NB triangle by the first 2 NB lanes of wave 0: lane b (draw) and lane NB + b (mean) keep their own unknown; the
-    // unknowns are finished from the last one up and handed to the lanes in front by v_readlane
-    if (wave == 0) {
+      if (gg == 0) { Sx[gb] = px; Sm[gb] = pm; }
+      // the NB x NB triangle by the first 2 NB lanes: lane b (draw) and lane NB + b (mean) keep their own unknown; the unknowns
+      // are finished from the last one up and handed to the lanes in front by v_readlane.  (One wave: its LDS operations are
+      // carried out in order, no barrier between the writes above and the reads below.)
       const bool is_m = lane >= NB;
       const int b = lane & (NB - 1);
       const bool on = lane < 2 * NB && b < nb && (!is_m || mc);
-      double* dst = is_m ? mc : xc;
-      double acc = on ? tval - (is_m ? Sm[b] : Sx[b]) : 0.0;
-      const double dinv_b = (lane < 2 * NB && b < nb) ? Lb[b * PS + b] : 0.0;
-      double xv = 0.0;
+      const double sb = (is_m ? Sm : Sx)[b];
+      double acc = on ? tval - sb : 0.0;
+      const double dinv_b = Lb[diag_b + b];
+      // this lane's column of the triangle, read in one go and without a condition: what the steps above never write -- on and
+      // above the diagonal, outside the band, rows beyond the chain's end (the first block solved is the only short one) -- is
+      // zero from the start.  An unknown is complete once the unknowns behind it have been taken off: lane b's acc does not
+      // change after step b + 1 (its entries against the unknowns in front of it are those zeros).
+      double lcol[NB];
 #pragma unroll
-      for (int a = NB - 1; a >= 0; --a) {
-        // unknown a is complete in lanes a and NB + a
-        const double fin = acc * dinv_b;
-        if (b == a) xv = fin;
-        const double xa = readlane_d(fin, a), ma = readlane_d(fin, NB + a);
-        const double l = (a < nb && b < a && a - b <= w && lane < 2 * NB) ? Lb[a * PS + b] : 0.0;
-        acc = fma(-l, is_m ? ma : xa, acc);
+      for (int a = 0; a < NB; ++a) lcol[a] = Lb[a * PS + b];
+      if (mc) {
+#pragma unroll
+        for (int a = NB - 1; a > 0; --a) {
+          const double fin = acc * dinv_b;   // (complete in lanes a and NB + a)
+          const double xa = readlane_d(fin, a), ma = readlane_d(fin, NB + a);
+          acc = fma(-lcol[a], is_m ? ma : xa, acc);
+        }
+      } else {
+#pragma unroll
+        for (int a = NB - 1; a > 0; --a) acc = fma(-lcol[a], readlane_d(acc * dinv_b, a), acc);
       }
+      const double xv = acc * dinv_b;
       if (on) {
-        dst[j + b] = xv;
         int sl = slotJ + b;
         if (sl >= WS) sl -= WS;
         (is_m ? ms : xs)[sl] = xv;
       }
     }
-    slotJ -= NB;
-    if (slotJ < 0) slotJ += WS;
+    slotJ = slotP;
+    if (dbg) tback += __builtin_readcyclecounter() - tb0;   // (this wave's own work, without the wait at the barrier)
     lds_barrier_w();
     WSTAMP(7);
   }
+  if (wave == 1) store_block(0, slotJ + NB >= WS ? slotJ + NB - WS : slotJ + NB);
   if (dbg && blockIdx.x == 0 && tid == 0)
     for (int i = 0; i < 8; ++i) dbg[i] = tacc[i];
-  if (dbg && blockIdx.x == 0 && lane == 0) dbg[8 + wave] = twork;   // S3 per wave
+  if (dbg && blockIdx.x == 0 && lane == 0) {
+    dbg[8 + wave] = twork;    // S3 per wave
+    dbg[16 + wave] = tback;   // a step of the backward pass per wave
+  }
 #undef WSTAMP
 }
 
