@@ -4,14 +4,21 @@
 //
 // k_band_sample pays two workgroup barriers per column for a rank-1 update of the (w x w)/2 window (3.6 us per column at
 // w = 100: 145 ms per draw of 1024 chains at n = 10 000, 0.75 TFLOP/s) and two more per column on the way back.  Here a block
-// of NB columns is: (1) the NB x NB diagonal block factorised by ONE wave in registers (rows in lanes, the pivot column's entries
-// by v_readlane: no LDS, no barrier between its columns), (2) the w x NB panel below it solved against that block, a thread per
-// row, (3) the trailing (w x w)/2 window updated by a rank-NB product on the MATRIX CORES (v_mfma_f64_16x16x4_f64: 16 x 16
-// tiles of P P'), the right-hand side riding along as one more row -- four barriers per NB columns.  The backward pass takes NB
-// columns per step as well: the products with the part of the solution behind the block spread over the lanes (16 per
-// column), the NB x NB triangle by one lane per right-hand side.
+// of NB columns is
+//   (1) the block column -- the NB x NB diagonal block, the w x NB panel below it and the right-hand side as one more row --
+//       factorised as ONE tall right-looking factorisation in registers by one to three waves (rows in lanes, the pivot column's
+//       entries by v_readlane: no LDS, no barrier between its columns);
+//   (2) the trailing (w x w)/2 window updated by a rank-NB product on the MATRIX CORES (v_mfma_f64_16x16x4_f64: 16 x 16 tiles of
+//       P P'), the block's columns of the factor written to the workspace.
+// Block j + NB is factorised AHEAD: it only needs the first tile column of block j's update, so (1) for block j + NB runs beside
+// the rest of (2) for block j, out of a second copy of the block column in LDS; the rest of (2) is a list of items the waves take
+// from a counter in LDS, the factorising waves too once they are done.  Three barriers per NB columns.
+// The backward pass takes NB columns per step and ONE barrier: the products with the solution two blocks and more behind are
+// summed for the next block by seven waves while the first solves the current one (the rows of the block behind it and the block's
+// own triangle across lanes).  Every request to global memory is made a block before it is used.
 // Same factor layout in the workspace as k_band_sample ([column][w + 1], 1 / L_jj in the diagonal slot), same random
-// streams, same log det accumulation; results agree with it to rounding (another summation order), parity tests as for it.
+// streams; results agree with it to rounding (another summation order), parity tests as for it.  Sums are taken in fixed orders:
+// results do not depend on timing.
 #include <math.h>
 #include <string.h>
 
@@ -75,7 +82,7 @@ __device__ __forceinline__ double dpp_d(double v) {
 // dkeep: lane K keeps 1 / L_KK.
 template <int K, int NB>
 struct DiagStep {
-  static __device__ __forceinline__ void run(double (&D)[NB], double& dkeep, int& nfail, double& ld_mant, long long& ld_exp, bool keep_ld) {
+  static __device__ __forceinline__ void run(double (&D)[NB], double& dkeep, int& nfail) {
     const double piv = readlane_d(D[K], K);
     nfail += (piv > 0.0) ? 0 : 1;
     // 1/sqrt(pivot) by rsq + two Newton steps, as k_band_sample does it
@@ -87,23 +94,17 @@ struct DiagStep {
     e = fma(-sq, sq, piv);
     sq = fma(e, h, sq);
     const double rinv = omc_rcp_nr(sq);
-    if (keep_ld) {  // (uniform: one wave keeps the log determinant; identity padding beyond the chain's end adds log 1)
-      ld_mant *= __builtin_amdgcn_frexp_mant(piv);
-      ld_exp += __builtin_amdgcn_frexp_exp(piv);
-      ld_exp += __builtin_amdgcn_frexp_exp(ld_mant);
-      ld_mant = __builtin_amdgcn_frexp_mant(ld_mant);
-    }
     if ((int)(threadIdx.x & 63) == K) dkeep = rinv;
     const double lk = D[K] * rinv;
     D[K] = lk;  // (lane K: L_KK to rounding; the diagonal is never read from here, 1 / L_KK is)
 #pragma unroll
     for (int cc = K + 1; cc < NB; ++cc) D[cc] = fma(-lk, readlane_d(lk, cc), D[cc]);
-    DiagStep<K + 1, NB>::run(D, dkeep, nfail, ld_mant, ld_exp, keep_ld);
+    DiagStep<K + 1, NB>::run(D, dkeep, nfail);
   }
 };
 template <int NB>
 struct DiagStep<NB, NB> {
-  static __device__ __forceinline__ void run(double (&)[NB], double&, int&, double&, long long&, bool) {}
+  static __device__ __forceinline__ void run(double (&)[NB], double&, int&) {}
 };
 
 typedef double wide_d4 __attribute__((ext_vector_type(4)));
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   double* dv = P + (int64_t)WP * PS;               // NB: 1 / L_jj of the block
   double* Us = dv + NB;                            // NB: forward-substituted right-hand side of the block
   const int FBS = WP * PS + NB * PS + 2 * NB;
-  double* misc = Ld + 2 * FBS;                     // [0] fail flag, [1] a zero to read, [2 .. 65] a slot per lane to write to in vain
+  double* misc = Ld + 2 * FBS;                     // [0] fail flag, [1] a zero to read, [2 .. 65] a slot per lane to write to in vain, [66] a counter
   const int64_t c = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double s[MT];
@@ -145,12 +146,15 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
     ring[col * W1 + d] = entry_w(T, s, n, col, d);
   }
   for (int t = tid; t < WS; t += NT) rring[t] = rhs_w(T, s, n, t, rc);
-  if (tid == 0) misc[0] = misc[1] = 0.0;  // [0] a pivot was not positive, [1] a zero to read
+  if (tid == 0) {
+    misc[0] = misc[1] = 0.0;  // [0] a pivot was not positive, [1] a zero to read
+    *(int*)(misc + 66) = 0;   // [66] the next item of the block's list (see drain_items)
+  }
   for (int t = tid; t < WP * PS; t += NT) P[t] = P[FBS + t] = 0.0;  // (rows w .. WP - 1 pad the last tile: never written again)
   __syncthreads();
 
-  double ld_mant = 1.0;
-  long long ld_exp = 0;
+  double ld_mant = 1.0;   // (threads 0 .. NB-1: the product of this lane's 1 / L_KK, see factor_block)
+  int ld_exp = 0;
   // the NB entering columns (their W1 band entries and their right-hand side, entry W1): NT / NB threads per column, no division.
   // What does not change from block to block -- which term has an entry at this thread's distance from the diagonal, and where
   // its row of the band storage starts -- is worked out once: a block then asks for its entries with a compare and a load each.
@@ -228,7 +232,15 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
     }
     int nfail = 0;
     double dkeep = 0.0;
-    DiagStep<0, NB>::run(D, dkeep, nfail, ld_mant, ld_exp, wave == 0);
+    DiagStep<0, NB>::run(D, dkeep, nfail);
+    // log det: lane K of the first wave keeps the running product of its 1 / L_KK over the blocks as mantissa and exponent
+    // (identity padding beyond the chain's end: factors 1); the lanes are put together at the end
+    if (tid < NB) {
+      ld_mant *= __builtin_amdgcn_frexp_mant(dkeep);
+      ld_exp += __builtin_amdgcn_frexp_exp(dkeep);
+      ld_exp += __builtin_amdgcn_frexp_exp(ld_mant);
+      ld_mant = __builtin_amdgcn_frexp_mant(ld_mant);
+    }
     // rows of the block (first wave only; entries on and above the diagonal are never read), rows of the panel, the right-hand side
     double* dst = lane < NB ? (wave == 0 ? Ldn + lane * PS : nullptr) : (frow_i < w ? Pn + frow_i * PS : (f_rhs ? Usn : nullptr));
     if (dst) {
@@ -286,50 +298,41 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
     }
   };
   const int nt = WP / 16;  // tiles per side of the window (<= 8)
-  // block j's columns of the factor to the workspace (lanes along a column's entries) and the tiles (ti >= tj >= 1) of its window
-  // update, by the waves w0 .. NT / 64 - 1
-  // The tiles a wave takes do not change from block to block: up to three pairs, worked out once (wave-uniform, kept in scalar
-  // registers): ti0 | tj0 << 4 | ti1 << 8 | tj1 << 12 | two << 16 | any << 17, rows and columns counted from tile 1
-  const int w0_tiles = ahead ? npw : 0;  // first of the waves that apply block j beside the factorisation of block j + NB
-  int tile_tab[3];
-  {
-    const int nwk = NT / 64 - w0_tiles, wk = wave - w0_tiles, ntiles = nt * (nt - 1) / 2;
-#pragma unroll
-    for (int pr = 0; pr < 3; ++pr) {
-      const int tile = wk + 2 * pr * nwk;
-      int e = 0;
-      if (wk >= 0 && tile < ntiles) {
-        int ti0 = 0, tj0 = tile;
-        while (tj0 > ti0) { tj0 -= ti0 + 1; ++ti0; }
-        const bool two = tile + nwk < ntiles;
-        int ti1 = 0, tj1 = two ? tile + nwk : tile;
-        while (tj1 > ti1) { tj1 -= ti1 + 1; ++ti1; }
-        e = (ti0 + 1) | (tj0 + 1) << 4 | (ti1 + 1) << 8 | (tj1 + 1) << 12 | (two ? 1 << 16 : 0) | 1 << 17;
-      }
-      tile_tab[pr] = __builtin_amdgcn_readfirstlane(e);
-    }
-  }
-  // block j's columns of the factor to the workspace (lanes along a column's entries: 1 / L_jj in the diagonal slot, then the rows
-  // of the block column, which lie one behind the other in LDS) and the tiles (ti >= tj >= 1) of its window update, by the waves
-  // w0_tiles .. NT / 64 - 1
-  auto store_and_tiles = [&](const int64_t j, const int nb, const int slot0, const int cur) {
-    const int nwk = NT / 64 - w0_tiles, wk = wave - w0_tiles;
+  // What is left of block j once block j + NB can be factorised -- the tiles (ti >= tj >= 1) of its window update, two at a time,
+  // and its columns of the factor, to be written to the workspace (lanes along a column's entries: 1 / L_jj in the diagonal slot,
+  // then the rows of the block column, which lie one behind the other in LDS) -- is a list of items the waves TAKE from a
+  // counter in LDS: the waves that factorise join when they are done, and nobody waits for the slowest share.  The items touch
+  // disjoint entries: who takes which does not change a bit of the result.
+  int* const q_next = (int*)(misc + 66);
+  auto drain_items = [&](const int64_t j, const int nb, const int slot0, const int cur) {
+    const int ntiles = nt * (nt - 1) / 2, n_tile_items = (ntiles + 1) / 2, n_items = n_tile_items + (nb + 1) / 2;
     const int ld_at = (int)(Ld - ring) + cur * FBS, dv_at = (int)(dv - ring) + cur * FBS;
-    for (int b = wk; b < nb; b += nwk) {
-      double* col = Lc + (j + b) * W1;
-      for (int d = lane; d < W1; d += 64) {
-        const int row = b + d;
-        const bool ok = row < nb || (row >= NB && row - NB < w);
-        col[d] = ring[d == 0 ? dv_at + b : (ok ? ld_at + row * PS + b : zero_at)];
-      }
-    }
     const double* Pc = P + cur * FBS;
-#pragma unroll
-    for (int pr = 0; pr < 3; ++pr) {
-      const int e = tile_tab[pr];
-      if (e >> 17) {
-        if ((e >> 16) & 1) window_tiles(std::true_type{}, j, slot0, Pc, e & 15, (e >> 4) & 15, (e >> 8) & 15, (e >> 12) & 15);
-        else window_tiles(std::false_type{}, j, slot0, Pc, e & 15, (e >> 4) & 15, (e >> 8) & 15, (e >> 12) & 15);
+    for (;;) {
+      int it = 0;
+      if (lane == 0) it = atomicAdd(q_next, 1);
+      it = __builtin_amdgcn_readfirstlane(it);
+      if (it >= n_items) break;
+      if (it < n_tile_items) {
+        int ti0 = 0, tj0 = 2 * it;
+        while (tj0 > ti0) { tj0 -= ti0 + 1; ++ti0; }
+        if (2 * it + 1 < ntiles) {
+          int ti1 = ti0, tj1 = tj0 + 1;   // the tile after (ti0, tj0) in the same order
+          if (tj1 > ti1) { ++ti1; tj1 = 0; }
+          window_tiles(std::true_type{}, j, slot0, Pc, ti0 + 1, tj0 + 1, ti1 + 1, tj1 + 1);
+        } else {
+          window_tiles(std::false_type{}, j, slot0, Pc, ti0 + 1, tj0 + 1, ti0 + 1, tj0 + 1);
+        }
+      } else {
+        const int b0 = 2 * (it - n_tile_items);
+        for (int b = b0; b < b0 + 2 && b < nb; ++b) {
+          double* col = Lc + (j + b) * W1;
+          for (int d = lane; d < W1; d += 64) {
+            const int row = b + d;
+            const bool ok = row < nb || (row >= NB && row - NB < w);
+            col[d] = ring[d == 0 ? dv_at + b : (ok ? ld_at + row * PS + b : zero_at)];
+          }
+        }
       }
     }
   };
@@ -389,11 +392,12 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
       }
       // (the block's forward-substituted right-hand side: overwritten by the draw in the backward pass)
       if (tid >= NT - 64 && lane < nb) xc[j + lane] = Usc[lane];
-      if (!ahead) store_and_tiles(j, nb, slot0, cur);
+      if (!ahead) drain_items(j, nb, slot0, cur);
       lds_barrier_w();
       WSTAMP(2);
       if (!ahead) {
         BAND_REFILL();
+        if (tid == 0) *q_next = 0;
         lds_barrier_w();
         WSTAMP(4);
       }
@@ -407,16 +411,14 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
     }
     // ---- S3: block j + NB factorised by the first waves, beside the rest of block j's work on the others
     const unsigned long long tw0 = dbg ? __builtin_readcyclecounter() : 0;
-    if (wave < npw) {
-      if (j + NB < n) factor_block(j + NB, slot1, P + nxt * FBS, Ld + nxt * FBS, dv + nxt * FBS, Us + nxt * FBS);
-    } else if (ahead && apply) {
-      store_and_tiles(j, nb, slot0, cur);
-    }
+    if (wave < npw && j + NB < n) factor_block(j + NB, slot1, P + nxt * FBS, Ld + nxt * FBS, dv + nxt * FBS, Us + nxt * FBS);
+    if (ahead && apply) drain_items(j, nb, slot0, cur);
     if (dbg) twork += __builtin_readcyclecounter() - tw0;   // (this wave's own work in S3, without the wait at the barrier)
     lds_barrier_w();
     WSTAMP(3);
     if (ahead && apply) {
       BAND_REFILL();
+      if (tid == 0) *q_next = 0;
       lds_barrier_w();
       WSTAMP(4);
     }
@@ -425,9 +427,16 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   }
 #undef BAND_REFILL
   const bool failed = misc[0] != 0.0;
-  if (tid == 0) {
-    if (logdet) logdet[c] = log(ld_mant) + (double)ld_exp * 0.69314718055994530942;
-    if (failed) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+  if (wave == 0) {
+    // log det Q = -2 sum log(1 / L_KK): the lanes' shares in lane order
+    const double share = (lane < NB) ? log(ld_mant) + (double)ld_exp * 0.69314718055994530942 : 0.0;
+    double total = 0.0;
+#pragma unroll
+    for (int K = 0; K < NB; ++K) total += readlane_d(share, K);
+    if (tid == 0) {
+      if (logdet) logdet[c] = -2.0 * total;
+      if (failed) atomicMin((unsigned long long*)bad, (unsigned long long)c);
+    }
   }
   __syncthreads();
   if (failed) {
@@ -684,7 +693,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
 // LDS bytes of a block size NB at bandwidth w (the factor phase is the larger one)
 static size_t blocked_lds(int w, int NB) {
   const size_t W1 = (size_t)w + 1, WS = (size_t)w + NB, WP = ((size_t)w + 15) & ~(size_t)15, PS = (size_t)NB + 1;
-  return (WS * W1 + WS + 2 * (WP * PS + (size_t)NB * PS + 2 * (size_t)NB) + 2 + 64) * sizeof(double);
+  return (WS * W1 + WS + 2 * (WP * PS + (size_t)NB * PS + 2 * (size_t)NB) + 2 + 64 + 2) * sizeof(double);
 }
 
 // terms: omc_band.hip's BandTermsDev (the same layout as BandTermsW above); Lws: [C][n][w + 1] doubles.  Returns false if no block

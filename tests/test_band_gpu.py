@@ -407,6 +407,29 @@ def test_blocked_wide_band_kernel_four_terms(w, n, algo):
     eng.close()
 
 
+def test_blocked_wide_band_kernel_repeats_itself_bit_for_bit():
+    """The waves of the blocked kernel take their shares of a block's window update from a counter (who takes which differs from
+    run to run) and the backward pass sums through LDS: the orders of summation are fixed all the same, so a repeated call
+    returns the same bits -- draw, mean and log det."""
+    rng = np.random.default_rng(77)
+    n, w, C = 700, 100, 6
+    eng = make_engine(C)
+    M = random_band_spd(n, w, rng)
+    terms = [{"band": eng.to_device(band_of(M, w)), "scale": eng.to_device(rng.random(C) + 0.5)},
+             {"rhs": eng.to_device(rng.standard_normal(n)), "scale": eng.to_device(rng.random(C) + 0.5)}]
+    z, extra = eng.to_device(rng.standard_normal((C, n))), eng.to_device(rng.standard_normal((C, n)))
+    out = []
+    for rep in range(4):
+        x, mu, ld = eng.empty(C, n), eng.empty(C, n), eng.empty(C)
+        eng.band_sample_canonical(n, terms, x, z=z, rhs_chain=extra, mean_out=mu, logdet_out=ld)
+        eng.check_status()
+        out.append((x.cpu().numpy(), mu.cpu().numpy(), ld.cpu().numpy()))
+    for rep in range(1, 4):
+        for a, b in zip(out[0], out[rep]):
+            assert np.array_equal(a, b)
+    eng.close()
+
+
 def test_blocked_wide_band_kernel_latches_a_failed_chain_and_draws_in_kernel():
     n, w, C = 300, 40, 3
     rng = np.random.default_rng(5)
