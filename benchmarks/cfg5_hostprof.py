@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=None)
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--no-cpu", action="store_true", default=True)
     args = ap.parse_args()
     torch.cuda.set_device(0)
     torch.cuda.set_stream(torch.cuda.Stream())

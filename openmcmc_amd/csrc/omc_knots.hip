@@ -100,49 +100,89 @@ __global__ void __launch_bounds__(KN_THREADS) k_knot_loop(int64_t C, int64_t n, 
   double* thc = theta + c * kmax;
   double* sp = sm;
   double* sb = sm + 4 * kmax;
+  int* live = (int*)(sm + 5 * kmax);   // the columns with a non-zero coefficient, in order; live[kmax]: how many
   for (int e = tid; e < 4 * k_live; e += KN_THREADS) sp[e] = prop[4 * c * kmax + e];
   for (int e = tid; e < (int)kmax; e += KN_THREADS) sb[e] = beta[c * kmax + e];
   __syncthreads();
+  if (tid == 0) {
+    int nl = 0;
+    for (int j = 0; j < (int)kmax; ++j)
+      if (sb[j] != 0.0) live[nl++] = j;
+    live[kmax] = nl;
+  }
+  __syncthreads();
   const bool unit = scale0 == 1.0;
+  // Every load below is unconditional: a thread whose row lies beyond n reads row n - 1 and drops the value.  (A load under
+  // `if (i < n)` is a branch with the wait for its data inside: the NR rows of a column, then the columns, then y, the offsets,
+  // the weights and X came in one memory round trip after the other -- some forty of them before the first step.)
+  int ic[NR];
+  bool in[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    const int i = tid + q * KN_THREADS;
+    in[q] = i < (int)n;
+    ic[q] = in[q] ? i : (int)n - 1;
+  }
 
   // residual and quadratic form of the current state -- k_design_resid_sq's arithmetic: columns in order, zero
-  // coefficients skipped
+  // coefficients skipped (CH columns in flight at a time; a chunk's last columns may repeat the last live one with a zero
+  // coefficient, which leaves the sums as they are)
   constexpr bool LEAN = NR > 5;
   constexpr int NK = LEAN ? 1 : NR;
+  constexpr int CH = LEAN ? 1 : 4;
   double r[NR], x[NK], wt[NK];
   double acc = 0.0;
 #pragma unroll
   for (int q = 0; q < NR; ++q) r[q] = 0.0;
-  for (int64_t j = 0; j < kmax; ++j) {  // column by column (the branch is uniform): NR independent loads per column
-    const double cf = sb[j];
-    if (cf != 0.0) {
+  const int n_live_cols = live[kmax];
+  for (int t = 0; t < n_live_cols; t += CH) {
+    double v[CH][NR], cf[CH];
 #pragma unroll
-      for (int q = 0; q < NR; ++q) {
-        const int64_t i = tid + (int64_t)q * KN_THREADS;
-        if (i < n) r[q] = fma(Bc[j * n + i], cf, r[q]);
-      }
+    for (int u = 0; u < CH; ++u) {
+      const bool have = t + u < n_live_cols;
+      const int j = live[have ? t + u : n_live_cols - 1];
+      cf[u] = have ? sb[j] : 0.0;
+      const double* colj = Bc + (int64_t)j * n;
+#pragma unroll
+      for (int q = 0; q < NR; ++q) v[u][q] = colj[ic[q]];
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+#pragma unroll
+      for (int q = 0; q < NR; ++q) r[q] = fma(v[u][q], cf[u], r[q]);
     }
   }
 #pragma unroll
-  for (int q = 0; q < NR; ++q) {
-    const int64_t i = tid + (int64_t)q * KN_THREADS;
-    if (!LEAN) { x[q] = 0.0; wt[q] = 0.0; }
-    if (i < n) {
-      const double f = r[q] + (add_chain ? add_chain[c * n + i] : 0.0) + (add_shared ? add_shared[i] : 0.0);
-      r[q] = y[i] - f;
-      const double wq = w ? w[i] : 1.0;
-      if (!LEAN) { x[q] = X[i]; wt[q] = wq; }
-      acc = fma(wq * r[q], r[q], acc);
-    } else {
-      r[q] = 0.0;
+  for (int g = 0; g < NR; g += 5) {  // five rows' loads in flight at a time (registers)
+    double yv[5], av[5], sv[5], wv[5], xv[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int q = g + u;
+      yv[u] = y[ic[q]];
+      av[u] = add_chain ? add_chain[c * n + ic[q]] : 0.0;
+      sv[u] = add_shared ? add_shared[ic[q]] : 0.0;
+      wv[u] = w ? w[ic[q]] : 1.0;
+      xv[u] = LEAN ? 0.0 : X[ic[q]];
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int q = g + u;
+      if (!LEAN) { x[q] = in[q] ? xv[u] : 0.0; wt[q] = in[q] ? wv[u] : 0.0; }
+      if (in[q]) {
+        const double f = r[q] + av[u] + sv[u];
+        r[q] = yv[u] - f;
+        acc = fma(wv[u] * r[q], r[q], acc);
+      } else {
+        r[q] = 0.0;
+      }
     }
   }
   double cn[NK];  // the current column of the step about to run
   if (!LEAN) {
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
-      const int64_t i = tid + (int64_t)q * KN_THREADS;
-      cn[q] = (k_live > 0 && i < n) ? Bc[i] : 0.0;
+      const double v0 = Bc[ic[q]];
+      cn[q] = (k_live > 0 && in[q]) ? v0 : 0.0;
     }
   }
   double quad = kn_block_sum(acc, red, tid);
@@ -155,23 +195,33 @@ __global__ void __launch_bounds__(KN_THREADS) k_knot_loop(int64_t C, int64_t n, 
     double pn[NR], rn[NK];
     acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < NR; ++q) {
-      const int64_t i = tid + (int64_t)q * KN_THREADS;
-      pn[q] = 0.0;
-      if (!LEAN) rn[q] = 0.0;
-      if (i < n) {
-        pn[q] = kn_basis(LEAN ? X[i] : x[q], z, scale0, unit);
-        const double rq = fma(-bj, pn[q] - (LEAN ? col[i] : cn[q]), r[q]);
-        if (!LEAN) rn[q] = rq;
-        acc = fma((LEAN ? (w ? w[i] : 1.0) : wt[q]) * rq, rq, acc);
+    for (int g = 0; g < NR; g += 5) {
+      // (the lean form re-reads X, the column and the weights every step: unconditional loads, five rows in flight at a time)
+      double xq[5], cq[5], wq[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int q = g + u;
+        xq[u] = LEAN ? X[ic[q]] : x[q];
+        cq[u] = LEAN ? col[ic[q]] : cn[q];
+        wq[u] = LEAN ? (w ? w[ic[q]] : 1.0) : wt[q];
+      }
+      if (LEAN) asm volatile("" ::: "memory");  // (keeps the next five rows' loads behind this group's arithmetic)
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int q = g + u;
+        pn[q] = 0.0;
+        if (!LEAN) rn[q] = 0.0;
+        if (in[q]) {
+          pn[q] = kn_basis(xq[u], z, scale0, unit);
+          const double rq = fma(-bj, pn[q] - cq[u], r[q]);
+          if (!LEAN) rn[q] = rq;
+          acc = fma(wq[u] * rq, rq, acc);
+        }
       }
     }
     if (!LEAN && j + 1 < k_live) {  // next step's column: in flight under the reduction
 #pragma unroll
-      for (int q = 0; q < NR; ++q) {
-        const int64_t i = tid + (int64_t)q * KN_THREADS;
-        if (i < n) cn[q] = col[n + i];
-      }
+      for (int q = 0; q < NR; ++q) cn[q] = col[n + ic[q]];
     }
     const double quad_n = kn_block_sum(acc, red, tid);
     const double la = (-0.5 * tc * quad_n) + sp[4 * j + 2] - ((-0.5 * tc * quad) + sp[4 * j + 1]);
@@ -183,10 +233,9 @@ __global__ void __launch_bounds__(KN_THREADS) k_knot_loop(int64_t C, int64_t n, 
     if (ok) {
 #pragma unroll
       for (int q = 0; q < NR; ++q) {
-        const int64_t i = tid + (int64_t)q * KN_THREADS;
-        if (i < n) {
-          r[q] = LEAN ? fma(-bj, pn[q] - col[i], r[q]) : rn[q];  // (the value the sum above was taken over)
-          col[i] = pn[q];
+        if (in[q]) {
+          r[q] = LEAN ? fma(-bj, pn[q] - col[ic[q]], r[q]) : rn[q];  // (the value the sum above was taken over)
+          col[ic[q]] = pn[q];
         }
       }
       if (tid == 0) thc[j] = z;
@@ -210,7 +259,7 @@ extern "C" omc_status omc_knot_loop(omc_ctx* ctx, int64_t n, int64_t kmax, const
       !(lower < upper))
     return OMC_INVALID_ARG;
   const int64_t rows = (n + KN_THREADS - 1) / KN_THREADS;
-  const size_t lds = (size_t)(5 * kmax) * sizeof(double);
+  const size_t lds = (size_t)(5 * kmax) * sizeof(double) + (size_t)(kmax + 2) * sizeof(int);  // + the list of live columns
   if (rows > 10 || lds > 32 * 1024) return OMC_INVALID_ARG;  // the chain's residual lives in registers: n <= 10 240
   OMC_HIP_CHECK(hipSetDevice(ctx->device));
   const int64_t Cn = ctx->n_chains;
