@@ -137,3 +137,52 @@ def test_spectral_route_at_cfg2_size_has_the_factorisation_routes_conditional_la
     assert abs(np.mean(W[:, 1:] * W[:, :-1])) < 5.0 / np.sqrt(m)
     assert abs(np.mean(W[:, :, 1:] * W[:, :, :-1])) < 5.0 / np.sqrt(m)
     eng.close()
+
+
+def test_lattice_gmrf_at_full_size_solves_its_system_on_both_band_kernels():
+    """SURVEY section 8f rank 1 at its size: a 100 x 100 lattice GMRF (10 000 nodes, bandwidth 100; gmrf.py:489-520 on a sparse
+    precision of that shape), Q_c = lambda_c (L + kappa I) + tau_c I, a few chains.  Size-independent properties of the draw
+    through the blocked kernel (omc_bandwide.hip): the mean solves Q_c mu_c = b_c, an injected z = 0 returns the mean itself, the
+    draw minus the mean solves L' d = z (so Q d = L z has the right norm relation d' Q d = z' z), and mean, draw and log det
+    agree with the column-at-a-time kernel."""
+    from scipy import sparse
+
+    from openmcmc_amd.engine import Engine
+
+    R = K = 100
+    n, w, C = R * K, K, 5
+    rng = np.random.default_rng(11)
+    # 5-point Laplacian of the lattice in row-major order: bandwidth K
+    ex, ey = np.ones(K), np.ones(R)
+    Tx = sparse.diags([-ex[:-1], 2 * ex, -ex[:-1]], [-1, 0, 1])
+    Ty = sparse.diags([-ey[:-1], 2 * ey, -ey[:-1]], [-1, 0, 1])
+    Lap = (sparse.kron(sparse.identity(R), Tx) + sparse.kron(Ty, sparse.identity(K)) + 0.05 * sparse.identity(n)).tocsc()
+    band = np.zeros((w + 1, n))
+    for d in range(w + 1):
+        band[d, : n - d] = Lap.diagonal(-d)
+    lam, tau = 1.0 + rng.random(C), 0.5 + rng.random(C)
+    y = rng.standard_normal(n)
+    z = rng.standard_normal((C, n))
+    eng = Engine(C, seed=4)
+    terms = [{"band": eng.to_device(band), "scale": eng.to_device(lam)}, {"rhs": eng.to_device(y), "scale": eng.to_device(tau)}]
+    out = {}
+    for algo in (3, 2):
+        eng.set_option("band_algo", algo)
+        x, mu, ld, x0 = eng.empty(C, n), eng.empty(C, n), eng.empty(C), eng.empty(C, n)
+        eng.band_sample_canonical(n, terms, x, z=eng.to_device(z), mean_out=mu, logdet_out=ld)
+        eng.band_sample_canonical(n, terms, x0, z=eng.to_device(np.zeros((C, n))))
+        eng.check_status()
+        out[algo] = (x.cpu().numpy(), mu.cpu().numpy(), ld.cpu().numpy(), x0.cpu().numpy())
+    xb, mb, lb, x0b = out[3]
+    xo, mo, lo, _ = out[2]
+    assert np.array_equal(x0b, mb)                                           # z = 0: the draw is the mean, bit for bit
+    for c in range(C):
+        Q = lam[c] * Lap + tau[c] * sparse.identity(n)
+        b = tau[c] * y
+        assert np.max(np.abs(Q @ mb[c] - b)) < 1e-10 * np.max(np.abs(b))      # Q mu = b
+        d = xb[c] - mb[c]
+        assert abs(d @ (Q @ d) - z[c] @ z[c]) < 1e-10 * (z[c] @ z[c])         # d = L^-T z  =>  d' Q d = z' z
+    scale = np.max(np.abs(xo))
+    assert np.max(np.abs(xb - xo)) < 1e-11 * scale and np.max(np.abs(mb - mo)) < 1e-11 * scale
+    assert np.max(np.abs(lb - lo)) < 1e-12 * np.max(np.abs(lo))
+    eng.close()
