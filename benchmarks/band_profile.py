@@ -23,6 +23,8 @@ from openmcmc_amd.engine import Engine
 n, C = a.n, a.chains
 eng = Engine(C, seed=2)
 eng.set_option("band_algo", a.algo)
+if os.environ.get("OMC_BLOCKED_THREADS", "0") not in ("", "0"):
+    eng.set_option("band_blocked_threads", int(os.environ["OMC_BLOCKED_THREADS"]))
 if a.segments:
     eng.set_option("band_seg_count", a.segments)
 if a.overlap:

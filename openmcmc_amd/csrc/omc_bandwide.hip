@@ -114,7 +114,7 @@ template <int NB, int NT, int MT>
 __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_offset, int64_t n, int w, BandTermsW T, const double* rhs_chain,
                                                       int64_t ld_rhs, const double* z_in, int64_t ld_z, omc_rng_key key, double* Lws, double* x,
                                                       int64_t ld_x, double* mean, int64_t ld_mean, double* logdet, long long* bad, unsigned long long* dbg) {
-  static_assert(NT == 512, "eight waves: one per tile of the window's first tile column");
+  static_assert(NT == 512 || NT == 256, "eight waves: one per tile of the window's first tile column; four for bands up to 15");
   extern __shared__ double sm[];
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter(), twork = 0, tback = 0;
 #define WSTAMP(i) do { if (dbg) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; } } while (0)
@@ -159,7 +159,8 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   // What does not change from block to block -- which term has an entry at this thread's distance from the diagonal, and where
   // its row of the band storage starts -- is worked out once: a block then asks for its entries with a compare and a load each.
   constexpr int TPC = NT / NB;                                   // threads per column
-  constexpr int WMAX_NB = (NB == 16) ? BAND_W16_MAX : BAND_WMAX_W;  // widest band this block size is launched for
+  // widest band this instantiation is launched for (the four-wave form: bands narrower than a block, several workgroups per CU)
+  constexpr int WMAX_NB = (NT == 256) ? 15 : ((NB == 16) ? BAND_W16_MAX : BAND_WMAX_W);
   constexpr int NPRE = (WMAX_NB + 2 + TPC - 1) / TPC;             // entries per thread
   const int pcol = tid / TPC, pq = tid % TPC;                    // (NB is a power of two: shifts)
   const double* pbase[NPRE][MT];                      // term k's row d of the band (or its right-hand side), NULL: no entry
@@ -475,7 +476,7 @@ __global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_of
   double* Lb = Sm + NB;        // NB x PS: the block's own triangle of the factor, Lb[a][b] = L[j+a][j+b], a > b; dinv on the diagonal
   constexpr int TPF = (NT - 64) / NB;   // threads per column for the far rows
   constexpr int QPC = TPF / 4;          // their quads per column
-  constexpr int NPF = (WMAX_NB - NB + TPF - 1) / TPF;  // far entries per thread (d = 2 NB - b .. w: at most w - NB of them, b = NB - 1)
+  constexpr int NPF = (WMAX_NB > NB) ? (WMAX_NB - NB + TPF - 1) / TPF : 1;  // far entries per thread (d = 2 NB - b .. w: at most w - NB of them, b = NB - 1)
   constexpr int LPC = 64 / NB;          // lanes of wave 0 per column for the block's own and the near rows
   constexpr int KN = 2 * NB / LPC;      // entries per lane there (d = 0 .. 2 NB - 1 - b)
   static_assert(TPF % 4 == 0 && TPF * NB == NT - 64, "quads of far threads do not straddle columns");
@@ -706,18 +707,24 @@ bool omc_band_blocked_launch(omc_ctx* ctx, int64_t n, int w, const void* terms, 
   memcpy(&T, terms, sizeof(T));
   const size_t limit = 160 * 1024;
   const bool few = T.n_terms <= 2;
-#define OMC_BLOCKED_LAUNCH(NB_, MT_)                                                                                                  \
-  hipLaunchKernelGGL((k_band_blocked<NB_, 512, MT_>), dim3((unsigned)ctx->n_chains), dim3(512), blocked_lds(w, NB_), ctx->stream,      \
+#define OMC_BLOCKED_LAUNCH(NB_, NT_, MT_)                                                                                             \
+  hipLaunchKernelGGL((k_band_blocked<NB_, NT_, MT_>), dim3((unsigned)ctx->n_chains), dim3(NT_), blocked_lds(w, NB_), ctx->stream,      \
                      ctx->n_chains, ctx->chain_offset, n, w, T, rhs_chain, ld_rhs, z_inject, ld_z, key, Lws, x, ld_x, mean, ld_mean,  \
                      logdet, ctx->d_bad_chain, ctx->stamps)
+  if (w <= 15 && ctx->band_blocked_threads != 512) {
+    // bands narrower than a block: four waves do (one tile, one factorising wave), and a CU takes several workgroups
+    if (few) OMC_BLOCKED_LAUNCH(16, 256, 2);
+    else OMC_BLOCKED_LAUNCH(16, 256, OMC_MAX_TERMS);
+    return true;
+  }
   if (w <= BAND_W16_MAX && blocked_lds(w, 16) <= limit) {
-    if (few) OMC_BLOCKED_LAUNCH(16, 2);
-    else OMC_BLOCKED_LAUNCH(16, OMC_MAX_TERMS);
+    if (few) OMC_BLOCKED_LAUNCH(16, 512, 2);
+    else OMC_BLOCKED_LAUNCH(16, 512, OMC_MAX_TERMS);
     return true;
   }
   if (blocked_lds(w, 8) <= limit) {
-    if (few) OMC_BLOCKED_LAUNCH(8, 2);
-    else OMC_BLOCKED_LAUNCH(8, OMC_MAX_TERMS);
+    if (few) OMC_BLOCKED_LAUNCH(8, 512, 2);
+    else OMC_BLOCKED_LAUNCH(8, 512, OMC_MAX_TERMS);
     return true;
   }
 #undef OMC_BLOCKED_LAUNCH

@@ -71,7 +71,7 @@ omc_status omc_ctx_create(int32_t device, int64_t n_chains, uint64_t seed, int64
   c->gram_use_rocblas = 0;
   c->mh_use_rocblas = 0;
   c->mh_gemm_ksplit = 4;
-  c->band_algo = 0; c->band_seg_overlap = 192; c->band_seg_count = 0;
+  c->band_algo = 0; c->band_seg_overlap = 192; c->band_seg_count = 0; c->band_blocked_threads = 0;
   if (c->own_stream) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { omc_set_error("hipStreamCreate", e); delete c; return OMC_HIP_ERROR; }
@@ -273,6 +273,11 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "band_seg_count")) {
     if (value < 0 || value == 1 || value > 128) return OMC_INVALID_ARG;
     ctx->band_seg_count = (int)value;
+    return OMC_OK;
+  }
+  if (!strcmp(name, "band_blocked_threads")) {
+    if (value != 0 && value != 512) return OMC_INVALID_ARG;
+    ctx->band_blocked_threads = (int)value;
     return OMC_OK;
   }
   if (!strcmp(name, "mh_gemm_ksplit")) {
