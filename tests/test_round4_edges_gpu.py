@@ -138,3 +138,32 @@ def test_truncated_scan_at_edge_sizes(n, C):
             xr[i] = stats.truncnorm.ppf(u[c, i], al, be) * sd + mean
         assert relerr(got[c], xr) < 1e-9, c
     eng.close()
+
+
+@pytest.mark.parametrize("n,w", [(1, 1), (2, 1), (3, 2), (5, 4), (5, 9), (8, 12), (17, 16), (33, 40), (16, 15), (32, 31), (48, 5)])
+@pytest.mark.parametrize("algo", [0, 3])
+def test_band_draw_on_chains_shorter_than_the_band(n, w, algo):
+    """Declared bandwidths up to and beyond n - 1 (a dense matrix in band storage), lengths of one block and one more, on the
+    automatic choice of kernel and on the blocked one: draw and log det against a dense Cholesky factor."""
+    from openmcmc_amd.engine import Engine
+
+    rng = np.random.default_rng(1000 * n + w)
+    A = rng.standard_normal((n, n))
+    M = A @ A.T
+    M[np.abs(np.subtract.outer(np.arange(n), np.arange(n))) > w] = 0.0
+    M += (np.abs(M).sum(1).max() + 1.0) * np.eye(n)
+    band = np.zeros((w + 1, n))
+    for d in range(min(w, n - 1) + 1):
+        band[d, : n - d] = np.diag(M, -d)
+    C = 3
+    eng = Engine(C, seed=1)
+    eng.set_option("band_algo", algo)
+    z, b = rng.standard_normal((C, n)), rng.standard_normal(n)
+    x, ld = eng.empty(C, n), eng.empty(C)
+    eng.band_sample_canonical(n, [{"band": eng.to_device(band), "rhs": eng.to_device(b)}], x, z=eng.to_device(z), logdet_out=ld)
+    eng.check_status()
+    L = np.linalg.cholesky(M)
+    want = np.linalg.solve(L.T, np.linalg.solve(L, b)[:, None] + z.T).T
+    assert np.max(np.abs(x.cpu().numpy() - want)) < 1e-12 * max(1.0, np.abs(want).max())
+    assert np.max(np.abs(ld.cpu().numpy() - 2 * np.log(np.diag(L)).sum())) < 1e-11 * max(1.0, abs(2 * np.log(np.diag(L)).sum()))
+    eng.close()
