@@ -110,8 +110,9 @@ struct DiagStep<NB, NB> {
 typedef double wide_d4 __attribute__((ext_vector_type(4)));
 
 // MT: the number of terms the kernel is compiled for (2 covers most models: their entries a block ahead are half the registers)
-template <int NB, int NT, int MT>
-__global__ void __launch_bounds__(NT) k_band_blocked(int64_t C, int64_t chain_offset, int64_t n, int w, BandTermsW T, const double* rhs_chain,
+// WPE: waves per SIMD the register allocation leaves room for (4: 128 registers -- two 512-thread or four 256-thread workgroups on a CU)
+template <int NB, int NT, int MT, int WPE>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) k_band_blocked(int64_t C, int64_t chain_offset, int64_t n, int w, BandTermsW T, const double* rhs_chain,
                                                       int64_t ld_rhs, const double* z_in, int64_t ld_z, omc_rng_key key, double* Lws, double* x,
                                                       int64_t ld_x, double* mean, int64_t ld_mean, double* logdet, long long* bad, unsigned long long* dbg) {
   static_assert(NT == 512 || NT == 256, "eight waves: one per tile of the window's first tile column; four for bands up to 15");
@@ -707,24 +708,39 @@ bool omc_band_blocked_launch(omc_ctx* ctx, int64_t n, int w, const void* terms, 
   memcpy(&T, terms, sizeof(T));
   const size_t limit = 160 * 1024;
   const bool few = T.n_terms <= 2;
-#define OMC_BLOCKED_LAUNCH(NB_, NT_, MT_)                                                                                             \
-  hipLaunchKernelGGL((k_band_blocked<NB_, NT_, MT_>), dim3((unsigned)ctx->n_chains), dim3(NT_), blocked_lds(w, NB_), ctx->stream,      \
+#define OMC_BLOCKED_LAUNCH(NB_, NT_, MT_, WPE_)                                                                                       \
+  hipLaunchKernelGGL((k_band_blocked<NB_, NT_, MT_, WPE_>), dim3((unsigned)ctx->n_chains), dim3(NT_), blocked_lds(w, NB_), ctx->stream,      \
                      ctx->n_chains, ctx->chain_offset, n, w, T, rhs_chain, ld_rhs, z_inject, ld_z, key, Lws, x, ld_x, mean, ld_mean,  \
                      logdet, ctx->d_bad_chain, ctx->stamps)
-  if (w <= 15 && ctx->band_blocked_threads != 512) {
-    // bands narrower than a block: four waves do (one tile, one factorising wave), and a CU takes several workgroups
-    if (few) OMC_BLOCKED_LAUNCH(16, 256, 2);
-    else OMC_BLOCKED_LAUNCH(16, 256, OMC_MAX_TERMS);
+  // Which form, by what fits a CU (measured on 10 000-node lattices, profiles/r04q_band.txt):
+  //  * bands narrower than a block take four waves per chain (one tile, one factorising wave); with more chains than three
+  //    workgroups per CU hold, the form compiled for 128 registers puts four there (1024 chains at w = 8: 8.0 -> 4.6 ms);
+  //  * bands up to ~64 on more chains than CUs: 8 columns per step at 128 registers, two workgroups to a CU (1024 chains at
+  //    w = 32: 15.6 -> 11.1 ms; slower where one workgroup per CU is all there is: 3.9 -> 4.9 ms at 256 chains);
+  //  * otherwise 16 columns per step, eight waves, one workgroup per CU (8 columns where the window would not fit the LDS).
+  // "band_blocked_threads": 0 this choice; 512 eight waves and no register limit whatever the shape; 4 / 8 the two 128-register
+  // forms wherever they apply (A/B runs and tests).  Only the forms compiled for two terms have the 128-register variants.
+  int dev_cus = 256;
+  hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  const int forced = ctx->band_blocked_threads;
+  if (w <= 15 && forced != 512 && forced != 8) {
+    if (few && (forced == 4 || (forced == 0 && ctx->n_chains > 3 * (int64_t)dev_cus))) OMC_BLOCKED_LAUNCH(16, 256, 2, 4);
+    else if (few) OMC_BLOCKED_LAUNCH(16, 256, 2, 1);
+    else OMC_BLOCKED_LAUNCH(16, 256, OMC_MAX_TERMS, 1);
+    return true;
+  }
+  if (few && 2 * blocked_lds(w, 8) <= limit && (forced == 8 || (forced == 0 && ctx->n_chains > (int64_t)dev_cus))) {
+    OMC_BLOCKED_LAUNCH(8, 512, 2, 4);
     return true;
   }
   if (w <= BAND_W16_MAX && blocked_lds(w, 16) <= limit) {
-    if (few) OMC_BLOCKED_LAUNCH(16, 512, 2);
-    else OMC_BLOCKED_LAUNCH(16, 512, OMC_MAX_TERMS);
+    if (few) OMC_BLOCKED_LAUNCH(16, 512, 2, 1);
+    else OMC_BLOCKED_LAUNCH(16, 512, OMC_MAX_TERMS, 1);
     return true;
   }
   if (blocked_lds(w, 8) <= limit) {
-    if (few) OMC_BLOCKED_LAUNCH(8, 512, 2);
-    else OMC_BLOCKED_LAUNCH(8, 512, OMC_MAX_TERMS);
+    if (few) OMC_BLOCKED_LAUNCH(8, 512, 2, 1);
+    else OMC_BLOCKED_LAUNCH(8, 512, OMC_MAX_TERMS, 1);
     return true;
   }
 #undef OMC_BLOCKED_LAUNCH

@@ -66,7 +66,7 @@ struct omc_ctx {
   int band_algo;  // 0 auto, 1 lane-per-chain in one piece (narrow bands), 2 workgroup-per-chain
   int band_seg_overlap;  // segmented lane kernel: columns of warm-up before a segment (default 192)
   int band_seg_count;    // segmented lane kernel: number of segments (0 = chosen for the SIMDs; tuning and tests)
-  int band_blocked_threads;  // blocked band kernel on bands narrower than a block: 0 = four waves per chain, 512 = eight (A/B)
+  int band_blocked_threads;  // blocked band kernel: 0 = form chosen by what fits a CU; 512, 4, 8 force one (A/B, tests; omc_bandwide.hip)
   int mh_gemm_ksplit;  // omc_dgemm_small: groups of four waves per workgroup cutting the contraction (1, 2 or 4)
   int mh_use_rocblas;  // 1: the products of the fused Metropolis-Hastings steps through rocBLAS DGEMM instead of omc_dgemm_small (cross-checks)
   int gram_use_rocblas;  // 1: X' diag(w) X through rocBLAS (scaled copy of X + DGEMM) instead of the own MFMA kernel (cross-checks)

@@ -407,6 +407,33 @@ def test_blocked_wide_band_kernel_four_terms(w, n, algo):
     eng.close()
 
 
+@pytest.mark.parametrize("w,n,form", [(5, 130, 4), (12, 333, 4), (15, 48, 4), (9, 200, 8), (20, 400, 8), (40, 95, 8), (64, 200, 8), (16, 17, 8),
+                                      (12, 333, 512), (64, 200, 512)])
+def test_blocked_wide_band_kernel_forms_for_many_chains(w, n, form):
+    """The forms of the blocked kernel the library picks when there are more chains than CUs -- four waves per chain at 128
+    registers (bands narrower than a block), 8 columns per step at 128 registers (bands up to ~64) -- and the one-workgroup-per-CU
+    form, each forced: against the oracle, and against the column-at-a-time kernel."""
+    rng = np.random.default_rng(7 * w + n + form)
+    C = 5
+    eng = make_engine(C)
+    eng.set_option("band_algo", 3)
+    eng.set_option("band_blocked_threads", form)
+    for per_chain in (True, False):
+        worst = check_case(eng, random_band_spd(n, w, rng), w, rng, C, per_chain_rhs=per_chain)
+        assert worst < RTOL, (worst, per_chain)
+    M = random_band_spd(n, w, rng)
+    band = eng.to_device(band_of(M, w))
+    z = eng.to_device(rng.standard_normal((C, n)))
+    a, b, la, lb = eng.empty(C, n), eng.empty(C, n), eng.empty(C), eng.empty(C)
+    eng.band_sample_canonical(n, [{"band": band}], a, z=z, logdet_out=la)
+    eng.set_option("band_algo", 2)
+    eng.band_sample_canonical(n, [{"band": band}], b, z=z, logdet_out=lb)
+    eng.check_status()
+    assert np.max(np.abs(a.cpu().numpy() - b.cpu().numpy())) < 1e-11 * max(1.0, np.abs(b.cpu().numpy()).max())
+    assert np.max(np.abs(la.cpu().numpy() - lb.cpu().numpy())) < 1e-12 * max(1.0, np.abs(lb.cpu().numpy()).max())
+    eng.close()
+
+
 def test_blocked_wide_band_kernel_repeats_itself_bit_for_bit():
     """The waves of the blocked kernel take their shares of a block's window update from a counter (who takes which differs from
     run to run) and the backward pass sums through LDS: the orders of summation are fixed all the same, so a repeated call
