@@ -101,7 +101,7 @@ omc_status omc_ctx_synchronize(omc_ctx* ctx);
  * explicit setting holds for every chain count),
  * "band_algo" (0 auto; 1 narrow bands one lane per chain in ONE piece; 2 one workgroup per chain, a column per step; 3 one
  * workgroup per chain in blocks of 16 columns, the next block factorised ahead, the window update on the matrix cores -- auto
- * takes it from w = 9, and from w = 4 on up to 2048 chains, where a lane per chain leaves the SIMDs to lone waves), "band_seg_overlap"
+ * takes it from w = 9, and from w = 4 on up to 3072 chains, where a lane per chain leaves the SIMDs to lone waves), "band_seg_overlap"
  * (8..65536, default 192: columns of warm-up before a segment of the segmented narrow-band route), "band_seg_count" (0, 2..128;
  * default 0: the number of segments of that route is chosen for the device's SIMDs; same results to rounding),
  * "band_blocked_threads" (0, 4, 8 or 512; default 0: the blocked band kernel picks its form by what fits a CU -- four waves per

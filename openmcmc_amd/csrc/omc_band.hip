@@ -1281,11 +1281,11 @@ omc_status omc_band_sample_canonical(omc_ctx* ctx, int64_t n, int64_t w, const o
   const int64_t Cn = ctx->n_chains;
   const int64_t groups = (Cn + 63) / 64;
   BandLaneArgs LP{};
-  // Bands of width 4 .. 8 on up to 2048 chains take the blocked workgroup-per-chain kernel as well: a lane per chain is a lone
+  // Bands of width 4 .. 8 on up to 3072 chains take the blocked workgroup-per-chain kernel as well: a lane per chain is a lone
   // wave per SIMD at 1.4-2.1 us a column whatever the number of chains (14-21 ms per draw at n = 10 000, measured), the blocked
-  // kernel in its four-wave form 3.9 ms per 768 chains (three workgroups to a CU): 8 ms at 1024 chains, 25 ms at 4096
+  // kernel in its four-wave forms 3.9 ms per 768 chains, 4.6 ms per 1024 (four workgroups to a CU): 18 ms at 4096
   // ("band_algo" 1 keeps the lane kernel, 3 takes the blocked one for every width).
-  const bool blocked_first = ctx->band_algo == 3 || (ctx->band_algo == 0 && w >= 4 && Cn <= 2048);
+  const bool blocked_first = ctx->band_algo == 3 || (ctx->band_algo == 0 && w >= 4 && Cn <= 3072);
   const bool lane_fits = w >= 1 && w <= 8 && ctx->band_algo != 2 && !blocked_first && band_lane_args(T, &LP);
   // Segmented route: segments of at least 96 columns and at least half the warm-up, their number chosen for the SIMDs.
   // The factor phase is bound by instruction issue, not by latency (measured: 0.5 us a column for a wave alone on its
