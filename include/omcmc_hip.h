@@ -104,9 +104,9 @@ omc_status omc_ctx_synchronize(omc_ctx* ctx);
  * takes it from w = 9, and from w = 4 on up to 3072 chains, where a lane per chain leaves the SIMDs to lone waves), "band_seg_overlap"
  * (8..65536, default 192: columns of warm-up before a segment of the segmented narrow-band route), "band_seg_count" (0, 2..128;
  * default 0: the number of segments of that route is chosen for the device's SIMDs; same results to rounding),
- * "band_blocked_threads" (0, 4, 8 or 512; default 0: the blocked band kernel picks its form by what fits a CU -- four waves per
+ * "band_blocked_threads" (0, 4, 8, 16 or 512; default 0: the blocked band kernel picks its form by what fits a CU -- four waves per
  * chain for bands narrower than 16, 128-register forms with several workgroups to a CU when there are more chains than CUs;
- * 512 keeps eight waves and one workgroup per CU, 4 / 8 force the two 128-register forms: same results to rounding),
+ * 512 keeps eight waves and one workgroup per CU, 4 / 16 / 8 force the 128-register forms: same results to rounding),
  * "dense_overlap" (0/1, default 1: the blocked dense factorisation runs the two halves of the chains on two streams,
  * forked from and joined into the context's stream by events; bit-identical results), "dense_use_rocsolver" (1: rocSOLVER's
  * potrf instead of the blocked route; cross-checks), "dense_blocked_min" (default 144: smallest order that takes the blocked

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8)
   // its row of the band storage starts -- is worked out once: a block then asks for its entries with a compare and a load each.
   constexpr int TPC = NT / NB;                                   // threads per column
   // widest band this instantiation is launched for (the four-wave form: bands narrower than a block, several workgroups per CU)
-  constexpr int WMAX_NB = (NT == 256) ? 15 : ((NB == 16) ? BAND_W16_MAX : BAND_WMAX_W);
+  constexpr int WMAX_NB = (NT == 256) ? ((NB == 16) ? 15 : 64) : ((NB == 16) ? BAND_W16_MAX : BAND_WMAX_W);
   constexpr int NPRE = (WMAX_NB + 2 + TPC - 1) / TPC;             // entries per thread
   const int pcol = tid / TPC, pq = tid % TPC;                    // (NB is a power of two: shifts)
   const double* pbase[NPRE][MT];                      // term k's row d of the band (or its right-hand side), NULL: no entry
@@ -715,10 +715,12 @@ bool omc_band_blocked_launch(omc_ctx* ctx, int64_t n, int w, const void* terms, 
   // Which form, by what fits a CU (measured on 10 000-node lattices, profiles/r04q_band.txt):
   //  * bands narrower than a block take four waves per chain (one tile, one factorising wave); with more chains than three
   //    workgroups per CU hold, the form compiled for 128 registers puts four there (1024 chains at w = 8: 8.0 -> 4.6 ms);
-  //  * bands up to ~64 on more chains than CUs: 8 columns per step at 128 registers, two workgroups to a CU (1024 chains at
-  //    w = 32: 15.6 -> 11.1 ms; slower where one workgroup per CU is all there is: 3.9 -> 4.9 ms at 256 chains);
+  //  * bands up to ~64 on more chains than CUs: 8 columns per step at 128 registers -- four waves per chain and four workgroups
+  //    to a CU while their LDS fits (w <= 55: 1024 chains at w = 32 15.6 -> 6.2 ms, at w = 16 15.6 -> 5.6 ms), eight waves and
+  //    two to a CU beyond (w = 64: 16.4 -> 14.6 ms); slower where one workgroup per CU is all there is (3.9 -> 4.9 ms at 256
+  //    chains);
   //  * otherwise 16 columns per step, eight waves, one workgroup per CU (8 columns where the window would not fit the LDS).
-  // "band_blocked_threads": 0 this choice; 512 eight waves and no register limit whatever the shape; 4 / 8 the two 128-register
+  // "band_blocked_threads": 0 this choice; 512 eight waves and no register limit whatever the shape; 4 / 16 / 8 the 128-register
   // forms wherever they apply (A/B runs and tests).  Only the forms compiled for two terms have the 128-register variants.
   int dev_cus = 256;
   hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -729,8 +731,12 @@ bool omc_band_blocked_launch(omc_ctx* ctx, int64_t n, int w, const void* terms, 
     else OMC_BLOCKED_LAUNCH(16, 256, OMC_MAX_TERMS, 1);
     return true;
   }
+  if (few && w <= 64 && 4 * blocked_lds(w, 8) <= limit && (forced == 16 || (forced == 0 && ctx->n_chains > (int64_t)dev_cus))) {
+    OMC_BLOCKED_LAUNCH(8, 256, 2, 4);   // 8 columns per step, four waves, four workgroups to a CU
+    return true;
+  }
   if (few && 2 * blocked_lds(w, 8) <= limit && (forced == 8 || (forced == 0 && ctx->n_chains > (int64_t)dev_cus))) {
-    OMC_BLOCKED_LAUNCH(8, 512, 2, 4);
+    OMC_BLOCKED_LAUNCH(8, 512, 2, 4);   // 8 columns per step, eight waves, two workgroups to a CU
     return true;
   }
   if (w <= BAND_W16_MAX && blocked_lds(w, 16) <= limit) {

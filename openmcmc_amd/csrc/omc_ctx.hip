@@ -276,7 +276,7 @@ omc_status omc_ctx_set_option(omc_ctx* ctx, const char* name, int64_t value) {
     return OMC_OK;
   }
   if (!strcmp(name, "band_blocked_threads")) {
-    if (value != 0 && value != 512 && value != 4 && value != 8) return OMC_INVALID_ARG;
+    if (value != 0 && value != 512 && value != 4 && value != 8 && value != 16) return OMC_INVALID_ARG;
     ctx->band_blocked_threads = (int)value;
     return OMC_OK;
   }
