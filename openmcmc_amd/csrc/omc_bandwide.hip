@@ -464,15 +464,18 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8)
   __syncthreads();
 
   WSTAMP(5);
-  // ---- backward pass L' x = t, NB columns per step, ONE barrier per step.  xs / ms: the last WS solutions, slot = column % WS.
+  // ---- backward pass L' x = t, NB columns per step, ONE barrier per step.  xs / ms: the last WB solutions, slot = column % WB.
   // Column b of block J needs sum_d L[j+b+d][j+b] x[j+b+d] over the rows behind it.  The rows from block J + 2 on ("far":
   // d >= 2 NB - b) are known a whole step before block J is solved: waves 1 .. 7 add them up for block J - 1 WHILE wave 0 solves
   // block J -- the rows of block J + 1 ("near"), the far sums handed over through LDS, and the block's own triangle across its
   // lanes.  Every sum is taken in a fixed order (partial sums per quad of threads, then in quad order): results do not depend on
   // timing.
+  // (the ring of solutions has w + 2 NB slots, not w + NB: block J + 1 is still being copied out of it by wave 1 while wave 0
+  // writes block J -- with w < NB the two blocks would share slots in a ring of w + NB)
+  const int WB = w + 2 * NB;
   double* xs = sm;
-  double* ms = xs + WS;
-  double* Sx = ms + WS;        // NB: sum over the rows behind the block, per column
+  double* ms = xs + WB;
+  double* Sx = ms + WB;        // NB: sum over the rows behind the block, per column
   double* Sm = Sx + NB;
   double* Lb = Sm + NB;        // NB x PS: the block's own triangle of the factor, Lb[a][b] = L[j+a][j+b], a > b; dinv on the diagonal
   constexpr int TPF = (NT - 64) / NB;   // threads per column for the far rows
@@ -484,7 +487,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8)
   const int dump_b = NB * PS + 4 * NB * QPC + lane;  // (behind Part: a slot per lane to write to in vain)
   const int diag_b = NB * PS + 4 * NB * QPC + 64;    // (and the block's 1 / L_jj: NB of them)
   double* Part = Lb + NB * PS;  // [2][2][NB][QPC]: the far sums of the quads, for blocks of even and odd number, draw and mean
-  for (int t = tid; t < 2 * WS; t += NT) sm[t] = 0.0;
+  for (int t = tid; t < 2 * WB; t += NT) sm[t] = 0.0;
   for (int t = tid; t < NB * PS; t += NT) Lb[t] = 0.0;
   if (tid < NB) Lb[diag_b + tid] = 0.0;
   __syncthreads();
@@ -550,9 +553,9 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     double px = 0.0, pm = 0.0;
 #pragma unroll
     for (int k = 0; k < NPF; ++k) {
-      // an entry that exists meets a row no further than w + NB - 1 = WS - 1 from the block's first column: one wrap at most
+      // an entry that exists meets a row no further than w + NB - 1 = w + NB - 1 from the block's first column: one wrap at most
       int sl = slotT + 2 * NB + fq + TPF * k;
-      if (sl >= WS) sl -= WS;
+      if (sl >= WB) sl -= WB;
       const bool ok = (fm >> k) & 1;
       sl = ok ? sl : 0;
       const double l = ok ? fl[k] : 0.0;
@@ -578,11 +581,11 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     const int64_t i = Jb * NB + b;
     if (lane < 2 * NB && i < n && (lane < NB || mc)) {
       int sl = slotB + b;
-      if (sl >= WS) sl -= WS;
+      if (sl >= WB) sl -= WB;
       (lane < NB ? xc : mc)[i] = (lane < NB ? xs : ms)[sl];
     }
   };
-  int slotJ = (int)(((nblk - 1) * NB) % WS);  // slot of the block's first column, kept incrementally
+  int slotJ = (int)(((nblk - 1) * NB) % WB);  // slot of the block's first column, kept incrementally
   request((int)nblk - 1);
   if (wave > 0) far_part((int)nblk - 1, slotJ);    // (nothing behind the last block but zeros: its sums are written all the same)
   lds_barrier_w();
@@ -591,11 +594,11 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     const int64_t j = J * NB;
     const int nb = (int)((n - j < NB) ? n - j : NB);
     int slotP = slotJ - NB;                   // slot of block J - 1's first column
-    if (slotP < 0) slotP += WS;
+    if (slotP < 0) slotP += WB;
     const unsigned long long tb0 = dbg ? __builtin_readcyclecounter() : 0;
     if (wave > 0) {
       if (J > 0) far_part((int)J - 1, slotP);
-      if (wave == 1 && J + 1 < nblk) store_block(J + 1, slotJ + NB >= WS ? slotJ + NB - WS : slotJ + NB);
+      if (wave == 1 && J + 1 < nblk) store_block(J + 1, slotJ + NB >= WB ? slotJ + NB - WB : slotJ + NB);
     } else {
       double nl[KN];
       const unsigned nm = nmask_next;
@@ -616,9 +619,9 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8)
         const int d = gg + LPC * k, r = gb + d;
         const bool ok = (nm >> k) & 1;
         const bool mine = r < NB;                              // inside the block
-        // (rows of entries that exist lie no further than WS - 1 from the block's first column)
+        // (rows of entries that exist lie no further than w + NB - 1 from the block's first column)
         int sl = slotJ + r;
-        if (sl >= WS) sl -= WS;
+        if (sl >= WB) sl -= WB;
         sl = (ok && !mine) ? sl : 0;
         const double l = (ok && !mine) ? nl[k] : 0.0;
         px = fma(l, xs[sl], px);
@@ -671,7 +674,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8)
       const double xv = acc * dinv_b;
       if (on) {
         int sl = slotJ + b;
-        if (sl >= WS) sl -= WS;
+        if (sl >= WB) sl -= WB;
         (is_m ? ms : xs)[sl] = xv;
       }
     }
@@ -680,7 +683,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     lds_barrier_w();
     WSTAMP(7);
   }
-  if (wave == 1) store_block(0, slotJ + NB >= WS ? slotJ + NB - WS : slotJ + NB);
+  if (wave == 1) store_block(0, slotJ + NB >= WB ? slotJ + NB - WB : slotJ + NB);
   if (dbg && blockIdx.x == 0 && tid == 0)
     for (int i = 0; i < 8; ++i) dbg[i] = tacc[i];
   if (dbg && blockIdx.x == 0 && lane == 0) {

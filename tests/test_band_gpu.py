@@ -434,13 +434,19 @@ def test_blocked_wide_band_kernel_forms_for_many_chains(w, n, form):
     eng.close()
 
 
-def test_blocked_wide_band_kernel_repeats_itself_bit_for_bit():
+@pytest.mark.parametrize("n,w,C,form", [(700, 100, 6, 0), (3000, 8, 1100, 0), (3000, 8, 1100, 4), (2000, 12, 1500, 0), (3000, 32, 1100, 0),
+                                        (3000, 32, 600, 8), (1500, 3, 900, 0)])
+def test_blocked_wide_band_kernel_repeats_itself_bit_for_bit(n, w, C, form):
     """The waves of the blocked kernel take their shares of a block's window update from a counter (who takes which differs from
     run to run) and the backward pass sums through LDS: the orders of summation are fixed all the same, so a repeated call
-    returns the same bits -- draw, mean and log det."""
+    returns the same bits -- draw, mean and log det.  With more chains than the CUs hold workgroups at once, on every form of the
+    kernel: workgroups then start on CUs others have left and run four to a CU, which is where a hand-over between waves that is
+    not fenced shows (one did: the solved block was copied out of a ring another wave was already refilling, bands narrower than
+    a block only)."""
     rng = np.random.default_rng(77)
-    n, w, C = 700, 100, 6
     eng = make_engine(C)
+    eng.set_option("band_algo", 3)
+    eng.set_option("band_blocked_threads", form)
     M = random_band_spd(n, w, rng)
     terms = [{"band": eng.to_device(band_of(M, w)), "scale": eng.to_device(rng.random(C) + 0.5)},
              {"rhs": eng.to_device(rng.standard_normal(n)), "scale": eng.to_device(rng.random(C) + 0.5)}]
