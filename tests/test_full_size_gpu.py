@@ -139,7 +139,8 @@ def test_spectral_route_at_cfg2_size_has_the_factorisation_routes_conditional_la
     eng.close()
 
 
-@pytest.mark.parametrize("R,K,C", [(100, 100, 5), (312, 32, 300), (1250, 8, 1100)], ids=["w100", "w32-many-chains", "w8-many-chains"])
+@pytest.mark.parametrize("R,K,C", [(100, 100, 5), (100, 100, 520), (312, 32, 1100), (1250, 8, 1100), (666, 15, 2100)],
+                         ids=["w100", "w100-many-chains", "w32-many-chains", "w8-many-chains", "w15-many-chains"])
 def test_lattice_gmrf_at_full_size_solves_its_system_on_both_band_kernels(R, K, C):
     """SURVEY section 8f rank 1 at its size: a 100 x 100 lattice GMRF (10 000 nodes, bandwidth 100; gmrf.py:489-520 on a sparse
     precision of that shape), Q_c = lambda_c (L + kappa I) + tau_c I, a few chains.  Size-independent properties of the draw
