@@ -695,10 +695,16 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8)
 
 }  // namespace
 
-// LDS bytes of a block size NB at bandwidth w (the factor phase is the larger one)
-static size_t blocked_lds(int w, int NB) {
+// LDS bytes of a block size NB at bandwidth w with NT threads: the larger of the two passes' images (the factor phase's, except for
+// bands of a few entries)
+static size_t blocked_lds(int w, int NB, int NT = 512) {
   const size_t W1 = (size_t)w + 1, WS = (size_t)w + NB, WP = ((size_t)w + 15) & ~(size_t)15, PS = (size_t)NB + 1;
-  return (WS * W1 + WS + 2 * (WP * PS + (size_t)NB * PS + 2 * (size_t)NB) + 2 + 64 + 2) * sizeof(double);
+  const size_t fwd = WS * W1 + WS + 2 * (WP * PS + (size_t)NB * PS + 2 * (size_t)NB) + 2 + 64 + 2;
+  // the backward pass lays its own image over the same memory: two solution rings of w + 2 NB, the block's sums and triangle, the
+  // far sums of the quads (two blocks, draw and mean), a slot per lane to write to in vain, the block's 1 / L_jj
+  const size_t qpc = (size_t)(NT - 64) / NB / 4;
+  const size_t bwd = 2 * ((size_t)w + 2 * NB) + 2 * (size_t)NB + (size_t)NB * PS + 4 * (size_t)NB * qpc + 64 + (size_t)NB;
+  return (fwd > bwd ? fwd : bwd) * sizeof(double);
 }
 
 // terms: omc_band.hip's BandTermsDev (the same layout as BandTermsW above); Lws: [C][n][w + 1] doubles.  Returns false if no block
@@ -712,7 +718,7 @@ bool omc_band_blocked_launch(omc_ctx* ctx, int64_t n, int w, const void* terms, 
   const size_t limit = 160 * 1024;
   const bool few = T.n_terms <= 2;
 #define OMC_BLOCKED_LAUNCH(NB_, NT_, MT_, WPE_)                                                                                       \
-  hipLaunchKernelGGL((k_band_blocked<NB_, NT_, MT_, WPE_>), dim3((unsigned)ctx->n_chains), dim3(NT_), blocked_lds(w, NB_), ctx->stream,      \
+  hipLaunchKernelGGL((k_band_blocked<NB_, NT_, MT_, WPE_>), dim3((unsigned)ctx->n_chains), dim3(NT_), blocked_lds(w, NB_, NT_), ctx->stream, \
                      ctx->n_chains, ctx->chain_offset, n, w, T, rhs_chain, ld_rhs, z_inject, ld_z, key, Lws, x, ld_x, mean, ld_mean,  \
                      logdet, ctx->d_bad_chain, ctx->stamps)
   // Which form, by what fits a CU (measured on 10 000-node lattices, profiles/r04q_band.txt):
@@ -734,7 +740,7 @@ bool omc_band_blocked_launch(omc_ctx* ctx, int64_t n, int w, const void* terms, 
     else OMC_BLOCKED_LAUNCH(16, 256, OMC_MAX_TERMS, 1);
     return true;
   }
-  if (few && w <= 64 && 4 * blocked_lds(w, 8) <= limit && (forced == 16 || (forced == 0 && ctx->n_chains > (int64_t)dev_cus))) {
+  if (few && w <= 64 && 4 * blocked_lds(w, 8, 256) <= limit && (forced == 16 || (forced == 0 && ctx->n_chains > (int64_t)dev_cus))) {
     OMC_BLOCKED_LAUNCH(8, 256, 2, 4);   // 8 columns per step, four waves, four workgroups to a CU
     return true;
   }

@@ -408,7 +408,8 @@ def test_blocked_wide_band_kernel_four_terms(w, n, algo):
 
 
 @pytest.mark.parametrize("w,n,form", [(5, 130, 4), (12, 333, 4), (15, 48, 4), (9, 200, 8), (20, 400, 8), (40, 95, 8), (64, 200, 8), (16, 17, 8),
-                                      (9, 200, 16), (20, 400, 16), (44, 95, 16), (33, 200, 16), (16, 17, 16), (12, 333, 512), (64, 200, 512)])
+                                      (9, 200, 16), (20, 400, 16), (44, 95, 16), (33, 200, 16), (16, 17, 16), (12, 333, 512), (64, 200, 512),
+                                      (1, 50, 8), (3, 200, 8), (2, 100, 16), (1, 90, 16), (1, 9, 512), (3, 50, 4), (1, 70, 4)])
 def test_blocked_wide_band_kernel_forms_for_many_chains(w, n, form):
     """The forms of the blocked kernel the library picks when there are more chains than CUs -- four waves per chain at 128
     registers (bands narrower than a block), 8 columns per step at 128 registers with four or eight waves (bands up to ~64) -- and the one-workgroup-per-CU
